@@ -1,0 +1,283 @@
+/*
+ * oicc_hip.h -- C-ABI of the MI355X-native continuous-time IMU-camera spline
+ * calibration solver (liboicc_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of urbste/OpenImuCameraCalibrator:
+ * the work done behind  OpenICC::core::SplineTrajectoryEstimator<6>
+ *   reference: include/OpenCameraCalibrator/core/spline_trajectory_estimator.h:31-218
+ *              include/OpenCameraCalibrator/core/spline_trajectory_estimator.impl.h
+ * i.e. problem construction (Add*Measurement), ceres::Solve (residuals,
+ * Jacobians, normal equations, Levenberg-Marquardt) and the trajectory getters.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the ABI; every call returns OICC_OK (0) or a
+ *    negative oicc_status; oicc_last_error() gives a message.
+ *  - all floating point is IEEE fp64; timestamps are int64 nanoseconds.
+ *  - caller-owned HOST buffers are copied on entry; the library owns all
+ *    device memory.  One problem = one GPU (one process per GPU).
+ *  - quaternions are (x, y, z, w) in memory (Eigen coeffs(), Sophus so3.hpp:185);
+ *    SE(3) is [qx qy qz qw tx ty tz] (Sophus se3.hpp:511).
+ *  - there is NO CPU fallback: if no HIP device is usable oicc_create fails.
+ *  - thread-compatible, not thread-safe (same as the reference estimator).
+ */
+#ifndef OICC_HIP_H_
+#define OICC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OICC_SPLINE_N 6      /* imu_camera_calibrator.h:27  SPLINE_N            */
+#define OICC_BIAS_SPLINE_N 3 /* ceres_calib_split_residuals.h:21 BIAS_SPLINE_N  */
+
+typedef struct oicc_problem oicc_problem;
+
+typedef enum oicc_status {
+  OICC_OK = 0,
+  OICC_ERR_INVALID_ARG = -1,
+  OICC_ERR_NO_DEVICE = -2,
+  OICC_ERR_HIP = -3,
+  OICC_ERR_STATE = -4,
+  OICC_ERR_UNSUPPORTED = -5
+} oicc_status;
+
+/* theia::CameraIntrinsicsModelType values (pyTheiaSfM 69c3d37, [EXT]); the
+ * dispatch they drive is ceres_calib_split_residuals.h:247-270,366-389. */
+typedef enum oicc_camera_model {
+  OICC_CAM_PINHOLE = 0,                   /* f, aspect, skew, cx, cy, k1, k2           */
+  OICC_CAM_PINHOLE_RADIAL_TANGENTIAL = 1, /* f, aspect, skew, cx, cy, k1,k2,k3, t1,t2  */
+  OICC_CAM_FISHEYE = 2,                   /* f, aspect, skew, cx, cy, k1..k4           */
+  OICC_CAM_DIVISION_UNDISTORTION = 4,     /* f, aspect, cx, cy, k                      */
+  OICC_CAM_DOUBLE_SPHERE = 5,             /* f, aspect, skew, cx, cy, xi, alpha        */
+  OICC_CAM_EXTENDED_UNIFIED = 6           /* f, aspect, skew, cx, cy, alpha, beta      */
+} oicc_camera_model;
+
+/* SplineOptimFlags, spline_trajectory_estimator.h:17-27 (same bit values). */
+typedef enum oicc_optim_flags {
+  OICC_POINTS = 1 << 0, /* not supported (never set by the reference CLI) */
+  OICC_T_I_C = 1 << 1,
+  OICC_IMU_BIASES = 1 << 2,
+  OICC_IMU_INTRINSICS = 1 << 3,
+  OICC_GRAVITY_DIR = 1 << 4,
+  OICC_CAM_LINE_DELAY = 1 << 5,
+  OICC_SPLINE = 1 << 6,
+  OICC_ACC_BIAS = 1 << 7,
+  OICC_GYR_BIAS = 1 << 8
+} oicc_optim_flags;
+
+/* ceres::TerminationType subset reported by the LM loop (A9). */
+typedef enum oicc_termination {
+  OICC_CONVERGENCE = 0,
+  OICC_NO_CONVERGENCE = 1,
+  OICC_FAILURE = 2
+} oicc_termination;
+
+/* What ceres::Solver::Summary carries that the callers look at, plus timing
+ * buckets mirroring Summary::FullReport() (impl.h:273). */
+typedef struct oicc_summary {
+  int32_t termination;            /* oicc_termination                           */
+  int32_t num_iterations;         /* LM iterations run (successful+unsuccessful) */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_parameters_tangent; /* P: tangent dimension of the active set     */
+  int32_t band_dim;               /* time-banded part of P                      */
+  int32_t arrow_dim;              /* dense "arrow" part of P                    */
+  int32_t half_bandwidth;         /* of the band part, in scalars               */
+  int64_t num_residual_blocks;    /* views + accel samples + gyro samples       */
+  int64_t num_residuals;
+  double initial_cost;
+  double final_cost;
+  double final_radius;
+  double final_gradient_max_norm;
+  double seconds_total;           /* wall clock of oicc_optimize                */
+  double seconds_jacobian;        /* residual+Jacobian+normal-equation passes   */
+  double seconds_residual;        /* cost-only passes                           */
+  double seconds_linear_solver;   /* damped band+arrow Cholesky solves          */
+  char message[128];
+} oicc_summary;
+
+/* Per-iteration trace (optional, for parity tests): cost, cost change,
+ * gradient max norm, step norm, trust region radius, rho, success. */
+typedef struct oicc_iteration {
+  int32_t iteration;
+  int32_t step_is_successful;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+} oicc_iteration;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* device_ordinal: HIP device index (LOCAL_RANK); fails with OICC_ERR_NO_DEVICE
+ * when no gfx950-class HIP device is usable -- there is no CPU path. */
+int oicc_create(oicc_problem** out, int device_ordinal);
+void oicc_destroy(oicc_problem* p);
+const char* oicc_last_error(const oicc_problem* p);
+const char* oicc_version(void);
+/* Run all device work on this hipStream_t (e.g. torch's current stream). */
+int oicc_set_stream(oicc_problem* p, void* hip_stream);
+
+/* ---- setup: mirrors SplineTrajectoryEstimator setters ------------------ */
+/* SetTimes, impl.h:38-51. nr_knots = (end-start)/dt + 6 (integer division). */
+int oicc_set_times(oicc_problem* p, int64_t dt_so3_ns, int64_t dt_r3_ns,
+                   int64_t start_ns, int64_t end_ns);
+int64_t oicc_get_num_so3_knots(const oicc_problem* p); /* impl.h:810 */
+int64_t oicc_get_num_r3_knots(const oicc_problem* p);  /* impl.h:815 */
+int64_t oicc_get_min_time_ns(const oicc_problem* p);   /* impl.h:825 */
+int64_t oicc_get_max_time_ns(const oicc_problem* p);   /* impl.h:820 */
+
+/* Knot values produced by BatchInitSO3R3VisPoses (impl.h:279-339; the slerp/
+ * lerp resampling itself is host-side code in the C++ facade). */
+int oicc_set_so3_knots(oicc_problem* p, const double* quat_xyzw, int64_t n);
+int oicc_set_r3_knots(oicc_problem* p, const double* xyz, int64_t n);
+int oicc_get_so3_knots(const oicc_problem* p, double* quat_xyzw, int64_t n);
+int oicc_get_r3_knots(const oicc_problem* p, double* xyz, int64_t n);
+
+/* InitBiasSplines, impl.h:54-90 (order-3 R^3 splines, constant init,
+ * inv_dt = 1/dt_ns as in the reference, quirk Q3). */
+int oicc_init_bias_splines(oicc_problem* p, const double accl_bias[3],
+                           const double gyro_bias[3], int64_t dt_accl_ns,
+                           int64_t dt_gyro_ns, double max_accl_range,
+                           double max_gyro_range);
+
+int oicc_set_T_i_c(oicc_problem* p, const double q_xyzw_t_xyz[7]); /* impl.h:862 */
+int oicc_set_gravity(oicc_problem* p, const double g[3]);          /* impl.h:857 */
+int oicc_set_camera_line_delay(oicc_problem* p, double seconds);   /* impl.h:873 */
+/* SetIMUIntrinsics, impl.h:1237-1248: accl = [misYZ misZY misZX sX sY sZ],
+ * gyro = [misYZ misZY misZX misXZ misXY misYX sX sY sZ]. */
+int oicc_set_imu_intrinsics(oicc_problem* p, const double accl[6],
+                            const double gyro[9]);
+/* The per-view theia::Camera intrinsics copied at
+ * ceres_calib_split_residuals.h:218-221,333-336 (constant on this path). */
+int oicc_set_camera(oicc_problem* p, int32_t camera_model,
+                    const double* intrinsics, int32_t num_intrinsics);
+/* Board points = tracks of the reconstruction, homogeneous (x,y,z,w). */
+int oicc_set_scene_points(oicc_problem* p, const double* xyzw, int64_t n);
+
+/* ---- problem construction: mirrors Add*Measurement --------------------- */
+/* AddRSCameraMeasurement (impl.h:539-613) / AddGSCameraMeasurement
+ * (impl.h:479-536), batched over views.  t_ns[v] = int64(view timestamp * 1e9).
+ * Corners of view v are [corner_offset[v], corner_offset[v+1]).
+ * uv = observed pixel (x,y) pairs; cov_diag = per-corner (cov_xx, cov_yy) or
+ * NULL for identity (continuous_time_imu_to_camera_calibration.cc:157).
+ * accepted[v] (optional) receives the reference's bool return value.
+ * GS views carry the reference's HuberLoss(0.0) (quirk Q2) unless
+ * oicc_set_option("gs_unit_loss",1) is set. */
+int oicc_add_rs_camera_measurements(oicc_problem* p, int64_t n_views,
+                                    const int64_t* t_ns,
+                                    const int64_t* corner_offset,
+                                    const double* uv, const double* cov_diag,
+                                    const int32_t* point_index,
+                                    uint8_t* accepted);
+int oicc_add_gs_camera_measurements(oicc_problem* p, int64_t n_views,
+                                    const int64_t* t_ns,
+                                    const int64_t* corner_offset,
+                                    const double* uv, const double* cov_diag,
+                                    const int32_t* point_index,
+                                    uint8_t* accepted);
+/* AddAccelerometerMeasurement impl.h:342-420 / AddGyroscopeMeasurement
+ * impl.h:423-476, batched.  weight = 1/std (imu_camera_calibrator.cc:111,117). */
+int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n,
+                                        const int64_t* t_ns,
+                                        const double* meas_xyz, double weight,
+                                        uint8_t* accepted);
+int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
+                                    const int64_t* t_ns,
+                                    const double* meas_xyz, double weight,
+                                    uint8_t* accepted);
+
+/* ---- solve: mirrors Optimize(max_iters, flags), impl.h:255-276 ---------- */
+/* Named numeric options.  Ceres 2.1.0 defaults unless the reference overrides
+ * them (impl.h:257-266):
+ *   function_tolerance 1e-4, parameter_tolerance 1e-7, gradient_tolerance 1e-10,
+ *   initial_trust_region_radius 1e4, max_trust_region_radius 1e16,
+ *   min_trust_region_radius 1e-32, min_relative_decrease 1e-3,
+ *   min_lm_diagonal 1e-6, max_lm_diagonal 1e32, jacobi_scaling 1,
+ *   max_num_consecutive_invalid_steps 5,
+ *   gs_unit_loss 0 (1: trivial loss on GS views instead of quirk Q2),
+ *   rs_time_in_seconds 0 (1: documented fix of quirk Q1),
+ *   verbose 0.
+ * Inner iterations (impl.h:266) are NOT reproduced (DESIGN.md deviation D1). */
+int oicc_set_option(oicc_problem* p, const char* name, double value);
+int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,
+                  oicc_summary* summary);
+/* Trace of the last oicc_optimize call; returns number of entries written. */
+int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out,
+                        int32_t capacity);
+
+/* ---- multi-GPU: residual blocks are sharded by the caller (each
+ * rank adds only its own views / IMU samples, all ranks hold all parameters).
+ * After every local normal-equation / cost pass the library calls
+ *   reduce(user, device_ptr, count_doubles, hip_stream)
+ * which must SUM the fp64 buffer across ranks in place, ordered on the given
+ * stream (RCCL all-reduce; torch.distributed does this in bench.py).
+ * NULL = single GPU. */
+typedef int (*oicc_allreduce_fn)(void* user, void* device_ptr, int64_t count,
+                                 void* hip_stream);
+int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user);
+
+/* ---- evaluation hooks (parity tests, bench) ----------------------------- */
+/* Tangent layout of the active set for `flags`: band variables ordered by
+ * (knot time in ns, kind: SO3 before R3), then the arrow in the fixed order
+ * T_i_c(6: upsilon,omega) | gravity(3) | line_delay(1) | accl bias knots(3 each)
+ * | gyro bias knots(3 each) | accl intrinsics(6) | gyro intrinsics(9).
+ * Outputs (each optional) receive the tangent offset or -1 if inactive. */
+int oicc_get_tangent_layout(oicc_problem* p, int32_t flags, int32_t* num_tangent,
+                            int32_t* so3_offsets, int32_t* r3_offsets,
+                            int32_t* accl_bias_offsets,
+                            int32_t* gyro_bias_offsets,
+                            int32_t other_offsets[5] /* T_i_c,g,ld,acc_intr,gyr_intr */);
+/* One residual + Jacobian + normal-equation pass at the current parameters.
+ * cost = 0.5*sum r^2.  H_dense (P*P row-major, symmetric) and g (P) optional. */
+int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H_dense,
+                  double* g, int32_t P_capacity);
+/* Cost-only pass (what LM runs for a candidate point). */
+int oicc_evaluate_cost(oicc_problem* p, int32_t flags, double* cost);
+/* Per-block residuals and tangent Jacobians for parity tests.
+ * kind: 0 = camera views, 1 = accelerometer, 2 = gyroscope.
+ * Camera: residuals [2*total_corners]; jacobian rows hold the block-local
+ * columns [6 SO3 knots x3 | 6 R3 knots x3 | T_i_c 6 | line delay 1] = 43.
+ * Accel: residuals [3*n]; columns [18 | 18 | g 3 | bias knots 9 | intr 6] = 54.
+ * Gyro : residuals [3*n]; columns [18 | bias knots 9 | intr 9] = 36.
+ * Columns of inactive parameters are zero. jacobians may be NULL. */
+int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind,
+                         double* residuals, double* jacobians);
+/* Time `repeats` back-to-back Jacobian+assembly passes with HIP events on the
+ * library's stream; returns average milliseconds per pass and, optionally, the
+ * per-kernel averages [views, accel, gyro]. */
+int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats,
+                            double* ms_per_pass, double kernel_ms[3]);
+/* Same for the damped band+arrow solve of the last assembled system. */
+int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats,
+                           double* ms_per_solve);
+
+/* ---- read-back: mirrors the getters ------------------------------------- */
+int oicc_get_T_i_c(const oicc_problem* p, double q_xyzw_t_xyz[7]);  /* impl.h:1133 */
+int oicc_get_gravity(const oicc_problem* p, double g[3]);           /* impl.h:1128 */
+int oicc_get_rs_line_delay(const oicc_problem* p, double* seconds); /* impl.h:1138 */
+int oicc_get_imu_intrinsics(const oicc_problem* p, double accl[6], double gyro[9]);
+int oicc_get_bias_knots(const oicc_problem* p, double* accl_xyz, int64_t n_accl,
+                        double* gyro_xyz, int64_t n_gyro);
+int64_t oicc_get_num_accl_bias_knots(const oicc_problem* p);
+int64_t oicc_get_num_gyro_bias_knots(const oicc_problem* p);
+/* GetMeanReprojectionError, impl.h:994-1072 (always the RS functor; skips
+ * corners with a zero residual component; 0.0 on an empty/out-of-range view). */
+int oicc_get_mean_reprojection_error(oicc_problem* p, double* mean_px,
+                                     int64_t* num_points);
+/* Batched trajectory getters (impl.h:879-991, 1181-1234). valid[i]=0 where the
+ * reference getter returns false (outputs untouched / zero bias).
+ *  pose: [qx qy qz qw tx ty tz] = GetPose; gyro = GetAngularVelocity;
+ *  accel = GetAcceleration (R^T (a_w + g)); biases = GetGyroBias / GetAcclBias.
+ * Any output may be NULL. */
+int oicc_get_trajectory(oicc_problem* p, int64_t n, const int64_t* t_ns,
+                        double* pose7, double* gyro3, double* accel3,
+                        double* gyro_bias3, double* accl_bias3, uint8_t* valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OICC_HIP_H_ */

@@ -1,0 +1,26 @@
+"""Loader for the product library liboicc_hip.so (HIP kernels + C-ABI).
+
+There is deliberately no fallback: if the shared object is missing or does not
+export every symbol of include/oicc_hip.h this raises, and oicc_create itself
+fails when no HIP device is usable.
+"""
+import ctypes
+import os
+
+from ._abi import Bound
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liboicc_hip.so")
+_bound = None
+
+
+def load():
+    global _bound
+    if _bound is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liboicc_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C openimucameracalibrator_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        _bound = Bound(lib, "oicc_", device=True)
+    return _bound
