@@ -219,6 +219,12 @@ int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out,
 typedef int (*oicc_allreduce_fn)(void* user, void* device_ptr, int64_t count,
                                  void* hip_stream);
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user);
+/* Tell this rank about measurements held by OTHER ranks (timestamps only), so
+ * that every rank derives the same tangent layout (which knots are in the
+ * problem, bandwidth, which parameter blocks exist).
+ * kind: 0 = RS camera view, 1 = accelerometer, 2 = gyroscope, 3 = GS camera view. */
+int oicc_declare_remote_measurements(oicc_problem* p, int32_t kind, int64_t n,
+                                     const int64_t* t_ns);
 
 /* ---- evaluation hooks (parity tests, bench) ----------------------------- */
 /* Tangent layout of the active set for `flags`: band variables ordered by

@@ -98,6 +98,7 @@ SIGNATURES = {
 DEVICE_ONLY = {
     "set_stream": (C.c_int, [H, C.c_void_p]),
     "set_allreduce": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
+    "declare_remote_measurements": (C.c_int, [H, C.c_int32, C.c_int64, c_i64p]),
     "time_jacobian_pass": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_dp]),
     "time_linear_solve": (C.c_int, [H, C.c_int32, C.c_int32, c_dp]),
 }

@@ -1,0 +1,75 @@
+// Shared host/device structures of liboicc_hip (internal, not part of the ABI).
+#pragma once
+#include <cstdint>
+
+namespace oicc {
+
+// Parameter vector x (fp64, one contiguous device buffer; two copies: current and
+// candidate).  Offsets in doubles.
+struct ParamLayout {
+  int64_t so3, r3, ab, gb, tic, g, ld, ai, gi, total;
+  int32_t n_so3, n_r3, n_ab, n_gb;
+};
+
+// Tangent layout of the active set (the ordering contract of include/oicc_hip.h).
+struct TangentLayout {
+  const int32_t* so3;  // [n_so3] offset or -1
+  const int32_t* r3;   // [n_r3]
+  const int32_t* ab;   // [n_ab]
+  const int32_t* gb;   // [n_gb]
+  int32_t tic, g, ld, ai, gi;  // arrow offsets or -1
+  int32_t P, Pb, a, hb, W;     // W = hb + 1 (band row length)
+};
+
+// Normal equations in band + arrow storage, ONE contiguous fp64 buffer so that a
+// multi-GPU run reduces it with a single all-reduce:
+//   [ band Pb*W | Et a*Pb | C a*a | g P | cost 1 ]
+// band[i*W + (j-i)] = H(i,j) for i <= j <= i+hb   (upper band by rows)
+// Et[c*Pb + i]      = H(i, Pb+c)                  (arrow rows, contiguous in i)
+// C[r*a + c]        = H(Pb+r, Pb+c)               (full symmetric)
+struct NormalEq {
+  double* base;
+  int64_t off_E, off_C, off_g, off_cost, total;
+  __host__ __device__ double* band() const { return base; }
+  __host__ __device__ double* Et() const { return base + off_E; }
+  __host__ __device__ double* C() const { return base + off_C; }
+  __host__ __device__ double* g() const { return base + off_g; }
+  __host__ __device__ double* cost() const { return base + off_cost; }
+};
+
+struct ViewData {  // SoA over corners (sorted by view) and over views
+  int64_t n_views, n_corners;
+  const int32_t* corner_view;
+  const double* corner_u; const double* corner_v;      // observed pixel
+  const double* corner_isx; const double* corner_isy;  // 1/sqrt(cov)
+  const int32_t* corner_pt;
+  const int64_t* view_c0;  // [n_views+1] first corner
+  const int32_t* view_s_so3; const int32_t* view_s_r3;
+  const double* view_u_so3; const double* view_u_r3;
+  const uint8_t* view_rs;      // rolling-shutter functor (1) or global-shutter (0)
+};
+
+struct ImuData {  // SoA over samples of one sensor (time sorted)
+  int64_t n;
+  const int32_t* s_so3; const int32_t* s_r3; const int32_t* s_b;
+  const double* u_so3; const double* u_r3; const double* u_b;
+  const double* mx; const double* my; const double* mz;
+  const double* w;       // per-sample weight 1/std
+};
+
+struct EvalCtx {
+  const double* x;        // parameter vector
+  ParamLayout pl;
+  TangentLayout tl;
+  NormalEq ne;
+  const double* pts;      // [np][4]
+  double inv_so3_dt, inv_r3_dt;
+  double intr[10];
+  int32_t cam_model;
+  int32_t gs_unit_loss;   // 0: GS views carry HuberLoss(0) = no weight (quirk Q2)
+  int32_t rs_time_in_seconds;  // 1: documented fix of quirk Q1
+  double* dbg_res;        // optional per-row residual dump (parity tests)
+  double* dbg_jac;        // optional per-row Jacobian dump in the fixed ABI layout
+};
+
+}  // namespace oicc

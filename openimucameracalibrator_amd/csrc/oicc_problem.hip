@@ -1,0 +1,845 @@
+// liboicc_hip: C-ABI implementation (include/oicc_hip.h) -- problem state, device
+// buffers, tangent layout, and the Levenberg-Marquardt driver.
+//
+// Host-side counterpart of OpenICC::core::SplineTrajectoryEstimator<6>
+// (reference include/OpenCameraCalibrator/core/spline_trajectory_estimator.impl.h):
+//   SetTimes :38-51, InitBiasSplines :54-90, SetFixedParams :93-252, Optimize
+//   :255-276, Add*Measurement :342-613, CalcTimes :764-788, getters :879-1248.
+// The arithmetic of the solve runs in the HIP kernels of kernels_blocks.hip and
+// kernels_solve.hip; this file never computes residuals, Jacobians or solves on
+// the CPU (there is no CPU fallback).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/oicc_hip.h"
+#include "oicc_device.h"
+
+namespace oicc {
+// kernels_blocks.hip
+void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st);
+void launch_imu_blocks(int kind, const EvalCtx& ctx, const ImuData& id, bool spline_active, bool bias_active, bool jac, hipStream_t st);
+void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, const int32_t* s_r3, const double* u_so3,
+                       const double* u_r3, const int32_t* s_gb, const double* u_gb, const int32_t* s_ab, const double* u_ab,
+                       double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
+                       hipStream_t st);
+// kernels_solve.hip
+struct LmState { double radius, model_cost_change, step_norm_sq, x_norm_sq, gradient_max_norm, cand_cost; int32_t chol_failed, pad; };
+struct SolveBuffers { double *Mb, *Mt, *Mc, *scale, *diag, *D2, *step_s; LmState* st; };
+void launch_lm_scale(const NormalEq& ne, const TangentLayout& tl, double* scale, int jacobi, hipStream_t st);
+void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st);
+void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
+                     double max_diag, hipStream_t st);
+int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st);
+void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
+                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
+}  // namespace oicc
+
+using namespace oicc;
+
+namespace {
+
+constexpr int kN = OICC_SPLINE_N;
+constexpr int kNb = OICC_BIAS_SPLINE_N;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool resize(size_t count) {
+    if (count <= n && p) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (count == 0) return true;
+    if (hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
+    n = count; return true;
+  }
+  bool upload(const std::vector<T>& h, hipStream_t st) {
+    if (!resize(std::max<size_t>(h.size(), 1))) return false;
+    if (h.empty()) return true;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st) == hipSuccess;
+  }
+};
+
+struct ImuHost {
+  std::vector<int32_t> s_so3, s_r3, s_b;
+  std::vector<double> u_so3, u_r3, u_b, mx, my, mz, w;
+  size_t size() const { return s_so3.size(); }
+};
+struct ImuDev { DevBuf<int32_t> s_so3, s_r3, s_b; DevBuf<double> u_so3, u_r3, u_b, mx, my, mz, w; };
+
+struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g; };
+
+struct HostLayout {
+  std::vector<int32_t> so3, r3, ab, gb;
+  int32_t other[5];
+  int32_t P, Pb, a, hb;
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// CalcTimes, impl.h:764-788
+bool calc_times(int64_t sensor_time, int64_t start_ns, int64_t dt_ns, size_t nr_knots, int N, double* u, int64_t* s) {
+  const int64_t st_ns = sensor_time - start_ns;
+  if (st_ns < 0) { *u = 0.0; return false; }
+  *s = st_ns / dt_ns;
+  if (*s < 0) return false;
+  if (size_t(*s + N) > nr_knots) return false;
+  *u = double(st_ns % dt_ns) / double(dt_ns);
+  return true;
+}
+
+}  // namespace
+
+struct oicc_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // spline meta (impl.h:38-51)
+  int64_t dt_so3 = 0, dt_r3 = 0, start_ns = 0, end_ns = 0;
+  double inv_so3_dt = 0, inv_r3_dt = 0;
+  int64_t dt_ab = 0, dt_gb = 0; double inv_ab_dt = 0, inv_gb_dt = 0, max_ab = 1.0, max_gb = 1e-2;
+  // host mirror of the parameter vector
+  ParamLayout pl{};
+  std::vector<double> x;
+  bool x_host_dirty = true;       // host mirror newer than device
+  std::vector<char> so3_in, r3_in, ab_in, gb_in;   // *_knot_in_problem_, impl.h:282-283
+  int cam_model = 0, n_intr = 0; double intr[10] = {0};
+  std::vector<double> pts;
+  // measurements (host SoA)
+  std::vector<int32_t> corner_view, corner_pt; std::vector<double> cu, cv, cisx, cisy;
+  std::vector<int64_t> view_c0{0}; std::vector<int32_t> view_s_so3, view_s_r3; std::vector<double> view_u_so3, view_u_r3;
+  std::vector<uint8_t> view_rs;
+  ImuHost acc, gyr;
+  // knot windows of measurements held by OTHER ranks (multi-GPU): only for layout/bandwidth
+  std::vector<int32_t> remote_so3, remote_r3;   // pairs; r3 = -1 for gyro
+  bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
+  bool meas_dirty = true;
+  std::map<std::string, double> opt;
+  std::vector<oicc_iteration> trace;
+  oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
+  // device
+  DevBuf<double> d_x, d_xc, d_pts;
+  DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
+  DevBuf<double> d_cu, d_cv, d_cisx, d_cisy, d_view_u_so3, d_view_u_r3;
+  DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
+  ImuDev d_acc, d_gyr;
+  DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
+  DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
+  DevBuf<int32_t> d_traj_i;
+  DevBuf<LmState> d_state;
+  // cached layout
+  int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{};
+  Active act{};
+
+  oicc_problem() {
+    opt["function_tolerance"] = 1e-4; opt["parameter_tolerance"] = 1e-7; opt["gradient_tolerance"] = 1e-10;
+    opt["initial_trust_region_radius"] = 1e4; opt["max_trust_region_radius"] = 1e16;
+    opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
+    opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
+    opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
+    opt["verbose"] = 0; opt["num_threads"] = 0;
+  }
+};
+
+namespace {
+
+#define HIPCK(p, call)                                                                 \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      (p)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+      return OICC_ERR_HIP;                                                             \
+    }                                                                                  \
+  } while (0)
+#define ARG(p, c, msg) do { if (!(c)) { (p)->err = msg; return OICC_ERR_INVALID_ARG; } } while (0)
+
+double* xs(oicc_problem* p, int64_t off) { return p->x.data() + off; }
+
+void rebuild_param_layout(oicc_problem* p, int64_t n_so3, int64_t n_r3, int64_t n_ab, int64_t n_gb) {
+  // keep calibration scalars when the knot counts change
+  double T_i_c[7] = {0, 0, 0, 1, 0, 0, 0}, g[3] = {0, 0, 9.81}, ld = 0, ai[6] = {0, 0, 0, 1, 1, 1}, gi[9] = {0, 0, 0, 0, 0, 0, 1, 1, 1};
+  std::vector<double> so3, r3, ab, gb;
+  if (!p->x.empty()) {
+    std::memcpy(T_i_c, xs(p, p->pl.tic), sizeof(T_i_c)); std::memcpy(g, xs(p, p->pl.g), sizeof(g)); ld = p->x[p->pl.ld];
+    std::memcpy(ai, xs(p, p->pl.ai), sizeof(ai)); std::memcpy(gi, xs(p, p->pl.gi), sizeof(gi));
+    so3.assign(xs(p, p->pl.so3), xs(p, p->pl.so3) + 4 * p->pl.n_so3); r3.assign(xs(p, p->pl.r3), xs(p, p->pl.r3) + 3 * p->pl.n_r3);
+    ab.assign(xs(p, p->pl.ab), xs(p, p->pl.ab) + 3 * p->pl.n_ab); gb.assign(xs(p, p->pl.gb), xs(p, p->pl.gb) + 3 * p->pl.n_gb);
+  }
+  ParamLayout& pl = p->pl;
+  pl.n_so3 = int32_t(n_so3); pl.n_r3 = int32_t(n_r3); pl.n_ab = int32_t(n_ab); pl.n_gb = int32_t(n_gb);
+  int64_t o = 0;
+  pl.so3 = o; o += 4 * n_so3; pl.r3 = o; o += 3 * n_r3; pl.ab = o; o += 3 * n_ab; pl.gb = o; o += 3 * n_gb;
+  pl.tic = o; o += 7; pl.g = o; o += 3; pl.ld = o; o += 1; pl.ai = o; o += 6; pl.gi = o; o += 9; pl.total = o;
+  p->x.assign(o, 0.0);
+  for (int64_t i = 0; i < n_so3; ++i) p->x[pl.so3 + 4 * i + 3] = 1.0;
+  auto keep = [&](const std::vector<double>& v, int64_t off, size_t cnt) { if (v.size() == cnt && cnt) std::copy(v.begin(), v.end(), p->x.begin() + off); };
+  keep(so3, pl.so3, 4 * n_so3); keep(r3, pl.r3, 3 * n_r3); keep(ab, pl.ab, 3 * n_ab); keep(gb, pl.gb, 3 * n_gb);
+  std::memcpy(xs(p, pl.tic), T_i_c, sizeof(T_i_c)); std::memcpy(xs(p, pl.g), g, sizeof(g)); p->x[pl.ld] = ld;
+  std::memcpy(xs(p, pl.ai), ai, sizeof(ai)); std::memcpy(xs(p, pl.gi), gi, sizeof(gi));
+  p->x_host_dirty = true; p->layout_flags = -1;
+}
+
+int sync_params_to_device(oicc_problem* p) {
+  if (!p->x_host_dirty) return OICC_OK;
+  if (!p->d_x.resize(p->x.size()) || !p->d_xc.resize(p->x.size())) { p->err = "hipMalloc params"; return OICC_ERR_HIP; }
+  HIPCK(p, hipMemcpyAsync(p->d_x.p, p->x.data(), p->x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  p->x_host_dirty = false;
+  return OICC_OK;
+}
+int sync_params_to_host(oicc_problem* p) {
+  HIPCK(p, hipMemcpyAsync(p->x.data(), p->d_x.p, p->x.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  return OICC_OK;
+}
+
+bool upload_imu(oicc_problem* p, const ImuHost& h, ImuDev& d) {
+  hipStream_t st = p->stream;
+  return d.s_so3.upload(h.s_so3, st) && d.s_r3.upload(h.s_r3, st) && d.s_b.upload(h.s_b, st) && d.u_so3.upload(h.u_so3, st) &&
+         d.u_r3.upload(h.u_r3, st) && d.u_b.upload(h.u_b, st) && d.mx.upload(h.mx, st) && d.my.upload(h.my, st) &&
+         d.mz.upload(h.mz, st) && d.w.upload(h.w, st);
+}
+
+int sync_measurements(oicc_problem* p) {
+  if (!p->meas_dirty) return OICC_OK;
+  hipStream_t st = p->stream;
+  bool ok = p->d_corner_view.upload(p->corner_view, st) && p->d_corner_pt.upload(p->corner_pt, st) && p->d_cu.upload(p->cu, st) &&
+            p->d_cv.upload(p->cv, st) && p->d_cisx.upload(p->cisx, st) && p->d_cisy.upload(p->cisy, st) &&
+            p->d_view_c0.upload(p->view_c0, st) && p->d_view_s_so3.upload(p->view_s_so3, st) &&
+            p->d_view_s_r3.upload(p->view_s_r3, st) && p->d_view_u_so3.upload(p->view_u_so3, st) &&
+            p->d_view_u_r3.upload(p->view_u_r3, st) && p->d_view_rs.upload(p->view_rs, st) && p->d_pts.upload(p->pts, st) &&
+            upload_imu(p, p->acc, p->d_acc) && upload_imu(p, p->gyr, p->d_gyr);
+  std::vector<uint8_t> all(p->view_rs.size(), 1);
+  ok = ok && p->d_view_rs_all.upload(all, st);
+  if (!ok) { p->err = "device upload of measurements failed"; return OICC_ERR_HIP; }
+  HIPCK(p, hipStreamSynchronize(st));
+  p->meas_dirty = false;
+  return OICC_OK;
+}
+
+// SetFixedParams, impl.h:93-252 -> which parameter blocks are variable.
+Active active_set(const oicc_problem* p, int flags) {
+  Active a;
+  a.tic = (flags & OICC_T_I_C) != 0;                                   // impl.h:95-106
+  const double ld = p->x.empty() ? 0.0 : p->x[p->pl.ld];
+  // impl.h:109-119: the block's state is only touched when line delay != 0,
+  // otherwise it keeps Ceres' default (variable).
+  a.ld = p->has_ld_block && (ld != 0.0 ? (flags & OICC_CAM_LINE_DELAY) != 0 : true);
+  a.g = (flags & OICC_GRAVITY_DIR) != 0;                               // impl.h:122-133
+  const bool both = p->has_acc && p->has_gyr;                          // impl.h:157-168
+  a.intr_a = both ? (flags & OICC_IMU_INTRINSICS) != 0 : true;
+  a.intr_g = both ? (flags & OICC_IMU_INTRINSICS) != 0 : true;
+  a.spline = (flags & OICC_SPLINE) != 0;                               // impl.h:180-204
+  a.ab = (flags & (OICC_ACC_BIAS | OICC_IMU_BIASES)) != 0;             // impl.h:208-229
+  a.gb = (flags & (OICC_GYR_BIAS | OICC_IMU_BIASES)) != 0;             // impl.h:230-251
+  return a;
+}
+
+// Tangent layout: the ordering contract of include/oicc_hip.h.
+int make_layout(oicc_problem* p, int flags) {
+  const Active a = active_set(p, flags);
+  // the layout also depends on whether line delay is currently zero (active_set) -> recompute when it might differ
+  HostLayout& L = p->L;
+  const ParamLayout& pl = p->pl;
+  L.so3.assign(pl.n_so3, -1); L.r3.assign(pl.n_r3, -1); L.ab.assign(pl.n_ab, -1); L.gb.assign(pl.n_gb, -1);
+  for (int i = 0; i < 5; ++i) L.other[i] = -1;
+  int off = 0;
+  if (a.spline) {
+    struct K { int64_t t; int kind; int idx; };
+    std::vector<K> ks; ks.reserve(pl.n_so3 + pl.n_r3);
+    for (int i = 0; i < pl.n_so3; ++i) if (p->so3_in[i]) ks.push_back({int64_t(i) * p->dt_so3, 0, i});
+    for (int i = 0; i < pl.n_r3; ++i) if (p->r3_in[i]) ks.push_back({int64_t(i) * p->dt_r3, 1, i});
+    std::sort(ks.begin(), ks.end(), [](const K& x, const K& y) {
+      if (x.t != y.t) return x.t < y.t;
+      if (x.kind != y.kind) return x.kind < y.kind;
+      return x.idx < y.idx;
+    });
+    for (const K& k : ks) { (k.kind == 0 ? L.so3 : L.r3)[k.idx] = off; off += 3; }
+  }
+  L.Pb = off;
+  if (a.tic && p->has_tic_block) { L.other[0] = off; off += 6; }
+  if (a.g && p->has_acc) { L.other[1] = off; off += 3; }
+  if (a.ld) { L.other[2] = off; off += 1; }
+  if (a.ab) for (int i = 0; i < pl.n_ab; ++i) if (p->ab_in[i]) { L.ab[i] = off; off += 3; }
+  if (a.gb) for (int i = 0; i < pl.n_gb; ++i) if (p->gb_in[i]) { L.gb[i] = off; off += 3; }
+  if (a.intr_a && p->has_acc) { L.other[3] = off; off += 6; }
+  if (a.intr_g && p->has_gyr) { L.other[4] = off; off += 9; }
+  L.P = off; L.a = off - L.Pb;
+  int hb = 0;
+  auto span = [&](int s_so3, int s_r3) {
+    int lo = 1 << 30, hi = -1;
+    for (int i = 0; i < kN; ++i) { const int o = L.so3[s_so3 + i]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o + 2); } }
+    if (s_r3 >= 0) for (int i = 0; i < kN; ++i) { const int o = L.r3[s_r3 + i]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o + 2); } }
+    if (hi >= 0) hb = std::max(hb, hi - lo);
+  };
+  if (a.spline) {
+    for (size_t v = 0; v < p->view_s_so3.size(); ++v) span(p->view_s_so3[v], p->view_s_r3[v]);
+    for (size_t i = 0; i < p->acc.size(); ++i) span(p->acc.s_so3[i], p->acc.s_r3[i]);
+    for (size_t i = 0; i < p->gyr.size(); ++i) span(p->gyr.s_so3[i], -1);
+    for (size_t i = 0; i < p->remote_so3.size(); ++i) span(p->remote_so3[i], p->remote_r3[i]);
+  }
+  L.hb = hb;
+  p->act = a;
+  // device copies
+  hipStream_t st = p->stream;
+  if (!p->d_tl_so3.upload(L.so3, st) || !p->d_tl_r3.upload(L.r3, st) || !p->d_tl_ab.upload(L.ab, st) || !p->d_tl_gb.upload(L.gb, st)) {
+    p->err = "layout upload failed"; return OICC_ERR_HIP; }
+  TangentLayout& tl = p->tl;
+  tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
+  tl.tic = L.other[0]; tl.g = L.other[1]; tl.ld = L.other[2]; tl.ai = L.other[3]; tl.gi = L.other[4];
+  tl.P = L.P; tl.Pb = L.Pb; tl.a = L.a; tl.hb = L.hb; tl.W = L.hb + 1;
+  NormalEq& ne = p->ne;
+  const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
+  ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
+  const int ar = tl.a + 1;
+  if (!p->d_ne.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
+      !p->d_Mc.resize(int64_t(ar) * ar) || !p->d_scale.resize(std::max(tl.P, 1)) || !p->d_diag.resize(std::max(tl.P, 1)) ||
+      !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1)) {
+    p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
+  ne.base = p->d_ne.p;
+  p->layout_flags = flags;
+  return OICC_OK;
+}
+
+int prepare(oicc_problem* p, int flags) {
+  ARG(p, p->pl.n_so3 > 0, "oicc_set_times has not been called");
+  ARG(p, !(flags & OICC_POINTS), "OICC_POINTS (board point refinement) is not supported on this path");
+  HIPCK(p, hipSetDevice(p->device));
+  int rc = sync_measurements(p); if (rc) return rc;
+  rc = sync_params_to_device(p); if (rc) return rc;
+  return make_layout(p, flags);
+}
+
+EvalCtx make_ctx(oicc_problem* p, const double* x) {
+  EvalCtx c{};
+  c.x = x; c.pl = p->pl; c.tl = p->tl; c.ne = p->ne; c.pts = p->d_pts.p;
+  c.inv_so3_dt = p->inv_so3_dt; c.inv_r3_dt = p->inv_r3_dt;
+  std::memcpy(c.intr, p->intr, sizeof(c.intr)); c.cam_model = p->cam_model;
+  c.gs_unit_loss = p->opt["gs_unit_loss"] != 0.0; c.rs_time_in_seconds = p->opt["rs_time_in_seconds"] != 0.0;
+  c.dbg_res = nullptr; c.dbg_jac = nullptr;
+  return c;
+}
+ViewData view_data(oicc_problem* p, bool force_rs = false) {
+  ViewData v{};
+  v.n_views = int64_t(p->view_rs.size()); v.n_corners = int64_t(p->corner_view.size());
+  v.corner_view = p->d_corner_view.p; v.corner_u = p->d_cu.p; v.corner_v = p->d_cv.p; v.corner_isx = p->d_cisx.p;
+  v.corner_isy = p->d_cisy.p; v.corner_pt = p->d_corner_pt.p; v.view_c0 = p->d_view_c0.p; v.view_s_so3 = p->d_view_s_so3.p;
+  v.view_s_r3 = p->d_view_s_r3.p; v.view_u_so3 = p->d_view_u_so3.p; v.view_u_r3 = p->d_view_u_r3.p;
+  v.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
+  return v;
+}
+ImuData imu_data(const ImuHost& h, const ImuDev& d) {
+  ImuData i{};
+  i.n = int64_t(h.size()); i.s_so3 = d.s_so3.p; i.s_r3 = d.s_r3.p; i.s_b = d.s_b.p; i.u_so3 = d.u_so3.p; i.u_r3 = d.u_r3.p;
+  i.u_b = d.u_b.p; i.mx = d.mx.p; i.my = d.my.p; i.mz = d.mz.p; i.w = d.w.p;
+  return i;
+}
+
+// One residual(+Jacobian+normal equation) pass at parameter vector x (device).
+int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1) {
+  hipStream_t st = p->stream;
+  EvalCtx ctx = make_ctx(p, x);
+  ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac;
+  if (jac) HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), st));
+  else HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), st));
+  const Active& a = p->act;
+  if (only_kind < 0 || only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
+  if (only_kind < 0 || only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
+  if (only_kind < 0 || only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
+  HIPCK(p, hipGetLastError());
+  if (p->reduce) {
+    int rc = jac ? p->reduce(p->reduce_user, p->ne.base, p->ne.total, st) : p->reduce(p->reduce_user, p->ne.cost(), 1, st);
+    if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+  }
+  return OICC_OK;
+}
+
+int read_cost(oicc_problem* p, double* cost) {
+  HIPCK(p, hipMemcpyAsync(cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  return OICC_OK;
+}
+
+}  // namespace
+
+// ================================= C API =======================================
+extern "C" {
+
+const char* oicc_version(void) { return "oicc-hip-gfx950-r1"; }
+
+int oicc_create(oicc_problem** out, int device_ordinal) {
+  if (!out) return OICC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return OICC_ERR_NO_DEVICE;   // no CPU fallback
+  if (device_ordinal < 0 || device_ordinal >= n) return OICC_ERR_NO_DEVICE;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return OICC_ERR_NO_DEVICE;
+  oicc_problem* p = new oicc_problem();
+  p->device = device_ordinal;
+  rebuild_param_layout(p, 0, 0, 0, 0);
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return OICC_ERR_HIP; }
+  p->own_stream = true;
+  *out = p;
+  return OICC_OK;
+}
+void oicc_destroy(oicc_problem* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+const char* oicc_last_error(const oicc_problem* p) { return p ? p->err.c_str() : "null problem"; }
+int oicc_set_stream(oicc_problem* p, void* s) {
+  if (p->own_stream && p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+  p->stream = reinterpret_cast<hipStream_t>(s); p->own_stream = false; return OICC_OK;
+}
+int oicc_set_option(oicc_problem* p, const char* name, double value) {
+  auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name); it->second = value; return OICC_OK;
+}
+int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user) { p->reduce = fn; p->reduce_user = user; return OICC_OK; }
+
+int oicc_set_times(oicc_problem* p, int64_t dt_so3, int64_t dt_r3, int64_t start_ns, int64_t end_ns) {
+  ARG(p, dt_so3 > 0 && dt_r3 > 0 && end_ns >= start_ns, "bad spline times");
+  p->dt_so3 = dt_so3; p->dt_r3 = dt_r3; p->start_ns = start_ns; p->end_ns = end_ns;
+  const int64_t duration = end_ns - start_ns;
+  const int64_t ns = duration / dt_so3 + kN, nr = duration / dt_r3 + kN;   // impl.h:46-48
+  ARG(p, ns < (1 << 30) && nr < (1 << 30), "too many knots");
+  p->inv_so3_dt = 1e9 / double(dt_so3); p->inv_r3_dt = 1e9 / double(dt_r3);   // impl.h:49-50
+  rebuild_param_layout(p, ns, nr, p->pl.n_ab, p->pl.n_gb);
+  for (int64_t i = 0; i < ns; ++i) { double* q = xs(p, p->pl.so3 + 4 * i); q[0] = q[1] = q[2] = 0; q[3] = 1; }
+  std::fill(xs(p, p->pl.r3), xs(p, p->pl.r3) + 3 * nr, 0.0);
+  p->so3_in.assign(ns, 0); p->r3_in.assign(nr, 0);
+  return OICC_OK;
+}
+int64_t oicc_get_num_so3_knots(const oicc_problem* p) { return p->pl.n_so3; }
+int64_t oicc_get_num_r3_knots(const oicc_problem* p) { return p->pl.n_r3; }
+int64_t oicc_get_min_time_ns(const oicc_problem* p) { return p->start_ns; }
+int64_t oicc_get_max_time_ns(const oicc_problem* p) { return p->start_ns + (int64_t(p->pl.n_so3) - kN + 1) * p->dt_so3 - 1; }
+int oicc_set_so3_knots(oicc_problem* p, const double* q, int64_t n) {
+  ARG(p, n == p->pl.n_so3, "so3 knot count"); std::copy(q, q + 4 * n, xs(p, p->pl.so3)); p->x_host_dirty = true; return OICC_OK; }
+int oicc_set_r3_knots(oicc_problem* p, const double* v, int64_t n) {
+  ARG(p, n == p->pl.n_r3, "r3 knot count"); std::copy(v, v + 3 * n, xs(p, p->pl.r3)); p->x_host_dirty = true; return OICC_OK; }
+int oicc_get_so3_knots(const oicc_problem* p, double* q, int64_t n) { std::copy(p->x.begin() + p->pl.so3, p->x.begin() + p->pl.so3 + 4 * n, q); return OICC_OK; }
+int oicc_get_r3_knots(const oicc_problem* p, double* v, int64_t n) { std::copy(p->x.begin() + p->pl.r3, p->x.begin() + p->pl.r3 + 3 * n, v); return OICC_OK; }
+
+int oicc_init_bias_splines(oicc_problem* p, const double ab[3], const double gb[3], int64_t dt_a, int64_t dt_g, double max_a, double max_g) {
+  ARG(p, p->pl.n_so3 > 0, "set_times first"); ARG(p, dt_a > 0 && dt_g > 0, "bad bias dt");
+  p->max_ab = max_a; p->max_gb = max_g; p->dt_ab = dt_a; p->dt_gb = dt_g;
+  p->inv_ab_dt = 1.0 / double(dt_a); p->inv_gb_dt = 1.0 / double(dt_g);   // quirk Q3, impl.h:67-68
+  const int64_t duration = p->end_ns - p->start_ns;
+  const int64_t na = duration / dt_a + kNb, ng = duration / dt_g + kNb;    // impl.h:71-72
+  rebuild_param_layout(p, p->pl.n_so3, p->pl.n_r3, na, ng);
+  for (int64_t i = 0; i < na; ++i) for (int c = 0; c < 3; ++c) p->x[p->pl.ab + 3 * i + c] = ab[c];
+  for (int64_t i = 0; i < ng; ++i) for (int c = 0; c < 3; ++c) p->x[p->pl.gb + 3 * i + c] = gb[c];
+  p->ab_in.assign(na, 0); p->gb_in.assign(ng, 0);
+  return OICC_OK;
+}
+int oicc_set_T_i_c(oicc_problem* p, const double v[7]) { std::memcpy(xs(p, p->pl.tic), v, 7 * sizeof(double)); p->x_host_dirty = true; return OICC_OK; }
+int oicc_set_gravity(oicc_problem* p, const double g[3]) { std::memcpy(xs(p, p->pl.g), g, 3 * sizeof(double)); p->x_host_dirty = true; return OICC_OK; }
+int oicc_set_camera_line_delay(oicc_problem* p, double s) { p->x[p->pl.ld] = s; p->x_host_dirty = true; p->layout_flags = -1; return OICC_OK; }
+int oicc_set_imu_intrinsics(oicc_problem* p, const double a[6], const double g[9]) {
+  std::memcpy(xs(p, p->pl.ai), a, 6 * sizeof(double)); std::memcpy(xs(p, p->pl.gi), g, 9 * sizeof(double)); p->x_host_dirty = true; return OICC_OK; }
+int oicc_set_camera(oicc_problem* p, int32_t model, const double* intr, int32_t n) {
+  ARG(p, n >= 0 && n <= 10, "num_intrinsics");
+  ARG(p, model == OICC_CAM_PINHOLE || model == OICC_CAM_PINHOLE_RADIAL_TANGENTIAL || model == OICC_CAM_FISHEYE ||
+             model == OICC_CAM_DIVISION_UNDISTORTION || model == OICC_CAM_DOUBLE_SPHERE || model == OICC_CAM_EXTENDED_UNIFIED, "camera model");
+  p->cam_model = model; p->n_intr = n; std::fill(p->intr, p->intr + 10, 0.0); std::copy(intr, intr + n, p->intr); return OICC_OK; }
+int oicc_set_scene_points(oicc_problem* p, const double* xyzw, int64_t n) { p->pts.assign(xyzw, xyzw + 4 * n); p->meas_dirty = true; return OICC_OK; }
+
+static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, const int64_t* coff, const double* uv, const double* cov,
+                     const int32_t* pidx, uint8_t* accepted) {
+  ARG(p, p->pl.n_so3 > 0, "set_times first");
+  for (int64_t v = 0; v < nv; ++v) {
+    double u_r3, u_so3; int64_t s_r3, s_so3;
+    const bool ok = calc_times(t_ns[v], p->start_ns, p->dt_r3, p->pl.n_r3, kN, &u_r3, &s_r3) &&      // impl.h:546-555
+                    calc_times(t_ns[v], p->start_ns, p->dt_so3, p->pl.n_so3, kN, &u_so3, &s_so3);
+    if (accepted) accepted[v] = ok;
+    if (!ok) continue;
+    const int32_t vid = int32_t(p->view_rs.size());
+    for (int64_t c = coff[v]; c < coff[v + 1]; ++c) {
+      ARG(p, pidx[c] >= 0 && size_t(pidx[c]) < p->pts.size() / 4, "point index out of range (set_scene_points first)");
+      p->corner_view.push_back(vid); p->corner_pt.push_back(pidx[c]);
+      p->cu.push_back(uv[2 * c]); p->cv.push_back(uv[2 * c + 1]);
+      p->cisx.push_back(1.0 / std::sqrt(cov ? cov[2 * c] : 1.0)); p->cisy.push_back(1.0 / std::sqrt(cov ? cov[2 * c + 1] : 1.0));
+    }
+    p->view_c0.push_back(int64_t(p->corner_view.size()));
+    p->view_s_so3.push_back(int32_t(s_so3)); p->view_s_r3.push_back(int32_t(s_r3));
+    p->view_u_so3.push_back(u_so3); p->view_u_r3.push_back(u_r3); p->view_rs.push_back(rs ? 1 : 0);
+    for (int i = 0; i < kN; ++i) { p->so3_in[s_so3 + i] = 1; p->r3_in[s_r3 + i] = 1; }
+    p->has_tic_block = true; if (rs) p->has_ld_block = true;
+  }
+  p->meas_dirty = true; p->layout_flags = -1;
+  return OICC_OK;
+}
+int oicc_add_rs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* t, const int64_t* co, const double* uv, const double* cov,
+                                    const int32_t* pi, uint8_t* acc) { return add_views(p, true, nv, t, co, uv, cov, pi, acc); }
+int oicc_add_gs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* t, const int64_t* co, const double* uv, const double* cov,
+                                    const int32_t* pi, uint8_t* acc) { return add_views(p, false, nv, t, co, uv, cov, pi, acc); }
+
+int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
+  ARG(p, p->pl.n_ab > 0, "init_bias_splines first");
+  for (int64_t i = 0; i < n; ++i) {
+    double u_r3, u_so3, u_b; int64_t s_r3, s_so3, s_b;
+    const bool ok = calc_times(t_ns[i], p->start_ns, p->dt_r3, p->pl.n_r3, kN, &u_r3, &s_r3) &&      // impl.h:348-367
+                    calc_times(t_ns[i], p->start_ns, p->dt_so3, p->pl.n_so3, kN, &u_so3, &s_so3) &&
+                    calc_times(t_ns[i], p->start_ns, p->dt_ab, p->pl.n_ab, kNb, &u_b, &s_b);
+    if (accepted) accepted[i] = ok;
+    if (!ok) continue;
+    ImuHost& h = p->acc;
+    h.s_so3.push_back(int32_t(s_so3)); h.s_r3.push_back(int32_t(s_r3)); h.s_b.push_back(int32_t(s_b));
+    h.u_so3.push_back(u_so3); h.u_r3.push_back(u_r3); h.u_b.push_back(u_b);
+    h.mx.push_back(m[3 * i]); h.my.push_back(m[3 * i + 1]); h.mz.push_back(m[3 * i + 2]); h.w.push_back(w);
+    for (int k = 0; k < kN; ++k) { p->so3_in[s_so3 + k] = 1; p->r3_in[s_r3 + k] = 1; }
+    for (int k = 0; k < kNb; ++k) p->ab_in[s_b + k] = 1;
+    p->has_acc = true;
+  }
+  p->meas_dirty = true; p->layout_flags = -1;
+  return OICC_OK;
+}
+int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
+  ARG(p, p->pl.n_gb > 0, "init_bias_splines first");
+  for (int64_t i = 0; i < n; ++i) {
+    double u_so3, u_b; int64_t s_so3, s_b;
+    const bool ok = calc_times(t_ns[i], p->start_ns, p->dt_so3, p->pl.n_so3, kN, &u_so3, &s_so3) &&   // impl.h:429-444
+                    calc_times(t_ns[i], p->start_ns, p->dt_gb, p->pl.n_gb, kNb, &u_b, &s_b);
+    if (accepted) accepted[i] = ok;
+    if (!ok) continue;
+    ImuHost& h = p->gyr;
+    h.s_so3.push_back(int32_t(s_so3)); h.s_r3.push_back(0); h.s_b.push_back(int32_t(s_b));
+    h.u_so3.push_back(u_so3); h.u_r3.push_back(0.0); h.u_b.push_back(u_b);
+    h.mx.push_back(m[3 * i]); h.my.push_back(m[3 * i + 1]); h.mz.push_back(m[3 * i + 2]); h.w.push_back(w);
+    for (int k = 0; k < kN; ++k) p->so3_in[s_so3 + k] = 1;
+    for (int k = 0; k < kNb; ++k) p->gb_in[s_b + k] = 1;
+    p->has_gyr = true;
+  }
+  p->meas_dirty = true; p->layout_flags = -1;
+  return OICC_OK;
+}
+
+// Multi-GPU: measurements held by other ranks only shape the layout (which knots
+// are in the problem, bandwidth, which parameter blocks exist).
+int oicc_declare_remote_measurements(oicc_problem* p, int32_t kind, int64_t n, const int64_t* t_ns) {
+  ARG(p, p->pl.n_so3 > 0, "set_times first");
+  for (int64_t i = 0; i < n; ++i) {
+    double u; int64_t s_so3 = 0, s_r3 = -1, s_b = 0;
+    bool ok = calc_times(t_ns[i], p->start_ns, p->dt_so3, p->pl.n_so3, kN, &u, &s_so3);
+    if (kind != 2) ok = ok && calc_times(t_ns[i], p->start_ns, p->dt_r3, p->pl.n_r3, kN, &u, &s_r3);
+    if (kind == 1) ok = ok && calc_times(t_ns[i], p->start_ns, p->dt_ab, p->pl.n_ab, kNb, &u, &s_b);
+    if (kind == 2) ok = ok && calc_times(t_ns[i], p->start_ns, p->dt_gb, p->pl.n_gb, kNb, &u, &s_b);
+    if (!ok) continue;
+    for (int k = 0; k < kN; ++k) { p->so3_in[s_so3 + k] = 1; if (kind != 2) p->r3_in[s_r3 + k] = 1; }
+    if (kind == 1) for (int k = 0; k < kNb; ++k) p->ab_in[s_b + k] = 1;
+    if (kind == 2) for (int k = 0; k < kNb; ++k) p->gb_in[s_b + k] = 1;
+    if (kind == 0) { p->has_tic_block = true; p->has_ld_block = true; }
+    if (kind == 3) { p->has_tic_block = true; }
+    if (kind == 1) p->has_acc = true;
+    if (kind == 2) p->has_gyr = true;
+    p->remote_so3.push_back(int32_t(s_so3)); p->remote_r3.push_back(kind == 2 ? -1 : int32_t(s_r3));
+  }
+  p->layout_flags = -1;
+  return OICC_OK;
+}
+
+int oicc_get_tangent_layout(oicc_problem* p, int32_t flags, int32_t* nt, int32_t* so3, int32_t* r3, int32_t* ab, int32_t* gb, int32_t other[5]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  const HostLayout& L = p->L;
+  if (nt) *nt = L.P;
+  if (so3) std::copy(L.so3.begin(), L.so3.end(), so3);
+  if (r3) std::copy(L.r3.begin(), L.r3.end(), r3);
+  if (ab) std::copy(L.ab.begin(), L.ab.end(), ab);
+  if (gb) std::copy(L.gb.begin(), L.gb.end(), gb);
+  if (other) std::copy(L.other, L.other + 5, other);
+  return OICC_OK;
+}
+
+int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H, double* g, int32_t Pcap) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  std::vector<double> h(p->ne.total);
+  HIPCK(p, hipMemcpyAsync(h.data(), p->ne.base, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  const TangentLayout& tl = p->tl;
+  if (cost) *cost = h[p->ne.off_cost];
+  if (g) { ARG(p, Pcap >= tl.P, "P_capacity"); std::copy(h.begin() + p->ne.off_g, h.begin() + p->ne.off_g + tl.P, g); }
+  if (H) {
+    ARG(p, Pcap >= tl.P, "P_capacity");
+    const int P = tl.P, Pb = tl.Pb, a = tl.a, W = tl.W;
+    std::fill(H, H + size_t(P) * P, 0.0);
+    for (int i = 0; i < Pb; ++i) for (int k = 0; k < W && i + k < Pb; ++k) { const double v = h[size_t(i) * W + k]; H[size_t(i) * P + i + k] = v; H[size_t(i + k) * P + i] = v; }
+    for (int c = 0; c < a; ++c) for (int i = 0; i < Pb; ++i) { const double v = h[p->ne.off_E + size_t(c) * Pb + i]; H[size_t(i) * P + Pb + c] = v; H[size_t(Pb + c) * P + i] = v; }
+    for (int r = 0; r < a; ++r) for (int c = 0; c < a; ++c) H[size_t(Pb + r) * P + Pb + c] = h[p->ne.off_C + size_t(r) * a + c];
+  }
+  return OICC_OK;
+}
+int oicc_evaluate_cost(oicc_problem* p, int32_t flags, double* cost) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  rc = eval_pass(p, p->d_x.p, false); if (rc) return rc;
+  return read_cost(p, cost);
+}
+int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind, double* residuals, double* jacobians) {
+  ARG(p, kind >= 0 && kind <= 2, "kind");
+  int rc = prepare(p, flags); if (rc) return rc;
+  const size_t rows = kind == 0 ? 2 * p->corner_view.size() : 3 * (kind == 1 ? p->acc.size() : p->gyr.size());
+  const size_t ncols = kind == 0 ? 43 : (kind == 1 ? 54 : 36);
+  if (rows == 0) return OICC_OK;
+  if (!p->d_dbg_res.resize(rows) || (jacobians && !p->d_dbg_jac.resize(rows * ncols))) { p->err = "hipMalloc dbg"; return OICC_ERR_HIP; }
+  auto saved = p->reduce; p->reduce = nullptr;   // block dumps are local
+  rc = eval_pass(p, p->d_x.p, jacobians != nullptr, p->d_dbg_res.p, jacobians ? p->d_dbg_jac.p : nullptr, kind);
+  p->reduce = saved;
+  if (rc) return rc;
+  HIPCK(p, hipMemcpyAsync(residuals, p->d_dbg_res.p, rows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  if (jacobians) HIPCK(p, hipMemcpyAsync(jacobians, p->d_dbg_jac.p, rows * ncols * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  return OICC_OK;
+}
+
+// Optimize, impl.h:255-276 -> ceres::Solve [EXT Ceres 2.1.0 TrustRegionMinimizer +
+// LevenbergMarquardtStrategy semantics; options impl.h:257-266].  The host only
+// sequences kernels and reads one small struct per iteration.
+int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summary* sum) {
+  const double t_start = now_s();
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  const TangentLayout& tl = p->tl;
+  const int P = tl.P;
+  oicc_summary S; std::memset(&S, 0, sizeof(S));
+  S.num_parameters_tangent = P; S.band_dim = tl.Pb; S.arrow_dim = tl.a; S.half_bandwidth = tl.hb;
+  S.num_residual_blocks = int64_t(p->view_rs.size() + p->acc.size() + p->gyr.size());
+  S.num_residuals = int64_t(2 * p->corner_view.size() + 3 * p->acc.size() + 3 * p->gyr.size());
+  p->trace.clear();
+  const double ftol = p->opt["function_tolerance"], ptol = p->opt["parameter_tolerance"], gtol = p->opt["gradient_tolerance"];
+  double radius = p->opt["initial_trust_region_radius"]; const double max_radius = p->opt["max_trust_region_radius"];
+  const double min_radius = p->opt["min_trust_region_radius"], min_rel_dec = p->opt["min_relative_decrease"];
+  const double min_diag = p->opt["min_lm_diagonal"], max_diag = p->opt["max_lm_diagonal"];
+  const int max_invalid = int(p->opt["max_num_consecutive_invalid_steps"]);
+  const bool verbose = p->opt["verbose"] != 0;
+  double decrease_factor = 2.0; bool reuse_diagonal = false;
+  double cost = 0.0, gmax = 0.0;
+  auto finish = [&](int term, const char* msg) {
+    S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
+    std::snprintf(S.message, sizeof(S.message), "%s", msg);
+    int r2 = sync_params_to_host(p);
+    S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
+  auto timed_sync = [&](double& bucket, double t0) { (void)hipStreamSynchronize(st); bucket += now_s() - t0; };
+
+  double t0 = now_s();
+  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  rc = read_cost(p, &cost); if (rc) return rc;
+  S.seconds_jacobian += now_s() - t0;
+  S.initial_cost = cost;
+  if (P == 0) return finish(OICC_CONVERGENCE, "no variable parameters");
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+  LmState hs; std::memset(&hs, 0, sizeof(hs));
+  auto read_state = [&]() -> int {
+    HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipStreamSynchronize(st)); return OICC_OK; };
+  auto write_state = [&]() -> int { HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st)); return OICC_OK; };
+  hs.radius = radius; rc = write_state(); if (rc) return rc;
+  launch_lm_gradmax(p->ne, P, p->d_state.p, st);
+  rc = read_state(); if (rc) return rc;
+  gmax = hs.gradient_max_norm;
+  { oicc_iteration it{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius}; p->trace.push_back(it); }
+  if (verbose) std::printf("[oicc] iter 0 cost %.12e gmax %.3e radius %.3e P=%d (band %d hb %d arrow %d)\n", cost, gmax, radius, P, tl.Pb, tl.hb, tl.a);
+  if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
+  int iter = 0, invalid = 0;
+  while (true) {
+    if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.");
+    if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
+    ++iter; S.num_iterations = iter;
+    // --- trust-region step: damped band+arrow Cholesky solve on the device
+    t0 = now_s();
+    std::memset(&hs, 0, sizeof(hs)); hs.radius = radius; hs.gradient_max_norm = gmax;
+    rc = write_state(); if (rc) return rc;
+    launch_lm_build(p->ne, tl, sb, reuse_diagonal ? 1 : 0, min_diag, max_diag, st);
+    if (launch_band_arrow_cholesky(tl, sb, st) != 0) {
+      p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
+      return OICC_ERR_UNSUPPORTED; }
+    launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
+    HIPCK(p, hipGetLastError());
+    timed_sync(S.seconds_linear_solver, t0);
+    // --- candidate cost
+    t0 = now_s();
+    rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+    double cand_cost = 0.0;
+    rc = read_cost(p, &cand_cost); if (rc) return rc;
+    S.seconds_residual += now_s() - t0;
+    rc = read_state(); if (rc) return rc;
+    const double model_cost_change = hs.model_cost_change;
+    bool ok = hs.chol_failed == 0 && std::isfinite(model_cost_change) && std::isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
+    const double x_norm = std::sqrt(hs.x_norm_sq);   // ambient norm of the current x over active blocks
+    if (!ok) {   // invalid step (LINEAR_SOLVER_FAILURE or non-positive model decrease)
+      if (++invalid >= max_invalid) return finish(OICC_FAILURE, "Number of consecutive invalid steps more than max.");
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; ++S.num_unsuccessful_steps;
+      oicc_iteration it{iter, 0, cost, 0.0, gmax, 0.0, 0.0, radius}; p->trace.push_back(it);
+      continue;
+    }
+    invalid = 0;
+    const double step_norm = std::sqrt(hs.step_norm_sq);
+    const double cost_change = cost - cand_cost;
+    const double rel_dec = cost_change / model_cost_change;
+    if (verbose) std::printf("[oicc] iter %d cand %.12e change %.3e model %.3e rho %.3f |step| %.3e radius %.3e\n", iter, cand_cost, cost_change, model_cost_change, rel_dec, step_norm, radius);
+    if (step_norm <= ptol * (x_norm + ptol)) {
+      oicc_iteration it{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
+      return finish(OICC_CONVERGENCE, "Parameter tolerance reached.");
+    }
+    if (std::fabs(cost_change) <= ftol * cost) {
+      oicc_iteration it{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
+      return finish(OICC_CONVERGENCE, "Function tolerance reached.");
+    }
+    if (rel_dec > min_rel_dec) {
+      std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current
+      cost = cand_cost;
+      t0 = now_s();
+      rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+      launch_lm_gradmax(p->ne, P, p->d_state.p, st);
+      rc = read_state(); if (rc) return rc;
+      S.seconds_jacobian += now_s() - t0;
+      gmax = hs.gradient_max_norm;
+      ++S.num_successful_steps;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
+      radius = std::min(max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
+      oicc_iteration it{iter, 1, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
+      if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
+    } else {
+      ++S.num_unsuccessful_steps;
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      oicc_iteration it{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
+    }
+  }
+}
+int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out, int32_t cap) {
+  const int n = std::min<int>(cap, int(p->trace.size())); std::copy(p->trace.begin(), p->trace.begin() + n, out); return n; }
+
+int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_pass, double kernel_ms[3]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true);   // warm-up
+  if (!rc) { HIPCK(p, hipEventRecord(e0, st)); for (int i = 0; i < repeats && !rc; ++i) rc = eval_pass(p, p->d_x.p, true); HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1)); }
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_pass) *ms_per_pass = double(ms) / std::max(repeats, 1);
+  if (kernel_ms && !rc) {
+    for (int k = 0; k < 3 && !rc; ++k) {
+      HIPCK(p, hipEventRecord(e0, st));
+      for (int i = 0; i < repeats && !rc; ++i) {
+        EvalCtx ctx = make_ctx(p, p->d_x.p);
+        if (k == 0) launch_view_blocks(ctx, view_data(p), p->act.spline, true, st);
+        if (k == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), p->act.spline, p->act.ab, true, st);
+        if (k == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), p->act.spline, p->act.gb, true, st);
+      }
+      HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
+      (void)hipEventElapsedTime(&ms, e0, e1); kernel_ms[k] = double(ms) / std::max(repeats, 1);
+    }
+    rc = eval_pass(p, p->d_x.p, true);   // leave a consistent system behind
+  }
+  p->reduce = saved;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_solve) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
+  const TangentLayout& tl = p->tl;
+  if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+  LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
+  HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
+  if (launch_band_arrow_cholesky(tl, sb, st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+  HIPCK(p, hipEventRecord(e0, st));
+  for (int i = 0; i < repeats; ++i) {
+    launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
+    launch_band_arrow_cholesky(tl, sb, st);
+  }
+  HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_solve) *ms_per_solve = double(ms) / std::max(repeats, 1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return OICC_OK;
+}
+
+int oicc_get_T_i_c(const oicc_problem* p, double v[7]) { std::memcpy(v, p->x.data() + p->pl.tic, 7 * sizeof(double)); return OICC_OK; }
+int oicc_get_gravity(const oicc_problem* p, double g[3]) { std::memcpy(g, p->x.data() + p->pl.g, 3 * sizeof(double)); return OICC_OK; }
+int oicc_get_rs_line_delay(const oicc_problem* p, double* s) { *s = p->x[p->pl.ld]; return OICC_OK; }
+int oicc_get_imu_intrinsics(const oicc_problem* p, double a[6], double g[9]) {
+  std::memcpy(a, p->x.data() + p->pl.ai, 6 * sizeof(double)); std::memcpy(g, p->x.data() + p->pl.gi, 9 * sizeof(double)); return OICC_OK; }
+int64_t oicc_get_num_accl_bias_knots(const oicc_problem* p) { return p->pl.n_ab; }
+int64_t oicc_get_num_gyro_bias_knots(const oicc_problem* p) { return p->pl.n_gb; }
+int oicc_get_bias_knots(const oicc_problem* p, double* a, int64_t na, double* g, int64_t ng) {
+  if (a) std::copy(p->x.begin() + p->pl.ab, p->x.begin() + p->pl.ab + 3 * na, a);
+  if (g) std::copy(p->x.begin() + p->pl.gb, p->x.begin() + p->pl.gb + 3 * ng, g);
+  return OICC_OK; }
+
+// GetMeanReprojectionError, impl.h:994-1072: RS functor residuals of every view.
+int oicc_get_mean_reprojection_error(oicc_problem* p, double* mean_px, int64_t* num) {
+  int rc = prepare(p, p->layout_flags >= 0 ? p->layout_flags : 0); if (rc) return rc;
+  const size_t nc = p->corner_view.size();
+  for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) if (p->view_c0[v + 1] == p->view_c0[v]) { *mean_px = 0.0; if (num) *num = 0; return OICC_OK; }  // quirk Q6
+  if (nc == 0) { *mean_px = std::nan(""); if (num) *num = 0; return OICC_OK; }
+  if (!p->d_dbg_res.resize(2 * nc)) { p->err = "hipMalloc"; return OICC_ERR_HIP; }
+  EvalCtx ctx = make_ctx(p, p->d_x.p);
+  ctx.dbg_res = p->d_dbg_res.p;
+  HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), p->stream));
+  launch_view_blocks(ctx, view_data(p, /*force_rs=*/true), p->act.spline, false, p->stream);
+  std::vector<double> r(2 * nc);
+  HIPCK(p, hipMemcpyAsync(r.data(), p->d_dbg_res.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  double sum = 0; int64_t n = 0;
+  for (size_t i = 0; i < nc; ++i) if (r[2 * i] != 0.0 && r[2 * i + 1] != 0.0) { sum += std::sqrt(r[2 * i] * r[2 * i] + r[2 * i + 1] * r[2 * i + 1]); ++n; }   // impl.h:1058-1063
+  *mean_px = sum / double(n); if (num) *num = n;
+  return OICC_OK;
+}
+
+// GetPose / GetAngularVelocity / GetAcceleration / GetGyroBias / GetAcclBias, batched.
+int oicc_get_trajectory(oicc_problem* p, int64_t n, const int64_t* t_ns, double* pose7, double* gyro3, double* accel3, double* gb3,
+                        double* ab3, uint8_t* valid) {
+  int rc = prepare(p, p->layout_flags >= 0 ? p->layout_flags : 0); if (rc) return rc;
+  if (n == 0) return OICC_OK;
+  std::vector<int32_t> si(4 * n, -1); std::vector<double> ui(4 * n, 0.0);
+  for (int64_t i = 0; i < n; ++i) {
+    double u; int64_t s;
+    const bool ok_r = calc_times(t_ns[i], p->start_ns, p->dt_r3, p->pl.n_r3, kN, &u, &s); if (ok_r) { si[n + i] = int32_t(s); ui[n + i] = u; }
+    const bool ok_s = calc_times(t_ns[i], p->start_ns, p->dt_so3, p->pl.n_so3, kN, &u, &s); if (ok_s) { si[i] = int32_t(s); ui[i] = u; }
+    if (!(ok_r && ok_s)) { si[i] = -1; si[n + i] = -1; }
+    if (valid) valid[i] = ok_r && ok_s;
+    if (p->pl.n_gb > 0 && calc_times(t_ns[i], p->start_ns, p->dt_gb, p->pl.n_gb, kNb, &u, &s)) { si[2 * n + i] = int32_t(s); ui[2 * n + i] = u; }
+    if (p->pl.n_ab > 0 && calc_times(t_ns[i], p->start_ns, p->dt_ab, p->pl.n_ab, kNb, &u, &s)) { si[3 * n + i] = int32_t(s); ui[3 * n + i] = u; }
+  }
+  if (!p->d_traj_i.upload(si, p->stream) || !p->d_traj.resize(size_t(4 * n) + size_t(19) * n)) { p->err = "hipMalloc traj"; return OICC_ERR_HIP; }
+  double* du = p->d_traj.p; double* out = du + 4 * n;
+  HIPCK(p, hipMemcpyAsync(du, ui.data(), ui.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  HIPCK(p, hipMemsetAsync(out, 0, size_t(19) * n * sizeof(double), p->stream));
+  EvalCtx ctx = make_ctx(p, p->d_x.p);
+  const int32_t* s = p->d_traj_i.p;
+  launch_trajectory(ctx, n, s, s + n, du, du + n, s + 2 * n, du + 2 * n, s + 3 * n, du + 3 * n, p->inv_gb_dt, p->inv_ab_dt,
+                    out, out + 7 * n, out + 10 * n, out + 13 * n, out + 16 * n, p->stream);
+  std::vector<double> h(size_t(19) * n);
+  HIPCK(p, hipMemcpyAsync(h.data(), out, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  for (int64_t i = 0; i < n; ++i) {
+    const bool ok = si[i] >= 0;
+    if (pose7 && ok) std::copy(h.begin() + 7 * i, h.begin() + 7 * i + 7, pose7 + 7 * i);
+    if (gyro3 && ok) std::copy(h.begin() + 7 * n + 3 * i, h.begin() + 7 * n + 3 * i + 3, gyro3 + 3 * i);
+    if (accel3 && ok) std::copy(h.begin() + 10 * n + 3 * i, h.begin() + 10 * n + 3 * i + 3, accel3 + 3 * i);
+    if (gb3) std::copy(h.begin() + 13 * n + 3 * i, h.begin() + 13 * n + 3 * i + 3, gb3 + 3 * i);
+    if (ab3) std::copy(h.begin() + 16 * n + 3 * i, h.begin() + 16 * n + 3 * i + 3, ab3 + 3 * i);
+  }
+  return OICC_OK;
+}
+
+}  // extern "C"
