@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on the MI355X hot path.
+
+metric : residual+Jacobian blocks/sec (whole job), with ms_per_step = wall-clock
+         per LM iteration of the GoPro9 continuous-time calibration (config C2).
+step   : the device work and host synchronisation of ONE successful Levenberg-
+         Marquardt iteration over all residual blocks (one block per view, per
+         accelerometer sample, per gyroscope sample): residual + analytic Jacobian
+         + J^T J / J^T r assembly, [RCCL all-reduce when N > 1], damped band+arrow
+         Cholesky solve, retraction, candidate cost pass, state read-back
+         (liboicc_hip: oicc_run_lm_iterations == loop body of oicc_optimize).
+N = 1  : BASELINE config[1] = C2 (GoPro9 Division-Undistortion 960x540, 200 views x
+         40 corners, 4000 IMU samples, dt_r3/so3 = 0.1/0.05 s), synthetic, seeded.
+N > 1  : weak scaling: N x C2 laid end to end in time (N*20 s trajectory); rank r
+         holds the r-th 20 s window of views/IMU samples, every rank holds all
+         knots; J^T J/J^T r/cost are all-reduced (fp64 sum) over RCCL each pass.
+
+Launch:  python bench.py                      (N=1)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def algorithmic_model(cal, ds, summary_dims):
+    """algorithmic bytes / FLOPs per Jacobian+assembly pass."""
+    nv = int(cal.views_accepted.sum()); nc = cal.num_corners
+    na = int(cal.accl_accepted.sum()); ng = int(cal.gyro_accepted.sum())
+    tr = cal.trajectory_
+    n_so3, n_r3 = tr.GetNumSO3Knots(), tr.GetNumR3Knots()
+    P, Pb, a, hb = summary_dims
+    params = 32 * n_so3 + 24 * n_r3 + 32 * len(ds.points) + 250
+    out = 8 * (Pb * (hb + 1) + Pb * a + a * a + P)
+    bytes_ = dict(view=24 * nc + 12 * nv + params + out, accel=28 * na + params + out, gyro=28 * ng + 32 * n_so3 + out,
+                  solve=2 * 8 * (Pb * (hb + 1) + (a + 1) * Pb + (a + 1) ** 2) + 8 * P)
+    flops = dict(view=6.9e3 * nc, accel=7.6e3 * na, gyro=3.7e3 * ng, solve=float(Pb) * hb * hb + 2.0 * Pb * hb * (a + 1))
+    return bytes_, flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C5-size single-GPU Jacobian-pass measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from openimucameracalibrator_amd import synthetic, estimator as E
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
+    # ---- workload: N x C2 (N = 1: exactly C2) ---------------------------------
+    base = dict(synthetic.CONFIGS["C2"])
+    ds = synthetic.make_dataset(name="C2" if world == 1 else "C2x%d" % world, **dict(
+        base, num_views=base["num_views"] * world, duration=base["duration"] * world))
+    cal = E.ImuCameraCalibrator(device=local_rank)
+    tr = cal.trajectory_
+    if world > 1:   # share torch's stream so the RCCL all-reduce is ordered with the kernels
+        tr.SetStream(torch.cuda.current_stream().cuda_stream)
+    cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
+
+    if world > 1:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        staging = {}
+
+        def allreduce(ptr, count, strm):
+            # fp64 SUM over ranks of the library's packed {J^T J band, arrow, J^T r, cost}
+            # buffer: staged through a torch tensor so RCCL runs via torch.distributed.
+            t = staging.get(count)
+            if t is None:
+                t = staging[count] = torch.empty(count, dtype=torch.float64, device="cuda")
+            nbytes = count * 8
+            assert hip.hipMemcpyAsync(t.data_ptr(), ptr, nbytes, 3, strm) == 0
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            assert hip.hipMemcpyAsync(ptr, t.data_ptr(), nbytes, 3, strm) == 0
+        tr.SetAllReduce(allreduce)
+
+    n_blocks_local = cal.num_blocks
+    blocks = torch.tensor([n_blocks_local, cal.num_corners], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(blocks)
+    n_blocks, n_corners = int(blocks[0]), int(blocks[1])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        tr.RunLmIterations(flags, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    tr.RunLmIterations(flags, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+    ms_per_step = 1e3 * dt / args.steps
+    value = n_blocks * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel HIP-event timings (library stream) and roofline ----------
+        if world > 1:
+            tr.SetAllReduce(None)
+        pass_ms, kern_ms = tr.TimeJacobianPass(flags, repeats=20)
+        solve_ms = tr.TimeLinearSolve(flags, repeats=20)
+        lay = tr.GetTangentLayout(flags)
+        P = lay["P"]; Pb = 3 * int((lay["so3"] >= 0).sum() + (lay["r3"] >= 0).sum()); a = P - Pb
+        # full calibration wall clock on this rank's data (N = 1: the whole C2 problem)
+        summ = None
+        if world == 1:
+            t1 = time.perf_counter()
+            summ = tr.Optimize(50, flags)
+            reproj = tr.GetMeanReprojectionError()
+            s2 = tr.Optimize(10, E.CAM_LINE_DELAY)
+            full_calib_s = time.perf_counter() - t1
+            hb = summ["half_bandwidth"]
+        else:
+            hb = 0
+        b_alg, f_alg = algorithmic_model(cal, ds, (P, Pb, a, hb))
+        times = dict(view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
+        dom = max(times, key=lambda k: times[k])
+        names = dict(view="view_blocks_kernel<true>", accel="imu_blocks_kernel<accel>", gyro="imu_blocks_kernel<gyro>",
+                     solve="lm_build_kernel+band_arrow_cholesky_kernel")
+        kernels = {k: dict(kernel=names[k], ms=times[k], alg_bytes=b_alg[k], alg_flops=f_alg[k],
+                           hbm_GBps=b_alg[k] / (times[k] * 1e-3) / 1e9 if times[k] > 0 else 0.0,
+                           fp64_TFLOPs=f_alg[k] / (times[k] * 1e-3) / 1e12 if times[k] > 0 else 0.0) for k in times}
+        ach = kernels[dom]["hbm_GBps"]
+        roofline = dict(bound="hbm", kernel=names[dom], achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None,
+                        note="path is fp64-VALU/latency bound (SURVEY.md 8d); fp64 fraction of the same kernel: %.4g of 78.6 TFLOP/s"
+                             % (kernels[dom]["fp64_TFLOPs"] / 78.6),
+                        kernels=kernels)
+        out = {
+            "metric": "residual+Jacobian blocks/sec; wall-clock per LM iter, GoPro9 full calib",
+            "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (seed 20241115)",
+            "config": {"workload": "C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s%s"
+                                   % (ds.num_views, n_corners, n_blocks - ds.num_views, "" if world == 1 else " (C2 x %d, time-sharded, all-reduce of JtJ/Jtr)" % world),
+                       "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR",
+                       "step": "one LM iteration: Jacobian+assembly, solve, retraction, cost pass"},
+            "corners_per_s": n_corners * args.steps / dt,
+            "jacobian_pass_ms": pass_ms,
+            "roofline": roofline,
+        }
+        if summ is not None:
+            out["full_calibration"] = dict(seconds=full_calib_s, stage1_iterations=summ["num_iterations"], stage1_seconds=summ["seconds_total"],
+                                           stage2_iterations=s2["num_iterations"], final_reproj_error_px=reproj,
+                                           seconds_jacobian=summ["seconds_jacobian"], seconds_residual=summ["seconds_residual"],
+                                           seconds_linear_solver=summ["seconds_linear_solver"])
+        # ---- CPU baseline: the oracle (CPU restatement of the Ceres path) ----------
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_backend
+            ob = oracle_backend.load()
+            ob.raw.oicc_oracle_num_threads.restype = ctypes.c_int
+            cores = int(ob.raw.oicc_oracle_num_threads())
+            ccal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+            iters = 3
+            t1 = time.perf_counter()
+            cs = ccal.trajectory_.Optimize(iters, flags)
+            cdt = time.perf_counter() - t1
+            out["cpu_baseline"] = dict(value=n_blocks * cs["num_iterations"] / cdt, unit="blocks/s", cores=cores, kind="port",
+                                       sample="first %d LM iterations of the same C2 problem (forward-mode Jet autodiff in strides of 4, "
+                                              "OpenMP over residual blocks, band+arrow Cholesky): %.2f s" % (cs["num_iterations"], cdt),
+                                       ms_per_lm_iteration=1e3 * cdt / max(cs["num_iterations"], 1))
+        # ---- extra: C5-size Jacobian pass on one GPU --------------------------------
+        if not args.no_extra and world == 1:
+            try:
+                ds5 = synthetic.make_config("C5")
+                c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
+                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5,
+                                                  kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
+                                                  blocks_per_s_jacobian_pass=c5.num_blocks / (p5 * 1e-3),
+                                                  fp64_TFLOPs=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 1e12)
+            except Exception as e:  # the extra must never break the bench line
+                out["extra_c5_single_gpu"] = {"error": str(e)[:200]}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

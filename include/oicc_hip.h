@@ -257,6 +257,10 @@ int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind,
  * per-kernel averages [views, accel, gyro]. */
 int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats,
                             double* ms_per_pass, double kernel_ms[3]);
+/* Run the device work and host synchronisation of `steps` successful LM
+ * iterations at the current point without accepting the steps (bench.py's
+ * "step": Jacobian+assembly, [all-reduce], damped solve, retraction, cost). */
+int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps);
 /* Same for the damped band+arrow solve of the last assembled system. */
 int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats,
                            double* ms_per_solve);

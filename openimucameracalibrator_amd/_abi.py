@@ -91,6 +91,7 @@ SIGNATURES = {
     "get_num_accl_bias_knots": (C.c_int64, [H]),
     "get_num_gyro_bias_knots": (C.c_int64, [H]),
     "get_mean_reprojection_error": (C.c_int, [H, c_dp, c_i64p]),
+    "declare_remote_measurements": (C.c_int, [H, C.c_int32, C.c_int64, c_i64p]),
     "get_trajectory": (C.c_int, [H, C.c_int64, c_i64p, c_dp, c_dp, c_dp, c_dp, c_dp, c_u8p]),
 }
 
@@ -98,9 +99,9 @@ SIGNATURES = {
 DEVICE_ONLY = {
     "set_stream": (C.c_int, [H, C.c_void_p]),
     "set_allreduce": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
-    "declare_remote_measurements": (C.c_int, [H, C.c_int32, C.c_int64, c_i64p]),
     "time_jacobian_pass": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_dp]),
     "time_linear_solve": (C.c_int, [H, C.c_int32, C.c_int32, c_dp]),
+    "run_lm_iterations": (C.c_int, [H, C.c_int32, C.c_int32]),
 }
 
 

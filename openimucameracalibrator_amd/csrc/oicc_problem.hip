@@ -720,6 +720,38 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
 int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out, int32_t cap) {
   const int n = std::min<int>(cap, int(p->trace.size())); std::copy(p->trace.begin(), p->trace.begin() + n, out); return n; }
 
+
+// The device work + host synchronisation of ONE successful LM iteration (Jacobian
+// pass + assembly, [all-reduce], gradient norm, damped system build, band+arrow
+// Cholesky solve, retraction, candidate cost pass, state read-back), repeated
+// `steps` times at the current point without accepting the step.  bench.py times
+// this as its "step"; it is exactly the loop body of oicc_optimize.
+int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  const TangentLayout& tl = p->tl;
+  if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  LmState hs;
+  for (int it = 0; it < steps; ++it) {
+    rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+    if (it == 0) launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+    std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
+    HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
+    launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
+    if (launch_band_arrow_cholesky(tl, sb, st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+    launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
+    rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+    double cand = 0.0;
+    rc = read_cost(p, &cand); if (rc) return rc;
+    HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipStreamSynchronize(st));
+    if (hs.chol_failed) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
+  }
+  return OICC_OK;
+}
+
 int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_pass, double kernel_ms[3]) {
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;

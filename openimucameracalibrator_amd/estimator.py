@@ -277,6 +277,13 @@ class SplineTrajectoryEstimator:
         self._ck(self._b.time_jacobian_pass(self._h, int(flags), int(repeats), C.byref(ms), _dp(k)))
         return ms.value, k
 
+    def RunLmIterations(self, flags, steps):
+        self._ck(self._b.run_lm_iterations(self._h, int(flags), int(steps)))
+
+    def DeclareRemoteMeasurements(self, kind, t_ns):
+        t_ns = np.ascontiguousarray(t_ns, dtype=np.int64)
+        self._ck(self._b.declare_remote_measurements(self._h, int(kind), len(t_ns), t_ns.ctypes.data_as(_abi.c_i64p)))
+
     def TimeLinearSolve(self, flags, repeats=10):
         ms = C.c_double(0)
         self._ck(self._b.time_linear_solve(self._h, int(flags), int(repeats), C.byref(ms)))
@@ -419,6 +426,13 @@ class ImuCameraCalibrator:
         self.accl_accepted = tr.AddAccelerometerMeasurements(ds.accel[keep], ti, 1.0 / ds.std_r3)
         self.gyro_accepted = tr.AddGyroscopeMeasurements(ds.gyro[keep], ti, 1.0 / ds.std_so3)
         self.imu_t_ns = ti
+        if shard is not None and shard[1] > 1:
+            # other ranks' measurements: timestamps only, so that every rank derives the same tangent layout
+            mine = np.zeros(ds.num_views, bool); mine[d.shard_view_index] = True
+            tr.DeclareRemoteMeasurements(0 if ds.line_delay_init != 0.0 else 3, (ds.view_t_s[~mine] * S_TO_NS).astype(np.int64))
+            other = (t >= self.t0_s_) & (t < self.tend_s_) & ~isel
+            to = (t[other] * S_TO_NS).astype(np.int64)
+            tr.DeclareRemoteMeasurements(1, to); tr.DeclareRemoteMeasurements(2, to)
         tr.SetGravity(ds.gravity_init if known_gravity is None else known_gravity)
         self.num_blocks = int(self.views_accepted.sum() + self.accl_accepted.sum() + self.gyro_accepted.sum())
         self.num_corners = int(off[-1])

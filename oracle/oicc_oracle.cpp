@@ -55,7 +55,8 @@ struct Problem {
   std::vector<double> pts;               // n*4
   std::vector<ViewBlk> views; std::vector<double> uv, cov; std::vector<int32_t> pidx;
   std::vector<ImuBlk> acc, gyr;
-  bool has_ld_block = false, has_tic_block = false;
+  bool has_ld_block = false, has_tic_block = false, remote_acc = false, remote_gyr = false;
+  std::vector<int> remote_so3, remote_r3;
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
   Problem() {
@@ -77,7 +78,7 @@ Active active_set(const Problem& p, int flags) {
   // otherwise the block keeps Ceres' default state (variable).
   a.ld = p.has_ld_block && (p.ld != 0.0 ? (flags & OICC_CAM_LINE_DELAY) != 0 : true);
   a.g = (flags & OICC_GRAVITY_DIR) != 0;                              // impl.h:122-133
-  const bool both = !p.acc.empty() && !p.gyr.empty();                 // impl.h:157-168
+  const bool both = (!p.acc.empty() || p.remote_acc) && (!p.gyr.empty() || p.remote_gyr);   // impl.h:157-168
   a.intr_a = both ? (flags & OICC_IMU_INTRINSICS) != 0 : true;
   a.intr_g = both ? (flags & OICC_IMU_INTRINSICS) != 0 : true;
   a.spline = (flags & OICC_SPLINE) != 0;                              // impl.h:180-204
@@ -105,12 +106,12 @@ Layout make_layout(const Problem& p, int flags) {
   }
   L.P_band = off;
   if (a.tic && p.has_tic_block) { L.other[0] = off; off += 6; }
-  if (a.g && !p.acc.empty()) { L.other[1] = off; off += 3; }
+  if (a.g && (!p.acc.empty() || p.remote_acc)) { L.other[1] = off; off += 3; }
   if (a.ld) { L.other[2] = off; off += 1; }
   if (a.ab) for (size_t i = 0; i < L.ab.size(); ++i) if (p.ab_in[i]) { L.ab[i] = off; off += 3; }
   if (a.gb) for (size_t i = 0; i < L.gb.size(); ++i) if (p.gb_in[i]) { L.gb[i] = off; off += 3; }
-  if (a.intr_a && !p.acc.empty()) { L.other[3] = off; off += 6; }
-  if (a.intr_g && !p.gyr.empty()) { L.other[4] = off; off += 9; }
+  if (a.intr_a && (!p.acc.empty() || p.remote_acc)) { L.other[3] = off; off += 6; }
+  if (a.intr_g && (!p.gyr.empty() || p.remote_gyr)) { L.other[4] = off; off += 9; }
   L.P = off; L.arrow = off - L.P_band;
   // half bandwidth of the band part
   int hb = 0;
@@ -124,6 +125,7 @@ Layout make_layout(const Problem& p, int flags) {
     for (const auto& v : p.views) span(v.s_so3, v.s_r3, true);
     for (const auto& b : p.acc) span(b.s_so3, b.s_r3, true);
     for (const auto& b : p.gyr) span(b.s_so3, 0, false);
+    for (size_t i = 0; i < p.remote_so3.size(); ++i) span(p.remote_so3[i], std::max(p.remote_r3[i], 0), p.remote_r3[i] >= 0);
   }
   L.hb = hb;
   return L;
@@ -626,6 +628,28 @@ int oicc_oracle_add_gyroscope_measurements(oicc_problem* prob, int64_t n, const 
     for (int k = 0; k < kN; ++k) P_.so3_in[b.s_so3 + k] = 1;
     for (int k = 0; k < kNb; ++k) P_.gb_in[b.s_b + k] = 1;
     P_.gyr.push_back(b);
+  }
+  return OICC_OK;
+}
+
+
+// multi-GPU layout hint (see include/oicc_hip.h): timestamps of measurements held by other ranks
+int oicc_oracle_declare_remote_measurements(oicc_problem* prob, int32_t kind, int64_t n, const int64_t* t_ns) {
+  for (int64_t i = 0; i < n; ++i) {
+    double u; int64_t s_so3 = 0, s_r3 = 0, s_b = 0;
+    bool ok = calc_times(t_ns[i], P_.start_ns, P_.dt_so3, P_.so3.size() / 4, kN, &u, &s_so3);
+    if (kind != 2) ok = ok && calc_times(t_ns[i], P_.start_ns, P_.dt_r3, P_.r3.size() / 3, kN, &u, &s_r3);
+    if (kind == 1) ok = ok && calc_times(t_ns[i], P_.start_ns, P_.dt_ab, P_.ab.size() / 3, kNb, &u, &s_b);
+    if (kind == 2) ok = ok && calc_times(t_ns[i], P_.start_ns, P_.dt_gb, P_.gb.size() / 3, kNb, &u, &s_b);
+    if (!ok) continue;
+    for (int k = 0; k < kN; ++k) { P_.so3_in[s_so3 + k] = 1; if (kind != 2) P_.r3_in[s_r3 + k] = 1; }
+    if (kind == 1) for (int k = 0; k < kNb; ++k) P_.ab_in[s_b + k] = 1;
+    if (kind == 2) for (int k = 0; k < kNb; ++k) P_.gb_in[s_b + k] = 1;
+    if (kind == 0) { P_.has_tic_block = true; P_.has_ld_block = true; }
+    if (kind == 3) P_.has_tic_block = true;
+    if (kind == 1) P_.remote_acc = true;
+    if (kind == 2) P_.remote_gyr = true;
+    P_.remote_so3.push_back(int(s_so3)); P_.remote_r3.push_back(kind == 2 ? -1 : int(s_r3));
   }
   return OICC_OK;
 }

@@ -52,7 +52,7 @@ def test_block_residuals_and_jacobians(tiny, flags):
         rc, Jc = cpu.trajectory_.EvaluateBlocks(flags, kind, nrows[kind])
         assert np.abs(rg - rc).max() <= 1e-12 * (1 + np.abs(rc).max()), (kind, np.abs(rg - rc).max())
         # row scale with a floor: rows whose true derivative is ~0 (constant knots past the last view) hold rounding noise
-        scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-9 * np.abs(Jc).max() + 1e-30
+        scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc).max() + 1e-30
         err = np.abs(Jg - Jc) / scale
         assert err.max() < 1e-8, (kind, err.max(), np.unravel_index(err.argmax(), err.shape))
 
@@ -77,7 +77,7 @@ def test_all_camera_models(camera):
     rg, Jg = gpu.trajectory_.EvaluateBlocks(flags, 0, n)
     rc, Jc = cpu.trajectory_.EvaluateBlocks(flags, 0, n)
     assert np.abs(rg - rc).max() <= 1e-11 * (1 + np.abs(rc).max())
-    scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-9 * np.abs(Jc).max() + 1e-30
+    scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc).max() + 1e-30
     assert (np.abs(Jg - Jc) / scale).max() < 1e-8
 
 
