@@ -32,7 +32,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        hipStream_t st);
 // kernels_solve.hip
 struct LmState { double radius, model_cost_change, step_norm_sq, x_norm_sq, gradient_max_norm, cand_cost; int32_t chol_failed, pad; };
-struct SolveBuffers { double *Mb, *Mt, *Mc, *scale, *diag, *D2, *step_s; LmState* st; };
+struct SolveBuffers { double *Mb, *Mt, *Mc, *scale, *diag, *D2, *step_s; LmState* st; long long* prof; };
 void launch_lm_scale(const NormalEq& ne, const TangentLayout& tl, double* scale, int jacobi, hipStream_t st);
 void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st);
 void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
@@ -637,7 +637,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   S.seconds_jacobian += now_s() - t0;
   S.initial_cost = cost;
   if (P == 0) return finish(OICC_CONVERGENCE, "no variable parameters");
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs));
   auto read_state = [&]() -> int {
@@ -731,7 +731,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
   LmState hs;
   for (int it = 0; it < steps; ++it) {
     rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
@@ -786,7 +786,7 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
@@ -802,6 +802,27 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   if (ms_per_solve) *ms_per_solve = double(ms) / std::max(repeats, 1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return OICC_OK;
+}
+
+// Debug: shader-cycle counters of the solver kernel's phases for the current system
+// [init, prefetch, stepA, barrier1, stepB, barrier2, corner+t, backward].
+int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  const TangentLayout& tl = p->tl;
+  DevBuf<long long> d; if (!d.resize(12)) return OICC_ERR_HIP;
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p};
+  launch_lm_scale(p->ne, tl, sb.scale, 1, st);
+  LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = 1e4;
+  HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+  for (int rep = 0; rep < 2; ++rep) {
+    launch_lm_build(p->ne, tl, sb, 0, 1e-6, 1e32, st);
+    if (launch_band_arrow_cholesky(tl, sb, st) != 0) return OICC_ERR_UNSUPPORTED;
+  }
+  HIPCK(p, hipMemcpyAsync(out, d.p, 12 * sizeof(long long), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipStreamSynchronize(st));
   return OICC_OK;
 }
 
