@@ -1,0 +1,126 @@
+"""CPU-only checks of the drop-in boundary and the host logic:
+ * liboicc_hip.so loads and exports every entry point include/oicc_hip.h declares
+   (no compute calls: there is no GPU here) and fails loudly without a device;
+ * the reference's bookkeeping semantics (CalcTimes acceptance, knot counts,
+   GetMaxTimeNs, tangent layout ordering, SetFixedParams quirks) through the
+   SplineTrajectoryEstimator mirror, driven on the CPU checker backend;
+ * time-sharding of a dataset covers every measurement exactly once.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_backend
+from openimucameracalibrator_amd import synthetic, estimator as E, _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "oicc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(oicc_[a-z0-9_A-Z]+)\s*\(", src)) - {"oicc_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # the ctypes table binds only declared functions
+    for n in list(_abi.SIGNATURES) + list(_abi.DEVICE_ONLY):
+        assert "oicc_" + n in names, n
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    b = _lib.load()
+    h = _abi.H()
+    assert b.create(ctypes.byref(h), 0) == -2      # OICC_ERR_NO_DEVICE
+    with pytest.raises(E.OiccError):
+        E.SplineTrajectoryEstimator()
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    ds = synthetic.make_config("tiny")
+    return ds, E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+
+
+def test_set_times_knot_counts_and_time_range(cpu):
+    ds, cal = cpu
+    tr = cal.trajectory_
+    dur = tr.end_t_ns - tr.start_t_ns
+    assert tr.GetNumSO3Knots() == dur // tr.dt_so3_ns + 6          # impl.h:46-48
+    assert tr.GetNumR3Knots() == dur // tr.dt_r3_ns + 6
+    assert tr.GetMinTimeNs() == tr.start_t_ns
+    assert tr.GetMaxTimeNs() == tr.start_t_ns + (tr.GetNumSO3Knots() - 6 + 1) * tr.dt_so3_ns - 1   # impl.h:820-822
+
+
+def test_measurement_acceptance_follows_calc_times():
+    b = oracle_backend.load()
+    tr = E.SplineTrajectoryEstimator(backend=b)
+    tr.SetTimes(50_000_000, 100_000_000, 1_000_000_000, 2_000_000_000)
+    tr.InitBiasSplines(np.zeros(3), np.zeros(3), 10 ** 10, 10 ** 10, 1.0, 0.1)
+    n_so3 = tr.GetNumSO3Knots()
+    t = np.array([999_999_999, 1_000_000_000, 1_500_000_000, 1_000_000_000 + (n_so3 - 6 + 1) * 50_000_000 - 1,
+                  1_000_000_000 + (n_so3 - 6 + 1) * 50_000_000], dtype=np.int64)
+    acc = tr.AddGyroscopeMeasurements(np.zeros((5, 3)), t, 1.0)
+    assert acc.tolist() == [False, True, True, True, False]        # impl.h:764-788
+    # accelerometer additionally needs the R3 window (coarser dt => ends earlier or equal)
+    acc2 = tr.AddAccelerometerMeasurements(np.zeros((5, 3)), t, 1.0)
+    assert acc2[0] == False and acc2[1] == True and acc2[4] == False
+
+
+def test_tangent_layout_contract(cpu):
+    ds, cal = cpu
+    tr = cal.trajectory_
+    flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
+    lay = tr.GetTangentLayout(flags)
+    so3, r3 = lay["so3"], lay["r3"]
+    # band variables ordered by knot time, SO3 before R3 at equal times
+    items = [(i * tr.dt_so3_ns, 0, o) for i, o in enumerate(so3) if o >= 0] + [(i * tr.dt_r3_ns, 1, o) for i, o in enumerate(r3) if o >= 0]
+    items.sort()
+    assert [o for _, _, o in items] == list(range(0, 3 * len(items), 3))
+    Pb = 3 * len(items)
+    assert lay["other"].tolist() == [Pb, Pb + 6, -1, -1, -1] and lay["P"] == Pb + 9
+    # stage 2 (line delay only): a single scalar variable
+    lay2 = tr.GetTangentLayout(E.CAM_LINE_DELAY)
+    assert lay2["P"] == 1 and lay2["other"][2] == 0 and (lay2["so3"] < 0).all()
+    # bias knots and intrinsics enter the arrow after T_i_c, g, line delay
+    lay3 = tr.GetTangentLayout(flags | E.IMU_BIASES | E.IMU_INTRINSICS | E.CAM_LINE_DELAY)
+    na, ng = (lay3["accl_bias"] >= 0).sum(), (lay3["gyro_bias"] >= 0).sum()
+    assert lay3["P"] == Pb + 6 + 3 + 1 + 3 * na + 3 * ng + 6 + 9
+
+
+def test_line_delay_block_quirk_when_zero():
+    """impl.h:109-119: with line delay == 0 the block is never set constant."""
+    ds = synthetic.make_config("tiny")
+    cal = E.ImuCameraCalibrator(backend=oracle_backend.load())
+    cal.BatchInitSpline(ds)
+    tr = cal.trajectory_
+    tr.SetCameraLineDelay(0.0)
+    assert tr.GetTangentLayout(E.SPLINE)["other"][2] >= 0       # variable although CAM_LINE_DELAY is not set
+    tr.SetCameraLineDelay(3e-5)
+    assert tr.GetTangentLayout(E.SPLINE)["other"][2] == -1
+
+
+def test_shards_cover_every_measurement_once():
+    ds = synthetic.make_config("tiny", num_views=24, duration=2.4)
+    world = 3
+    views = np.concatenate([ds.shard(r, world).shard_view_index for r in range(world)])
+    assert sorted(views.tolist()) == list(range(ds.num_views))
+    imu = np.stack([ds.shard(r, world).shard_imu for r in range(world)]).sum(0)
+    keep = (ds.imu_t_s >= ds.view_t_s.min()) & (ds.imu_t_s < ds.view_t_s.max())
+    assert (imu[keep] == 1).all()
+    nc = sum(int(ds.shard(r, world).shard_corner_offset[-1]) for r in range(world))
+    assert nc == ds.num_corners
