@@ -1,0 +1,533 @@
+// Band + arrow Cholesky solve of the damped LM system on the device (A9: the
+// SPARSE_NORMAL_CHOLESKY step of ceres::Solve [EXT], called at
+// spline_trajectory_estimator.impl.h:272), sequential in time inside a workgroup
+// and PARALLEL across time partitions.
+//
+// System (scaled, damped):   [ B   E   -g_b ]   B: Pb x Pb, half bandwidth hb (knots in time order)
+//                            [ E^T C   -g_a ]   E: arrow (T_i_c, gravity, line delay, biases, intrinsics)
+//
+// One workgroup sweeps a column range [c0, c1) with a bordered band Cholesky:
+//   * the (hb+8)-column window lives in LDS (column major, power-of-two circular),
+//   * 8-column panels are factored wave-synchronously (lane = row, v_readlane
+//     broadcasts, v_rsq_f64 + 2 Newton steps),
+//   * the trailing update is spread over 16 waves with batched LDS loads,
+//   * rows entering the window are prefetched one panel ahead,
+//   * "border" rows ride along: the arrow rows, the right-hand side as one more
+//     row and -- for an interior time partition -- the LEFT SEPARATOR (hb rows), so
+//     that the Schur complement onto (separators + arrow) falls out of the sweep.
+//
+// p == 1 : one workgroup factors everything, solves the arrow corner and runs the
+//          backward sweep.
+// p  > 1 : the band is cut into p partitions separated by p-1 separators of hb
+//          columns.  (1) p workgroups eliminate their interiors concurrently and add
+//          their Schur updates into the reduced (separator + arrow) system with fp64
+//          atomics; (2) one workgroup solves the reduced system (itself band + arrow,
+//          half bandwidth 2hb-1); (3) p workgroups back-substitute concurrently.
+#include <hip/hip_runtime.h>
+#include "oicc_device.h"
+
+namespace oicc {
+
+constexpr int PW = 8;                 // panel width
+constexpr int kCholThreads = 1024;    // 16 waves: step B is spread wide, step A runs on 1-3 waves
+
+struct CholSys { double* Mb; double* Mt; double* Mc; int Pb, W, hb, a; };
+
+struct CholArgs {
+  CholSys sys;          // system swept by this launch (factor written in place; diagonal slot = 1/L_ii)
+  double* Msep;         // [hb][Pb]: left-separator border rows of the partitions' factors
+  CholSys red;          // reduced system (target of the partitions' Schur updates)
+  double* sol;          // full mode: solution of `sys` [Pb + a]
+  int p;                // number of partitions of `sys` (partition modes)
+  int L;                // interior length of partitions 0..p-2 (multiple of PW)
+  int32_t* fail;        // LmState::chol_failed (atomicOr)
+  long long* prof;      // optional cycle counters (debug)
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// partition geometry (all derived from p, L, hb, Pb)
+struct Part { int c0, c1, nsep, rs_left, rs_right; };
+__device__ __forceinline__ Part part_of(const CholArgs& A, int k) {
+  Part P;
+  const int hb = A.sys.hb, Pb_pad = ((A.sys.Pb + PW - 1) / PW) * PW;
+  if (A.p <= 1) { P.c0 = 0; P.c1 = Pb_pad; P.nsep = 0; P.rs_left = -1; P.rs_right = -1; return P; }
+  P.c0 = k * (A.L + hb);
+  P.c1 = k < A.p - 1 ? P.c0 + A.L : P.c0 + ((A.sys.Pb - P.c0 + PW - 1) / PW) * PW;
+  P.nsep = k > 0 ? hb : 0;
+  P.rs_left = k > 0 ? (k - 1) * hb : -1;
+  P.rs_right = k < A.p - 1 ? k * hb : -1;
+  return P;
+}
+
+// ---- backward sweep over columns [c0, c1) of a factored band (one wave) --------
+// t (right-hand side after the forward sweep and border correction) is read from
+// and the solution written to x[gi]; xb must hold the already-known solution of
+// rows >= c1 (circular, 2*MCAP entries).
+template <int MCAP>
+__device__ __forceinline__ void backward_sweep(const double* Mb, int W, int hb, int Pb, int c0, int c1, double* x, double* xb, int lane) {
+  constexpr int KMAX = MCAP / 8;
+  constexpr int xmask = 2 * MCAP - 1;
+  const int ri = lane >> 3, sl = lane & 7;
+  const int k0 = (PW - ri) + sl;            // first band offset of this lane's slice
+  double n_part[KMAX], n_tri[PW], n_dinv, n_t;
+  auto load_block = [&](int jb) {
+    const int gi = jb + ri;
+    const double* prow = Mb + (int64_t)gi * W + k0;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      const int k = k0 + 8 * t;
+      n_part[t] = (gi < Pb && k <= hb && gi + k < Pb) ? prow[8 * t] : 0.0;
+    }
+    const int gl = jb + lane;   // lanes 0..7: row of the diagonal block
+    const double* trow = Mb + (int64_t)gl * W - lane;
+#pragma unroll
+    for (int r = 0; r < PW; ++r) n_tri[r] = (lane < r && r - lane <= hb && jb + r < Pb) ? trow[r] : 0.0;
+    n_dinv = (lane < PW && gl < Pb) ? Mb[(int64_t)gl * W] : 1.0;
+    n_t = (lane < PW && gl < Pb) ? x[gl] : 0.0;
+  };
+  if (c1 - PW < c0) return;
+  load_block(c1 - PW);
+  for (int jb = c1 - PW; jb >= c0; jb -= PW) {
+    double c_part[KMAX], c_tri[PW];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) c_part[t] = n_part[t];
+#pragma unroll
+    for (int r = 0; r < PW; ++r) c_tri[r] = n_tri[r];
+    const double c_dinv = n_dinv, c_t = n_t;
+    if (jb - PW >= c0) load_block(jb - PW);
+    double p0 = 0.0, p1 = 0.0;
+    const int xi = jb + ri + k0;
+#pragma unroll
+    for (int t = 0; t < KMAX; t += 2) {
+      p0 = fma(c_part[t], xb[(xi + 8 * t) & xmask], p0);
+      p1 = fma(c_part[t + 1], xb[(xi + 8 * t + 8) & xmask], p1);
+    }
+    double part = p0 + p1;
+    part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+    double tv = c_t - __shfl(part, (lane & 7) * 8, 64);   // lane r (0..7): row jb + r
+    double xv = 0.0;
+#pragma unroll
+    for (int r = PW - 1; r >= 0; --r) {
+      const double xr = readlane_f64(tv, r) * readlane_f64(c_dinv, r);
+      if (lane == r) xv = xr;
+      tv = fma(-c_tri[r], xr, tv);     // c_tri[r] = L(jb+r, jb+lane) for lane < r, else 0
+    }
+    if (lane < PW) { const int gr = jb + lane; xb[gr & xmask] = xv; if (gr < Pb) x[gr] = xv; }
+  }
+}
+
+// LDS layout (doubles), MCAP in {64,128} >= m = hb + PW, br = border rows, brp = br | 1:
+//   Wc [MCAP][MCAP]  column major window: (gr,gc) -> Wc[(gc&mask)*MCAP + (gr&mask)], gr >= gc
+//   At [MCAP][brp]   border rows:         (b,gc)  -> At[(gc&mask)*brp + b]
+//   Cq [br][brp]     border corner:       (b1,b2) -> Cq[b2*brp + b1], b1 >= b2
+//   Lp [MCAP+br][PW] current panel of L (row major)
+//   xb [2*MCAP], da [br], dinv [PW], fail flag
+// MODE 0: full solve (p == 1, or the reduced system); MODE 1: partition forward sweep.
+template <int MCAP, int MODE>
+__global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholArgs A, int brp) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int mask = MCAP - 1;
+  constexpr int LOG = MCAP == 64 ? 6 : 7;
+  constexpr int NPW = PW * MCAP / kCholThreads > 0 ? PW * MCAP / kCholThreads : 1;
+  constexpr int NPASS = MCAP / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Pb = A.sys.Pb, a = A.sys.a, hb = A.sys.hb, W = A.sys.W, ar = a + 1;
+  const Part pt = part_of(A, MODE == 1 ? blockIdx.x : 0);
+  const int c0 = pt.c0, c1 = pt.c1, nsep = MODE == 1 ? pt.nsep : 0;
+  const int br = nsep + ar;                     // border rows: [left separator | arrow | rhs]
+  const int m = hb + PW;                        // window size (<= MCAP)
+  double* const Wc = smem;
+  double* const At = Wc + (size_t)MCAP * MCAP;
+  double* const Cq = At + (size_t)MCAP * brp;
+  double* const Lp = Cq + (((size_t)br * brp + 1) & ~(size_t)1);
+  double* const xb = Lp + (size_t)(MCAP + br) * PW;
+  double* const da = xb + 2 * MCAP;
+  double* const dinv = da + br;
+  int* const fail_flag_p = reinterpret_cast<int*>(dinv + PW);
+  if (tid == 0) *fail_flag_p = 0;
+  double* const Mb = A.sys.Mb;
+  double* const Mt = A.sys.Mt;
+  const bool prof = A.prof != nullptr && blockIdx.x == 0;
+  long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = prof ? clock64() : 0;
+#define PROF_MARK(i) do { if (prof) { const long long tn_ = clock64(); pc[i] += tn_ - tprev; tprev = tn_; } } while (0)
+
+  // original (damped) band entry (gr, gc), gr >= gc, identity beyond Pb
+  auto band_orig = [&](int gr, int gc) -> double {
+    const int k = gr - gc;
+    if (k > hb) return 0.0;
+    return gr < Pb ? Mb[(int64_t)gc * W + k] : (k == 0 ? 1.0 : 0.0);
+  };
+  // original border entry (border row b, column gc >= c0)
+  auto border_orig = [&](int b, int gc) -> double {
+    if (gc >= Pb) return 0.0;
+    if (b < nsep) { const int s = c0 - nsep + b; const int k = gc - s; return k <= hb ? Mb[(int64_t)s * W + k] : 0.0; }
+    return Mt[(int64_t)(b - nsep) * Pb + gc];
+  };
+
+  // initial window: global rows/cols [c0, c0+m)
+  for (int e = tid; e < MCAP * MCAP; e += kCholThreads) {
+    const int ci = e >> LOG, rr = e & mask;
+    if (rr >= ci && rr < m) Wc[((c0 + ci) & mask) * MCAP + ((c0 + rr) & mask)] = band_orig(c0 + rr, c0 + ci);
+  }
+  for (int e = tid; e < m * br; e += kCholThreads) {
+    const int ci = e / br, b = e - ci * br;
+    At[((c0 + ci) & mask) * brp + b] = border_orig(b, c0 + ci);
+  }
+  for (int e = tid; e < br * br; e += kCholThreads) {
+    const int b2 = e / br, b1 = e - b2 * br;
+    Cq[b2 * brp + b1] = MODE == 0 ? A.sys.Mc[b1 * ar + b2] : 0.0;
+  }
+  const int pa_cc = tid < PW * br ? tid / br : -1;
+  const int pa_b = tid < PW * br ? tid - pa_cc * br : 0;
+  __syncthreads();
+
+  // step-A row ownership: lanes 0..7 = the panel's diagonal rows, lanes 8..63 = entries
+  // [w*56, w*56+56) of the list {band rows PW..m-1, border rows 0..br-1}
+  const int RN = (m - PW) + br;
+  int rhoA;
+  if (lane < PW) rhoA = lane;
+  else { const int li = wave * 56 + (lane - PW); rhoA = li < RN ? (li < m - PW ? PW + li : m + (li - (m - PW))) : -1; }
+  const bool publishA = rhoA >= 0 && (lane >= PW || wave == 0);
+
+  PROF_MARK(0);
+  for (int j0 = c0; j0 < c1; j0 += PW) {
+    // ---- prefetch what enters the window after this panel
+    const int nj0 = j0 + PW;
+    double pre_w[NPW], pre_a;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int e = tid + i * kCholThreads;
+      const int rr = e >> LOG, ci = e & mask;
+      const int gr = j0 + m + rr, gc = nj0 + ci;
+      pre_w[i] = (e < PW * MCAP && ci < m && gc <= gr) ? band_orig(gr, gc) : 0.0;
+    }
+    pre_a = pa_cc >= 0 ? border_orig(pa_b, j0 + m + pa_cc) : 0.0;
+    PROF_MARK(1);
+    // ---------------- step A: factor the panel (wave synchronous) -------------
+    if (wave * 56 < RN) {
+      const int rho = rhoA;
+      double av[PW];
+#pragma unroll
+      for (int c = 0; c < PW; ++c) {
+        double v = 0.0;
+        if (rho >= 0) {
+          if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * MCAP + ((j0 + rho) & mask)]; }
+          else v = At[((j0 + c) & mask) * brp + (rho - m)];
+        }
+        av[c] = v;
+      }
+      double rsd = 1.0;
+#pragma unroll
+      for (int c = 0; c < PW; ++c) {
+        double piv = readlane_f64(av[c], c);
+        if (!(piv > 0.0)) { if (lane == 0) *fail_flag_p = 1; piv = 1.0; }
+        const double h = 0.5 * piv;
+        double y = __builtin_amdgcn_rsq(piv);      // v_rsq_f64 seed + two Newton steps
+        y = y * fma(-h * y, y, 1.5);
+        y = y * fma(-h * y, y, 1.5);
+        const double l = av[c] * y;
+        av[c] = l;
+        if (lane == c) rsd = y;
+#pragma unroll
+        for (int c2 = c + 1; c2 < PW; ++c2) {
+          const double lc2 = readlane_f64(l, c2);
+          av[c2] = fma(-l, lc2, av[c2]);
+        }
+      }
+      if (publishA) {
+        double* lp = Lp + (size_t)rho * PW;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) lp[c] = (rho < c) ? 0.0 : av[c];
+        if (lane < PW && wave == 0) dinv[lane] = rsd;
+      }
+    }
+    PROF_MARK(2);
+    __syncthreads();
+    PROF_MARK(3);
+    // ---------------- step B (1): band rows, lane = window row, wave = column group
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int rho = lane + 64 * ps;
+      if (rho < m) {
+        double lr[PW];
+        const double* lrp = Lp + (size_t)rho * PW;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) lr[c] = lrp[c];
+        const int gr = j0 + rho;
+        if (gr < Pb && wave < PW) {   // wave w publishes panel column w of this row (global factor)
+          const int c = wave, k = rho - c;
+          if (k >= 0 && k <= hb && j0 + c < Pb) Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinv[c] : lrp[c];
+        }
+        double* const wrow = Wc + ((j0 + rho) & mask);
+        constexpr int NG = kCholThreads / 64;
+        for (int g0 = PW + wave; g0 <= rho; g0 += 4 * NG) {
+          double cur[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; cur[g] = gamma <= rho ? wrow[((j0 + gamma) & mask) * MCAP] : 0.0; }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int gamma = g0 + NG * g;
+            const double* lc = Lp + (size_t)(gamma < m ? gamma : m - 1) * PW;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
+            cur[g] -= s0 + s1;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; if (gamma <= rho) wrow[((j0 + gamma) & mask) * MCAP] = cur[g]; }
+        }
+      }
+    }
+    PROF_MARK(8);
+    // ---------------- step B (2): border rows b: band columns -> At, border columns b2 <= b -> Cq
+    {
+      const int ncol = (m - PW) + br;
+      for (int e = tid; e < br * ncol; e += kCholThreads) {
+        const int ci = e / br, b = e - ci * br;
+        const int gamma = PW + ci;
+        if (gamma >= m && gamma - m > b) continue;
+        const double* lr = Lp + (size_t)(m + b) * PW;
+        const double* lc = Lp + (size_t)gamma * PW;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
+        double* d = gamma < m ? &At[((j0 + gamma) & mask) * brp + b] : &Cq[(gamma - m) * brp + b];
+        *d -= s0 + s1;
+      }
+      // border part of the global factor
+      for (int e = tid; e < br * PW; e += kCholThreads) {
+        const int b = e >> 3, c = e & 7;
+        if (j0 + c < Pb) {
+          const double v = Lp[(size_t)(m + b) * PW + c];
+          if (b < nsep) A.Msep[(int64_t)b * Pb + j0 + c] = v; else Mt[(int64_t)(b - nsep) * Pb + j0 + c] = v;
+        }
+      }
+    }
+    PROF_MARK(9);
+    // ---------------- step B (3): window advance (entering rows alias only finished slots)
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int e = tid + i * kCholThreads;
+      const int rr = e >> LOG, ci = e & mask;
+      const int gr = j0 + m + rr, gc = nj0 + ci;
+      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * MCAP + (gr & mask)] = pre_w[i];
+    }
+    if (pa_cc >= 0) At[((j0 + m + pa_cc) & mask) * brp + pa_b] = pre_a;
+    PROF_MARK(4);
+    __syncthreads();
+    PROF_MARK(5);
+  }
+
+  if (MODE == 1) {
+    // ---- Schur updates of this partition onto the reduced (separators + arrow) system
+    const CholSys& R = A.red;
+    // (a) right separator S: window columns [c1, c1+hb): band block, border x S
+    if (pt.rs_right >= 0) {
+      for (int e = tid; e < hb * hb; e += kCholThreads) {
+        const int ci = e / hb, rr = e - ci * hb;
+        if (rr < ci) continue;
+        const int gr = c1 + rr, gc = c1 + ci;
+        const double d = Wc[(gc & mask) * MCAP + (gr & mask)] - band_orig(gr, gc);
+        if (d != 0.0) unsafeAtomicAdd(&R.Mb[(int64_t)(pt.rs_right + ci) * R.W + (rr - ci)], d);
+      }
+      for (int e = tid; e < hb * br; e += kCholThreads) {
+        const int ci = e / br, b = e - ci * br;
+        const int gc = c1 + ci;
+        const double v = At[(gc & mask) * brp + b];
+        if (b < nsep) {       // coupling S_left(b) x S_right(ci): reduced band entry (row right, col left)
+          if (v != 0.0) unsafeAtomicAdd(&R.Mb[(int64_t)(pt.rs_left + b) * R.W + (pt.rs_right + ci - pt.rs_left - b)], v);
+        } else {
+          const double d = v - border_orig(b, gc);
+          if (d != 0.0) unsafeAtomicAdd(&R.Mt[(int64_t)(b - nsep) * R.Pb + pt.rs_right + ci], d);
+        }
+      }
+    }
+    // (b) border x border corner
+    for (int e = tid; e < br * br; e += kCholThreads) {
+      const int b2 = e / br, b1 = e - b2 * br;
+      if (b1 < b2) continue;
+      const double v = Cq[b2 * brp + b1];
+      if (v == 0.0) continue;
+      if (b1 < nsep) {                       // left sep x left sep
+        unsafeAtomicAdd(&R.Mb[(int64_t)(pt.rs_left + b2) * R.W + (b1 - b2)], v);
+      } else if (b2 < nsep) {                // arrow/rhs row x left sep column
+        unsafeAtomicAdd(&R.Mt[(int64_t)(b1 - nsep) * R.Pb + pt.rs_left + b2], v);
+      } else {                               // arrow x arrow (full symmetric storage)
+        const int q1 = b1 - nsep, q2 = b2 - nsep;
+        unsafeAtomicAdd(&R.Mc[q1 * ar + q2], v);
+        if (q1 != q2) unsafeAtomicAdd(&R.Mc[q2 * ar + q1], v);
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && *fail_flag_p) atomicOr(A.fail, 1);
+    if (prof && tid == 0) for (int i = 0; i < 12; ++i) A.prof[i] = pc[i];
+    return;
+  }
+
+  // ---------------- MODE 0: arrow corner, dense Cholesky of the a x a Schur complement
+  for (int c = 0; c < a; ++c) {
+    if (tid == 0) { double piv = Cq[c * brp + c]; if (!(piv > 0.0)) { *fail_flag_p = 1; piv = 1.0; } Cq[c * brp + c] = sqrt(piv); }
+    __syncthreads();
+    const double d = Cq[c * brp + c];
+    for (int r = c + 1 + tid; r < ar; r += kCholThreads) Cq[c * brp + r] /= d;
+    __syncthreads();
+    const int nrem = ar - (c + 1);
+    for (int e = tid; e < nrem * nrem; e += kCholThreads) {
+      const int c2 = c + 1 + e / nrem, r = c + 1 + e % nrem;
+      if (r >= c2 && c2 < a) Cq[c2 * brp + r] -= Cq[c * brp + r] * Cq[c * brp + c2];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int i = a - 1; i >= 0; --i) {
+      double s = Cq[i * brp + a];
+      for (int k = i + 1; k < a; ++k) s -= Cq[i * brp + k] * da[k];
+      da[i] = s / Cq[i * brp + i];
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < a; q += kCholThreads) A.sol[Pb + q] = da[q];
+  // t = y - Y da for every band row (coalesced), parked in sol
+  for (int i = tid; i < Pb; i += kCholThreads) {
+    double t = Mt[(int64_t)a * Pb + i];
+    for (int q = 0; q < a; ++q) t = fma(-Mt[(int64_t)q * Pb + i], da[q], t);
+    A.sol[i] = t;
+  }
+  __syncthreads();
+  PROF_MARK(6);
+  if (wave == 0 && Pb > 0) {
+    for (int i = lane; i < 2 * MCAP; i += 64) xb[i] = 0.0;
+    backward_sweep<MCAP>(Mb, W, hb, Pb, 0, c1, A.sol, xb, lane);
+  }
+  __syncthreads();
+  PROF_MARK(7);
+  if (tid == 0 && *fail_flag_p) atomicOr(A.fail, 1);
+  if (prof && tid == 0) for (int i = 0; i < 12; ++i) A.prof[i] = pc[i];
+#undef PROF_MARK
+}
+
+// ---- reduced system = original separator / arrow entries (partitions add updates) ---
+__global__ void reduced_init_kernel(CholArgs A) {
+  const CholSys& S = A.sys; const CholSys& R = A.red;
+  const int hb = S.hb, ar = S.a + 1;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = tid; e < (int64_t)R.Pb * R.W; e += nth) {
+    const int ri = int(e / R.W), k = int(e - (int64_t)ri * R.W);
+    const int s = ri / hb, j = ri - s * hb;                 // separator s (0-based), offset j
+    double v = 0.0;
+    if (j + k < hb) { const int gc = s * (A.L + hb) + A.L + j; v = k <= hb ? S.Mb[(int64_t)gc * S.W + k] : 0.0; }
+    R.Mb[e] = v;
+  }
+  for (int64_t e = tid; e < (int64_t)ar * R.Pb; e += nth) {
+    const int q = int(e / R.Pb), ri = int(e - (int64_t)q * R.Pb);
+    const int s = ri / hb, j = ri - s * hb;
+    const int gc = s * (A.L + hb) + A.L + j;
+    R.Mt[e] = S.Mt[(int64_t)q * S.Pb + gc];
+  }
+  for (int64_t e = tid; e < (int64_t)ar * ar; e += nth) R.Mc[e] = S.Mc[e];
+}
+
+// ---- partition back-substitution: x_I = L_I^-T (y_I - Y_I^T x_border), grid = p -------
+template <int MCAP>
+__global__ void __launch_bounds__(256) partition_backward_kernel(CholArgs A, const double* xr /*reduced solution [Pbr + a]*/) {
+  __shared__ double xb[2 * MCAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Pb = A.sys.Pb, a = A.sys.a, hb = A.sys.hb, W = A.sys.W;
+  const Part pt = part_of(A, blockIdx.x);
+  const int c0 = pt.c0, c1 = pt.c1, nsep = pt.nsep, Pbr = A.red.Pb;
+  constexpr int xmask = 2 * MCAP - 1;
+  for (int i = tid; i < 2 * MCAP; i += 256) xb[i] = 0.0;
+  __syncthreads();
+  if (pt.rs_right >= 0) for (int j = tid; j < hb; j += 256) { const double v = xr[pt.rs_right + j]; xb[(c1 + j) & xmask] = v; A.sol[c1 + j] = v; }
+  if (blockIdx.x == 0) for (int q = tid; q < a; q += 256) A.sol[Pb + q] = xr[Pbr + q];
+  const int c1r = c1 < Pb ? c1 : Pb;
+  for (int i = c0 + tid; i < c1r; i += 256) {
+    double t = A.sys.Mt[(int64_t)a * Pb + i];
+    for (int b = 0; b < nsep; ++b) t = fma(-A.Msep[(int64_t)b * Pb + i], xr[pt.rs_left + b], t);
+    for (int q = 0; q < a; ++q) t = fma(-A.sys.Mt[(int64_t)q * Pb + i], xr[Pbr + q], t);
+    A.sol[i] = t;
+  }
+  __syncthreads();
+  if (wave == 0) backward_sweep<MCAP>(A.sys.Mb, W, hb, Pb, c0, c1, A.sol, xb, lane);
+}
+
+// ---- host side ----------------------------------------------------------------------
+static size_t lds_bytes(int mcap, int br) {
+  const int brp = br | 1;
+  const size_t dbl = (size_t)mcap * mcap + (size_t)mcap * brp + (((size_t)br * brp + 1) & ~(size_t)1) + (size_t)(mcap + br) * PW + 2 * mcap + br + PW + 8;
+  return dbl * sizeof(double);
+}
+
+// number of time partitions for (Pb, hb): minimise  interior_panels + 1.6 * reduced_panels
+int choose_partitions(int Pb, int hb, int a) {
+  if (Pb < 8 * (hb + 8) || hb + PW > 64 || 2 * hb - 1 + PW > 128) return 1;
+  if (lds_bytes(64, hb + a + 1) > 160 * 1024 - 256 || lds_bytes(128, a + 1) > 160 * 1024 - 256) return 1;
+  if ((64 - PW) + hb + a + 1 > 16 * 56 || PW * (hb + a + 1) > kCholThreads) return 1;
+  int best = 1; double best_cost = Pb / 8.0;
+  for (int p = 2; p <= 192; ++p) {
+    const int L = (((Pb - (p - 1) * hb) / p) / PW) * PW;
+    if (L < 2 * hb || L < 64) break;
+    const double cost = 1.5 * (L / 8.0) + 1.8 * ((p - 1) * hb / 8.0) + 6.0;
+    if (cost < best_cost) { best_cost = cost; best = p; }
+  }
+  return best;
+}
+
+int64_t solve_workspace_doubles(const TangentLayout& tl) {
+  const int p = 192;   // upper bound used by choose_partitions
+  const int64_t Pbr = (int64_t)(p - 1) * tl.hb, Wr = 2 * tl.hb, ar = tl.a + 1;
+  return (int64_t)tl.hb * tl.Pb + Pbr * Wr + ar * Pbr + ar * ar + (Pbr + ar) + 64;
+}
+
+template <int MCAP, int MODE>
+static void launch_sweep(const CholArgs& A, int grid, int br, hipStream_t st) {
+  const size_t lds = lds_bytes(MCAP, br);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<MCAP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((band_arrow_cholesky_kernel<MCAP, MODE>), dim3(grid), dim3(kCholThreads), lds, st, A, br | 1);
+}
+
+int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st) {
+  const int ar = tl.a + 1;
+  const int m = tl.hb + PW;
+  if (m > 128) return -1;
+  const int mcap = m <= 64 ? 64 : 128;
+  CholArgs A{};
+  A.sys = CholSys{sb.Mb, sb.Mt, sb.Mc, tl.Pb, tl.W, tl.hb, tl.a};
+  A.sol = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof; A.p = 1; A.L = 0; A.Msep = nullptr;
+  int p = sb.force_p > 0 ? sb.force_p : choose_partitions(tl.Pb, tl.hb, tl.a);
+  if (sb.ws == nullptr || sb.ws_doubles < solve_workspace_doubles(tl)) p = 1;
+  if (p > 1) {
+    const int L = (((tl.Pb - (p - 1) * tl.hb) / p) / PW) * PW;
+    if (L < tl.hb + PW) p = 1; else A.L = L;
+  }
+  if (p <= 1) {
+    if (lds_bytes(mcap, ar) > 160 * 1024 - 256) return -1;
+    if ((m - PW) + ar > 16 * 56 || PW * ar > kCholThreads) return -1;
+    if (mcap == 64) launch_sweep<64, 0>(A, 1, ar, st); else launch_sweep<128, 0>(A, 1, ar, st);
+    return 0;
+  }
+  // workspace carve: Msep | reduced band | reduced arrow rows | reduced corner | reduced solution
+  A.p = p;
+  const int Pbr = (p - 1) * tl.hb, hbr = 2 * tl.hb - 1, Wr = hbr + 1;
+  double* w = sb.ws;
+  A.Msep = w; w += (int64_t)tl.hb * tl.Pb;
+  A.red = CholSys{w, nullptr, nullptr, Pbr, Wr, hbr, tl.a}; w += (int64_t)Pbr * Wr;
+  A.red.Mt = w; w += (int64_t)ar * Pbr;
+  A.red.Mc = w; w += (int64_t)ar * ar;
+  double* xr = w;
+  hipLaunchKernelGGL(reduced_init_kernel, dim3(64), dim3(256), 0, st, A);
+  launch_sweep<64, 1>(A, p, tl.hb + ar, st);
+  CholArgs R{};
+  R.sys = A.red; R.sol = xr; R.fail = A.fail; R.prof = nullptr; R.p = 1; R.L = 0; R.Msep = nullptr;
+  launch_sweep<128, 0>(R, 1, ar, st);
+  hipLaunchKernelGGL((partition_backward_kernel<64>), dim3(p), dim3(256), 0, st, A, (const double*)xr);
+  return 0;
+}
+
+}  // namespace oicc

@@ -24,33 +24,6 @@
 
 namespace oicc {
 
-constexpr int PW = 8;          // panel width
-constexpr int kSolveThreads = 1024;   // 16 waves: step B is spread wide, step A runs on 1-2 waves
-
-struct LmState {               // device-resident scalars of the LM iteration
-  double radius;
-  double model_cost_change;
-  double step_norm_sq;         // ambient ||x - x_cand||^2 over active blocks
-  double x_norm_sq;            // ambient ||x||^2 over active blocks
-  double gradient_max_norm;
-  double cand_cost;
-  int32_t chol_failed;
-  int32_t pad;
-};
-
-struct SolveBuffers {
-  // damped, scaled system (input of the factorisation; overwritten by the factor)
-  double* Mb;      // [Pb][W]   band
-  double* Mt;      // [ar][Pb]  arrow rows, ar = a + 1 (last row: -g_s band part)
-  double* Mc;      // [ar][ar]  corner
-  double* scale;   // [P] Jacobi scaling
-  double* diag;    // [P] clamped diagonal of the scaled J^T J (kept for reuse_diagonal)
-  double* D2;      // [P]
-  double* step_s;  // [P] solution in the scaled space
-  LmState* st;
-  long long* prof;   // optional: 8 cycle counters of the solver phases (debug)
-};
-
 // ---- build the damped system  M = S H S + diag(D2),  rhs = -S g ----------------
 __global__ void lm_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                 double min_diag, double max_diag) {
@@ -121,320 +94,6 @@ __global__ void lm_gradmax_kernel(NormalEq ne, int P, LmState* st) {
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]); __syncthreads(); }
   if (threadIdx.x == 0) st->gradient_max_norm = sm[0];
-}
-
-// ---- bordered band Cholesky + solve, one workgroup ----------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// window geometry (all in LDS, doubles); MCAP (64 or 128) >= m = hb + PW is a
-// power of two so that circular indices are masks:
-//   Wc  [MCAP][MCAP]   column major: (gr, gc) -> Wc[(gc & mask) * MCAP + (gr & mask)], gr >= gc
-//   At  [MCAP][arp]    arrow rows:   (q, gc)  -> At[(gc & mask) * arp + q]
-//   Cq  [ar][arp]      corner:       (q1, q2) -> Cq[q2 * arp + q1] (lower, q1 >= q2)
-//   Lp  [MCAP + ar][PW] current panel of L, row major (8 contiguous doubles per row)
-//   xb  [2*MCAP]       circular buffer of solved step entries (backward sweep)
-// Global factor storage (in place of the damped system): Mb[gc*W + k] = L(gc+k, gc)
-// for k >= 1 and 1/L(gc,gc) for k = 0;  Mt[q*Pb + gc] = Y(q, gc).
-constexpr int NPA = 1;   // arrow prefetch slots per thread: PW*ar <= NPA*kSolveThreads  (arrow <= 127)
-
-template <int MCAP>
-__global__ void __launch_bounds__(kSolveThreads) band_arrow_cholesky_kernel(TangentLayout tl, SolveBuffers sb, int arp) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int mask = MCAP - 1;
-  constexpr int LOG = MCAP == 64 ? 6 : 7;
-  constexpr int NPW = PW * MCAP / kSolveThreads > 0 ? PW * MCAP / kSolveThreads : 1;   // window prefetch slots per thread
-  constexpr int KMAX = MCAP / 8;                      // backward sweep: band entries per lane
-  constexpr int NPASS = MCAP / 64;                    // row passes of step B (lane = row)
-  constexpr int xmask = 2 * MCAP - 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Pb = tl.Pb, a = tl.a, hb = tl.hb, W = tl.W, ar = a + 1;
-  const int m = hb + PW;                       // window size (<= MCAP)
-  double* const Wc = smem;
-  double* const At = Wc + (size_t)MCAP * MCAP;
-  double* const Cq = At + (size_t)MCAP * arp;
-  double* const Lp = Cq + (((size_t)ar * arp + 1) & ~(size_t)1);
-  double* const xb = Lp + (size_t)(MCAP + ar) * PW;
-  double* const da = xb + 2 * MCAP;
-  double* const dinv = da + ar;
-  int* const fail_flag_p = reinterpret_cast<int*>(dinv + PW);
-  if (tid == 0) *fail_flag_p = 0;
-  const int Pb_pad = ((Pb + PW - 1) / PW) * PW;  // virtual identity columns beyond Pb
-  const double* const Mb = sb.Mb;
-  const double* const Mt = sb.Mt;
-  const bool prof = sb.prof != nullptr;
-  long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = prof ? clock64() : 0;
-#define PROF_MARK(i) do { if (prof) { const long long tn_ = clock64(); pc[i] += tn_ - tprev; tprev = tn_; } } while (0)
-
-  // initial window: global rows/cols [0, m); entries outside the band are zero
-  for (int e = tid; e < MCAP * MCAP; e += kSolveThreads) {
-    const int gc = e >> LOG, gr = e & mask;
-    if (gr >= gc && gr < m) {
-      const int k = gr - gc;
-      Wc[gc * MCAP + gr] = k > hb ? 0.0 : (gr < Pb ? Mb[(int64_t)gc * W + k] : (k == 0 ? 1.0 : 0.0));
-    }
-  }
-  for (int e = tid; e < m * ar; e += kSolveThreads) {
-    const int gc = e / ar, q = e - gc * ar;
-    At[(gc & mask) * arp + q] = gc < Pb ? Mt[(int64_t)q * Pb + gc] : 0.0;
-  }
-  for (int e = tid; e < ar * ar; e += kSolveThreads) {
-    const int q2 = e / ar, q1 = e - q2 * ar;
-    Cq[q2 * arp + q1] = sb.Mc[q1 * ar + q2];
-  }
-  // per-thread constants of the window-advance prefetch
-  int pa_cc[NPA], pa_q[NPA];
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) { const int e = tid + i * kSolveThreads; pa_cc[i] = e < PW * ar ? e / ar : -1; pa_q[i] = e < PW * ar ? e - pa_cc[i] * ar : 0; }
-  __syncthreads();
-
-  // rows handled in step A by wave w: lanes 0..7 = the panel's diagonal rows,
-  // lanes 8..63 = entries [w*56, w*56+56) of the list {band rows PW..m-1, arrow rows 0..ar-1}
-  const int RN = (m - PW) + ar;
-  int rhoA;  // row id: < m band window row (relative), >= m arrow row (m + q), -1 none
-  if (lane < PW) rhoA = lane;
-  else { const int li = wave * 56 + (lane - PW); rhoA = li < RN ? (li < m - PW ? PW + li : m + (li - (m - PW))) : -1; }
-  const bool publishA = rhoA >= 0 && (lane >= PW || wave == 0);
-
-  PROF_MARK(0);
-  for (int j0 = 0; j0 < Pb_pad; j0 += PW) {
-    // ---- prefetch the rows / arrow columns that enter the window after this panel
-    const int nj0 = j0 + PW;
-    double pre_w[NPW], pre_a[NPA];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int e = tid + i * kSolveThreads;
-      const int rr = e >> LOG, ci = e & mask;
-      const int gr = j0 + m + rr, gc = nj0 + ci;
-      const int k = gr - gc;
-      double v = 0.0;
-      if (e < PW * MCAP && ci < m && k >= 0 && k <= hb) v = gr < Pb ? Mb[(int64_t)gc * W + k] : (k == 0 ? 1.0 : 0.0);
-      pre_w[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      double v = 0.0;
-      const int gc = j0 + m + pa_cc[i];
-      if (pa_cc[i] >= 0 && gc < Pb) v = Mt[(int64_t)pa_q[i] * Pb + gc];
-      pre_a[i] = v;
-    }
-    PROF_MARK(1);
-    // ---------------- step A: factor the panel (wave synchronous) -------------
-    if (wave * 56 < RN) {
-      const int rho = rhoA;
-      double av[PW];
-#pragma unroll
-      for (int c = 0; c < PW; ++c) {
-        double v = 0.0;
-        if (rho >= 0) {
-          if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * MCAP + ((j0 + rho) & mask)]; }
-          else v = At[((j0 + c) & mask) * arp + (rho - m)];
-        }
-        av[c] = v;
-      }
-      double rsd = 1.0;   // 1/L(c,c) for the diagonal row this lane holds
-#pragma unroll
-      for (int c = 0; c < PW; ++c) {
-        double piv = readlane_f64(av[c], c);
-        if (!(piv > 0.0)) { if (lane == 0) *fail_flag_p = 1; piv = 1.0; }
-        // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps (full fp64 accuracy)
-        const double h = 0.5 * piv;
-        double y = __builtin_amdgcn_rsq(piv);
-        y = y * fma(-h * y, y, 1.5);
-        y = y * fma(-h * y, y, 1.5);
-        const double l = av[c] * y;
-        av[c] = l;
-        if (lane == c) rsd = y;
-#pragma unroll
-        for (int c2 = c + 1; c2 < PW; ++c2) {
-          const double lc2 = readlane_f64(l, c2);
-          av[c2] = fma(-l, lc2, av[c2]);
-        }
-      }
-      // LDS copy of the panel for step B (the global factor is written there too)
-      if (publishA) {
-        double* lp = Lp + (size_t)rho * PW;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) lp[c] = (rho < c) ? 0.0 : av[c];
-        if (lane < PW && wave == 0) dinv[lane] = rsd;
-      }
-    }
-    PROF_MARK(2);
-    __syncthreads();
-    PROF_MARK(3);
-    // ---------------- step B: trailing update + window advance ----------------
-    // (1) band rows: lane = window row rho, wave = column group gamma = PW+wave, +4, ... <= rho
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int rho = lane + 64 * ps;
-      if (rho < m) {
-        double lr[PW];
-        const double* lrp = Lp + (size_t)rho * PW;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) lr[c] = lrp[c];
-        // global factor: wave w publishes panel columns 2w, 2w+1 of this row
-        const int gr = j0 + rho;
-        if (gr < Pb) {
-          if (wave < PW) {   // wave w publishes panel column w of this row
-            const int c = wave, k = rho - c;
-            if (k >= 0 && k <= hb) sb.Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinv[c] : lrp[c];   // lrp: LDS (no dynamic register indexing)
-          }
-        }
-        double* const wrow = Wc + ((j0 + rho) & mask);
-        constexpr int NG = kSolveThreads / 64;
-        for (int g0 = PW + wave; g0 <= rho; g0 += 4 * NG) {
-          double cur[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; cur[g] = gamma <= rho ? wrow[((j0 + gamma) & mask) * MCAP] : 0.0; }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int gamma = g0 + NG * g;
-            const double* lc = Lp + (size_t)(gamma < m ? gamma : m - 1) * PW;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
-            cur[g] -= s0 + s1;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; if (gamma <= rho) wrow[((j0 + gamma) & mask) * MCAP] = cur[g]; }
-        }
-      }
-    }
-    PROF_MARK(8);
-    // (2) arrow rows q: columns gamma in [PW, m) -> At, arrow columns q2 <= q -> Cq
-    {
-      const int ncol = (m - PW) + ar;
-      for (int e = tid; e < ar * ncol; e += kSolveThreads) {
-        const int ci = e / ar, q = e - ci * ar;
-        const int gamma = PW + ci;                 // < m: band column, else arrow column gamma - m
-        if (gamma >= m && gamma - m > q) continue;
-        const double* lr = Lp + (size_t)(m + q) * PW;
-        const double* lc = Lp + (size_t)gamma * PW;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
-        double* d = gamma < m ? &At[((j0 + gamma) & mask) * arp + q] : &Cq[(gamma - m) * arp + q];
-        *d -= s0 + s1;
-      }
-      // arrow part of the global factor
-      for (int e = tid; e < ar * PW; e += kSolveThreads) {
-        const int q = e >> 3, c = e & 7;
-        if (j0 + c < Pb) sb.Mt[(int64_t)q * Pb + j0 + c] = Lp[(size_t)(m + q) * PW + c];
-      }
-    }
-    PROF_MARK(9);
-    // (3) window advance: the entering rows alias only slots of the finished panel
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int e = tid + i * kSolveThreads;
-      const int rr = e >> LOG, ci = e & mask;
-      const int gr = j0 + m + rr, gc = nj0 + ci;
-      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * MCAP + (gr & mask)] = pre_w[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NPA; ++i)
-      if (pa_cc[i] >= 0) At[((j0 + m + pa_cc[i]) & mask) * arp + pa_q[i]] = pre_a[i];
-    PROF_MARK(4);
-    __syncthreads();
-    PROF_MARK(5);
-  }
-
-  // ---------------- corner: dense Cholesky of the a x a Schur complement --------
-  // Cq holds [C - Y^T Y | rhs_a]; row a is the right-hand-side row.
-  for (int c = 0; c < a; ++c) {
-    if (tid == 0) { double piv = Cq[c * arp + c]; if (!(piv > 0.0)) { *fail_flag_p = 1; piv = 1.0; } Cq[c * arp + c] = sqrt(piv); }
-    __syncthreads();
-    const double d = Cq[c * arp + c];
-    for (int r = c + 1 + tid; r < ar; r += kSolveThreads) Cq[c * arp + r] /= d;
-    __syncthreads();
-    const int nrem = ar - (c + 1);
-    for (int e = tid; e < nrem * nrem; e += kSolveThreads) {
-      const int c2 = c + 1 + e / nrem, r = c + 1 + e % nrem;
-      if (r >= c2 && c2 < a) Cq[c2 * arp + r] -= Cq[c * arp + r] * Cq[c * arp + c2];
-    }
-    __syncthreads();
-  }
-  // back substitution on the arrow: da = Lc^-T y_a, y_a = row `a` of Cq
-  if (tid == 0) {
-    for (int i = a - 1; i >= 0; --i) {
-      double s = Cq[i * arp + a];
-      for (int k = i + 1; k < a; ++k) s -= Cq[i * arp + k] * da[k];
-      da[i] = s / Cq[i * arp + i];
-    }
-  }
-  __syncthreads();
-  for (int q = tid; q < a; q += kSolveThreads) sb.step_s[Pb + q] = da[q];
-  // t = y - Y da for every band row, all threads (coalesced); parked in step_s
-  for (int i = tid; i < Pb; i += kSolveThreads) {
-    double t = Mt[(int64_t)a * Pb + i];
-    for (int q = 0; q < a; ++q) t = fma(-Mt[(int64_t)q * Pb + i], da[q], t);
-    sb.step_s[i] = t;
-  }
-  __syncthreads();
-  PROF_MARK(6);
-
-  // ---------------- backward sweep: d_b = L^-T t ---------------------------------
-  // 8-row blocks from the bottom, one wave; the factor entries of the NEXT block are
-  // prefetched into registers while the current block is solved.
-  if (wave == 0 && Pb > 0) {
-    for (int i = lane; i < 2 * MCAP; i += 64) xb[i] = 0.0;
-    const int ri = lane >> 3, sl = lane & 7;
-    const int k0 = (PW - ri) + sl;            // first band offset of this lane's slice
-    double n_part[KMAX], n_tri[PW], n_dinv, n_t;
-    auto load_block = [&](int jb) {
-      const int gi = jb + ri;
-      const double* prow = Mb + (int64_t)gi * W + k0;
-#pragma unroll
-      for (int t = 0; t < KMAX; ++t) {
-        const int k = k0 + 8 * t;
-        n_part[t] = (k <= hb && gi + k < Pb) ? prow[8 * t] : 0.0;
-      }
-      const int gl = jb + lane;   // lanes 0..7: row of the diagonal block
-      const double* trow = Mb + (int64_t)gl * W - lane;
-#pragma unroll
-      for (int r = 0; r < PW; ++r) n_tri[r] = (lane < r && r - lane <= hb && jb + r < Pb) ? trow[r] : 0.0;
-      n_dinv = (lane < PW && gl < Pb) ? Mb[(int64_t)gl * W] : 1.0;
-      n_t = (lane < PW && gl < Pb) ? sb.step_s[gl] : 0.0;
-    };
-    load_block(Pb_pad - PW);
-    for (int jb = Pb_pad - PW; jb >= 0; jb -= PW) {
-      double c_part[KMAX], c_tri[PW];
-#pragma unroll
-      for (int t = 0; t < KMAX; ++t) c_part[t] = n_part[t];
-#pragma unroll
-      for (int r = 0; r < PW; ++r) c_tri[r] = n_tri[r];
-      const double c_dinv = n_dinv, c_t = n_t;
-      if (jb >= PW) load_block(jb - PW);
-      // part_i = sum_{gr >= jb+PW} L(gr, i) x_gr, row i = jb + ri, 8 lanes per row
-      double p0 = 0.0, p1 = 0.0;
-      const int xi = jb + ri + k0;
-#pragma unroll
-      for (int t = 0; t < KMAX; t += 2) {
-        p0 = fma(c_part[t], xb[(xi + 8 * t) & xmask], p0);
-        p1 = fma(c_part[t + 1], xb[(xi + 8 * t + 8) & xmask], p1);
-      }
-      double part = p0 + p1;
-      part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-      double tv = c_t - __shfl(part, (lane & 7) * 8, 64);   // lane r (0..7): row jb + r
-      double xv = 0.0;
-#pragma unroll
-      for (int r = PW - 1; r >= 0; --r) {
-        const double xr = readlane_f64(tv, r) * readlane_f64(c_dinv, r);
-        if (lane == r) xv = xr;
-        tv = fma(-c_tri[r], xr, tv);     // c_tri[r] = L(jb+r, jb+lane) for lane < r, else 0
-      }
-      if (lane < PW) { const int gr = jb + lane; xb[gr & xmask] = xv; if (gr < Pb) sb.step_s[gr] = xv; }
-    }
-  }
-  __syncthreads();
-  PROF_MARK(7);
-  if (tid == 0) sb.st->chol_failed = *fail_flag_p;
-  if (prof && tid == 0) for (int i = 0; i < 12; ++i) sb.prof[i] = pc[i];
-#undef PROF_MARK
 }
 
 // ---- retraction x_cand = x (+) (scale .* step_s), reductions -------------------
@@ -552,32 +211,6 @@ void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   int64_t work = (int64_t)tl.Pb * tl.W + (int64_t)(tl.a + 1) * tl.Pb + 1024;
   int grid = int((work + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(lm_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag);
-}
-// returns LDS bytes needed; mcap = 64 or 128 (0 if the window does not fit)
-size_t solve_lds_bytes(const TangentLayout& tl, int* mcap_out, int* arp_out) {
-  const int m = tl.hb + PW;
-  const int mcap = m <= 64 ? 64 : (m <= 128 ? 128 : 0);
-  const int ar = tl.a + 1;
-  const int arp = ar | 1;   // odd row pitch
-  *mcap_out = mcap; *arp_out = arp;
-  if (mcap == 0) return 0;
-  const size_t dbl = (size_t)mcap * mcap + (size_t)mcap * arp + (((size_t)ar * arp + 1) & ~(size_t)1) + (size_t)(mcap + ar) * PW + 2 * mcap + ar + PW + 8;
-  return dbl * sizeof(double);
-}
-int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st) {
-  int mcap, arp;
-  const size_t lds = solve_lds_bytes(tl, &mcap, &arp);
-  if (mcap == 0 || lds > 160 * 1024 - 64) return -1;
-  if (tl.hb + tl.a + 1 > 4 * 56) return -1;
-  if (PW * (tl.a + 1) > NPA * kSolveThreads) return -1;
-  if (mcap == 64) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(band_arrow_cholesky_kernel<64>, dim3(1), dim3(kSolveThreads), lds, st, tl, sb, arp);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(band_arrow_cholesky_kernel<128>, dim3(1), dim3(kSolveThreads), lds, st, tl, sb, arp);
-  }
-  return 0;
 }
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st) {

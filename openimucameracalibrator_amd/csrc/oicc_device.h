@@ -72,4 +72,25 @@ struct EvalCtx {
   double* dbg_jac;        // optional per-row Jacobian dump in the fixed ABI layout
 };
 
+// device-resident scalars of one LM iteration (the only per-iteration read-back)
+struct LmState {
+  double radius, model_cost_change, step_norm_sq, x_norm_sq, gradient_max_norm, cand_cost;
+  int32_t chol_failed, pad;
+};
+
+struct SolveBuffers {
+  double* Mb;      // [Pb][W]   damped scaled band; overwritten by the factor (diagonal slot = 1/L_ii)
+  double* Mt;      // [a+1][Pb] arrow rows + rhs row (-g_s); overwritten by Y = L^-1 E
+  double* Mc;      // [a+1][a+1] corner
+  double* scale;   // [P] Jacobi scaling
+  double* diag;    // [P] clamped diagonal of the scaled J^T J (kept for reuse_diagonal)
+  double* D2;      // [P]
+  double* step_s;  // [P] solution in the scaled space
+  LmState* st;
+  long long* prof; // optional: cycle counters of the solver phases (debug)
+  double* ws;      // workspace of the time-partitioned solve (separator rows, reduced system)
+  int64_t ws_doubles;
+  int force_p;     // > 0: force this many partitions (tests); 0: heuristic
+};
+
 }  // namespace oicc

@@ -31,8 +31,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
                        hipStream_t st);
 // kernels_solve.hip
-struct LmState { double radius, model_cost_change, step_norm_sq, x_norm_sq, gradient_max_norm, cand_cost; int32_t chol_failed, pad; };
-struct SolveBuffers { double *Mb, *Mt, *Mc, *scale, *diag, *D2, *step_s; LmState* st; long long* prof; };
+int64_t solve_workspace_doubles(const TangentLayout& tl);
 void launch_lm_scale(const NormalEq& ne, const TangentLayout& tl, double* scale, int jacobi, hipStream_t st);
 void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st);
 void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
@@ -133,6 +132,7 @@ struct oicc_problem {
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
   ImuDev d_acc, d_gyr;
   DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
+  DevBuf<double> d_ws;
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
   DevBuf<LmState> d_state;
@@ -146,7 +146,7 @@ struct oicc_problem {
     opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
-    opt["verbose"] = 0; opt["num_threads"] = 0;
+    opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0;
   }
 };
 
@@ -302,7 +302,8 @@ int make_layout(oicc_problem* p, int flags) {
   const int ar = tl.a + 1;
   if (!p->d_ne.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
       !p->d_Mc.resize(int64_t(ar) * ar) || !p->d_scale.resize(std::max(tl.P, 1)) || !p->d_diag.resize(std::max(tl.P, 1)) ||
-      !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1)) {
+      !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1) ||
+      !p->d_ws.resize(size_t(solve_workspace_doubles(tl)))) {
     p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   ne.base = p->d_ne.p;
   p->layout_flags = flags;
@@ -637,7 +638,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   S.seconds_jacobian += now_s() - t0;
   S.initial_cost = cost;
   if (P == 0) return finish(OICC_CONVERGENCE, "no variable parameters");
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs));
   auto read_state = [&]() -> int {
@@ -731,7 +732,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
   LmState hs;
   for (int it = 0; it < steps; ++it) {
     rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
@@ -786,7 +787,7 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
@@ -813,7 +814,7 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
   rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
   const TangentLayout& tl = p->tl;
   DevBuf<long long> d; if (!d.resize(12)) return OICC_ERR_HIP;
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
   launch_lm_scale(p->ne, tl, sb.scale, 1, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = 1e4;
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));

@@ -127,3 +127,23 @@ def test_c2_full_size_properties():
     qt = ds.truth["q_i_c"]
     ang = 2 * np.arccos(min(1.0, abs(float(q @ qt))))
     assert ang < np.deg2rad(0.5)
+
+
+@pytest.mark.parametrize("parts", [2, 3, 5])
+def test_time_partitioned_solver_matches_sequential(parts):
+    """The partitioned band+arrow Cholesky (p interior sweeps + reduced separator
+    system) must reproduce the single-workgroup solve: same LM iterates on C2."""
+    ds = synthetic.make_config("C2")
+    ref = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    ref.trajectory_.SetOption("solver_partitions", 1)
+    s1 = ref.trajectory_.Optimize(50, FLAGS1)
+    par = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    par.trajectory_.SetOption("solver_partitions", parts)
+    s2 = par.trajectory_.Optimize(50, FLAGS1)
+    assert s1["num_iterations"] == s2["num_iterations"] and s1["termination"] == s2["termination"]
+    c1 = [i["cost"] for i in ref.trajectory_.GetIterations()]
+    c2 = [i["cost"] for i in par.trajectory_.GetIterations()]
+    assert np.allclose(c1, c2, rtol=1e-9, atol=0)
+    assert np.abs(ref.trajectory_.GetT_i_c() - par.trajectory_.GetT_i_c()).max() < 1e-9
+    k1, k2 = ref.trajectory_.GetKnots(), par.trajectory_.GetKnots()
+    assert np.abs(k1[0] - k2[0]).max() < 1e-9 and np.abs(k1[1] - k2[1]).max() < 1e-9
