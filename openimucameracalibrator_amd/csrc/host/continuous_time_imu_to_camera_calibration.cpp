@@ -1,0 +1,292 @@
+// continuous_time_imu_to_camera_calibration -- CLI with the reference's flags and
+// JSON / UBJSON file contract, running the solve on the MI355X through liboicc_hip.
+//
+// Mirrors applications/continuous_time_imu_to_camera_calibration.cc:38-332 of the
+// reference (flags :38-80, input reading :91-184, two-stage optimisation :186-221,
+// result JSON :226-332).  Differences, all documented in DESIGN.md:
+//  * --input_pose_dataset takes a JSON twin of the TheiaSfM .calibdata file (cereal
+//    binary of theia::Reconstruction, unreadable without TheiaSfM):
+//      {"views": {"<name>": {"orientation_angle_axis": [3] (world->camera, as
+//       theia::Camera stores it), "position": [3]}}, "tracks": {"<id>": [x,y,z,w]}}
+//  * the two PLY files and the OpenCV debug overlay (:334-454) are not produced;
+//  * --dry_run parses and cross-checks every input without touching the GPU;
+//  * --device selects the HIP device.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <string>
+
+#include "estimator.hpp"
+#include "json_min.hpp"
+
+using namespace OpenICC;
+using namespace OpenICC::core;
+using oicc_json::Value;
+
+namespace {
+
+struct Flags {
+  std::map<std::string, std::string> s = {
+      {"telemetry_json", ""}, {"input_pose_dataset", ""}, {"input_corners", ""}, {"camera_calibration_json", ""},
+      {"gyro_to_cam_initial_calibration", ""}, {"imu_intrinsics", ""}, {"imu_bias_file", ""}, {"global_shutter", "false"},
+      {"spline_error_weighting_json", ""}, {"output_path", ""}, {"calibrate_cam_line_delay", "false"}, {"result_output_json", ""},
+      {"max_t", "1000."}, {"reestimate_biases", "false"}, {"gravity_const", "9.81"}, {"known_grav_dir_axis", "Z"},
+      {"debug_video_path", ""}, {"dry_run", "false"}, {"device", "0"}, {"solver_partitions", "0"}};
+  bool parse(int argc, char** argv) {
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a.rfind("--", 0) != 0) { std::cerr << "unexpected argument " << a << "\n"; return false; }
+      a = a.substr(2);
+      std::string k = a, v; bool has = false;
+      const size_t eq = a.find('=');
+      if (eq != std::string::npos) { k = a.substr(0, eq); v = a.substr(eq + 1); has = true; }
+      bool neg = false;
+      if (!s.count(k) && k.rfind("no", 0) == 0 && s.count(k.substr(2))) { k = k.substr(2); neg = true; }
+      if (!s.count(k)) { std::cerr << "unknown flag --" << k << "\n"; return false; }
+      const bool is_bool = s[k] == "true" || s[k] == "false";
+      if (!has) { if (is_bool) v = neg ? "false" : "true"; else if (i + 1 < argc) v = argv[++i]; else { std::cerr << "flag --" << k << " needs a value\n"; return false; } }
+      s[k] = v;
+    }
+    return true;
+  }
+  std::string str(const std::string& k) const { return s.at(k); }
+  bool b(const std::string& k) const { const std::string& v = s.at(k); return v == "true" || v == "1"; }
+  double d(const std::string& k) const { return std::stod(s.at(k)); }
+};
+
+#define CHECK_MSG(cond, msg) do { if (!(cond)) { std::cerr << "Check failed: " #cond " " << msg << std::endl; std::exit(1); } } while (0)
+
+int model_from_string(const std::string& s) {   // theia::StringToCameraIntrinsicsModelType
+  if (s == "PINHOLE") return OICC_CAM_PINHOLE;
+  if (s == "PINHOLE_RADIAL_TANGENTIAL") return OICC_CAM_PINHOLE_RADIAL_TANGENTIAL;
+  if (s == "FISHEYE") return OICC_CAM_FISHEYE;
+  if (s == "DIVISION_UNDISTORTION") return OICC_CAM_DIVISION_UNDISTORTION;
+  if (s == "DOUBLE_SPHERE") return OICC_CAM_DOUBLE_SPHERE;
+  if (s == "EXTENDED_UNIFIED") return OICC_CAM_EXTENDED_UNIFIED;
+  return -1;
+}
+
+// src/io/read_camera_calibration.cc:35-118
+bool read_camera_calibration(const std::string& path, CalibDataset* cam, double* fps) {
+  Value j; if (!oicc_json::parse_file(path, &j)) { std::cerr << "Could not open: " << path << "\n"; return false; }
+  const std::string type = j.at("intrinsic_type").as_string();
+  cam->camera_model = model_from_string(type);
+  if (cam->camera_model < 0) { std::cerr << "unsupported intrinsic_type " << type << "\n"; return false; }
+  cam->image_width = int(j.at("image_width").as_double()); cam->image_height = int(j.at("image_height").as_double());
+  const Value& in = j.at("intrinsics");
+  const double f = in.at("focal_length").as_double(), cx = in.at("principal_pt_x").as_double(), cy = in.at("principal_pt_y").as_double();
+  const double ar = in.contains("aspect_ratio") ? in.at("aspect_ratio").as_double() : 1.0;
+  *fps = j.at("fps").as_double();
+  auto g = [&](const char* k) { return in.at(k).as_double(); };
+  std::vector<double>& v = cam->intrinsics;
+  switch (cam->camera_model) {
+    case OICC_CAM_DIVISION_UNDISTORTION: v = {f, ar, cx, cy, g("div_undist_distortion")}; break;
+    case OICC_CAM_DOUBLE_SPHERE: v = {f, ar, 0.0, cx, cy, g("xi"), g("alpha")}; break;
+    case OICC_CAM_EXTENDED_UNIFIED: v = {f, ar, 0.0, cx, cy, g("alpha"), g("beta")}; break;
+    case OICC_CAM_FISHEYE: v = {f, ar, 0.0, cx, cy, g("radial_distortion_1"), g("radial_distortion_2"), g("radial_distortion_3"), g("radial_distortion_4")}; break;
+    case OICC_CAM_PINHOLE_RADIAL_TANGENTIAL: v = {f, ar, 0.0, cx, cy, g("radial_distortion_1"), g("radial_distortion_2"), g("radial_distortion_3"), g("tangential_distortion_1"), g("tangential_distortion_2")}; break;
+    case OICC_CAM_PINHOLE: v = {f, ar, 0.0, cx, cy, 0.0, 0.0}; break;   // the reference reads only the aspect ratio (:110-112)
+  }
+  return true;
+}
+
+// src/io/read_telemetry.cc:29-68
+bool ReadTelemetryJSON(const std::string& path, CameraTelemetryData* t) {
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  const Value& accl = j.at("accelerometer"); const Value& gyro = j.at("gyroscope"); const Value& ts = j.at("timestamps_ns");
+  if (gyro.size() != ts.size() || accl.size() != ts.size()) { std::cerr << "Telemetry should have the same amount of timestamps, accelerometer and gyroscope values.\n"; return false; }
+  for (size_t i = 0; i < ts.size(); ++i) {
+    const double t_s = ts.at(i).as_double() * NS_TO_S;
+    t->accelerometer.push_back({t_s, Vec3{{accl.at(i).at(0).as_double(), accl.at(i).at(1).as_double(), accl.at(i).at(2).as_double()}}});
+    t->gyroscope.push_back({t_s, Vec3{{gyro.at(i).at(0).as_double(), gyro.at(i).at(1).as_double(), gyro.at(i).at(2).as_double()}}});
+  }
+  if (j.contains("img_timestamps_ns")) for (size_t i = 0; i < j.at("img_timestamps_ns").size(); ++i) t->img_timestamps_s.push_back(j.at("img_timestamps_ns").at(i).as_double() * NS_TO_S);
+  return true;
+}
+// src/io/read_misc.cc:30-47
+bool ReadSplineErrorWeighting(const std::string& path, SplineWeightingData* w) {
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  w->cam_fps = j.at("camera_fps").as_double(); w->dt_r3 = j.at("r3").at("knot_spacing").as_double(); w->dt_so3 = j.at("so3").at("knot_spacing").as_double();
+  w->std_r3 = j.at("r3").at("weighting_factor").as_double(); w->std_so3 = j.at("so3").at("weighting_factor").as_double();
+  return true;
+}
+// src/io/read_misc.cc:65-82
+bool ReadIMU2CamInit(const std::string& path, Quat* imu_to_cam, double* time_offset) {
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  const Value& q = j.at("gyro_to_camera_rotation");
+  *imu_to_cam = Quat{q.at("x").as_double(), q.at("y").as_double(), q.at("z").as_double(), q.at("w").as_double()};
+  *time_offset = j.at("time_offset_gyro_to_cam").as_double();
+  return true;
+}
+// src/io/read_misc.cc:49-63,84-149
+bool ReadIMUIntrinsics(const std::string& path_intr, const std::string& path_bias, ThreeAxisSensorCalibParams* acc, ThreeAxisSensorCalibParams* gyr) {
+  if (!path_bias.empty()) {
+    Value j;
+    if (oicc_json::parse_file(path_bias, &j)) {
+      acc->bias = Vec3{{j.at("accl_bias").at("x").as_double(), j.at("accl_bias").at("y").as_double(), j.at("accl_bias").at("z").as_double()}};
+      gyr->bias = Vec3{{j.at("gyro_bias").at("x").as_double(), j.at("gyro_bias").at("y").as_double(), j.at("gyro_bias").at("z").as_double()}};
+    } else std::cerr << "Error loading IMU bias file: " << path_bias << "\n";
+  }
+  if (!path_intr.empty()) {
+    Value j; if (!oicc_json::parse_file(path_intr, &j)) return false;
+    auto M = [](const Value& m, int r, int c) { return m.at(size_t(r)).at(size_t(c)).as_double(); };
+    // misalignment matrix layout [[1,-yz,zy],[xz,1,-zx],[-xy,yx,1]] (utils/types.h:238-239)
+    const Value& ma = j.at("accelerometer").at("misalignment_matrix"); const Value& sa = j.at("accelerometer").at("scale_matrix");
+    acc->mis[0] = -M(ma, 0, 1); acc->mis[1] = M(ma, 0, 2); acc->mis[2] = -M(ma, 1, 2);     // accelerometer: upper triangle only
+    for (int i = 0; i < 3; ++i) acc->scale[i] = M(sa, i, i);
+    const Value& mg = j.at("gyroscope").at("misalignment_matrix"); const Value& sg = j.at("gyroscope").at("scale_matrix");
+    gyr->mis[0] = -M(mg, 0, 1); gyr->mis[1] = M(mg, 0, 2); gyr->mis[2] = -M(mg, 1, 2); gyr->mis[3] = M(mg, 1, 0); gyr->mis[4] = -M(mg, 2, 0); gyr->mis[5] = M(mg, 2, 1);
+    for (int i = 0; i < 3; ++i) gyr->scale[i] = M(sg, i, i);
+  }
+  return true;
+}
+// corner file: UBJSON (src/io/read_scene.cc:25-41) -- a .json text file is accepted too
+bool read_scene(const std::string& path, Value* scene) {
+  std::string bytes; if (!oicc_json::read_file(path, &bytes)) { std::cerr << "Can not open " << path << "\n"; return false; }
+  size_t i = 0; while (i < bytes.size() && (bytes[i] == ' ' || bytes[i] == '\n')) ++i;
+  const bool text = path.size() > 5 && path.substr(path.size() - 5) == ".json";
+  *scene = text ? oicc_json::Parser::parse(bytes) : oicc_json::UbjsonReader::parse(bytes);
+  return true;
+}
+// JSON twin of the TheiaSfM pose dataset
+bool read_pose_dataset(const std::string& path, std::map<std::string, View>* views, std::map<int, std::array<double, 4>>* tracks) {
+  if (path.size() > 10 && path.substr(path.size() - 10) == ".calibdata") {
+    std::cerr << "TheiaSfM .calibdata (cereal binary) cannot be read without TheiaSfM; export it to the JSON twin described in this file's header.\n"; return false; }
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  for (const auto& kv : j.at("views").obj) {
+    View v; v.name = kv.first;
+    const Value& o = kv.second;
+    if (o.contains("orientation_angle_axis")) { const Value& a = o.at("orientation_angle_axis"); v.q_wc = quat_conj(quat_from_angle_axis(Vec3{{a.at(0).as_double(), a.at(1).as_double(), a.at(2).as_double()}})); }
+    else { const Value& q = o.at("q_wc"); v.q_wc = quat_normalized(Quat{q.at("x").as_double(), q.at("y").as_double(), q.at("z").as_double(), q.at("w").as_double()}); }
+    const Value& p = o.at("position"); v.position = Vec3{{p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double()}};
+    (*views)[v.name] = v;
+  }
+  for (const auto& kv : j.at("tracks").obj) { const Value& p = kv.second; (*tracks)[std::stoi(kv.first)] = {p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double(), p.size() > 3 ? p.at(3).as_double() : 1.0}; }
+  return true;
+}
+
+Value xyz(const Vec3& v) { Value o; o["x"] = Value(v[0]); o["y"] = Value(v[1]); o["z"] = Value(v[2]); return o; }
+Value xyz(const double* v) { return xyz(Vec3{{v[0], v[1], v[2]}}); }
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  Flags F;
+  if (!F.parse(argc, argv)) return 2;
+
+  // pose dataset, corners, camera (cc:93-105)
+  std::map<std::string, View> pose_views; std::map<int, std::array<double, 4>> pose_tracks;
+  CHECK_MSG(read_pose_dataset(F.str("input_pose_dataset"), &pose_views, &pose_tracks), "Could not read Reconstruction file.");
+  Value scene_json;
+  CHECK_MSG(read_scene(F.str("input_corners"), &scene_json), "Failed to load " << F.str("input_corners"));
+  CalibDataset recon_calib_dataset; double fps = 0;
+  CHECK_MSG(read_camera_calibration(F.str("camera_calibration_json"), &recon_calib_dataset, &fps), "Could not read camera calibration: " << F.str("camera_calibration_json"));
+  recon_calib_dataset.tracks = pose_tracks;   // cc:107-119: the (possibly refined) tracks of the pose dataset
+
+  CameraTelemetryData telemetry_data;
+  CHECK_MSG(ReadTelemetryJSON(F.str("telemetry_json"), &telemetry_data), "Could not read: " << F.str("telemetry_json"));
+  const double t_offset_cam_s = telemetry_data.img_timestamps_s.empty() ? 0.0 : telemetry_data.img_timestamps_s[0];   // cc:126-129
+
+  size_t n_corners = 0;
+  for (const auto& view : scene_json.at("views").obj) {   // cc:131-161 (sorted string keys, like nlohmann's items())
+    const double timestamp_us = std::stod(view.first);
+    const std::string view_name = std::to_string(uint64_t(timestamp_us));
+    auto it = pose_views.find(view_name);
+    if (it == pose_views.end()) continue;                // view not in the pose dataset: removed again (cc:138-142)
+    View v = it->second;
+    v.timestamp_s = timestamp_us * US_TO_S + t_offset_cam_s;
+    for (const auto& pt : view.second.at("image_points").obj) {
+      const int id = std::stoi(pt.first);
+      if (!recon_calib_dataset.tracks.count(id)) continue;   // AddObservation fails for unknown tracks
+      v.features.push_back(Feature{id, pt.second.at(0).as_double(), pt.second.at(1).as_double()});
+    }
+    n_corners += v.features.size();
+    recon_calib_dataset.views.push_back(v);
+  }
+
+  Quat imu2cam; double time_offset_imu_to_cam = 0;
+  CHECK_MSG(ReadIMU2CamInit(F.str("gyro_to_cam_initial_calibration"), &imu2cam, &time_offset_imu_to_cam), "Could not read: " << F.str("gyro_to_cam_initial_calibration"));
+  SE3 T_i_c_init; T_i_c_init.q = quat_normalized(quat_conj(imu2cam));   // cc:170
+  ThreeAxisSensorCalibParams acc_intr, gyr_intr;
+  CHECK_MSG(ReadIMUIntrinsics(F.str("imu_intrinsics"), F.str("imu_bias_file"), &acc_intr, &gyr_intr), "Could not open " << F.str("imu_intrinsics"));
+  std::cout << "Loaded IMU intrinsics.\n";
+  CHECK_MSG(!F.str("spline_error_weighting_json").empty(), "You need to provide spline error weighting factors. Create with get_sew_for_dataset.py.");
+  SplineWeightingData weight_data;
+  CHECK_MSG(ReadSplineErrorWeighting(F.str("spline_error_weighting_json"), &weight_data), "Could not open " << F.str("spline_error_weighting_json"));
+
+  double init_line_delay_us = 1. / fps / recon_calib_dataset.image_height;   // [s] despite the name (cc:186-189, quirk Q1)
+  if (F.b("global_shutter")) init_line_delay_us = 0.0;
+
+  std::cout << "Inputs: " << recon_calib_dataset.views.size() << " views, " << n_corners << " corners, " << recon_calib_dataset.tracks.size()
+            << " board points, " << telemetry_data.accelerometer.size() << " IMU samples, camera model " << recon_calib_dataset.camera_model
+            << ", dt_r3/dt_so3 " << weight_data.dt_r3 << "/" << weight_data.dt_so3 << " s\n";
+  CHECK_MSG(!recon_calib_dataset.views.empty(), "no view of the corner file is in the pose dataset");
+  if (F.b("dry_run")) { std::cout << "dry run: inputs parsed, no solve.\n"; return 0; }
+
+  ImuCameraCalibrator imu_cam_calibrator(int(F.d("device")));
+  imu_cam_calibrator.trajectory_.SetOption("solver_partitions", F.d("solver_partitions"));
+  imu_cam_calibrator.BatchInitSpline(recon_calib_dataset, T_i_c_init, weight_data, time_offset_imu_to_cam, telemetry_data, init_line_delay_us, acc_intr, gyr_intr);
+  const std::string axis = F.str("known_grav_dir_axis");   // GravDirStringToInt, utils.cc:150-161
+  const int grav_dir_axis = axis == "X" ? 0 : (axis == "Y" ? 1 : (axis == "Z" ? 2 : -1));
+  int flags = SplineOptimFlags::SPLINE | SplineOptimFlags::T_I_C;
+  if (F.b("reestimate_biases")) flags |= SplineOptimFlags::IMU_BIASES;
+  if (grav_dir_axis != -1) {
+    Vec3 grav_dir{{0, 0, 0}}; grav_dir[size_t(grav_dir_axis)] = F.d("gravity_const");
+    imu_cam_calibrator.SetKnownGravityDir(grav_dir);
+    std::cout << "Setting a-priori gravity direction supplied by the user to: " << grav_dir[0] << " " << grav_dir[1] << " " << grav_dir[2] << "\n";
+  } else flags |= SplineOptimFlags::GRAVITY_DIR;
+
+  const double reproj_error = imu_cam_calibrator.Optimize(50, flags);   // cc:215
+  double reproj_error_after_ld = reproj_error;
+  if (F.b("calibrate_cam_line_delay") && !F.b("global_shutter")) {     // cc:217-221
+    flags = SplineOptimFlags::CAM_LINE_DELAY;
+    reproj_error_after_ld = imu_cam_calibrator.Optimize(10, flags);
+  }
+  std::cout << "Mean reprojection error " << reproj_error << "px\n";
+  std::cout << "Mean reprojection error after line delay optim " << reproj_error_after_ld << "px\n";
+
+  auto& tr = imu_cam_calibrator.trajectory_;
+  const Vec3 g = tr.GetGravity();
+  std::cout << "g: " << g[0] << " " << g[1] << " " << g[2] << std::endl;
+  const SE3 T = tr.GetT_i_c();
+  const double calib_line_delay_us = imu_cam_calibrator.GetCalibratedRSLineDelay() * S_TO_US;
+  std::cout << "T_i_c qw,qx,qy,qz: " << T.q.w << " " << T.q.x << " " << T.q.y << " " << T.q.z << std::endl;
+  std::cout << "T_i_c t: " << T.t[0] << " " << T.t[1] << " " << T.t[2] << std::endl;
+  std::cout << "Initialized line delay [us]: " << init_line_delay_us * S_TO_US << "\n";
+  std::cout << "Calibrated line delay [us]: " << calib_line_delay_us << "\n";
+
+  Value out;   // cc:247-262
+  out["q_i_c"]["w"] = Value(T.q.w); out["q_i_c"]["x"] = Value(T.q.x); out["q_i_c"]["y"] = Value(T.q.y); out["q_i_c"]["z"] = Value(T.q.z);
+  out["t_i_c"] = xyz(T.t);
+  out["final_reproj_error"] = Value(reproj_error);
+  out["r3_dt"] = Value(weight_data.dt_r3); out["so3_dt"] = Value(weight_data.dt_so3);
+  out["init_line_delay_us"] = Value(init_line_delay_us * S_TO_US);
+  out["calib_line_delay_us"] = Value(calib_line_delay_us);
+  out["time_offset_imu_to_cam_s"] = Value(time_offset_imu_to_cam);
+
+  // trajectory dump (cc:274-327): one batched device evaluation instead of per-sample getters
+  std::vector<int64_t> t_ns; std::vector<std::string> keys;
+  for (const auto& kv : imu_cam_calibrator.GetGyroMeasurements()) { const int64_t t = int64_t(kv.first * S_TO_NS); t_ns.push_back(t); keys.push_back(std::to_string(t)); }
+  std::vector<double> gyro, accel, gb, ab; std::vector<uint8_t> valid;
+  tr.GetTrajectory(t_ns, &gyro, &accel, &gb, &ab, &valid);
+  Value& traj = out["trajectory"];
+  size_t i = 0;
+  auto acc_it = imu_cam_calibrator.GetAcclMeasurements().begin();
+  for (const auto& kv : imu_cam_calibrator.GetGyroMeasurements()) {
+    Value& e = traj[keys[i]];
+    e["gyro_imu"] = xyz(kv.second); e["gyro_spline"] = xyz(&gyro[3 * i]); e["gyro_bias"] = xyz(&gb[3 * i]);
+    e["accl_imu"] = xyz(acc_it->second); e["accl_spline"] = xyz(&accel[3 * i]); e["accl_bias"] = xyz(&ab[3 * i]);
+    ++i; ++acc_it;
+  }
+  if (!F.str("result_output_json").empty()) {
+    std::ofstream f(F.str("result_output_json"));
+    CHECK_MSG(f.is_open(), "cannot write " << F.str("result_output_json"));
+    oicc_json::dump(out, f, 4); f << std::endl;   // std::setw(4), cc:330
+  }
+  const oicc_summary& s = imu_cam_calibrator.last_summary_;
+  std::cout << "done: P=" << s.num_parameters_tangent << " blocks=" << s.num_residual_blocks << "\n";
+  return 0;
+}

@@ -1,0 +1,64 @@
+"""The C++ CLI (csrc/host): reference flag names, JSON/UBJSON inputs, result JSON.
+CPU: --dry_run parses every input format; GPU: full calibration equals the Python
+mirror's result on the same dataset."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from openimucameracalibrator_amd import synthetic, io_files, estimator as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "openimucameracalibrator_amd", "csrc", "continuous_time_imu_to_camera_calibration")
+
+
+def ensure_cli():
+    if not os.path.exists(CLI):
+        subprocess.check_call(["make", "-C", os.path.dirname(CLI), "-s"])
+
+
+def run_cli(flags, *extra):
+    ensure_cli()
+    cmd = [CLI] + ["--%s=%s" % kv for kv in flags.items()] + list(extra)
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("camera", ["gopro9_division", "gopro6_fisheye", "pinhole_radtan"])
+def test_cli_dry_run_parses_all_input_formats(tmp_path, camera):
+    ds = synthetic.make_config("tiny", camera=camera)
+    flags = io_files.write_dataset_files(ds, str(tmp_path))
+    r = run_cli(flags, "--dry_run")
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("Inputs:")][0]
+    assert "%d views, %d corners, %d board points, %d IMU samples, camera model %d" % (
+        ds.num_views, ds.num_corners, len(ds.points), len(ds.imu_t_s), ds.camera_model) in line
+
+
+def test_cli_rejects_unknown_flags_and_missing_files(tmp_path):
+    assert run_cli({}, "--not_a_flag").returncode == 2
+    r = run_cli(dict(input_pose_dataset=str(tmp_path / "none.json")))
+    assert r.returncode == 1 and "Could not read Reconstruction file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_full_calibration_matches_python_mirror(tmp_path):
+    ds = synthetic.make_config("C1", camera="gopro9_division")
+    flags = io_files.write_dataset_files(ds, str(tmp_path))
+    r = run_cli(flags, "--known_grav_dir_axis=UNKNOWN", "--calibrate_cam_line_delay")
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.load(open(flags["result_output_json"]))
+    for k in ("q_i_c", "t_i_c", "final_reproj_error", "r3_dt", "so3_dt", "init_line_delay_us", "calib_line_delay_us", "time_offset_imu_to_cam_s", "trajectory"):
+        assert k in out
+    # same problem through the Python mirror (file round trip quantises timestamps to ns/us)
+    cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cal.Optimize(50, E.SPLINE | E.T_I_C | E.GRAVITY_DIR)
+    T = cal.trajectory_.GetT_i_c()
+    q = np.array([out["q_i_c"][c] for c in "xyzw"]); t = np.array([out["t_i_c"][c] for c in "xyz"])
+    assert min(np.abs(q - T[:4]).max(), np.abs(q + T[:4]).max()) < 1e-4
+    assert np.abs(t - T[4:]).max() < 1e-3
+    assert abs(out["final_reproj_error"] - cal.trajectory_.GetMeanReprojectionError()) < 1e-2
+    first = next(iter(out["trajectory"].values()))
+    assert set(first) == {"gyro_imu", "gyro_spline", "gyro_bias", "accl_imu", "accl_spline", "accl_bias"}
+    assert len(out["trajectory"]) == int(cal.gyro_accepted.sum())
