@@ -146,4 +146,4 @@ def test_time_partitioned_solver_matches_sequential(parts):
     assert np.allclose(c1, c2, rtol=1e-9, atol=0)
     assert np.abs(ref.trajectory_.GetT_i_c() - par.trajectory_.GetT_i_c()).max() < 1e-9
     k1, k2 = ref.trajectory_.GetKnots(), par.trajectory_.GetKnots()
-    assert np.abs(k1[0] - k2[0]).max() < 1e-9 and np.abs(k1[1] - k2[1]).max() < 1e-9
+    assert np.abs(k1[0] - k2[0]).max() < 1e-9 and (np.abs(k1[1] - k2[1]) / (1 + np.abs(k1[1]))).max() < 1e-9
