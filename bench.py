@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# keep stdout to the single JSON line: RCCL prints a version banner to stdout at NCCL_DEBUG=VERSION/INFO
+if os.environ.get("OICC_KEEP_NCCL_DEBUG") != "1":
+    os.environ["NCCL_DEBUG"] = "WARN"
 
 import numpy as np  # noqa: E402
 
@@ -70,7 +73,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # OICC_BENCH_FORCE_ALLREDUCE=1 exercises the RCCL hook with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("OICC_BENCH_FORCE_ALLREDUCE") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
@@ -80,11 +86,11 @@ def main():
         base, num_views=base["num_views"] * world, duration=base["duration"] * world))
     cal = E.ImuCameraCalibrator(device=local_rank)
     tr = cal.trajectory_
-    if world > 1:   # share torch's stream so the RCCL all-reduce is ordered with the kernels
+    if use_dist:   # share torch's stream so the RCCL all-reduce is ordered with the kernels
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
     cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
 
-    if world > 1:
+    if use_dist:
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         staging = {}
@@ -103,12 +109,12 @@ def main():
 
     n_blocks_local = cal.num_blocks
     blocks = torch.tensor([n_blocks_local, cal.num_corners], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(blocks)
     n_blocks, n_corners = int(blocks[0]), int(blocks[1])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -120,7 +126,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
     ms_per_step = 1e3 * dt / args.steps
@@ -129,7 +135,7 @@ def main():
     out = None
     if rank == 0:
         # ---- per-kernel HIP-event timings (library stream) and roofline ----------
-        if world > 1:
+        if use_dist:
             tr.SetAllReduce(None)
         pass_ms, kern_ms = tr.TimeJacobianPass(flags, repeats=20)
         solve_ms = tr.TimeLinearSolve(flags, repeats=20)
@@ -205,11 +211,12 @@ def main():
                                                   fp64_TFLOPs=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 1e12)
             except Exception as e:  # the extra must never break the bench line
                 out["extra_c5_single_gpu"] = {"error": str(e)[:200]}
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@
 namespace oicc {
 
 constexpr int PW = 8;                 // panel width
-constexpr int kCholThreads = 1024;    // 16 waves: step B is spread wide, step A runs on 1-3 waves
+constexpr int kCholThreads = 512;     // 16 waves: step B is spread wide, step A runs on 1-3 waves
 
 struct CholSys { double* Mb; double* Mt; double* Mc; int Pb, W, hb, a; };
 
@@ -128,34 +128,35 @@ __device__ __forceinline__ void backward_sweep(const double* Mb, int W, int hb, 
 //   Lp [MCAP+br][PW] current panel of L (row major)
 //   xb [2*MCAP], da [br], dinv [PW], fail flag
 // MODE 0: full solve (p == 1, or the reduced system); MODE 1: partition forward sweep.
-template <int MCAP, int MODE>
+template <int MCAP, int MODE, bool PROF>
 __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholArgs A, int brp) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int mask = MCAP - 1;
   constexpr int LOG = MCAP == 64 ? 6 : 7;
   constexpr int NPW = PW * MCAP / kCholThreads > 0 ? PW * MCAP / kCholThreads : 1;
   constexpr int NPASS = MCAP / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int LDW = MCAP + 2;                 // padded column pitch of the window (bank spread for the MFMA tiles)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index is uniform: keep it scalar
   const int Pb = A.sys.Pb, a = A.sys.a, hb = A.sys.hb, W = A.sys.W, ar = a + 1;
   const Part pt = part_of(A, MODE == 1 ? blockIdx.x : 0);
   const int c0 = pt.c0, c1 = pt.c1, nsep = MODE == 1 ? pt.nsep : 0;
   const int br = nsep + ar;                     // border rows: [left separator | arrow | rhs]
   const int m = hb + PW;                        // window size (<= MCAP)
   double* const Wc = smem;
-  double* const At = Wc + (size_t)MCAP * MCAP;
+  double* const At = Wc + (size_t)MCAP * LDW;
   double* const Cq = At + (size_t)MCAP * brp;
   double* const Lp = Cq + (((size_t)br * brp + 1) & ~(size_t)1);
-  double* const xb = Lp + (size_t)(MCAP + br) * PW;
+  double* const xb = Lp + (size_t)(MCAP + br + 16) * PW;
   double* const da = xb + 2 * MCAP;
   double* const dinv = da + br;
   int* const fail_flag_p = reinterpret_cast<int*>(dinv + PW);
   if (tid == 0) *fail_flag_p = 0;
   double* const Mb = A.sys.Mb;
   double* const Mt = A.sys.Mt;
-  const bool prof = A.prof != nullptr && blockIdx.x == 0;
+  const bool prof = PROF && A.prof != nullptr && (int)blockIdx.x == (MODE == 1 ? 1 : 0);
   long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = prof ? clock64() : 0;
-#define PROF_MARK(i) do { if (prof) { const long long tn_ = clock64(); pc[i] += tn_ - tprev; tprev = tn_; } } while (0)
+#define PROF_MARK(i) do { if (PROF && prof) { const long long tn_ = clock64(); pc[i] += tn_ - tprev; tprev = tn_; } } while (0)
 
   // original (damped) band entry (gr, gc), gr >= gc, identity beyond Pb
   auto band_orig = [&](int gr, int gc) -> double {
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   // initial window: global rows/cols [c0, c0+m)
   for (int e = tid; e < MCAP * MCAP; e += kCholThreads) {
     const int ci = e >> LOG, rr = e & mask;
-    if (rr >= ci && rr < m) Wc[((c0 + ci) & mask) * MCAP + ((c0 + rr) & mask)] = band_orig(c0 + rr, c0 + ci);
+    if (rr >= ci && rr < m) Wc[((c0 + ci) & mask) * LDW + ((c0 + rr) & mask)] = band_orig(c0 + rr, c0 + ci);
   }
   for (int e = tid; e < m * br; e += kCholThreads) {
     const int ci = e / br, b = e - ci * br;
@@ -194,6 +195,49 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   if (lane < PW) rhoA = lane;
   else { const int li = wave * 56 + (lane - PW); rhoA = li < RN ? (li < m - PW ? PW + li : m + (li - (m - PW))) : -1; }
   const bool publishA = rhoA >= 0 && (lane >= PW || wave == 0);
+
+  // ---- static MFMA tile descriptors of this wave (step B): tile t = wave + i*NW of the list
+  // {band x band lower | border x band | border x border lower}
+  constexpr int NW = kCholThreads / 64;
+  constexpr int TMAX = 8;
+  int tk_kind[TMAX], tk_lpa[TMAX], tk_lpb[TMAX], tk_row[TMAX], tk_col[TMAX], tk_c1[TMAX], tk_c2[TMAX], tk_c3[TMAX], tk_ok[TMAX];
+  int my_tiles = 0;
+  {
+    const int li = lane & 15, lq = lane >> 4;
+    const int nbt = (m - PW + 15) >> 4, nrt = (br + 15) >> 4;
+    const int T1 = nbt * (nbt + 1) / 2, T2 = nrt * nbt, T3 = nrt * (nrt + 1) / 2;
+    const int lp_last = m + br - 1;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+      const int t = wave + i * NW;
+      int kind = -1, rt = 0, ct = 0;
+      if (t < T1) { kind = 0; int rem = t; while (rem > rt) { rem -= rt + 1; ++rt; } ct = rem; }
+      else if (t < T1 + T2) { kind = 1; const int u = t - T1; rt = u / nbt; ct = u - rt * nbt; }
+      else if (t < T1 + T2 + T3) { kind = 2; int rem = t - T1 - T2; while (rem > rt) { rem -= rt + 1; ++rt; } ct = rem; }
+      if (kind >= 0) my_tiles = i + 1;
+      tk_kind[i] = kind;
+      const int lp_r0 = (kind == 0 ? PW : m) + 16 * rt, lp_c0 = (kind == 2 ? m : PW) + 16 * ct;
+      int ia = lp_c0 + li; ia = ia < lp_last ? ia : lp_last;
+      int ib = lp_r0 + li; ib = ib < lp_last ? ib : lp_last;
+      tk_lpa[i] = ia * PW + lq; tk_lpb[i] = ib * PW + lq;
+      int okm = 0;
+      if (kind == 0) {
+        const int rho = PW + 16 * rt + li, g = PW + 16 * ct + lq;
+        tk_row[i] = rho; tk_col[i] = g; tk_c1[i] = tk_c2[i] = tk_c3[i] = 0;
+        for (int r = 0; r < 4; ++r) if (rho < m && g + 4 * r <= rho) okm |= 1 << r;
+      } else if (kind == 1) {
+        const int b = 16 * rt + li, g = PW + 16 * ct + lq;
+        tk_row[i] = b < br ? b : br - 1; tk_col[i] = g; tk_c1[i] = tk_c2[i] = tk_c3[i] = 0;
+        for (int r = 0; r < 4; ++r) if (b < br && g + 4 * r < m) okm |= 1 << r;
+      } else {
+        const int b = 16 * rt + li, c2 = 16 * ct + lq;
+        tk_row[i] = b < br ? b : br - 1;
+        tk_col[i] = c2 < br ? c2 : br - 1; tk_c1[i] = c2 + 4 < br ? c2 + 4 : br - 1; tk_c2[i] = c2 + 8 < br ? c2 + 8 : br - 1; tk_c3[i] = c2 + 12 < br ? c2 + 12 : br - 1;
+        for (int r = 0; r < 4; ++r) if (b < br && c2 + 4 * r <= b) okm |= 1 << r;
+      }
+      tk_ok[i] = kind >= 0 ? okm : 0;
+    }
+  }
 
   PROF_MARK(0);
   for (int j0 = c0; j0 < c1; j0 += PW) {
@@ -217,7 +261,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
       for (int c = 0; c < PW; ++c) {
         double v = 0.0;
         if (rho >= 0) {
-          if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * MCAP + ((j0 + rho) & mask)]; }
+          if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * LDW + ((j0 + rho) & mask)]; }
           else v = At[((j0 + c) & mask) * brp + (rho - m)];
         }
         av[c] = v;
@@ -250,56 +294,53 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
     PROF_MARK(2);
     __syncthreads();
     PROF_MARK(3);
-    // ---------------- step B (1): band rows, lane = window row, wave = column group
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int rho = lane + 64 * ps;
-      if (rho < m) {
-        double lr[PW];
-        const double* lrp = Lp + (size_t)rho * PW;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) lr[c] = lrp[c];
-        const int gr = j0 + rho;
-        if (gr < Pb && wave < PW) {   // wave w publishes panel column w of this row (global factor)
-          const int c = wave, k = rho - c;
-          if (k >= 0 && k <= hb && j0 + c < Pb) Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinv[c] : lrp[c];
-        }
-        double* const wrow = Wc + ((j0 + rho) & mask);
-        constexpr int NG = kCholThreads / 64;
-        for (int g0 = PW + wave; g0 <= rho; g0 += 4 * NG) {
-          double cur[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; cur[g] = gamma <= rho ? wrow[((j0 + gamma) & mask) * MCAP] : 0.0; }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int gamma = g0 + NG * g;
-            const double* lc = Lp + (size_t)(gamma < m ? gamma : m - 1) * PW;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
-            cur[g] -= s0 + s1;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { const int gamma = g0 + NG * g; if (gamma <= rho) wrow[((j0 + gamma) & mask) * MCAP] = cur[g]; }
-        }
-      }
-    }
-    PROF_MARK(8);
-    // ---------------- step B (2): border rows b: band columns -> At, border columns b2 <= b -> Cq
+    // ---------------- step B: trailing (Schur) update  C -= L_panel L_panel^T  as 16x16 MFMA tiles
+    // (v_mfma_f64_16x16x4_f64, K = 8 -> two MFMAs per tile).  Tile kinds: band x band (lower),
+    // border x band, border x border (lower).  The MFMA computes the TRANSPOSED tile so that a
+    // lane's 4 results share one matrix row index pattern that is contiguous in the column-major
+    // LDS windows:  D(i', j') = C(row = R0 + j', col = C0 + i'),  A[i'][k] = L[col][k],  B[k][j'] = -L[row][k].
     {
-      const int ncol = (m - PW) + br;
-      for (int e = tid; e < br * ncol; e += kCholThreads) {
-        const int ci = e / br, b = e - ci * br;
-        const int gamma = PW + ci;
-        if (gamma >= m && gamma - m > b) continue;
-        const double* lr = Lp + (size_t)(m + b) * PW;
-        const double* lc = Lp + (size_t)gamma * PW;
-        double s0 = 0.0, s1 = 0.0;
+      // global factor storage of the panel's band rows: wave w publishes panel column w
+      if (wave < PW) {
 #pragma unroll
-        for (int c = 0; c < PW; c += 2) { s0 = fma(lr[c], lc[c], s0); s1 = fma(lr[c + 1], lc[c + 1], s1); }
-        double* d = gamma < m ? &At[((j0 + gamma) & mask) * brp + b] : &Cq[(gamma - m) * brp + b];
-        *d -= s0 + s1;
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int rho = lane + 64 * ps, c = wave, k = rho - c;
+          if (rho < m && j0 + rho < Pb && j0 + c < Pb && k >= 0 && k <= hb) Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinv[c] : Lp[(size_t)rho * PW + c];
+        }
       }
+      PROF_MARK(8);
+      // static tile descriptors of this wave (built before the panel loop): only the circular
+      // slot arithmetic depends on j0
+      typedef double v4d __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int i = 0; i < TMAX; ++i) {
+        if (i >= my_tiles) break;
+        const int kd = tk_kind[i];
+        const double a0 = Lp[tk_lpa[i]], a1 = Lp[tk_lpa[i] + 4];
+        const double b0 = -Lp[tk_lpb[i]], b1 = -Lp[tk_lpb[i] + 4];
+        const int cstride = kd == 0 ? LDW : brp;
+        double* const base = (kd == 0 ? Wc : (kd == 1 ? At : Cq)) + (kd == 0 ? ((j0 + tk_row[i]) & mask) : tk_row[i]);
+        const int c0i = tk_col[i];
+        double* p0; double* p1; double* p2; double* p3;
+        if (kd == 2) { p0 = base + c0i * cstride; p1 = base + tk_c1[i] * cstride; p2 = base + tk_c2[i] * cstride; p3 = base + tk_c3[i] * cstride; }
+        else { p0 = base + ((j0 + c0i) & mask) * cstride; p1 = base + ((j0 + c0i + 4) & mask) * cstride;
+               p2 = base + ((j0 + c0i + 8) & mask) * cstride; p3 = base + ((j0 + c0i + 12) & mask) * cstride; }
+        v4d acc;
+        acc[0] = *p0; acc[1] = *p1; acc[2] = *p2; acc[3] = *p3;
+        PROF_MARK(6);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        if (PROF && prof) { asm volatile("s_nop 0" :: "v"(acc[0])); }
+        PROF_MARK(7);
+        const int ok = tk_ok[i];
+        double* const trash = xb + 2 * MCAP - 64 + lane;   // xb is unused during the forward sweep
+        *((ok & 1) ? p0 : trash) = acc[0];
+        *((ok & 2) ? p1 : trash) = acc[1];
+        *((ok & 4) ? p2 : trash) = acc[2];
+        *((ok & 8) ? p3 : trash) = acc[3];
+        PROF_MARK(11);
+      }
+      PROF_MARK(10);
       // border part of the global factor
       for (int e = tid; e < br * PW; e += kCholThreads) {
         const int b = e >> 3, c = e & 7;
@@ -316,7 +357,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
       const int e = tid + i * kCholThreads;
       const int rr = e >> LOG, ci = e & mask;
       const int gr = j0 + m + rr, gc = nj0 + ci;
-      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * MCAP + (gr & mask)] = pre_w[i];
+      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * LDW + (gr & mask)] = pre_w[i];
     }
     if (pa_cc >= 0) At[((j0 + m + pa_cc) & mask) * brp + pa_b] = pre_a;
     PROF_MARK(4);
@@ -333,7 +374,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
         const int ci = e / hb, rr = e - ci * hb;
         if (rr < ci) continue;
         const int gr = c1 + rr, gc = c1 + ci;
-        const double d = Wc[(gc & mask) * MCAP + (gr & mask)] - band_orig(gr, gc);
+        const double d = Wc[(gc & mask) * LDW + (gr & mask)] - band_orig(gr, gc);
         if (d != 0.0) unsafeAtomicAdd(&R.Mb[(int64_t)(pt.rs_right + ci) * R.W + (rr - ci)], d);
       }
       for (int e = tid; e < hb * br; e += kCholThreads) {
@@ -437,7 +478,7 @@ __global__ void reduced_init_kernel(CholArgs A) {
 template <int MCAP>
 __global__ void __launch_bounds__(256) partition_backward_kernel(CholArgs A, const double* xr /*reduced solution [Pbr + a]*/) {
   __shared__ double xb[2 * MCAP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index is uniform: keep it scalar
   const int Pb = A.sys.Pb, a = A.sys.a, hb = A.sys.hb, W = A.sys.W;
   const Part pt = part_of(A, blockIdx.x);
   const int c0 = pt.c0, c1 = pt.c1, nsep = pt.nsep, Pbr = A.red.Pb;
@@ -460,7 +501,7 @@ __global__ void __launch_bounds__(256) partition_backward_kernel(CholArgs A, con
 // ---- host side ----------------------------------------------------------------------
 static size_t lds_bytes(int mcap, int br) {
   const int brp = br | 1;
-  const size_t dbl = (size_t)mcap * mcap + (size_t)mcap * brp + (((size_t)br * brp + 1) & ~(size_t)1) + (size_t)(mcap + br) * PW + 2 * mcap + br + PW + 8;
+  const size_t dbl = (size_t)mcap * (mcap + 2) + (size_t)mcap * brp + (((size_t)br * brp + 1) & ~(size_t)1) + (size_t)(mcap + br + 16) * PW + 2 * mcap + br + PW + 8;
   return dbl * sizeof(double);
 }
 
@@ -468,7 +509,7 @@ static size_t lds_bytes(int mcap, int br) {
 int choose_partitions(int Pb, int hb, int a) {
   if (Pb < 8 * (hb + 8) || hb + PW > 64 || 2 * hb - 1 + PW > 128) return 1;
   if (lds_bytes(64, hb + a + 1) > 160 * 1024 - 256 || lds_bytes(128, a + 1) > 160 * 1024 - 256) return 1;
-  if ((64 - PW) + hb + a + 1 > 16 * 56 || PW * (hb + a + 1) > kCholThreads) return 1;
+  if ((64 - PW) + hb + a + 1 > (kCholThreads / 64) * 56 || PW * (hb + a + 1) > kCholThreads) return 1;
   int best = 1; double best_cost = Pb / 8.0;
   for (int p = 2; p <= 192; ++p) {
     const int L = (((Pb - (p - 1) * hb) / p) / PW) * PW;
@@ -488,8 +529,13 @@ int64_t solve_workspace_doubles(const TangentLayout& tl) {
 template <int MCAP, int MODE>
 static void launch_sweep(const CholArgs& A, int grid, int br, hipStream_t st) {
   const size_t lds = lds_bytes(MCAP, br);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<MCAP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((band_arrow_cholesky_kernel<MCAP, MODE>), dim3(grid), dim3(kCholThreads), lds, st, A, br | 1);
+  if (A.prof) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<MCAP, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((band_arrow_cholesky_kernel<MCAP, MODE, true>), dim3(grid), dim3(kCholThreads), lds, st, A, br | 1);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<MCAP, MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((band_arrow_cholesky_kernel<MCAP, MODE, false>), dim3(grid), dim3(kCholThreads), lds, st, A, br | 1);
+  }
 }
 
 int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st) {
@@ -508,7 +554,7 @@ int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, 
   }
   if (p <= 1) {
     if (lds_bytes(mcap, ar) > 160 * 1024 - 256) return -1;
-    if ((m - PW) + ar > 16 * 56 || PW * ar > kCholThreads) return -1;
+    if ((m - PW) + ar > (kCholThreads / 64) * 56 || PW * ar > kCholThreads) return -1;
     if (mcap == 64) launch_sweep<64, 0>(A, 1, ar, st); else launch_sweep<128, 0>(A, 1, ar, st);
     return 0;
   }
