@@ -29,9 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# keep stdout to the single JSON line: RCCL prints a version banner to stdout at NCCL_DEBUG=VERSION/INFO
-if os.environ.get("OICC_KEEP_NCCL_DEBUG") != "1":
-    os.environ["NCCL_DEBUG"] = "WARN"
+# keep stdout to the single JSON line: RCCL writes its banner / warnings to fd 1, so everything
+# except the final line is routed to stderr
+_REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
 
 import numpy as np  # noqa: E402
 
@@ -216,7 +217,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
