@@ -99,6 +99,69 @@ __device__ __forceinline__ void gram_flush(const double* rows, int stride, int r
   }
 }
 
+// ---- phase 2 + 3 on the matrix pipe: the per-cell Gram product [J r]^T [J r] is a real GEMM
+// (K = rows of the cell, N = NT*16 columns), so it runs as v_mfma_f64_16x16x4_f64 tiles; only
+// the upper block triangle is formed.  Operand lane mapping (A[i][k] and B[k][j] with
+// i = j = lane&15, k = lane>>4) is the same for both operands, so one LDS read per 16-column
+// block and K-step feeds all tile pairs.  Results: lane holds G[16ti + (lane>>4) + 4r][16tj + (lane&15)].
+template <int NT>
+__device__ __forceinline__ void gram_flush_mfma(const double* rows, int stride, int r0, int r1, int ncols, int rescol,
+                                                const int* coloff, const EvalCtx& ctx, int lane) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  constexpr int NP = NT * (NT + 1) / 2;
+  v4d acc[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int li = lane & 15, lq = lane >> 4;
+  const bool prof = ctx.prof != nullptr && blockIdx.x == gridDim.x / 2;
+  const long long tq0 = prof ? clock64() : 0;
+  for (int kb = r0; kb < r1; kb += 4) {
+    const int k = kb + lq;
+    const double* pr = rows + (size_t)(k < r1 ? k : r1 - 1) * stride + li;
+    double a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const double v = pr[16 * t]; a[t] = k < r1 ? v : 0.0; }
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < NT; ++tj) { acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], a[tj], acc[idx], 0, 0, 0); ++idx; }
+  }
+  if (prof) { asm volatile("s_nop 0" :: "v"(acc[0][0])); }
+  const long long tq1 = prof ? clock64() : 0;
+  int idx = 0;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < NT; ++tj) {
+      const int cj = 16 * tj + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = 16 * ti + lq + 4 * r;
+        const double v = acc[idx][r];
+        if (ci < ncols && cj < ncols && ci <= cj) {
+          if (cj == rescol) {
+            if (ci == rescol) atomic_add_f64(ctx.ne.cost(), 0.5 * v);
+            else { const int oi = coloff[ci]; if (oi >= 0) atomic_add_f64(ctx.ne.g() + oi, v); }
+          } else {
+            const int oi = coloff[ci], oj = coloff[cj];
+            if (oi >= 0 && oj >= 0) ne_add(ctx.ne, ctx.tl, oi, oj, v);
+          }
+        }
+      }
+      ++idx;
+    }
+  if (prof && lane == 0) { const long long tq2 = clock64(); ctx.prof[2] += tq1 - tq0; ctx.prof[3] += tq2 - tq1; }
+}
+// dispatch on the number of 16-column blocks
+__device__ __forceinline__ void gram_flush_cell(const double* rows, int stride, int r0, int r1, int ncols, int rescol,
+                                                const int* coloff, const EvalCtx& ctx, int lane) {
+  if (ncols <= 16) gram_flush_mfma<1>(rows, stride, r0, r1, ncols, rescol, coloff, ctx, lane);
+  else if (ncols <= 32) gram_flush_mfma<2>(rows, stride, r0, r1, ncols, rescol, coloff, ctx, lane);
+  else if (ncols <= 48) gram_flush_mfma<3>(rows, stride, r0, r1, ncols, rescol, coloff, ctx, lane);
+  else gram_flush_mfma<4>(rows, stride, r0, r1, ncols, rescol, coloff, ctx, lane);
+}
+
 // Knot staging: copy knots [lo, lo+cnt) (K doubles each) of this wave's window
 // range into LDS; accessor falls back to global memory beyond the staged range.
 template <int K>
@@ -159,10 +222,9 @@ __host__ __device__ inline ViewCols view_cols(const TangentLayout& tl, bool spli
 }
 
 template <bool JAC>
-__global__ void __launch_bounds__(64) view_blocks_kernel(EvalCtx ctx, ViewData vd, ViewCols vc) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void view_block(const EvalCtx& ctx, const ViewData& vd, const ViewCols& vc, int bid, int nblk, double* smem) {
   const int lane = threadIdx.x;
-  const int64_t c_begin = (int64_t)blockIdx.x * kWave;
+  const int64_t c_begin = (int64_t)bid * kWave;
   const int64_t c = c_begin + lane;
   const bool valid = c < vd.n_corners;
   // LDS carve: knots | coloff | rows
@@ -179,6 +241,8 @@ __global__ void __launch_bounds__(64) view_blocks_kernel(EvalCtx ctx, ViewData v
   const StagedKnots<4> ks = stage_knots<4>(ctx.x + ctx.pl.so3, ctx.pl.n_so3, lo_s, hi_s, lds_so3, lane);
   const StagedKnots<3> kr = stage_knots<3>(ctx.x + ctx.pl.r3, ctx.pl.n_r3, lo_r, hi_r, lds_r3, lane);
   __syncthreads();
+  const bool prof = ctx.prof != nullptr && bid == nblk / 2;
+  long long tp0 = prof ? clock64() : 0, tp1 = 0, tp3 = 0;
 
   double cost_local = 0.0;
   const bool spline_active = vc.base_s >= 0;
@@ -325,6 +389,7 @@ __global__ void __launch_bounds__(64) view_blocks_kernel(EvalCtx ctx, ViewData v
     return;
   }
   __syncthreads();
+  if (prof) tp1 = clock64();
   // phase 2/3: one flush per view present in this chunk
   const int v_first = vd.corner_view[c_begin];
   const int64_t c_last = (c_begin + kWave < vd.n_corners ? c_begin + kWave : vd.n_corners) - 1;
@@ -345,9 +410,10 @@ __global__ void __launch_bounds__(64) view_blocks_kernel(EvalCtx ctx, ViewData v
       coloff[lane] = off;
     }
     __syncthreads();
-    gram_flush<5>(rows, vc.stride, int(2 * (a0 - c_begin)), int(2 * (a1 - c_begin)), vc.ncols, vc.rescol, coloff, ctx, lane);
+    gram_flush_cell(rows, vc.stride, int(2 * (a0 - c_begin)), int(2 * (a1 - c_begin)), vc.ncols, vc.rescol, coloff, ctx, lane);
     __syncthreads();
   }
+  if (prof && lane == 0) { tp3 = clock64(); ctx.prof[0] = tp1 - tp0; ctx.prof[1] = tp3 - tp1; }
 }
 
 // =============================================================================
@@ -380,11 +446,10 @@ __host__ __device__ inline ImuCols gyro_cols(const TangentLayout& tl, bool splin
 constexpr int kImuChunk = 32;  // samples per wave (LDS rows = 3*32)
 
 // KIND 0 = accelerometer, 1 = gyroscope
-template <int KIND, bool JAC, int TB>
-__global__ void __launch_bounds__(64) imu_blocks_kernel(EvalCtx ctx, ImuData id, ImuCols ic) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+template <int KIND, bool JAC>
+__device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id, const ImuCols& ic, int bid, double* smem) {
   const int lane = threadIdx.x;
-  const int64_t i_begin = (int64_t)blockIdx.x * kImuChunk;
+  const int64_t i_begin = (int64_t)bid * kImuChunk;
   const int64_t i = i_begin + lane;
   const bool valid = lane < kImuChunk && i < id.n;
   double* lds_so3 = smem;
@@ -567,15 +632,37 @@ __global__ void __launch_bounds__(64) imu_blocks_kernel(EvalCtx ctx, ImuData id,
       coloff[lane] = off;
     }
     __syncthreads();
-    gram_flush<TB>(rows, ic.stride, int(3 * (a0 - i_begin)), int(3 * (a1 - i_begin)), ic.ncols, ic.rescol, coloff, ctx, lane);
+    gram_flush_cell(rows, ic.stride, int(3 * (a0 - i_begin)), int(3 * (a1 - i_begin)), ic.ncols, ic.rescol, coloff, ctx, lane);
     __syncthreads();
     a0 = a1;
   }
 }
 
+// ---- kernels: standalone (timing / debugging one block type) and fused (one launch for
+// all three block types: they are independent and each is too small to fill 256 CUs) ----
+template <bool JAC>
+__global__ void __launch_bounds__(64) view_blocks_kernel(EvalCtx ctx, ViewData vd, ViewCols vc) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  view_block<JAC>(ctx, vd, vc, blockIdx.x, gridDim.x, smem);
+}
+template <int KIND, bool JAC>
+__global__ void __launch_bounds__(64) imu_blocks_kernel(EvalCtx ctx, ImuData id, ImuCols ic) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  imu_block<KIND, JAC>(ctx, id, ic, blockIdx.x, smem);
+}
+template <bool JAC>
+__global__ void __launch_bounds__(64) all_blocks_kernel(EvalCtx ctx, ViewData vd, ViewCols vc, ImuData ia, ImuCols ica, ImuData ig, ImuCols icg,
+                                                        int nb_view, int nb_acc) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x;
+  if (b < nb_view) view_block<JAC>(ctx, vd, vc, b, nb_view, smem);
+  else if (b < nb_view + nb_acc) imu_block<0, JAC>(ctx, ia, ica, b - nb_view, smem);
+  else imu_block<1, JAC>(ctx, ig, icg, b - nb_view - nb_acc, smem);
+}
+
 // ---- launchers ---------------------------------------------------------------
-size_t view_lds_bytes(const ViewCols& vc) { return (kMaxStagedKnots * 7 + 32 + (size_t)2 * kWave * vc.stride) * sizeof(double); }
-size_t imu_lds_bytes(const ImuCols& ic) { return (kMaxStagedKnots * 7 + 32 + (size_t)3 * kImuChunk * ic.stride) * sizeof(double); }
+size_t view_lds_bytes(const ViewCols& vc) { return (kMaxStagedKnots * 7 + 32 + (size_t)2 * kWave * vc.stride + 64) * sizeof(double); }
+size_t imu_lds_bytes(const ImuCols& ic) { return (kMaxStagedKnots * 7 + 32 + (size_t)3 * kImuChunk * ic.stride + 64) * sizeof(double); }
 
 void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st) {
   if (vd.n_corners == 0) return;
@@ -591,12 +678,26 @@ void launch_imu_blocks(int kind, const EvalCtx& ctx, const ImuData& id, bool spl
   const int grid = int((id.n + kImuChunk - 1) / kImuChunk);
   const size_t lds_cost = (kMaxStagedKnots * 7 + 32) * sizeof(double);
   if (kind == 0) {
-    if (jac) hipLaunchKernelGGL((imu_blocks_kernel<0, true, 4>), dim3(grid), dim3(64), imu_lds_bytes(ic), st, ctx, id, ic);
-    else hipLaunchKernelGGL((imu_blocks_kernel<0, false, 4>), dim3(grid), dim3(64), lds_cost, st, ctx, id, ic);
+    if (jac) hipLaunchKernelGGL((imu_blocks_kernel<0, true>), dim3(grid), dim3(64), imu_lds_bytes(ic), st, ctx, id, ic);
+    else hipLaunchKernelGGL((imu_blocks_kernel<0, false>), dim3(grid), dim3(64), lds_cost, st, ctx, id, ic);
   } else {
-    if (jac) hipLaunchKernelGGL((imu_blocks_kernel<1, true, 3>), dim3(grid), dim3(64), imu_lds_bytes(ic), st, ctx, id, ic);
-    else hipLaunchKernelGGL((imu_blocks_kernel<1, false, 3>), dim3(grid), dim3(64), lds_cost, st, ctx, id, ic);
+    if (jac) hipLaunchKernelGGL((imu_blocks_kernel<1, true>), dim3(grid), dim3(64), imu_lds_bytes(ic), st, ctx, id, ic);
+    else hipLaunchKernelGGL((imu_blocks_kernel<1, false>), dim3(grid), dim3(64), lds_cost, st, ctx, id, ic);
   }
+}
+
+// One launch for every residual block of the problem (views | accelerometer | gyroscope).
+void launch_all_blocks(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, bool spline_active, bool ab_active,
+                       bool gb_active, bool jac, hipStream_t st) {
+  const ViewCols vc = view_cols(ctx.tl, spline_active);
+  const ImuCols ica = accel_cols(ctx.tl, spline_active, ab_active), icg = gyro_cols(ctx.tl, spline_active, gb_active);
+  const int nb_view = int((vd.n_corners + kWave - 1) / kWave), nb_acc = int((ia.n + kImuChunk - 1) / kImuChunk), nb_gyr = int((ig.n + kImuChunk - 1) / kImuChunk);
+  const int grid = nb_view + nb_acc + nb_gyr;
+  if (grid == 0) return;
+  size_t lds = (kMaxStagedKnots * 7 + 32) * sizeof(double);
+  if (jac) { lds = view_lds_bytes(vc); if (imu_lds_bytes(ica) > lds) lds = imu_lds_bytes(ica); if (imu_lds_bytes(icg) > lds) lds = imu_lds_bytes(icg); }
+  if (jac) hipLaunchKernelGGL(all_blocks_kernel<true>, dim3(grid), dim3(64), lds, st, ctx, vd, vc, ia, ica, ig, icg, nb_view, nb_acc);
+  else hipLaunchKernelGGL(all_blocks_kernel<false>, dim3(grid), dim3(64), lds, st, ctx, vd, vc, ia, ica, ig, icg, nb_view, nb_acc);
 }
 
 // =============================================================================

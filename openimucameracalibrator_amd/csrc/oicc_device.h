@@ -70,6 +70,7 @@ struct EvalCtx {
   int32_t rs_time_in_seconds;  // 1: documented fix of quirk Q1
   double* dbg_res;        // optional per-row residual dump (parity tests)
   double* dbg_jac;        // optional per-row Jacobian dump in the fixed ABI layout
+  long long* prof;        // optional: per-phase cycle counters of one block (debug)
 };
 
 // device-resident scalars of one LM iteration (the only per-iteration read-back)

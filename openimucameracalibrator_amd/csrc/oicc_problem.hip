@@ -26,6 +26,8 @@ namespace oicc {
 // kernels_blocks.hip
 void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st);
 void launch_imu_blocks(int kind, const EvalCtx& ctx, const ImuData& id, bool spline_active, bool bias_active, bool jac, hipStream_t st);
+void launch_all_blocks(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, bool spline_active, bool ab_active,
+                       bool gb_active, bool jac, hipStream_t st);
 void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, const int32_t* s_r3, const double* u_so3,
                        const double* u_r3, const int32_t* s_gb, const double* u_gb, const int32_t* s_ab, const double* u_ab,
                        double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
@@ -325,7 +327,7 @@ EvalCtx make_ctx(oicc_problem* p, const double* x) {
   c.inv_so3_dt = p->inv_so3_dt; c.inv_r3_dt = p->inv_r3_dt;
   std::memcpy(c.intr, p->intr, sizeof(c.intr)); c.cam_model = p->cam_model;
   c.gs_unit_loss = p->opt["gs_unit_loss"] != 0.0; c.rs_time_in_seconds = p->opt["rs_time_in_seconds"] != 0.0;
-  c.dbg_res = nullptr; c.dbg_jac = nullptr;
+  c.dbg_res = nullptr; c.dbg_jac = nullptr; c.prof = nullptr;
   return c;
 }
 ViewData view_data(oicc_problem* p, bool force_rs = false) {
@@ -352,9 +354,10 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   if (jac) HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), st));
   else HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), st));
   const Active& a = p->act;
-  if (only_kind < 0 || only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
-  if (only_kind < 0 || only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
-  if (only_kind < 0 || only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
+  if (only_kind < 0) launch_all_blocks(ctx, view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
+  if (only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
+  if (only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
+  if (only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
   HIPCK(p, hipGetLastError());
   if (p->reduce) {
     int rc = jac ? p->reduce(p->reduce_user, p->ne.base, p->ne.total, st) : p->reduce(p->reduce_user, p->ne.cost(), 1, st);
@@ -824,6 +827,19 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
   }
   HIPCK(p, hipMemcpyAsync(out, d.p, 12 * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCK(p, hipStreamSynchronize(st));
+  return OICC_OK;
+}
+
+// Debug: cycle counters of one mid-grid view block: [phase 1 (spline+residual+Jacobian rows), phase 2+3 (Gram + atomic flush)]
+int oicc_debug_view_profile(oicc_problem* p, int32_t flags, long long out[4]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
+  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p;
+  HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), p->stream));
+  launch_view_blocks(ctx, view_data(p), p->act.spline, true, p->stream);
+  HIPCK(p, hipMemcpyAsync(out, d.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
   return OICC_OK;
 }
 

@@ -251,6 +251,37 @@ struct So3Out {
   double JW[6][9];
 };
 
+// Rotation matrix exp([phi]x), right Jacobian Jr(phi) and k*Jr(phi) from ONE half-angle
+// sincos (sh = sin(t/2), ch = cos(t/2), t2 = |phi|^2): sin t = 2 sh ch, 1 - cos t = 2 sh^2.
+OICC_DEV void rodrigues_and_Jr(const double phi[3], double t2, double sh, double ch, double R[9], double Jr[9]) {
+  double a, b, bj;  // a = sin t / t, b = (1 - cos t) / t^2, bj = (t - sin t) / t^3
+  if (t2 < 1e-4) {
+    a = 1.0 - t2 * (1.0 / 6.0) + t2 * t2 * (1.0 / 120.0) - t2 * t2 * t2 * (1.0 / 5040.0);
+    b = 0.5 - t2 * (1.0 / 24.0) + t2 * t2 * (1.0 / 720.0) - t2 * t2 * t2 * (1.0 / 40320.0);
+    bj = (1.0 / 6.0) - t2 * (1.0 / 120.0) + t2 * t2 * (1.0 / 5040.0) - t2 * t2 * t2 * (1.0 / 362880.0);
+  } else {
+    const double t = sqrt(t2);
+    const double st = 2.0 * sh * ch;
+    a = st / t; b = 2.0 * sh * sh / t2; bj = (t - st) / (t2 * t);
+  }
+  const double x = phi[0], y = phi[1], z = phi[2];
+  const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+  R[0] = 1.0 - b * (yy + zz); R[1] = -a * z + b * xy;     R[2] = a * y + b * xz;
+  R[3] = a * z + b * xy;      R[4] = 1.0 - b * (xx + zz); R[5] = -a * x + b * yz;
+  R[6] = -a * y + b * xz;     R[7] = a * x + b * yz;      R[8] = 1.0 - b * (xx + yy);
+  // Jr = I - b [phi]x + bj [phi]x^2
+  Jr[0] = 1.0 - bj * (yy + zz); Jr[1] = b * z + bj * xy;       Jr[2] = -b * y + bj * xz;
+  Jr[3] = -b * z + bj * xy;     Jr[4] = 1.0 - bj * (xx + zz);  Jr[5] = b * x + bj * yz;
+  Jr[6] = b * y + bj * xz;      Jr[7] = -b * x + bj * yz;      Jr[8] = 1.0 - bj * (xx + yy);
+}
+// Jr^-1(phi) = I + 1/2 [phi]x + c [phi]x^2 with c given (c = 1/t^2 - cot(t/2)/(2t)).
+OICC_DEV void so3_Jr_inv_c(const double phi[3], double c, double J[9]) {
+  const double x = phi[0], y = phi[1], z = phi[2];
+  J[0] = 1.0 - c * (y * y + z * z); J[1] = -0.5 * z + c * x * y;      J[2] = 0.5 * y + c * x * z;
+  J[3] = 0.5 * z + c * x * y;       J[4] = 1.0 - c * (x * x + z * z); J[5] = -0.5 * x + c * y * z;
+  J[6] = -0.5 * y + c * x * z;      J[7] = 0.5 * x + c * y * z;       J[8] = 1.0 - c * (x * x + y * y);
+}
+
 template <bool WANT_VAL, bool WANT_VEL, bool WANT_JAC, bool WANT_JVEL, class KnotAcc>
 OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out& o) {
   double p[6], k[6], dk[6];
@@ -260,17 +291,57 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
     base_coeffs6<1>(u, p);
     matvec6(kMc6, p, inv_dt, dk);
   }
+  constexpr bool JAC = WANT_JAC || WANT_JVEL;
   double delta[5][3];
-  double wpre[5][3];  // omega_{m-1}: angular velocity accumulated BEFORE segment m
+  double wpre[5][3];   // omega_{m-1}: angular velocity accumulated BEFORE segment m
+  double cinv[5];      // coefficient of Jr^-1(delta_i), from the half-angle of R_i^-1 R_{i+1}
+  double sh[5], ch[5]; // sin/cos of |k delta_i| / 2 (shared by exp, Rodrigues and Jr)
   Quat acc = K(0);
   double wv[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const Quat p0 = K(i), p1 = K(i + 1);
     const Quat r01 = so3_mul(so3_inverse(p0), p1);
-    so3_log(r01, delta[i]);
+    // log (so3.hpp:247-293), keeping n and w for the Jacobian coefficient
+    {
+      const double squared_n = r01.x * r01.x + r01.y * r01.y + r01.z * r01.z;
+      const double w = r01.w;
+      double f;
+      if (squared_n < kSophusEps * kSophusEps) {
+        f = 2.0 / w - (2.0 / 3.0) * squared_n / (w * (w * w));
+        if (JAC) cinv[i] = 1.0 / 12.0;
+      } else {
+        const double n = sqrt(squared_n);
+        if (fabs(w) < kSophusEps) f = (w > 0.0 ? M_PI : -M_PI) / n;
+        else f = 2.0 * atan(n / w) / n;
+        if (JAC) {
+          const double th = f * n, t2 = th * th;   // signed angle; c is even in th
+          cinv[i] = t2 < 1e-4 ? (1.0 / 12.0) + t2 * (1.0 / 720.0) + t2 * t2 * (1.0 / 30240.0) + t2 * t2 * t2 * (1.0 / 1209600.0)
+                              : 1.0 / t2 - (w / n) / (2.0 * th);
+        }
+      }
+      delta[i][0] = f * r01.x; delta[i][1] = f * r01.y; delta[i][2] = f * r01.z;
+    }
     const double kd[3] = {delta[i][0] * k[i + 1], delta[i][1] * k[i + 1], delta[i][2] * k[i + 1]};
-    const Quat e = so3_exp(kd);
+    // exp (so3.hpp:584-621), keeping the half-angle sine / cosine
+    Quat e;
+    {
+      const double theta_sq = kd[0] * kd[0] + kd[1] * kd[1] + kd[2] * kd[2];
+      double imag, real;
+      if (theta_sq < kSophusEps * kSophusEps) {
+        const double t4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * t4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * t4;
+        sh[i] = 0.0; ch[i] = 1.0;
+      } else {
+        const double theta = sqrt(theta_sq);
+        double s, c;
+        sincos(0.5 * theta, &s, &c);
+        imag = s / theta; real = c;
+        sh[i] = s; ch[i] = c;
+      }
+      e = Quat{imag * kd[0], imag * kd[1], imag * kd[2], real};
+    }
     if (WANT_VAL) acc = so3_mul(acc, e);
     if (WANT_VEL || WANT_JVEL) {
       wpre[i][0] = wv[0]; wpre[i][1] = wv[1]; wpre[i][2] = wv[2];
@@ -285,7 +356,7 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
   }
   if (WANT_VAL) o.R = acc;
   if (WANT_VEL) { o.w[0] = wv[0]; o.w[1] = wv[1]; o.w[2] = wv[2]; }
-  if (!(WANT_JAC || WANT_JVEL)) return;
+  if (!JAC) return;
 
   // Backward pass.  P_i = A_{i+1}...A_4 (P_4 = I), A_i = exp(k_{i+1} delta_i).
   //   G_i = P_i^T k_{i+1} Jr(k_{i+1} delta_i)
@@ -300,9 +371,8 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
   for (int i = 4; i >= 0; --i) {
     const double kd[3] = {delta[i][0] * k[i + 1], delta[i][1] * k[i + 1], delta[i][2] * k[i + 1]};
     double Jr[9], Jri[9], G[9], A[9];
-    so3_Jr(kd, Jr);
-    so3_Jr_inv(delta[i], Jri);
-    rodrigues(kd, A);
+    rodrigues_and_Jr(kd, kd[0] * kd[0] + kd[1] * kd[1] + kd[2] * kd[2], sh[i], ch[i], A, Jr);
+    so3_Jr_inv_c(delta[i], cinv[i], Jri);
 #pragma unroll
     for (int e = 0; e < 9; ++e) Jr[e] *= k[i + 1];
     mat3_tmul(Pm, Jr, G);  // G_i
