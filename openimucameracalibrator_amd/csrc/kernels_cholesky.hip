@@ -29,7 +29,7 @@
 namespace oicc {
 
 constexpr int PW = 8;                 // panel width
-constexpr int kCholThreads = 512;     // 16 waves: step B is spread wide, step A runs on 1-3 waves
+constexpr int kCholThreads = 1024;    // 16 waves: step B is spread wide, step A runs on 1-3 waves
 
 struct CholSys { double* Mb; double* Mt; double* Mc; int Pb, W, hb, a; };
 
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   // ---- static MFMA tile descriptors of this wave (step B): tile t = wave + i*NW of the list
   // {band x band lower | border x band | border x border lower}
   constexpr int NW = kCholThreads / 64;
-  constexpr int TMAX = 8;
+  constexpr int TMAX = 4;
   int tk_kind[TMAX], tk_lpa[TMAX], tk_lpb[TMAX], tk_row[TMAX], tk_col[TMAX], tk_c1[TMAX], tk_c2[TMAX], tk_c3[TMAX], tk_ok[TMAX];
   int my_tiles = 0;
   {
