@@ -44,6 +44,11 @@ struct CholArgs {
   long long* prof;      // optional cycle counters (debug)
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding GLOBAL load/store (vmcnt(0)), which would expose the latency of the window
+// prefetch and of the factor write-back at every panel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   constexpr int LOG = MCAP == 64 ? 6 : 7;
   constexpr int NPW = PW * MCAP / kCholThreads > 0 ? PW * MCAP / kCholThreads : 1;
   constexpr int NPASS = MCAP / 64;
-  constexpr int LDW = MCAP + 2;                 // padded column pitch of the window (bank spread for the MFMA tiles)
+  constexpr int LDW = MCAP == 64 ? MCAP + 2 : MCAP;   // padded column pitch of the window (bank spread for the MFMA tiles); no room at 128
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index is uniform: keep it scalar
   const int Pb = A.sys.Pb, a = A.sys.a, hb = A.sys.hb, W = A.sys.W, ar = a + 1;
   const Part pt = part_of(A, MODE == 1 ? blockIdx.x : 0);
@@ -146,10 +151,10 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   double* const At = Wc + (size_t)MCAP * LDW;
   double* const Cq = At + (size_t)MCAP * brp;
   double* const Lp = Cq + (((size_t)br * brp + 1) & ~(size_t)1);
-  double* const xb = Lp + (size_t)(MCAP + br + 16) * PW;
+  double* const xb = Lp + 2 * (size_t)(m + br + 16) * PW;    // Lp is double buffered (look-ahead)
   double* const da = xb + 2 * MCAP;
   double* const dinv = da + br;
-  int* const fail_flag_p = reinterpret_cast<int*>(dinv + PW);
+  int* const fail_flag_p = reinterpret_cast<int*>(dinv + 2 * PW);
   if (tid == 0) *fail_flag_p = 0;
   double* const Mb = A.sys.Mb;
   double* const Mt = A.sys.Mt;
@@ -196,174 +201,210 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
   else { const int li = wave * 56 + (lane - PW); rhoA = li < RN ? (li < m - PW ? PW + li : m + (li - (m - PW))) : -1; }
   const bool publishA = rhoA >= 0 && (lane >= PW || wave == 0);
 
-  // ---- static MFMA tile descriptors of this wave (step B): tile t = wave + i*NW of the list
-  // {band x band lower | border x band | border x border lower}
+  // ---- static MFMA tile descriptors (trailing / Schur update  C -= L_panel L_panel^T as 16x16
+  // v_mfma_f64_16x16x4_f64 tiles, K = 8 -> two MFMAs per tile).  Tile list: band x band (lower),
+  // border x band, border x border (lower).  The MFMA computes the TRANSPOSED tile so that a
+  // lane's results are contiguous along matrix rows in the column-major LDS windows:
+  //   D(i', j') = C(row = R0 + j', col = C0 + i'),  A[i'][k] = L[col][k],  B[k][j'] = -L[row][k].
+  // LOOK-AHEAD: tiles that touch the next panel's columns (column tile 0 of the band) are
+  // "critical" and run first (wave i owns critical tile i); all other tiles run on waves >= NA
+  // while waves < NA already factor the next panel (step A).
   constexpr int NW = kCholThreads / 64;
-  constexpr int TMAX = 4;
-  int tk_kind[TMAX], tk_lpa[TMAX], tk_lpb[TMAX], tk_row[TMAX], tk_col[TMAX], tk_c1[TMAX], tk_c2[TMAX], tk_c3[TMAX], tk_ok[TMAX];
-  int my_tiles = 0;
+  constexpr int TMAX = 4;           // rest tiles per wave (launcher checks)
+  const int NA = (RN + 55) / 56;    // waves that own rows in step A
+  const int NREST = NW - NA;        // waves that run the non-critical tiles
+  // descriptor slot 0 = this wave's critical tile, slots 1..TMAX = its rest tiles
+  int tk_kind[TMAX + 1], tk_lpa[TMAX + 1], tk_lpb[TMAX + 1], tk_row[TMAX + 1], tk_col[TMAX + 1], tk_c1[TMAX + 1], tk_c2[TMAX + 1], tk_c3[TMAX + 1], tk_ok[TMAX + 1];
+  int n_rest = 0;
   {
     const int li = lane & 15, lq = lane >> 4;
     const int nbt = (m - PW + 15) >> 4, nrt = (br + 15) >> 4;
-    const int T1 = nbt * (nbt + 1) / 2, T2 = nrt * nbt, T3 = nrt * (nrt + 1) / 2;
     const int lp_last = m + br - 1;
+    // ordinal -> (kind, rt, ct) within the critical or the rest list (wave-uniform scalar search)
+    auto decode = [nbt, nrt](bool want_crit, int ordinal, int& kind_o, int& rt_o, int& ct_o) __attribute__((always_inline)) -> bool {
+      int n = 0;
+      for (int kind = 0; kind < 3; ++kind) {
+        const int nr_t = kind == 0 ? nbt : nrt;
+        for (int rt = 0; rt < nr_t; ++rt) {
+          const int nc_t = kind == 1 ? nbt : rt + 1;
+          for (int ct = 0; ct < nc_t; ++ct) {
+            const bool crit = kind != 2 && ct == 0;
+            if (crit != want_crit) continue;
+            if (n == ordinal) { kind_o = kind; rt_o = rt; ct_o = ct; return true; }
+            ++n;
+          }
+        }
+      }
+      return false;
+    };
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i) {
-      const int t = wave + i * NW;
+    for (int i = 0; i <= TMAX; ++i) {
       int kind = -1, rt = 0, ct = 0;
-      if (t < T1) { kind = 0; int rem = t; while (rem > rt) { rem -= rt + 1; ++rt; } ct = rem; }
-      else if (t < T1 + T2) { kind = 1; const int u = t - T1; rt = u / nbt; ct = u - rt * nbt; }
-      else if (t < T1 + T2 + T3) { kind = 2; int rem = t - T1 - T2; while (rem > rt) { rem -= rt + 1; ++rt; } ct = rem; }
-      if (kind >= 0) my_tiles = i + 1;
-      tk_kind[i] = kind;
+      bool have;
+      if (i == 0) have = decode(true, wave, kind, rt, ct);
+      else have = NREST > 0 && wave >= NA && decode(false, (wave - NA) + (i - 1) * NREST, kind, rt, ct);
+      if (!have) kind = -1;
+      if (have && i > 0) n_rest = i;
       const int lp_r0 = (kind == 0 ? PW : m) + 16 * rt, lp_c0 = (kind == 2 ? m : PW) + 16 * ct;
       int ia = lp_c0 + li; ia = ia < lp_last ? ia : lp_last;
       int ib = lp_r0 + li; ib = ib < lp_last ? ib : lp_last;
-      tk_lpa[i] = ia * PW + lq; tk_lpb[i] = ib * PW + lq;
-      int okm = 0;
+      int okm = 0, row = 0, col = 0, c1v = 0, c2v = 0, c3v = 0;
       if (kind == 0) {
         const int rho = PW + 16 * rt + li, g = PW + 16 * ct + lq;
-        tk_row[i] = rho; tk_col[i] = g; tk_c1[i] = tk_c2[i] = tk_c3[i] = 0;
+        row = rho; col = g;
         for (int r = 0; r < 4; ++r) if (rho < m && g + 4 * r <= rho) okm |= 1 << r;
       } else if (kind == 1) {
         const int b = 16 * rt + li, g = PW + 16 * ct + lq;
-        tk_row[i] = b < br ? b : br - 1; tk_col[i] = g; tk_c1[i] = tk_c2[i] = tk_c3[i] = 0;
+        row = b < br ? b : br - 1; col = g;
         for (int r = 0; r < 4; ++r) if (b < br && g + 4 * r < m) okm |= 1 << r;
-      } else {
+      } else if (kind == 2) {
         const int b = 16 * rt + li, c2 = 16 * ct + lq;
-        tk_row[i] = b < br ? b : br - 1;
-        tk_col[i] = c2 < br ? c2 : br - 1; tk_c1[i] = c2 + 4 < br ? c2 + 4 : br - 1; tk_c2[i] = c2 + 8 < br ? c2 + 8 : br - 1; tk_c3[i] = c2 + 12 < br ? c2 + 12 : br - 1;
+        row = b < br ? b : br - 1;
+        col = c2 < br ? c2 : br - 1; c1v = c2 + 4 < br ? c2 + 4 : br - 1; c2v = c2 + 8 < br ? c2 + 8 : br - 1; c3v = c2 + 12 < br ? c2 + 12 : br - 1;
         for (int r = 0; r < 4; ++r) if (b < br && c2 + 4 * r <= b) okm |= 1 << r;
       }
-      tk_ok[i] = kind >= 0 ? okm : 0;
+      tk_kind[i] = kind; tk_lpa[i] = ia * PW + lq; tk_lpb[i] = ib * PW + lq; tk_row[i] = row; tk_col[i] = col;
+      tk_c1[i] = c1v; tk_c2[i] = c2v; tk_c3[i] = c3v; tk_ok[i] = kind >= 0 ? okm : 0;
     }
   }
-
-  PROF_MARK(0);
-  for (int j0 = c0; j0 < c1; j0 += PW) {
-    // ---- prefetch what enters the window after this panel
-    const int nj0 = j0 + PW;
-    double pre_w[NPW], pre_a;
+  // one tile: load C, two MFMAs, store (invalid entries go to a trash slot)
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  auto run_tile = [Wc, At, Cq, xb, brp, lane](int kd, int lpa, int lpb, int trow, int c0i, int c1i, int c2i, int c3i, int ok, const double* LpC, int j0) __attribute__((always_inline)) {
+    const double a0 = LpC[lpa], a1 = LpC[lpa + 4];
+    const double b0 = -LpC[lpb], b1 = -LpC[lpb + 4];
+    const int cstride = kd == 0 ? LDW : brp;
+    double* const base = (kd == 0 ? Wc : (kd == 1 ? At : Cq)) + (kd == 0 ? ((j0 + trow) & mask) : trow);
+    double* p0; double* p1; double* p2; double* p3;
+    if (kd == 2) { p0 = base + c0i * cstride; p1 = base + c1i * cstride; p2 = base + c2i * cstride; p3 = base + c3i * cstride; }
+    else { p0 = base + ((j0 + c0i) & mask) * cstride; p1 = base + ((j0 + c0i + 4) & mask) * cstride;
+           p2 = base + ((j0 + c0i + 8) & mask) * cstride; p3 = base + ((j0 + c0i + 12) & mask) * cstride; }
+    v4d acc;
+    acc[0] = *p0; acc[1] = *p1; acc[2] = *p2; acc[3] = *p3;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+    double* const trash = xb + 2 * MCAP - 64 + lane;   // xb is unused during the forward sweep
+    *((ok & 1) ? p0 : trash) = acc[0];
+    *((ok & 2) ? p1 : trash) = acc[1];
+    *((ok & 4) ? p2 : trash) = acc[2];
+    *((ok & 8) ? p3 : trash) = acc[3];
+  };
+  // step A: factor the panel at j0 (wave synchronous: lane = row, v_readlane broadcasts,
+  // v_rsq_f64 seed + two Newton steps); the panel of L goes to LpN / dinvN
+  auto step_A = [&](int j0, double* LpN, double* dinvN) __attribute__((always_inline)) {
+    const int rho = rhoA;
+    double av[PW];
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+      double v = 0.0;
+      if (rho >= 0) {
+        if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * LDW + ((j0 + rho) & mask)]; }
+        else v = At[((j0 + c) & mask) * brp + (rho - m)];
+      }
+      av[c] = v;
+    }
+    double rsd = 1.0;
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+      double piv = readlane_f64(av[c], c);
+      if (!(piv > 0.0)) { if (lane == 0) *fail_flag_p = 1; piv = 1.0; }
+      const double h = 0.5 * piv;
+      double y = __builtin_amdgcn_rsq(piv);
+      y = y * fma(-h * y, y, 1.5);
+      y = y * fma(-h * y, y, 1.5);
+      const double l = av[c] * y;
+      av[c] = l;
+      if (lane == c) rsd = y;
+#pragma unroll
+      for (int c2 = c + 1; c2 < PW; ++c2) {
+        const double lc2 = readlane_f64(l, c2);
+        av[c2] = fma(-l, lc2, av[c2]);
+      }
+    }
+    if (publishA) {
+      double* lp = LpN + (size_t)rho * PW;
+#pragma unroll
+      for (int c = 0; c < PW; ++c) lp[c] = (rho < c) ? 0.0 : av[c];
+      if (lane < PW && wave == 0) dinvN[lane] = rsd;
+    }
+  };
+  // rows / border columns entering the window after the panel at j0: global loads into
+  // registers (issued a phase early), LDS writes later
+  double pre_w[NPW], pre_a;
+  auto prefetch = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const int e = tid + i * kCholThreads;
       const int rr = e >> LOG, ci = e & mask;
-      const int gr = j0 + m + rr, gc = nj0 + ci;
+      const int gr = j0 + m + rr, gc = j0 + PW + ci;
       pre_w[i] = (e < PW * MCAP && ci < m && gc <= gr) ? band_orig(gr, gc) : 0.0;
     }
     pre_a = pa_cc >= 0 ? border_orig(pa_b, j0 + m + pa_cc) : 0.0;
-    PROF_MARK(1);
-    // ---------------- step A: factor the panel (wave synchronous) -------------
-    if (wave * 56 < RN) {
-      const int rho = rhoA;
-      double av[PW];
+  };
+  auto advance = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int c = 0; c < PW; ++c) {
-        double v = 0.0;
-        if (rho >= 0) {
-          if (rho < m) { if (rho >= c) v = Wc[((j0 + c) & mask) * LDW + ((j0 + rho) & mask)]; }
-          else v = At[((j0 + c) & mask) * brp + (rho - m)];
-        }
-        av[c] = v;
-      }
-      double rsd = 1.0;
-#pragma unroll
-      for (int c = 0; c < PW; ++c) {
-        double piv = readlane_f64(av[c], c);
-        if (!(piv > 0.0)) { if (lane == 0) *fail_flag_p = 1; piv = 1.0; }
-        const double h = 0.5 * piv;
-        double y = __builtin_amdgcn_rsq(piv);      // v_rsq_f64 seed + two Newton steps
-        y = y * fma(-h * y, y, 1.5);
-        y = y * fma(-h * y, y, 1.5);
-        const double l = av[c] * y;
-        av[c] = l;
-        if (lane == c) rsd = y;
-#pragma unroll
-        for (int c2 = c + 1; c2 < PW; ++c2) {
-          const double lc2 = readlane_f64(l, c2);
-          av[c2] = fma(-l, lc2, av[c2]);
-        }
-      }
-      if (publishA) {
-        double* lp = Lp + (size_t)rho * PW;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) lp[c] = (rho < c) ? 0.0 : av[c];
-        if (lane < PW && wave == 0) dinv[lane] = rsd;
-      }
+    for (int i = 0; i < NPW; ++i) {
+      const int e = tid + i * kCholThreads;
+      const int rr = e >> LOG, ci = e & mask;
+      const int gr = j0 + m + rr, gc = j0 + PW + ci;
+      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * LDW + (gr & mask)] = pre_w[i];
     }
+    if (pa_cc >= 0) At[((j0 + m + pa_cc) & mask) * brp + pa_b] = pre_a;
+  };
+  double* const LpB = Lp + (size_t)(m + br + 16) * PW;   // second panel buffer (look-ahead)
+  double* const dinvB = dinv + PW;
+
+  PROF_MARK(0);
+  // ---- prologue: first panel
+  if (c0 < c1) {
+    prefetch(c0);
+    if (wave < NA) step_A(c0, Lp, dinv);
+  }
+  lds_barrier();
+  int par = 0;
+  for (int j0 = c0; j0 < c1; j0 += PW, par ^= 1) {
+    const double* LpC = par ? LpB : Lp;
+    const double* dinvC = par ? dinvB : dinv;
+    // ---- phase C: critical tiles (touch the next panel's columns) + window advance
+    if (tk_kind[0] >= 0) run_tile(tk_kind[0], tk_lpa[0], tk_lpb[0], tk_row[0], tk_col[0], tk_c1[0], tk_c2[0], tk_c3[0], tk_ok[0], LpC, j0);
+    advance(j0);
+    PROF_MARK(1);
+    lds_barrier();
     PROF_MARK(2);
-    __syncthreads();
-    PROF_MARK(3);
-    // ---------------- step B: trailing (Schur) update  C -= L_panel L_panel^T  as 16x16 MFMA tiles
-    // (v_mfma_f64_16x16x4_f64, K = 8 -> two MFMAs per tile).  Tile kinds: band x band (lower),
-    // border x band, border x border (lower).  The MFMA computes the TRANSPOSED tile so that a
-    // lane's 4 results share one matrix row index pattern that is contiguous in the column-major
-    // LDS windows:  D(i', j') = C(row = R0 + j', col = C0 + i'),  A[i'][k] = L[col][k],  B[k][j'] = -L[row][k].
-    {
-      // global factor storage of the panel's band rows: wave w publishes panel column w
-      if (wave < PW) {
+    // ---- phase O: step A of the next panel (waves < NA)  ||  rest of the trailing update,
+    //      global factor storage of this panel (waves >= NA);  everyone prefetches
+    const bool more = j0 + PW < c1;
+    if (more) prefetch(j0 + PW);
+    if (wave < NA) {
+      if (more) {
+        __builtin_amdgcn_s_setprio(3);   // the panel factorisation is the critical path: win VALU arbitration over the update waves
+        step_A(j0 + PW, par ? Lp : LpB, par ? dinv : dinvB);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 1; i <= TMAX; ++i) if (i <= n_rest) run_tile(tk_kind[i], tk_lpa[i], tk_lpb[i], tk_row[i], tk_col[i], tk_c1[i], tk_c2[i], tk_c3[i], tk_ok[i], LpC, j0);
+      // global factor storage: band rows (lane = row, one panel column per wave slot), border rows
+      const int wr = wave - NA;
+      for (int c = wr; c < PW; c += NREST) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-          const int rho = lane + 64 * ps, c = wave, k = rho - c;
-          if (rho < m && j0 + rho < Pb && j0 + c < Pb && k >= 0 && k <= hb) Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinv[c] : Lp[(size_t)rho * PW + c];
+          const int rho = lane + 64 * ps, k = rho - c;
+          if (rho < m && j0 + rho < Pb && j0 + c < Pb && k >= 0 && k <= hb) Mb[(int64_t)(j0 + c) * W + k] = (k == 0) ? dinvC[c] : LpC[(size_t)rho * PW + c];
         }
       }
-      PROF_MARK(8);
-      // static tile descriptors of this wave (built before the panel loop): only the circular
-      // slot arithmetic depends on j0
-      typedef double v4d __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int i = 0; i < TMAX; ++i) {
-        if (i >= my_tiles) break;
-        const int kd = tk_kind[i];
-        const double a0 = Lp[tk_lpa[i]], a1 = Lp[tk_lpa[i] + 4];
-        const double b0 = -Lp[tk_lpb[i]], b1 = -Lp[tk_lpb[i] + 4];
-        const int cstride = kd == 0 ? LDW : brp;
-        double* const base = (kd == 0 ? Wc : (kd == 1 ? At : Cq)) + (kd == 0 ? ((j0 + tk_row[i]) & mask) : tk_row[i]);
-        const int c0i = tk_col[i];
-        double* p0; double* p1; double* p2; double* p3;
-        if (kd == 2) { p0 = base + c0i * cstride; p1 = base + tk_c1[i] * cstride; p2 = base + tk_c2[i] * cstride; p3 = base + tk_c3[i] * cstride; }
-        else { p0 = base + ((j0 + c0i) & mask) * cstride; p1 = base + ((j0 + c0i + 4) & mask) * cstride;
-               p2 = base + ((j0 + c0i + 8) & mask) * cstride; p3 = base + ((j0 + c0i + 12) & mask) * cstride; }
-        v4d acc;
-        acc[0] = *p0; acc[1] = *p1; acc[2] = *p2; acc[3] = *p3;
-        PROF_MARK(6);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-        if (PROF && prof) { asm volatile("s_nop 0" :: "v"(acc[0])); }
-        PROF_MARK(7);
-        const int ok = tk_ok[i];
-        double* const trash = xb + 2 * MCAP - 64 + lane;   // xb is unused during the forward sweep
-        *((ok & 1) ? p0 : trash) = acc[0];
-        *((ok & 2) ? p1 : trash) = acc[1];
-        *((ok & 4) ? p2 : trash) = acc[2];
-        *((ok & 8) ? p3 : trash) = acc[3];
-        PROF_MARK(11);
-      }
-      PROF_MARK(10);
-      // border part of the global factor
-      for (int e = tid; e < br * PW; e += kCholThreads) {
+      for (int e = wr * 64 + lane; e < br * PW; e += NREST * 64) {
         const int b = e >> 3, c = e & 7;
         if (j0 + c < Pb) {
-          const double v = Lp[(size_t)(m + b) * PW + c];
+          const double v = LpC[(size_t)(m + b) * PW + c];
           if (b < nsep) A.Msep[(int64_t)b * Pb + j0 + c] = v; else Mt[(int64_t)(b - nsep) * Pb + j0 + c] = v;
         }
       }
     }
-    PROF_MARK(9);
-    // ---------------- step B (3): window advance (entering rows alias only finished slots)
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      const int e = tid + i * kCholThreads;
-      const int rr = e >> LOG, ci = e & mask;
-      const int gr = j0 + m + rr, gc = nj0 + ci;
-      if (e < PW * MCAP && ci < m && gc <= gr) Wc[(gc & mask) * LDW + (gr & mask)] = pre_w[i];
-    }
-    if (pa_cc >= 0) At[((j0 + m + pa_cc) & mask) * brp + pa_b] = pre_a;
+    PROF_MARK(3);
+    lds_barrier();
     PROF_MARK(4);
-    __syncthreads();
-    PROF_MARK(5);
   }
+  __syncthreads();   // full fence: the factor written to global memory is read back below
 
   if (MODE == 1) {
     // ---- Schur updates of this partition onto the reduced (separators + arrow) system
@@ -499,17 +540,28 @@ __global__ void __launch_bounds__(256) partition_backward_kernel(CholArgs A, con
 }
 
 // ---- host side ----------------------------------------------------------------------
-static size_t lds_bytes(int mcap, int br) {
+static size_t lds_bytes(int mcap, int br, int m) {
   const int brp = br | 1;
-  const size_t dbl = (size_t)mcap * (mcap + 2) + (size_t)mcap * brp + (((size_t)br * brp + 1) & ~(size_t)1) + (size_t)(mcap + br + 16) * PW + 2 * mcap + br + PW + 8;
+  const size_t dbl = (size_t)mcap * (mcap == 64 ? mcap + 2 : mcap) + (size_t)mcap * brp + (((size_t)br * brp + 1) & ~(size_t)1) + 2 * (size_t)(m + br + 16) * PW + 2 * mcap + br + 2 * PW + 8;
   return dbl * sizeof(double);
+}
+
+// geometry limits of the look-ahead sweep: step-A waves, critical tiles (one per wave), rest tiles
+static bool sweep_geometry_ok(int m, int br) {
+  const int NW = kCholThreads / 64;
+  const int RN = (m - PW) + br, NA = (RN + 55) / 56;
+  const int nbt = (m - PW + 15) / 16, nrt = (br + 15) / 16;
+  const int T = nbt * (nbt + 1) / 2 + nrt * nbt + nrt * (nrt + 1) / 2, NC = nbt + nrt;
+  if (NA >= NW || NC > NW) return false;
+  if ((T - NC + (NW - NA) - 1) / (NW - NA) > 4) return false;   // TMAX rest tiles per wave
+  return PW * br <= kCholThreads;
 }
 
 // number of time partitions for (Pb, hb): minimise  interior_panels + 1.6 * reduced_panels
 int choose_partitions(int Pb, int hb, int a) {
   if (Pb < 8 * (hb + 8) || hb + PW > 64 || 2 * hb - 1 + PW > 128) return 1;
-  if (lds_bytes(64, hb + a + 1) > 160 * 1024 - 256 || lds_bytes(128, a + 1) > 160 * 1024 - 256) return 1;
-  if ((64 - PW) + hb + a + 1 > (kCholThreads / 64) * 56 || PW * (hb + a + 1) > kCholThreads) return 1;
+  if (lds_bytes(64, hb + a + 1, hb + PW) > 160 * 1024 - 64 || lds_bytes(128, a + 1, 2 * hb - 1 + PW) > 160 * 1024 - 64) return 1;
+  if (!sweep_geometry_ok(hb + PW, hb + a + 1) || !sweep_geometry_ok(2 * hb - 1 + PW, a + 1)) return 1;
   int best = 1; double best_cost = Pb / 8.0;
   for (int p = 2; p <= 192; ++p) {
     const int L = (((Pb - (p - 1) * hb) / p) / PW) * PW;
@@ -528,7 +580,7 @@ int64_t solve_workspace_doubles(const TangentLayout& tl) {
 
 template <int MCAP, int MODE>
 static void launch_sweep(const CholArgs& A, int grid, int br, hipStream_t st) {
-  const size_t lds = lds_bytes(MCAP, br);
+  const size_t lds = lds_bytes(MCAP, br, A.sys.hb + PW);
   if (A.prof) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_arrow_cholesky_kernel<MCAP, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((band_arrow_cholesky_kernel<MCAP, MODE, true>), dim3(grid), dim3(kCholThreads), lds, st, A, br | 1);
@@ -547,14 +599,15 @@ int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, 
   A.sys = CholSys{sb.Mb, sb.Mt, sb.Mc, tl.Pb, tl.W, tl.hb, tl.a};
   A.sol = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof; A.p = 1; A.L = 0; A.Msep = nullptr;
   int p = sb.force_p > 0 ? sb.force_p : choose_partitions(tl.Pb, tl.hb, tl.a);
+  if (p > 1 && choose_partitions(tl.Pb, tl.hb, tl.a) <= 1 && tl.Pb >= 8 * (tl.hb + 8)) p = 1;   // forced p: geometry must still fit
   if (sb.ws == nullptr || sb.ws_doubles < solve_workspace_doubles(tl)) p = 1;
   if (p > 1) {
     const int L = (((tl.Pb - (p - 1) * tl.hb) / p) / PW) * PW;
     if (L < tl.hb + PW) p = 1; else A.L = L;
   }
   if (p <= 1) {
-    if (lds_bytes(mcap, ar) > 160 * 1024 - 256) return -1;
-    if ((m - PW) + ar > (kCholThreads / 64) * 56 || PW * ar > kCholThreads) return -1;
+    if (lds_bytes(mcap, ar, m) > 160 * 1024 - 64) return -1;
+    if (!sweep_geometry_ok(m, ar)) return -1;
     if (mcap == 64) launch_sweep<64, 0>(A, 1, ar, st); else launch_sweep<128, 0>(A, 1, ar, st);
     return 0;
   }

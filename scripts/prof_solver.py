@@ -10,5 +10,5 @@ f.argtypes=[C.c_void_p, C.c_int32, C.POINTER(C.c_longlong)]
 out=(C.c_longlong*12)()
 tr.SetOption("solver_partitions", int(sys.argv[1]) if len(sys.argv)>1 else 0)
 rc=f(tr._h, E.SPLINE|E.T_I_C|E.GRAVITY_DIR, out)
-v=list(out); print(rc, dict(zip(["init","prefetch","stepA","bar1","B3_advance","bar2","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"],v)), sum(v))
+v=list(out); print(rc, dict(zip(["init","phaseC","barC","phaseO_A","barO","x5","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"],v)), sum(v))
 print(tr.GetTangentLayout(E.SPLINE|E.T_I_C|E.GRAVITY_DIR)["P"])
