@@ -1,0 +1,519 @@
+// Block cyclic reduction (nested dissection in time) of the damped LM system -- the
+// O(log n)-depth replacement of the panel-sequential band sweep for the
+// SPARSE_NORMAL_CHOLESKY step of ceres::Solve [EXT] (called at
+// spline_trajectory_estimator.impl.h:272).
+//
+// The band (half bandwidth hb <= 64, knots in time order) is cut into n blocks of 64
+// columns, which makes it block tridiagonal; the arrow rows (T_i_c, gravity, line delay,
+// biases, intrinsics) and the right-hand side ride along as dense border rows.
+//
+//   level l (stride s = 2^l): the active blocks are 0, s, 2s, ...; every block at an ODD
+//   position is a pivot and is eliminated by ONE workgroup, all pivots of a level
+//   concurrently:
+//        W = [ D_i ; S(left neighbour) ; S(right neighbour) ; F_i ]     (192 + a + 1) x 64
+//     dense right-looking Cholesky in 8-column panels (lane = row, v_readlane broadcasts,
+//     v_rsq_f64 + 2 Newton steps); the trailing matrix lives in REGISTERS as 16x16
+//     MFMA tiles (v_mfma_f64_16x16x4_f64) owned statically by the 16 waves, only the next
+//     panel's columns go back to LDS;
+//     Schur complement L_B L_B^T (K = 64) of the border onto the two neighbours, their
+//     new coupling, the arrow rows and the corner, again on MFMA: fp64 atomics for the
+//     shared targets, plain stores for the coupling.
+//   After ceil(log2 n) levels block 0 is alone: its workgroup also factors the arrow
+//   corner, solves it and starts the back substitution, which then runs level by level
+//   in reverse, again one workgroup per pivot.
+#include <hip/hip_runtime.h>
+#include "oicc_device.h"
+
+namespace oicc {
+
+constexpr int kBcrThreads = 1024;
+constexpr int kBcrSlots = 4;   // register-resident trailing tiles per wave
+
+struct BcrArgs {
+  double* D;    // [n][64*64]   diagonal blocks, column major (c*64 + r), lower part used
+  double* F;    // [n][64*a1]   border rows (arrow + rhs), column major (c*a1 + q)
+  double* S;    // couplings, 64*64 each, PIVOT major: Q[c*64 + r] = A(pivot var c, neighbour var r)
+  double* Lf;   // [n][Ru*64]   factor rows of each pivot, row major: L_ii (diag slot = 1/L_ii), left, right, border
+  double* Mc;   // [a1*a1]      arrow corner (full symmetric), target of the border Schur updates
+  double* x;    // [Pb + a]     solution
+  int32_t* fail;
+  long long* prof;   // optional cycle counters of block 0 / wave 0 (debug)
+  int n, a, Pb, rtf, LD;
+  int s;                       // stride of this level
+  int64_t offS_in, offS_out;   // first coupling of this level / of the next one
+};
+
+__device__ __forceinline__ void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ double bcr_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+typedef double bcr_v4d __attribute__((ext_vector_type(4)));
+
+// lower-triangular tile index 0..9 -> (xt >= yt) in a 4x4 tile grid
+__device__ __forceinline__ void tri10(int t, int& xt, int& yt) {
+  xt = t < 1 ? 0 : (t < 3 ? 1 : (t < 6 ? 2 : 3));
+  yt = t - (xt * (xt + 1)) / 2;
+}
+
+template <bool LAST, bool PROF>
+__global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int a = A.a, a1 = a + 1, LD = A.LD, rtf = A.rtf;
+  const int Ru = 192 + a1;
+  double* const W = lds;                 // [64][LD] column major: rows 0..63 pivot, 64.. left, 128.. right, 192.. border
+  double* const dinvs = W + 64 * LD;     // [64]
+  double* const da = dinvs + 64;         // [64] arrow solution (LAST)
+  int* const failp = reinterpret_cast<int*>(da + 64);
+
+  const int s = A.s;
+  const int i = LAST ? 0 : s * (2 * (int)blockIdx.x + 1);
+  const int il = i - s, ir = i + s;
+  const bool hasL = !LAST, hasR = !LAST && ir < A.n;
+  const double* Dg = A.D + (int64_t)i * 4096;
+  const double* Fg = A.F + (int64_t)i * 64 * a1;
+  const double* SL = hasL ? A.S + (A.offS_in + il / s) * 4096 : nullptr;
+  const double* SR = hasR ? A.S + (A.offS_in + i / s) * 4096 : nullptr;
+
+  const bool prof = PROF && A.prof != nullptr && blockIdx.x == 0 && wave == 0;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = prof ? clock64() : 0;
+#define BCR_MARK(k) do { if (PROF && prof) { const long long tn_ = clock64(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
+  if (tid == 0) *failp = 0;
+  {
+    // all global loads are issued before the first LDS write (one round trip instead of four)
+    const int fr = 16 * rtf;
+    double gd[4], gl[4], gr[4], gf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + k * kBcrThreads;
+      gd[k] = Dg[e];
+      gl[k] = hasL ? SL[e] : 0.0;
+      gr[k] = hasR ? SR[e] : 0.0;
+      const int c = e / fr, q = e - c * fr;
+      gf[k] = (e < 64 * fr && q < a1) ? Fg[c * a1 + q] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + k * kBcrThreads;
+      const int c = e >> 6, r = e & 63;
+      W[c * LD + r] = r >= c ? gd[k] : 0.0;
+      W[c * LD + 64 + r] = gl[k];
+      W[c * LD + 128 + r] = gr[k];
+      const int cf = e / fr, q = e - cf * fr;
+      if (e < 64 * fr) W[cf * LD + 192 + q] = gf[k];
+    }
+  }
+  __syncthreads();
+
+  // ---- static tile ownership: tile (rt, ct), rt >= ct, of the (12+rtf) x 4 tile grid
+  const int nrt = 12 + rtf;
+  int t_rt[kBcrSlots], t_ct[kBcrSlots]; bool t_ok[kBcrSlots];
+  bcr_v4d acc[kBcrSlots];
+#pragma unroll
+  for (int k = 0; k < kBcrSlots; ++k) {
+    int rem = wave + 16 * k, ct = 0;
+    while (ct < 4 && rem >= nrt - ct) { rem -= nrt - ct; ++ct; }
+    t_ok[k] = ct < 4; t_ct[k] = t_ok[k] ? ct : 0; t_rt[k] = t_ok[k] ? ct + rem : 0;
+    const double* src = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
+    acc[k][0] = src[0]; acc[k][1] = src[4 * LD]; acc[k][2] = src[8 * LD]; acc[k][3] = src[12 * LD];
+  }
+  BCR_MARK(0);
+  const int NAW = (Ru - 8 + 55) / 56;   // waves of the panel factorisation (lanes 0..7: diagonal rows, 8..63: one row each)
+
+  for (int j0 = 0; j0 < 64; j0 += 8) {
+    // ---- panel factorisation, in place in W
+    if (wave < NAW) {
+      const int rho = lane < 8 ? j0 + lane : 8 + wave * 56 + (lane - 8);
+      const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru);
+      double av[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) av[c] = (act && (lane >= 8 || lane >= c)) ? W[(j0 + c) * LD + rho] : 0.0;
+      double rsd = 1.0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double piv = bcr_readlane(av[c], c);
+        if (!(piv > 0.0)) { if (lane == 0) *failp = 1; piv = 1.0; }
+        const double h = 0.5 * piv;
+        double y = __builtin_amdgcn_rsq(piv);
+        y = y * fma(-h * y, y, 1.5);
+        y = y * fma(-h * y, y, 1.5);
+        const double l = av[c] * y;
+        av[c] = l;
+        if (lane == c) rsd = y;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2) {
+          const double lc2 = bcr_readlane(l, c2);
+          av[c2] = fma(-l, lc2, av[c2]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (act && (lane >= 8 || lane >= c) && (lane >= 8 || wave == 0)) W[(j0 + c) * LD + rho] = av[c];
+      if (wave == 0 && lane < 8) dinvs[j0 + lane] = rsd;
+    }
+    BCR_MARK(1);
+    bcr_lds_barrier();
+    BCR_MARK(2);
+    // ---- trailing update in registers; the next panel's columns go back to LDS
+    const int jn = j0 + 8;
+    if (jn < 64) {
+#pragma unroll
+      for (int k = 0; k < kBcrSlots; ++k) {
+        if (t_ok[k] && 16 * t_ct[k] + 15 >= jn) {
+          const double* pa = W + (j0 + lq) * LD + 16 * t_ct[k] + li;
+          const double* pb = W + (j0 + lq) * LD + 16 * t_rt[k] + li;
+          const double a0 = pa[0], a1v = pa[4 * LD];
+          const double b0 = -pb[0], b1 = -pb[4 * LD];
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1, acc[k], 0, 0, 0);
+          if (16 * t_ct[k] == (jn & ~15)) {
+            double* dst = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
+            if (jn & 8) { dst[8 * LD] = acc[k][2]; dst[12 * LD] = acc[k][3]; }
+            else { dst[0] = acc[k][0]; dst[4 * LD] = acc[k][1]; }
+          }
+        }
+      }
+    }
+    BCR_MARK(3);
+    bcr_lds_barrier();
+    BCR_MARK(4);
+  }
+
+  // ---- factor rows to global memory (row major; diagonal slot = 1/L_ii, upper part zero)
+  if (!LAST) {
+    double* Lg = A.Lf + (int64_t)i * Ru * 64;
+    for (int e = tid; e < Ru * 64; e += kBcrThreads) {
+      const int r = e >> 6, c = e & 63;
+      double v = W[c * LD + r];
+      if (r < 64) v = r > c ? v : (r == c ? dinvs[c] : 0.0);
+      Lg[e] = v;
+    }
+  }
+  BCR_MARK(5);
+
+  if (!LAST) {
+    // the Schur complement of the border rows is formed by bcr_schur_kernel from the factor rows just written
+    __syncthreads();
+    if (tid == 0 && *failp) atomicOr(A.fail, 1);
+    if (PROF && prof && lane == 0) for (int k = 0; k < 8; ++k) A.prof[k] = pc[k];
+    return;
+  }
+
+  // ---------------- LAST: arrow corner, back substitution of block 0
+  __syncthreads();
+  // Cq(r, c) = W[c*LD + 64 + r]   (rows 64.. are unused without neighbours)
+  for (int e = tid; e < a1 * a1; e += kBcrThreads) {
+    const int c = e / a1, r = e - c * a1;
+    double v0 = A.Mc[r * a1 + c], v1 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 64; k += 2) {
+      v0 = fma(-W[k * LD + 192 + r], W[k * LD + 192 + c], v0);
+      v1 = fma(-W[(k + 1) * LD + 192 + r], W[(k + 1) * LD + 192 + c], v1);
+    }
+    W[c * LD + 64 + r] = v0 + v1;
+  }
+  __syncthreads();
+  for (int c = 0; c < a; ++c) {
+    double* col = W + c * LD + 64;
+    if (tid == 0) { double piv = col[c]; if (!(piv > 0.0)) { *failp = 1; piv = 1.0; } col[c] = sqrt(piv); }
+    __syncthreads();
+    const double d = col[c];
+    for (int r = c + 1 + tid; r < a1; r += kBcrThreads) col[r] /= d;
+    __syncthreads();
+    const int nrem = a1 - (c + 1);
+    for (int e = tid; e < nrem * nrem; e += kBcrThreads) {
+      const int c2 = c + 1 + e / nrem, r = c + 1 + e % nrem;
+      if (r >= c2 && c2 < a) W[c2 * LD + 64 + r] -= col[r] * col[c2];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    // back substitution of the corner, lane = arrow column: z_q = Cq(a, q), L_c^T x_a = z
+    double z = lane < a ? W[lane * LD + 64 + a] : 0.0;
+    const double dc = lane < a ? 1.0 / W[lane * LD + 64 + lane] : 0.0;
+    double xq_mine = 0.0;
+    for (int q = a - 1; q >= 0; --q) {
+      const double xq = bcr_readlane(z * dc, q);
+      if (lane == q) xq_mine = xq;
+      const double l = lane < q ? W[lane * LD + 64 + q] : 0.0;    // L_c(q, lane)
+      z = fma(-l, xq, z);
+    }
+    if (lane < a) da[lane] = xq_mine;
+  }
+  __syncthreads();
+  for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
+  if (wave == 0) {
+    double z = W[lane * LD + 192 + a];
+    for (int q = 0; q < a; ++q) z = fma(-W[lane * LD + 192 + q], da[q], z);
+    double xv = 0.0;
+    const double dv = dinvs[lane];
+    for (int jb = 56; jb >= 0; jb -= 8) {
+      double l8[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) l8[t] = lane < jb + t ? -W[lane * LD + jb + t] : 0.0;   // L(jb+t, lane)
+#pragma unroll
+      for (int t = 7; t >= 0; --t) {
+        const double xj = bcr_readlane(z * dv, jb + t);
+        if (lane == jb + t) xv = xj;
+        z = fma(l8[t], xj, z);
+      }
+    }
+    if (lane < A.Pb) A.x[lane] = xv;
+  }
+  __syncthreads();
+  if (tid == 0 && *failp) atomicOr(A.fail, 1);
+#undef BCR_MARK
+}
+
+// ---- Schur complement of the border rows of the pivots of one level: -L_B L_B^T onto the two
+// neighbours, their new coupling, the arrow rows and the corner.  ONE WAVE PER 16x16 TILE
+// (grid.x = tile groups of 4 waves, grid.y = pivots): the fp64 MFMA pipe of one CU
+// (128 FLOP/clk) would need ~11k cycles for the 45 tiles, spread over the chip it is one
+// dependent chain of 16 MFMAs.  Operands come straight from the factor rows in global memory,
+// 16 consecutive doubles per lane (the K index is permuted identically for both operands).
+__global__ __launch_bounds__(256) void bcr_schur_kernel(BcrArgs A) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int a1 = A.a + 1, rtf = A.rtf, Ru = 192 + a1, s = A.s;
+  const int i = s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
+  const bool hasR = ir < A.n;
+  const int nRL = hasR ? 16 : 0, nLL = 10, nRR = hasR ? 10 : 0;
+  const int nFL = 4 * rtf, nFR = hasR ? 4 * rtf : 0, nFF = (rtf * (rtf + 1)) / 2;
+  const int ntot = nRL + nLL + nRR + nFL + nFR + nFF;
+  const int t = (int)blockIdx.x * 4 + wave;
+  if (t >= ntot) return;
+  // orientation of the new coupling (il, ir): the pivot of the next level is the one at an odd position
+  const bool il_is_pivot = ((il / (2 * s)) & 1) != 0;
+  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)ir * 4096;
+  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)ir * 64 * a1;
+  double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
+  const double* Lg = A.Lf + (int64_t)i * Ru * 64;
+  int kind, xt, yt, u = t;
+  if (u < nRL) { kind = 0; xt = u >> 2; yt = u & 3; }
+  else if ((u -= nRL) < nLL) { kind = 1; tri10(u, xt, yt); }
+  else if ((u -= nLL) < nRR) { kind = 2; tri10(u, xt, yt); }
+  else if ((u -= nRR) < nFL) { kind = 3; xt = u >> 2; yt = u & 3; }
+  else if ((u -= nFL) < nFR) { kind = 4; xt = u >> 2; yt = u & 3; }
+  else { u -= nFR; kind = 5; xt = 0; while (u >= xt + 1) { u -= xt + 1; ++xt; } yt = u; }
+  // factor rows that form the tile: x = "row" operand, y = "column" operand
+  const int xr0 = kind == 0 ? 128 + 16 * xt : kind == 1 ? 64 + 16 * xt : kind == 2 ? 128 + 16 * xt : 192 + 16 * xt;
+  const int yr0 = kind == 0 ? 64 + 16 * yt : kind == 1 ? 64 + 16 * yt : kind == 2 ? 128 + 16 * yt : kind == 3 ? 64 + 16 * yt : kind == 4 ? 128 + 16 * yt : 192 + 16 * yt;
+  const bool swap = kind == 0 && !il_is_pivot;   // store with the y index contiguous
+  const int ar0 = swap ? xr0 : yr0, br0 = swap ? yr0 : xr0;
+  int ra = ar0 + li, rb = br0 + li;
+  ra = ra < Ru ? ra : Ru - 1; rb = rb < Ru ? rb : Ru - 1;      // padding rows of the last border tile (masked below)
+  const double* pa = Lg + (int64_t)ra * 64 + 16 * lq;
+  const double* pb = Lg + (int64_t)rb * 64 + 16 * lq;
+  double va[16], vb[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { va[kk] = pa[kk]; vb[kk] = pb[kk]; }
+  bcr_v4d g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) g = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], g, 0, 0, 0);
+  // g[r] <-> (b-operand row br0 + li, a-operand row ar0 + lq + 4r)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double v = -g[r];
+    if (kind == 0) {
+      if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; }       // Q[c = il var][r = ir var]
+      else       { const int y = 16 * yt + li, x = 16 * xt + lq + 4 * r; So[x * 64 + y] = v; }       // Q[c = ir var][r = il var]
+    } else if (kind == 1 || kind == 2) {
+      const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
+      if (x >= y && v != 0.0) unsafeAtomicAdd((kind == 1 ? Dl : Dr) + y * 64 + x, v);
+    } else if (kind == 3 || kind == 4) {
+      const int q = 16 * xt + li, y = 16 * yt + lq + 4 * r;
+      if (q < a1 && v != 0.0) unsafeAtomicAdd((kind == 3 ? Fl : Fr) + y * a1 + q, v);
+    } else {
+      const int q1 = 16 * xt + li, q2 = 16 * yt + lq + 4 * r;
+      if (q1 < a1 && q2 <= q1 && v != 0.0) {
+        unsafeAtomicAdd(A.Mc + q1 * a1 + q2, v);
+        if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
+      }
+    }
+  }
+}
+
+// ---- back substitution of the pivots of one level (one workgroup of 4 waves per pivot):
+//   x_i = L_ii^-T ( y_i - L_left^T x_il - L_right^T x_ir - L_F^T x_arrow )
+// lane = column.  Every global load is issued before the first use; wave 0 keeps its column of
+// L_ii in registers so that the 64 dependent steps of the triangular solve are
+// mul -> v_readlane -> fma with nothing else on the chain.
+__global__ __launch_bounds__(256) void bcr_backward_kernel(BcrArgs A) {
+  __shared__ double xs[192];
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = A.a, a1 = a + 1, Ru = 192 + a1, s = A.s;
+  const int i = s * (2 * (int)blockIdx.x + 1), il = i - s, ir = i + s;
+  const bool hasR = ir < A.n;
+  const double* Lg = A.Lf + (int64_t)i * Ru * 64;
+  constexpr int RW = 48;                       // border rows per wave: 4 * 48 = 192 >= 128 + a
+  double lv[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int r = wave + 4 * k;
+    const int row = r < 128 ? 64 + r : 192 + (r - 128);
+    lv[k] = r < 128 + a ? Lg[row * 64 + lane] : 0.0;
+  }
+  double Lc[64], dv = 0.0, yv = 0.0;
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) Lc[j] = Lg[j * 64 + lane];       // L(j, lane); diagonal slot = 1/L_jj; upper part zero
+    dv = Lg[lane * 64 + lane];
+    yv = Lg[(192 + a) * 64 + lane];
+  }
+  double xin = 0.0;
+  if (tid < 64) { const int gi = il * 64 + tid; xin = gi < A.Pb ? A.x[gi] : 0.0; }
+  else if (tid < 128) { const int gi = ir * 64 + (tid - 64); xin = (hasR && gi < A.Pb) ? A.x[gi] : 0.0; }
+  else if (tid < 128 + a) xin = A.x[A.Pb + (tid - 128)];
+  if (tid < 192) xs[tid] = xin;
+  __syncthreads();
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < RW; ++k) { const int r = wave + 4 * k; sum = fma(lv[k], r < 128 + a ? xs[r] : 0.0, sum); }
+  part[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0) {
+    double z = yv - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    double xv = 0.0;
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+      const double xj = bcr_readlane(z * dv, j);
+      if (lane == j) xv = xj;
+      z = fma(lane < j ? -Lc[j] : 0.0, xj, z);
+    }
+    const int gi = i * 64 + lane;
+    if (gi < A.Pb) A.x[gi] = xv;
+  }
+}
+
+// ---- damped, scaled system in block form:  M = S H S + clamp(diag)/radius, rhs = -S g -----
+__global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal, double min_diag,
+                                 double max_diag, BcrArgs A) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
+  const double radius = sb.st->radius;
+  auto damp = [&](int64_t i, double hii) -> double {
+    const double sc = sb.scale[i];
+    return (reuse_diagonal ? sb.diag[i] : fmin(fmax(hii * sc * sc, min_diag), max_diag)) / radius;
+  };
+  for (int64_t i = tid; i < tl.P; i += nthreads) {
+    const double hii = i < Pb ? ne.band()[i * W] : ne.C()[(i - Pb) * a + (i - Pb)];
+    const double sc = sb.scale[i];
+    double d;
+    if (!reuse_diagonal) { d = fmin(fmax(hii * sc * sc, min_diag), max_diag); sb.diag[i] = d; }
+    else d = sb.diag[i];
+    sb.D2[i] = d / radius;
+  }
+  // diagonal blocks (lower part) and level-0 couplings
+  for (int64_t e = tid; e < (int64_t)n * 4096; e += nthreads) {
+    const int blk = int(e >> 12), c = int(e >> 6) & 63, r = int(e) & 63;
+    {
+      const int64_t gc = (int64_t)blk * 64 + c, gr = (int64_t)blk * 64 + r;
+      double v = 0.0;
+      if (r >= c) {
+        const int k = r - c;
+        if (gr < Pb) {
+          if (k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
+          if (k == 0) v += damp(gc, ne.band()[gc * W]);
+        } else if (gc >= Pb && k == 0) v = 1.0;    // identity padding of the last block
+      }
+      A.D[e] = v;
+    }
+    if (blk < n - 1) {
+      // coupling (blk, blk+1): the pivot of level 0 is the odd one
+      const bool right = (blk & 1) != 0;     // pivot = blk, neighbour = blk+1 (its right)
+      const int64_t gr = (int64_t)(blk + 1) * 64 + (right ? r : c);
+      const int64_t gc = (int64_t)blk * 64 + (right ? c : r);
+      const int64_t k = gr - gc;
+      double v = 0.0;
+      if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
+      A.S[e] = v;
+    }
+  }
+  // border rows: arrow + rhs
+  for (int64_t e = tid; e < (int64_t)n * 64 * a1; e += nthreads) {
+    const int64_t gi = e / a1; const int q = int(e - gi * a1);
+    double v = 0.0;
+    if (gi < Pb) v = q < a ? ne.Et()[(int64_t)q * Pb + gi] * sb.scale[gi] * sb.scale[Pb + q] : -ne.g()[gi] * sb.scale[gi];
+    A.F[e] = v;
+  }
+  // corner (same format as lm_build_kernel's Mc)
+  for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) {
+    const int r = int(e / a1), c = int(e - (int64_t)r * a1);
+    double v = 0.0;
+    if (r < a && c < a) {
+      v = ne.C()[r * a + c] * sb.scale[Pb + r] * sb.scale[Pb + c];
+      if (r == c) v += damp(Pb + r, ne.C()[r * a + r]);
+    } else if (r == a && c < a) v = -ne.g()[Pb + c] * sb.scale[Pb + c];
+    else if (c == a && r < a) v = -ne.g()[Pb + r] * sb.scale[Pb + r];
+    sb.Mc[e] = v;
+  }
+}
+
+// ---- host ------------------------------------------------------------------
+static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
+bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
+int64_t bcr_workspace_doubles(const TangentLayout& tl) {
+  if (!bcr_applicable(tl)) return 0;
+  const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
+  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64;
+}
+
+// build + factor + solve; the solution lands in sb.step_s.  Returns 0, or -1 if not applicable.
+int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal,
+                     double min_diag, double max_diag, hipStream_t st) {
+  if (!bcr_applicable(tl) || sb.ws == nullptr || sb.ws_doubles < bcr_workspace_doubles(tl)) return -1;
+  const int n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
+  BcrArgs A{};
+  double* w = sb.ws;
+  A.D = w; w += (int64_t)n * 4096;
+  A.F = w; w += (int64_t)n * 64 * a1;
+  A.S = w; w += (int64_t)2 * n * 4096;
+  A.Lf = w;
+  A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
+  A.n = n; A.a = tl.a; A.Pb = tl.Pb;
+  A.rtf = (a1 + 15) / 16;
+  const int Rp = 192 + 16 * A.rtf;
+  A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;
+  const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8) * sizeof(double);
+  if (lds > 160 * 1024 - 64) return -1;
+  {
+    int64_t work = (int64_t)n * 4096;
+    int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
+    A.s = 1; A.offS_in = 0; A.offS_out = 0;
+    hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int schur_groups = (36 + 8 * A.rtf + (A.rtf * (A.rtf + 1)) / 2 + 3) / 4;
+  // forward: levels while more than one block is active
+  int strides[40]; int npivs[40]; int nlev = 0;
+  int64_t off = 0;
+  for (int s = 1; s < n; s *= 2) {
+    const int m = (n + s - 1) / s;          // active blocks
+    const int npiv = m / 2;
+    A.s = s; A.offS_in = off; A.offS_out = off + (m - 1);
+    if (A.prof && s == 1) hipLaunchKernelGGL((bcr_eliminate_kernel<false, true>), dim3(npiv), dim3(kBcrThreads), lds, st, A);
+    else hipLaunchKernelGGL((bcr_eliminate_kernel<false, false>), dim3(npiv), dim3(kBcrThreads), lds, st, A);
+    hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, npiv), dim3(256), 0, st, A);
+    strides[nlev] = s; npivs[nlev] = npiv; ++nlev;
+    off += m - 1;
+  }
+  A.s = 0; A.offS_in = 0; A.offS_out = 0;
+  hipLaunchKernelGGL((bcr_eliminate_kernel<true, false>), dim3(1), dim3(kBcrThreads), lds, st, A);
+  for (int l = nlev - 1; l >= 0; --l) {
+    A.s = strides[l];
+    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(256), 0, st, A);
+  }
+  return 0;
+}
+
+}  // namespace oicc

@@ -92,6 +92,7 @@ struct SolveBuffers {
   double* ws;      // workspace of the time-partitioned solve (separator rows, reduced system)
   int64_t ws_doubles;
   int force_p;     // > 0: force this many partitions (tests); 0: heuristic
+  int algo;        // 0: auto, 1: time-partitioned band sweep, 2: block cyclic reduction
 };
 
 }  // namespace oicc

@@ -39,8 +39,20 @@ void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st);
 void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                      double max_diag, hipStream_t st);
 int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st);
+int64_t bcr_workspace_doubles(const TangentLayout& tl);
+int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
+                     double max_diag, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
+// damped system + factorisation + solve (solution in sb.step_s): block cyclic reduction when the
+// geometry allows (hb <= 64, arrow <= 63 columns), else the time-partitioned band sweep
+static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal,
+                                  double min_diag, double max_diag, hipStream_t st) {
+  if (sb.algo != 1 && launch_bcr_solve(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st) == 0) return 0;
+  if (sb.algo == 2 && tl.Pb > 0) return -1;
+  launch_lm_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st);
+  return launch_band_arrow_cholesky(tl, sb, st);
+}
 }  // namespace oicc
 
 using namespace oicc;
@@ -148,7 +160,7 @@ struct oicc_problem {
     opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
-    opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0;
+    opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0;
   }
 };
 
@@ -305,7 +317,7 @@ int make_layout(oicc_problem* p, int flags) {
   if (!p->d_ne.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
       !p->d_Mc.resize(int64_t(ar) * ar) || !p->d_scale.resize(std::max(tl.P, 1)) || !p->d_diag.resize(std::max(tl.P, 1)) ||
       !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1) ||
-      !p->d_ws.resize(size_t(solve_workspace_doubles(tl)))) {
+      !p->d_ws.resize(size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))))) {
     p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   ne.base = p->d_ne.p;
   p->layout_flags = flags;
@@ -641,7 +653,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   S.seconds_jacobian += now_s() - t0;
   S.initial_cost = cost;
   if (P == 0) return finish(OICC_CONVERGENCE, "no variable parameters");
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs));
   auto read_state = [&]() -> int {
@@ -664,8 +676,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     t0 = now_s();
     std::memset(&hs, 0, sizeof(hs)); hs.radius = radius; hs.gradient_max_norm = gmax;
     rc = write_state(); if (rc) return rc;
-    launch_lm_build(p->ne, tl, sb, reuse_diagonal ? 1 : 0, min_diag, max_diag, st);
-    if (launch_band_arrow_cholesky(tl, sb, st) != 0) {
+    if (launch_lm_solve(p->ne, tl, sb, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
       p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
       return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
@@ -735,7 +746,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   LmState hs;
   for (int it = 0; it < steps; ++it) {
     rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
@@ -743,8 +754,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
     std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
     HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
     launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
-    launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
-    if (launch_band_arrow_cholesky(tl, sb, st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+    if (launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
     double cand = 0.0;
@@ -790,17 +800,15 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
   hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
-  launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
-  if (launch_band_arrow_cholesky(tl, sb, st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+  if (launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
   HIPCK(p, hipEventRecord(e0, st));
   for (int i = 0; i < repeats; ++i) {
-    launch_lm_build(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
-    launch_band_arrow_cholesky(tl, sb, st);
+    launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
   }
   HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -817,13 +825,12 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
   rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
   const TangentLayout& tl = p->tl;
   DevBuf<long long> d; if (!d.resize(12)) return OICC_ERR_HIP;
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"])};
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   launch_lm_scale(p->ne, tl, sb.scale, 1, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = 1e4;
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
   for (int rep = 0; rep < 2; ++rep) {
-    launch_lm_build(p->ne, tl, sb, 0, 1e-6, 1e32, st);
-    if (launch_band_arrow_cholesky(tl, sb, st) != 0) return OICC_ERR_UNSUPPORTED;
+    if (launch_lm_solve(p->ne, tl, sb, 0, 1e-6, 1e32, st) != 0) return OICC_ERR_UNSUPPORTED;
   }
   HIPCK(p, hipMemcpyAsync(out, d.p, 12 * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCK(p, hipStreamSynchronize(st));

@@ -192,7 +192,7 @@ void eval_view(const Problem& p, const Layout& L, const Active& a, const ViewBlk
   ReprojFunctor f;
   f.rolling_shutter = v.rs; f.n = n; f.obs = &p.uv[2 * v.c0]; f.cov = &p.cov[2 * v.c0];
   f.u_so3 = v.u_so3; f.u_r3 = v.u_r3; f.inv_so3_dt = p.inv_so3_dt; f.inv_r3_dt = p.inv_r3_dt;
-  f.model = p.cam_model; f.n_intr = p.n_intr; f.intr_d = p.intr;
+  f.model = p.cam_model; f.n_intr = p.n_intr; f.intr_d = p.intr; f.rs_time_in_seconds = p.opt.at("rs_time_in_seconds") != 0.0;
   std::vector<const double*> par; std::vector<int> sz; std::vector<char> act;
   for (int i = 0; i < kN; ++i) { par.push_back(&p.so3[4 * (v.s_so3 + i)]); sz.push_back(4); act.push_back(a.spline); }
   for (int i = 0; i < kN; ++i) { par.push_back(&p.r3[3 * (v.s_r3 + i)]); sz.push_back(3); act.push_back(a.spline); }

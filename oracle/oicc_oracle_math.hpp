@@ -516,6 +516,7 @@ struct ReprojFunctor {
   const double* obs;     // 2n (x,y)
   const double* cov;     // 2n (cov_xx, cov_yy)
   double u_so3, u_r3, inv_so3_dt, inv_r3_dt;
+  bool rs_time_in_seconds = false;   // option: documented fix of quirk Q1 (row time shift in seconds)
   int model; int n_intr; const double* intr_d;
   template <class T>
   bool operator()(T const* const* k, T* res) const {
@@ -527,8 +528,8 @@ struct ReprojFunctor {
       const T* line_delay = k[N2 + 1];
       for (int i = 0; i < n; ++i) {
         const T y_coord = T(obs[2 * i + 1]) * line_delay[0];   // quirk Q1: seconds added to u
-        const T t_so3_row = T(u_so3) + y_coord;
-        const T t_r3_row = T(u_r3) + y_coord;
+        const T t_so3_row = T(u_so3) + (rs_time_in_seconds ? y_coord * T(inv_so3_dt) : y_coord);
+        const T t_r3_row = T(u_r3) + (rs_time_in_seconds ? y_coord * T(inv_r3_dt) : y_coord);
         Quat<T> R_w_i; evaluate_lie_so3<T, kN>(k, t_so3_row, T(inv_so3_dt), &R_w_i, (T*)nullptr);
         T t_w_i[3]; evaluate_rd<T, kN>(k + kN, 3, 0, t_r3_row, T(inv_r3_dt), t_w_i);
         reproject_corner<T>(R_w_i, t_w_i, T_i_c, k[N2 + 2 + i], model, intr, obs[2 * i], obs[2 * i + 1],

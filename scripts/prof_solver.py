@@ -2,13 +2,16 @@ import sys, ctypes as C
 sys.path.insert(0,'/root/repo')
 import numpy as np
 from openimucameracalibrator_amd import synthetic, estimator as E
+algo = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 ds = synthetic.make_config("C2")
 cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
 tr = cal.trajectory_
 f = tr._b.lib.oicc_debug_solver_profile
 f.argtypes=[C.c_void_p, C.c_int32, C.POINTER(C.c_longlong)]
 out=(C.c_longlong*12)()
-tr.SetOption("solver_partitions", int(sys.argv[1]) if len(sys.argv)>1 else 0)
+tr.SetOption("solver_algorithm", algo)
+tr.SetOption("solver_partitions", int(sys.argv[2]) if len(sys.argv)>2 else 0)
 rc=f(tr._h, E.SPLINE|E.T_I_C|E.GRAVITY_DIR, out)
-v=list(out); print(rc, dict(zip(["init","phaseC","barC","phaseO_A","barO","x5","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"],v)), sum(v))
-print(tr.GetTangentLayout(E.SPLINE|E.T_I_C|E.GRAVITY_DIR)["P"])
+v=list(out)
+names = ["load","stepA","bar1","update","bar2","lfac","schur","end"] if algo == 2 else ["init","phaseC","barC","phaseO_A","barO","x5","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"]
+print(rc, dict(zip(names,v)), sum(v))

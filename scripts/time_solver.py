@@ -2,13 +2,17 @@ import sys
 sys.path.insert(0, '/root/repo')
 from openimucameracalibrator_amd import synthetic, estimator as E
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+algos = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 1]
 ds = synthetic.make_config(cfg)
 cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
 tr = cal.trajectory_
 F = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
-for p in [1, 0, 2, 3, 4, 5, 6, 8, 12, 16, 24, 32, 48, 64]:
-    tr.SetOption("solver_partitions", p)
-    try:
-        print(cfg, "partitions", p if p else "auto", "solve ms", round(tr.TimeLinearSolve(F, 10), 4), flush=True)
-    except Exception as e:
-        print(p, "failed", e)
+for algo in algos:
+    tr.SetOption("solver_algorithm", algo)
+    for p in ([0] if algo == 2 else [1, 0]):
+        tr.SetOption("solver_partitions", p)
+        try:
+            print(cfg, "algorithm", {1: "band sweep", 2: "block cyclic reduction"}[algo], "partitions", p if p else "auto",
+                  "solve ms", round(tr.TimeLinearSolve(F, 10), 4), flush=True)
+        except Exception as e:
+            print(algo, p, "failed", e)

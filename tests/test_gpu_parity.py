@@ -129,15 +129,19 @@ def test_c2_full_size_properties():
     assert ang < np.deg2rad(0.5)
 
 
-@pytest.mark.parametrize("parts", [2, 3, 5])
-def test_time_partitioned_solver_matches_sequential(parts):
-    """The partitioned band+arrow Cholesky (p interior sweeps + reduced separator
-    system) must reproduce the single-workgroup solve: same LM iterates on C2."""
+@pytest.mark.parametrize("algo,parts", [(1, 2), (1, 3), (1, 5), (2, 0)])
+def test_parallel_solvers_match_sequential(algo, parts):
+    """The time-partitioned band+arrow Cholesky (algorithm 1: p interior sweeps + reduced
+    separator system) and the block cyclic reduction (algorithm 2: log-depth nested
+    dissection in time) must reproduce the single-workgroup sequential sweep: same LM
+    iterates on C2."""
     ds = synthetic.make_config("C2")
     ref = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    ref.trajectory_.SetOption("solver_algorithm", 1)
     ref.trajectory_.SetOption("solver_partitions", 1)
     s1 = ref.trajectory_.Optimize(50, FLAGS1)
     par = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    par.trajectory_.SetOption("solver_algorithm", algo)
     par.trajectory_.SetOption("solver_partitions", parts)
     s2 = par.trajectory_.Optimize(50, FLAGS1)
     assert s1["num_iterations"] == s2["num_iterations"] and s1["termination"] == s2["termination"]
@@ -147,3 +151,97 @@ def test_time_partitioned_solver_matches_sequential(parts):
     assert np.abs(ref.trajectory_.GetT_i_c() - par.trajectory_.GetT_i_c()).max() < 1e-9
     k1, k2 = ref.trajectory_.GetKnots(), par.trajectory_.GetKnots()
     assert np.abs(k1[0] - k2[0]).max() < 1e-9 and (np.abs(k1[1] - k2[1]) / (1 + np.abs(k1[1]))).max() < 1e-9
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_bias_and_intrinsics_active_lm_matches_oracle(algo):
+    """IMU_BIASES | IMU_INTRINSICS: 39+15 arrow columns, box-bounded bias knots; both solvers."""
+    ds = synthetic.make_config("tiny")
+    flags = FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    gpu.trajectory_.SetOption("solver_algorithm", algo)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    cg, Hg, gg = gpu.trajectory_.Evaluate(flags)
+    cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
+    assert rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    sg = gpu.trajectory_.Optimize(15, flags); sc = cpu.trajectory_.Optimize(15, flags)
+    assert sg["num_iterations"] == sc["num_iterations"] and sg["arrow_dim"] == sc["arrow_dim"] > 16
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-7 * sc["final_cost"]
+    ag, gg2 = gpu.trajectory_.GetBiasKnots(); ac, gc2 = cpu.trajectory_.GetBiasKnots()
+    assert np.abs(ag - ac).max() < 1e-6 and np.abs(gg2 - gc2).max() < 1e-6
+    assert np.abs(ag).max() <= 1.0 and np.abs(gg2).max() <= 0.1          # impl.h:213-218,235-240 bounds
+    ig, ic = gpu.trajectory_.GetIMUIntrinsics(), cpu.trajectory_.GetIMUIntrinsics()
+    assert np.abs(ig[0] - ic[0]).max() < 1e-6 and np.abs(ig[1] - ic[1]).max() < 1e-6
+
+
+@pytest.mark.parametrize("unit_loss", [0, 1])
+def test_global_shutter_views_quirk_q2(unit_loss):
+    """--global_shutter: GS functor with HuberLoss(0.0) leaves the views without weight
+    (impl.h:532); option gs_unit_loss gives them a trivial loss instead."""
+    ds = synthetic.make_config("tiny", rolling_shutter=False)
+    assert ds.line_delay_init == 0.0
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("gs_unit_loss", unit_loss)
+    cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1)
+    cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    if unit_loss == 0:   # only IMU blocks carry cost
+        ca = gpu.trajectory_.EvaluateBlocks(FLAGS1, 1, 3 * int(gpu.accl_accepted.sum()), False)[0]
+        cy = gpu.trajectory_.EvaluateBlocks(FLAGS1, 2, 3 * int(gpu.gyro_accepted.sum()), False)[0]
+        assert abs(0.5 * (ca @ ca + cy @ cy) - cg) <= 1e-10 * cg
+    # the mean reprojection error always uses the RS functor (impl.h:1017)
+    assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-9
+
+
+def test_rs_time_in_seconds_option():
+    ds = synthetic.make_config("tiny")
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("rs_time_in_seconds", 1)
+    flags = FLAGS1 | E.CAM_LINE_DELAY
+    n = 2 * gpu.num_corners
+    rg, Jg = gpu.trajectory_.EvaluateBlocks(flags, 0, n)
+    rc, Jc = cpu.trajectory_.EvaluateBlocks(flags, 0, n)
+    assert np.abs(rg - rc).max() <= 1e-11 * (1 + np.abs(rc).max())
+    scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc).max() + 1e-30
+    assert (np.abs(Jg - Jc) / scale).max() < 1e-8
+    # the fixed model shifts rows by ~20x more than the quirky one: residuals must differ
+    gpu.trajectory_.SetOption("rs_time_in_seconds", 0)
+    r0, _ = gpu.trajectory_.EvaluateBlocks(flags, 0, n, False)
+    assert np.abs(r0 - rg).max() > 1e-3
+
+
+def test_other_knot_spacings_change_bandwidth():
+    """dt_so3/dt_r3 = 0.056/0.128 (Readme.md:45): different half bandwidth, same parity."""
+    ds = synthetic.make_config("tiny", dt_so3=0.056, dt_r3=0.128, duration=2.4, num_views=24)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1); cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
+    assert rel_err(Hg, Hc) < 1e-12 and rel_err(gg, gc) < 1e-11
+    sg = gpu.trajectory_.Optimize(30, FLAGS1); sc = cpu.trajectory_.Optimize(30, FLAGS1)
+    assert sg["half_bandwidth"] == sc["half_bandwidth"] == 56
+    # With more rotation knots than views the valley floor is flat (cond(H) ~ 1e13): the
+    # first iterates agree tightly, later ones only in cost.
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    for a, b in list(zip(ig, ic))[:3]:
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 2e-3 * sc["final_cost"]
+
+
+def test_block_cyclic_reduction_deep_tree_c4():
+    """C4 (2000 views, ~18 k band columns -> ~290 blocks, 9 reduction levels): the first LM
+    iterations with the block cyclic reduction equal those of the partitioned band sweep."""
+    ds = synthetic.make_config("C4")
+    costs = []
+    for algo in (1, 2):
+        cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        cal.trajectory_.SetOption("solver_algorithm", algo)
+        cal.trajectory_.Optimize(3, FLAGS1)
+        costs.append([i["cost"] for i in cal.trajectory_.GetIterations()])
+        steps = [i["step_norm"] for i in cal.trajectory_.GetIterations()]
+        assert all(np.isfinite(steps))
+    assert len(costs[0]) == len(costs[1]) >= 3
+    assert np.allclose(costs[0], costs[1], rtol=1e-9, atol=0)
