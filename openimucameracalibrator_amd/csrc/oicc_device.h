@@ -74,10 +74,15 @@ struct EvalCtx {
 };
 
 // device-resident scalars of one LM iteration (the only per-iteration read-back)
+// radius is host -> device (8-byte write per LM iteration); gradient_max_norm is written by the gradient
+// kernel after a Jacobian pass; everything from model_cost_change on is zeroed before each step and
+// filled by the solve / retraction kernels.  One 56-byte read-back per LM iteration.
 struct LmState {
-  double radius, model_cost_change, step_norm_sq, x_norm_sq, gradient_max_norm, cand_cost;
+  double radius, gradient_max_norm;
+  double model_cost_change, step_norm_sq, x_norm_sq, cand_cost;
   int32_t chol_failed, pad;
 };
+constexpr size_t kLmStepResultsOffset = 2 * sizeof(double);
 
 struct SolveBuffers {
   double* Mb;      // [Pb][W]   damped scaled band; overwritten by the factor (diagonal slot = 1/L_ii)

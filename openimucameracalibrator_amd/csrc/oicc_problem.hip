@@ -150,6 +150,9 @@ struct oicc_problem {
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
   DevBuf<LmState> d_state;
+  struct HostPin { LmState st; double cost; double radius; };
+  HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // cached layout
   int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{};
   Active act{};
@@ -403,6 +406,9 @@ int oicc_create(oicc_problem** out, int device_ordinal) {
   rebuild_param_layout(p, 0, 0, 0, 0);
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { delete p; return OICC_ERR_HIP; }
   p->own_stream = true;
+  if (hipHostMalloc(reinterpret_cast<void**>(&p->pin), sizeof(*p->pin), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(p->stream); delete p; return OICC_ERR_HIP; }
+  std::memset(p->pin, 0, sizeof(*p->pin));
+  for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { oicc_destroy(p); return OICC_ERR_HIP; }
   *out = p;
   return OICC_OK;
 }
@@ -411,6 +417,8 @@ void oicc_destroy(oicc_problem* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  if (p->pin) (void)hipHostFree(p->pin);
   delete p;
 }
 const char* oicc_last_error(const oicc_problem* p) { return p ? p->err.c_str() : "null problem"; }
@@ -645,50 +653,67 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
     int r2 = sync_params_to_host(p);
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
-  auto timed_sync = [&](double& bucket, double t0) { (void)hipStreamSynchronize(st); bucket += now_s() - t0; };
+
+  // Host <-> device traffic of the loop: per LM iteration ONE 8-byte radius write, ONE zeroing of the
+  // step results and ONE read-back (LmState + candidate cost, pinned) followed by the only stream
+  // synchronisation.  The Jacobian pass of an accepted step is launched without waiting; its gradient
+  // norm arrives with the next iteration's read-back (the gradient-tolerance test is applied then,
+  // before the next step is taken, so the iterate sequence is the reference's).
+  oicc_problem::HostPin* pin = p->pin;
+  hipEvent_t* ev = p->ev;
+  auto read_back = [&]() -> int {
+    HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipStreamSynchronize(st)); return OICC_OK; };
+  auto elapsed_s = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? double(ms) * 1e-3 : 0.0; };
 
   double t0 = now_s();
   rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
-  rc = read_cost(p, &cost); if (rc) return rc;
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  HIPCK(p, hipMemsetAsync(p->d_state.p, 0, sizeof(LmState), st));
+  if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); launch_lm_gradmax(p->ne, P, p->d_state.p, st); }
+  rc = read_back(); if (rc) return rc;
+  cost = pin->cost; gmax = pin->st.gradient_max_norm;
   S.seconds_jacobian += now_s() - t0;
   S.initial_cost = cost;
   if (P == 0) return finish(OICC_CONVERGENCE, "no variable parameters");
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
-  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
-  LmState hs; std::memset(&hs, 0, sizeof(hs));
-  auto read_state = [&]() -> int {
-    HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-    HIPCK(p, hipStreamSynchronize(st)); return OICC_OK; };
-  auto write_state = [&]() -> int { HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st)); return OICC_OK; };
-  hs.radius = radius; rc = write_state(); if (rc) return rc;
-  launch_lm_gradmax(p->ne, P, p->d_state.p, st);
-  rc = read_state(); if (rc) return rc;
-  gmax = hs.gradient_max_norm;
   { oicc_iteration it{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius}; p->trace.push_back(it); }
   if (verbose) std::printf("[oicc] iter 0 cost %.12e gmax %.3e radius %.3e P=%d (band %d hb %d arrow %d)\n", cost, gmax, radius, P, tl.Pb, tl.hb, tl.a);
   if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
   int iter = 0, invalid = 0;
+  bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
+  auto settle_gmax = [&]() -> int {   // used on the exits that do not go through the per-iteration read-back
+    if (!gmax_pending) return OICC_OK;
+    int r = read_back(); if (r) return r;
+    gmax = pin->st.gradient_max_norm; p->trace.back().gradient_max_norm = gmax; gmax_pending = false;
+    S.seconds_jacobian += elapsed_s(ev[3], ev[4]);
+    return OICC_OK; };
   while (true) {
-    if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.");
-    if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
-    ++iter; S.num_iterations = iter;
-    // --- trust-region step: damped band+arrow Cholesky solve on the device
-    t0 = now_s();
-    std::memset(&hs, 0, sizeof(hs)); hs.radius = radius; hs.gradient_max_norm = gmax;
-    rc = write_state(); if (rc) return rc;
+    if (iter >= max_iters) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached."); }
+    if (radius <= min_radius) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_CONVERGENCE, "Minimum trust region radius reached."); }
+    // --- trust-region step: damped solve on the device, retraction, candidate cost
+    pin->radius = radius;
+    HIPCK(p, hipMemcpyAsync(&p->d_state.p->radius, &pin->radius, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCK(p, hipMemsetAsync(reinterpret_cast<char*>(p->d_state.p) + kLmStepResultsOffset, 0, sizeof(LmState) - kLmStepResultsOffset, st));
+    HIPCK(p, hipEventRecord(ev[0], st));
     if (launch_lm_solve(p->ne, tl, sb, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
       p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
       return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     HIPCK(p, hipGetLastError());
-    timed_sync(S.seconds_linear_solver, t0);
-    // --- candidate cost
-    t0 = now_s();
+    HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
-    double cand_cost = 0.0;
-    rc = read_cost(p, &cand_cost); if (rc) return rc;
-    S.seconds_residual += now_s() - t0;
-    rc = read_state(); if (rc) return rc;
+    HIPCK(p, hipEventRecord(ev[2], st));
+    rc = read_back(); if (rc) return rc;
+    const LmState hs = pin->st;
+    const double cand_cost = pin->cost;
+    S.seconds_linear_solver += elapsed_s(ev[0], ev[1]); S.seconds_residual += elapsed_s(ev[1], ev[2]);
+    if (gmax_pending) {   // gradient of the point accepted in the previous iteration
+      gmax = hs.gradient_max_norm; p->trace.back().gradient_max_norm = gmax; gmax_pending = false;
+      S.seconds_jacobian += elapsed_s(ev[3], ev[4]);
+      if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");   // the step just computed is discarded
+    }
+    ++iter; S.num_iterations = iter;
     const double model_cost_change = hs.model_cost_change;
     bool ok = hs.chol_failed == 0 && std::isfinite(model_cost_change) && std::isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
     const double x_norm = std::sqrt(hs.x_norm_sq);   // ambient norm of the current x over active blocks
@@ -714,17 +739,15 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (rel_dec > min_rel_dec) {
       std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current
       cost = cand_cost;
-      t0 = now_s();
+      HIPCK(p, hipEventRecord(ev[3], st));
       rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
       launch_lm_gradmax(p->ne, P, p->d_state.p, st);
-      rc = read_state(); if (rc) return rc;
-      S.seconds_jacobian += now_s() - t0;
-      gmax = hs.gradient_max_norm;
+      HIPCK(p, hipEventRecord(ev[4], st));
+      gmax_pending = true;
       ++S.num_successful_steps;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
       radius = std::min(max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
       oicc_iteration it{iter, 1, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
-      if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
     } else {
       ++S.num_unsuccessful_steps;
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
@@ -747,21 +770,21 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
-  LmState hs;
+  oicc_problem::HostPin* pin = p->pin;
   for (int it = 0; it < steps; ++it) {
     rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
     if (it == 0) launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
-    std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
-    HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+    pin->radius = p->opt["initial_trust_region_radius"];
+    HIPCK(p, hipMemcpyAsync(&p->d_state.p->radius, &pin->radius, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCK(p, hipMemsetAsync(reinterpret_cast<char*>(p->d_state.p) + kLmStepResultsOffset, 0, sizeof(LmState) - kLmStepResultsOffset, st));
     launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
     if (launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
-    double cand = 0.0;
-    rc = read_cost(p, &cand); if (rc) return rc;
-    HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipStreamSynchronize(st));
-    if (hs.chol_failed) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
+    if (pin->st.chol_failed) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
   }
   return OICC_OK;
 }
