@@ -49,6 +49,8 @@ def algorithmic_model(cal, ds, summary_dims):
     bytes_ = dict(view=24 * nc + 12 * nv + params + out, accel=28 * na + params + out, gyro=28 * ng + 32 * n_so3 + out,
                   solve=2 * 8 * (Pb * (hb + 1) + (a + 1) * Pb + (a + 1) ** 2) + 8 * P)
     flops = dict(view=6.9e3 * nc, accel=7.6e3 * na, gyro=3.7e3 * ng, solve=float(Pb) * hb * hb + 2.0 * Pb * hb * (a + 1))
+    bytes_["blocks"] = 24 * nc + 12 * nv + 28 * na + 28 * ng + params + out     # the fused launch: every input once, the output once
+    flops["blocks"] = flops["view"] + flops["accel"] + flops["gyro"]
     return bytes_, flops
 
 
@@ -154,17 +156,35 @@ def main():
         else:
             hb = 0
         b_alg, f_alg = algorithmic_model(cal, ds, (P, Pb, a, hb))
-        times = dict(view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
-        dom = max(times, key=lambda k: times[k])
-        names = dict(view="view_blocks_kernel<true>", accel="imu_blocks_kernel<accel>", gyro="imu_blocks_kernel<gyro>",
-                     solve="lm_build_kernel+band_arrow_cholesky_kernel")
+        # Kernel groups of one LM iteration.  "blocks" is the fused residual+Jacobian+Gram launch the
+        # metric is named after (ONE launch per pass: all_blocks_kernel<true>); view/accel/gyro are its
+        # three residual families timed as stand-alone launches; "solve" is the 17-launch block cyclic
+        # reduction (bcr_build/eliminate/schur/backward), a dependent-latency chain, reported as a group.
+        times = dict(blocks=pass_ms, view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
+        names = dict(blocks="all_blocks_kernel<true>", view="view_blocks_kernel<true>", accel="imu_blocks_kernel<0, true>",
+                     gyro="imu_blocks_kernel<1, true>", solve="bcr_build_kernel + bcr_eliminate_kernel + bcr_schur_kernel + bcr_backward_kernel")
         kernels = {k: dict(kernel=names[k], ms=times[k], alg_bytes=b_alg[k], alg_flops=f_alg[k],
                            hbm_GBps=b_alg[k] / (times[k] * 1e-3) / 1e9 if times[k] > 0 else 0.0,
                            fp64_TFLOPs=f_alg[k] / (times[k] * 1e-3) / 1e12 if times[k] > 0 else 0.0) for k in times}
-        ach = kernels[dom]["hbm_GBps"]
-        roofline = dict(bound="hbm", kernel=names[dom], achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None,
-                        note="path is fp64-VALU/latency bound (SURVEY.md 8d); fp64 fraction of the same kernel: %.4g of 78.6 TFLOP/s"
-                             % (kernels[dom]["fp64_TFLOPs"] / 78.6),
+        # The roofline object is for the dominant SINGLE kernel, the fused Jacobian/Gram launch.  SURVEY.md 8(d):
+        # arithmetic intensity 150-300 FLOP/B, so the binding roof is fp64 (MFMA f64 = vector f64 = 78.6 TFLOP/s
+        # dense on MI355X), not HBM; the HBM view of the same launch is given next to it.
+        dom = "blocks"
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01h_pmc_hbm_C2.csv")
+        if world == 1 and os.path.exists(pmc):     # per-launch FETCH_SIZE + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes
+            tot = 0.0
+            for line in open(pmc):
+                if "all_blocks_kernel<true>" in line:
+                    tot += float(line.rsplit(",", 1)[1]) * 1024.0
+            traffic = tot or None
+        roofline = dict(bound="mfma", kernel=names[dom], achieved=kernels[dom]["fp64_TFLOPs"], peak=78.6, unit="TFLOP/s",
+                        frac=kernels[dom]["fp64_TFLOPs"] / 78.6, traffic=traffic,
+                        hbm=dict(achieved=kernels[dom]["hbm_GBps"], peak=8000.0, unit="GB/s", frac=kernels[dom]["hbm_GBps"] / 8000.0),
+                        note="C2 is 8160 blocks (0.1 GFLOP, 1.5 MB): one launch of ~375 waves on 1024 SIMDs, latency bound; the same kernel on the C5-size "
+                             "problem is reported in extra_c5_single_gpu. traffic = HBM bytes per launch from profiles/r01h_pmc_hbm_C2.csv "
+                             "(fp64 atomics of the Gram scatter leave the XCD L2s: ~10x the algorithmic output).",
+                        step_share=dict(blocks_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step),
                         kernels=kernels)
         out = {
             "metric": "residual+Jacobian blocks/sec; wall-clock per LM iter, GoPro9 full calib",
@@ -174,7 +194,7 @@ def main():
             "config": {"workload": "C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s%s"
                                    % (ds.num_views, n_corners, n_blocks - ds.num_views, "" if world == 1 else " (C2 x %d, time-sharded, all-reduce of JtJ/Jtr)" % world),
                        "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR",
-                       "step": "one LM iteration: Jacobian+assembly, solve, retraction, cost pass"},
+                       "step": "one LM iteration: Jacobian+assembly, block-cyclic-reduction solve, retraction, cost pass, one host read-back"},
             "corners_per_s": n_corners * args.steps / dt,
             "jacobian_pass_ms": pass_ms,
             "roofline": roofline,
@@ -206,7 +226,9 @@ def main():
                 ds5 = synthetic.make_config("C5")
                 c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
                 p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
-                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5,
+                s5 = c5.trajectory_.TimeLinearSolve(flags, repeats=5)
+                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5,
+                                                  fp64_frac_of_78p6=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 78.6e12,
                                                   kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
                                                   blocks_per_s_jacobian_pass=c5.num_blocks / (p5 * 1e-3),
                                                   fp64_TFLOPs=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 1e12)
