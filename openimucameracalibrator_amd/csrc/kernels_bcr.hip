@@ -398,7 +398,10 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
-  const double radius = sb.st->radius;
+  const double radius = sb.radius;
+  if (tid == 0) {   // results of the step that starts here
+    sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
+  }
   auto damp = [&](int64_t i, double hii) -> double {
     const double sc = sb.scale[i];
     return (reuse_diagonal ? sb.diag[i] : fmin(fmax(hii * sc * sc, min_diag), max_diag)) / radius;

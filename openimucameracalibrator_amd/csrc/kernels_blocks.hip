@@ -27,7 +27,13 @@ namespace oicc {
 constexpr int kWave = 64;
 constexpr int kMaxStagedKnots = 24;  // knots of one kind staged per wave
 
+#if defined(OICC_DBG_ATOMICS) && OICC_DBG_ATOMICS == 1
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { if (v == 1.2345e300) *p = v; }              // experiment: no scatter at all
+#elif defined(OICC_DBG_ATOMICS) && OICC_DBG_ATOMICS == 2
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // experiment: L2-local atomics
+#else
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+#endif
 
 __device__ __forceinline__ void ne_add(const NormalEq& ne, const TangentLayout& tl, int i, int j, double v) {
   if (i > j) { const int t = i; i = j; j = t; }

@@ -30,7 +30,10 @@ __global__ void lm_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, 
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   const int Pb = tl.Pb, a = tl.a, W = tl.W, ar = a + 1;
-  const double radius = sb.st->radius;
+  const double radius = sb.radius;
+  if (tid == 0) {   // results of the step that starts here
+    sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
+  }
   // diagonal / damping
   for (int64_t i = tid; i < tl.P; i += nthreads) {
     const double hii = i < Pb ? ne.band()[i * W] : ne.C()[(i - Pb) * a + (i - Pb)];
@@ -125,7 +128,9 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   double step_sq = 0.0, x_sq = 0.0, model = 0.0;
-  // xc already holds a copy of x (hipMemcpyAsync in the launcher); only active blocks are rewritten.
+  // xc equals x on every inactive entry (copied once per Optimize call; inactive entries never change);
+  // all active blocks are rewritten here.  The cost slot is cleared for the candidate cost pass.
+  if (tid == 0) *ne.cost() = 0.0;
   // model cost change = 0.5 * d.(D2 d - g_s)  (from (H_s + D2) d = -g_s)
   for (int64_t i = tid; i < tl.P; i += nthreads) {
     const double d = sb.step_s[i];
@@ -216,7 +221,6 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st) {
   int64_t work = pl.total;
   int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  (void)hipMemcpyAsync(xc, x, pl.total * sizeof(double), hipMemcpyDeviceToDevice, st);
   hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb);
 }
 

@@ -98,6 +98,7 @@ struct SolveBuffers {
   int64_t ws_doubles;
   int force_p;     // > 0: force this many partitions (tests); 0: heuristic
   int algo;        // 0: auto, 1: time-partitioned band sweep, 2: block cyclic reduction
+  double radius;   // trust-region radius of this step (kernel argument, no host->device copy)
 };
 
 }  // namespace oicc

@@ -46,8 +46,9 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
 // damped system + factorisation + solve (solution in sb.step_s): block cyclic reduction when the
 // geometry allows (hb <= 64, arrow <= 63 columns), else the time-partitioned band sweep
-static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal,
+static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb_in, double radius, int reuse_diagonal,
                                   double min_diag, double max_diag, hipStream_t st) {
+  SolveBuffers sb = sb_in; sb.radius = radius;
   if (sb.algo != 1 && launch_bcr_solve(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st) == 0) return 0;
   if (sb.algo == 2 && tl.Pb > 0) return -1;
   launch_lm_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st);
@@ -362,12 +363,13 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
 }
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
-int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1) {
+int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
+              bool cost_already_zero = false) {
   hipStream_t st = p->stream;
   EvalCtx ctx = make_ctx(p, x);
   ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac;
   if (jac) HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), st));
-  else HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), st));
+  else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), st));
   const Active& a = p->act;
   if (only_kind < 0) launch_all_blocks(ctx, view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
   if (only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
@@ -680,6 +682,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   { oicc_iteration it{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius}; p->trace.push_back(it); }
   if (verbose) std::printf("[oicc] iter 0 cost %.12e gmax %.3e radius %.3e P=%d (band %d hb %d arrow %d)\n", cost, gmax, radius, P, tl.Pb, tl.hb, tl.a);
   if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
+  HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));   // inactive entries of the candidate
   int iter = 0, invalid = 0;
   bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
   auto settle_gmax = [&]() -> int {   // used on the exits that do not go through the per-iteration read-back
@@ -692,17 +695,14 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (iter >= max_iters) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached."); }
     if (radius <= min_radius) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_CONVERGENCE, "Minimum trust region radius reached."); }
     // --- trust-region step: damped solve on the device, retraction, candidate cost
-    pin->radius = radius;
-    HIPCK(p, hipMemcpyAsync(&p->d_state.p->radius, &pin->radius, sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCK(p, hipMemsetAsync(reinterpret_cast<char*>(p->d_state.p) + kLmStepResultsOffset, 0, sizeof(LmState) - kLmStepResultsOffset, st));
     HIPCK(p, hipEventRecord(ev[0], st));
-    if (launch_lm_solve(p->ne, tl, sb, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
+    if (launch_lm_solve(p->ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
       p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
       return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     HIPCK(p, hipGetLastError());
     HIPCK(p, hipEventRecord(ev[1], st));
-    rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipEventRecord(ev[2], st));
     rc = read_back(); if (rc) return rc;
     const LmState hs = pin->st;
@@ -771,16 +771,14 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   oicc_problem::HostPin* pin = p->pin;
+  HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));
   for (int it = 0; it < steps; ++it) {
     rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
     if (it == 0) launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
-    pin->radius = p->opt["initial_trust_region_radius"];
-    HIPCK(p, hipMemcpyAsync(&p->d_state.p->radius, &pin->radius, sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCK(p, hipMemsetAsync(reinterpret_cast<char*>(p->d_state.p) + kLmStepResultsOffset, 0, sizeof(LmState) - kLmStepResultsOffset, st));
     launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
-    if (launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+    if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
-    rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipStreamSynchronize(st));
@@ -828,10 +826,10 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
   hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
-  if (launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+  if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
   HIPCK(p, hipEventRecord(e0, st));
   for (int i = 0; i < repeats; ++i) {
-    launch_lm_solve(p->ne, tl, sb, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
+    launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
   }
   HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -853,7 +851,7 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = 1e4;
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
   for (int rep = 0; rep < 2; ++rep) {
-    if (launch_lm_solve(p->ne, tl, sb, 0, 1e-6, 1e32, st) != 0) return OICC_ERR_UNSUPPORTED;
+    if (launch_lm_solve(p->ne, tl, sb, 1e4, 0, 1e-6, 1e32, st) != 0) return OICC_ERR_UNSUPPORTED;
   }
   HIPCK(p, hipMemcpyAsync(out, d.p, 12 * sizeof(long long), hipMemcpyDeviceToHost, st));
   HIPCK(p, hipStreamSynchronize(st));
