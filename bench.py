@@ -234,6 +234,24 @@ def main():
                                                   fp64_TFLOPs=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 1e12)
             except Exception as e:  # the extra must never break the bench line
                 out["extra_c5_single_gpu"] = {"error": str(e)[:200]}
+        # ---- extra: spline-error-weighting pre-stage, device vs the numpy oracle ----
+        if not args.no_extra and world == 1:
+            try:
+                from openimucameracalibrator_amd import sew
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import sew_oracle
+                rng = np.random.default_rng(5)
+                n5 = 200000
+                big = np.cumsum(rng.standard_normal((3, n5)), axis=1) * 0.01 + 0.05 * rng.standard_normal((3, n5))
+                res = {}
+                for nm, sig, tt in (("C2_accel", ds.accel.T.copy(), ds.imu_t_s), ("C5_size_series", big, np.arange(n5) / 200.0)):
+                    sew.knot_spacing_and_variance(sig, tt, 0.96, min_dt=0.01, max_dt=0.15)   # warm-up (hipFFT plan, code load)
+                    t1 = time.perf_counter(); g = sew.knot_spacing_and_variance(sig, tt, 0.96, min_dt=0.01, max_dt=0.15); tg = time.perf_counter() - t1
+                    t1 = time.perf_counter(); o = sew_oracle.knot_spacing_and_variance(sig, tt, 0.96, min_dt=0.01, max_dt=0.15); to = time.perf_counter() - t1
+                    res[nm] = dict(samples=int(sig.shape[1]), device_ms=1e3 * tg, numpy_oracle_ms=1e3 * to, dt=g[0], dt_oracle=o[0])
+                out["extra_sew_prestage"] = res
+            except Exception as e:
+                out["extra_sew_prestage"] = {"error": str(e)[:200]}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

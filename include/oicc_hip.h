@@ -287,6 +287,28 @@ int oicc_get_trajectory(oicc_problem* p, int64_t n, const int64_t* t_ns,
                         double* pose7, double* gyro3, double* accel3,
                         double* gyro_bias3, double* accl_bias3, uint8_t* valid);
 
+
+/* ---- Spline error weighting pre-stage ---------------------
+ * knot_spacing_and_variance(signal, times, quality, min_dt, max_dt), python/sew.py:199-235,
+ * as called by python/get_sew_for_dataset.py:38-39 for the accelerometer (q_r3, R3 spline) and
+ * the gyroscope (q_so3, SO3 spline).  It fixes the knot spacings and the IMU residual weights
+ * 1/sqrt(variance) the spline solve consumes.
+ *   signal   [dims][n] row major (dims = 3 axes), times [n] in seconds (uniform sampling assumed,
+ *            sample rate = 1 / mean(diff(times)), sew.py:144)
+ *   spectrum Xhat_k = sqrt(1/dims) * || FFT(signal)[:, k] ||, DC removed (sew.py:170-179)
+ *   quality  fraction of signal energy the cubic-B-spline interpolation response
+ *            H(f, dt) = 3 sinc^4(f dt) / (2 + cos(2 pi f dt))  (sew.py:35-57, normalised :75-76)
+ *            must keep; the largest such dt in [min_dt, max_dt] is found by the end-point test,
+ *            halving back-off and Brent root finding of sew.py:83-137 (brentq defaults of SciPy:
+ *            xtol 2e-12, rtol 4 eps, 100 iterations)
+ *   variance signal_energy((1 - H) Xhat) / n at that dt (sew.py:192-195)
+ * min_dt <= 0 / max_dt <= 0 select the reference defaults 1/rate and (n/4)/rate (sew.py:153-157).
+ * FFT and the spectral reductions run on the device (hipFFT D2Z + one reduction launch per trial dt).
+ * Returns OICC_ERR_INVALID_ARG for n < 8 or a non-increasing time base. */
+int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_t dims, int64_t n, const double* signal,
+                                       const double* times, double quality, double min_dt, double max_dt,
+                                       double* dt, double* variance, int32_t* num_evaluations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,13 +138,17 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
       for (int c = 0; c < 8; ++c) {
         double piv = bcr_readlane(av[c], c);
         if (!(piv > 0.0)) { if (lane == 0) *failp = 1; piv = 1.0; }
-        const double h = 0.5 * piv;
-        double y = __builtin_amdgcn_rsq(piv);
-        y = y * fma(-h * y, y, 1.5);
-        y = y * fma(-h * y, y, 1.5);
-        const double l = av[c] * y;
+        // 1/sqrt(piv) by two coupled (Goldschmidt) steps on the v_rsq_f64 seed (2^-24): the same
+        // 2^-52 as two Newton steps, but the dependent chain piv -> l is 6 fp64 ops deep instead of 8
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double g0 = piv * y0, h0 = 0.5 * y0;
+        const double r0 = fma(-g0, h0, 0.5);
+        const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+        const double r1 = fma(-g1, h1, 0.5);
+        const double u = (av[c] + av[c]) * h1;
+        const double l = fma(u, r1, u);
         av[c] = l;
-        if (lane == c) rsd = y;
+        if (lane == c) { const double y1 = h1 + h1; rsd = fma(y1, r1, y1); }
 #pragma unroll
         for (int c2 = c + 1; c2 < 8; ++c2) {
           const double lc2 = bcr_readlane(l, c2);

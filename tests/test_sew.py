@@ -1,0 +1,104 @@
+"""Spline error weighting pre-stage (python/sew.py, get_sew_for_dataset.py).
+
+* not gpu: the numpy oracle (oracle/sew_oracle.py) against golden outputs of the REFERENCE module
+  (tests/golden/sew_golden.json, produced by tests/golden/make_sew_golden.py importing
+  /root/reference/python/sew.py) -- this oracle is pinned by the reference itself;
+* gpu: the HIP path (hipFFT + spectral reduction kernels behind oicc_sew_knot_spacing_and_variance)
+  against the same goldens and against the oracle.
+Tolerances: knot spacing 1e-9 relative (Brent's xtol is 2e-12), variance 1e-9 relative.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import sew_cases  # noqa: E402
+import sew_oracle  # noqa: E402
+
+GOLD = json.load(open(os.path.join(HERE, "golden", "sew_golden.json")))
+CASES = sew_cases.cases()
+
+
+def close(a, b, rel=1e-9):
+    return abs(a - b) <= rel * max(abs(a), abs(b))
+
+
+def test_cases_are_the_ones_the_goldens_were_made_from():
+    assert set(CASES) == set(GOLD)
+    for name, (sig, t, q, lo, hi) in CASES.items():
+        assert sew_cases.checksum(sig, t) == GOLD[name]["input_sha"], name
+        assert (q, lo, hi, len(t)) == (GOLD[name]["quality"], GOLD[name]["min_dt"], GOLD[name]["max_dt"], GOLD[name]["n"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_goldens(name):
+    sig, t, q, lo, hi = CASES[name]
+    dt, var = sew_oracle.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
+    assert close(dt, GOLD[name]["dt"]) and close(var, GOLD[name]["variance"])
+
+
+def test_oracle_response_properties():
+    f = np.linspace(0.0, 100.0, 2001)
+    for dt in (0.01, 0.05, 0.2):
+        H = sew_oracle.interpolation_response(f, dt)
+        assert H[0] == 1.0 and np.all(H <= 1.0 + 1e-15) and np.all(H >= 0.0)       # low-pass, unit DC gain (sew.py:75-76)
+        assert np.allclose(H, sew_oracle.interpolation_response(-f, dt), rtol=0, atol=0)   # even in f: half spectrum suffices
+    # a longer knot spacing removes more of any spectrum
+    xhat = sew_oracle.reference_spectrum(CASES["C2_accel_r3"][0])
+    fr = np.fft.fftfreq(len(xhat), d=1 / 200.0)
+    rem = [sew_oracle.energy((1 - sew_oracle.interpolation_response(fr, dt)) * xhat) for dt in (0.01, 0.02, 0.05, 0.1)]
+    assert all(a < b for a, b in zip(rem, rem[1:]))
+
+
+def test_brent_restatement_against_known_roots():
+    r = sew_oracle.brent_root(lambda x: np.cos(x) - x, 0.0, 1.0)
+    assert abs(r - 0.7390851332151607) < 1e-11
+    r = sew_oracle.brent_root(lambda x: x ** 3 - 2 * x - 5, 2.0, 3.0)
+    assert abs(r - 2.0945514815423265) < 1e-11
+    with pytest.raises(ValueError):
+        sew_oracle.brent_root(lambda x: x * x + 1, 0.0, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_matches_reference_goldens_and_oracle(name):
+    from openimucameracalibrator_amd import sew
+    sig, t, q, lo, hi = CASES[name]
+    dt, var = sew.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
+    assert close(dt, GOLD[name]["dt"]) and close(var, GOLD[name]["variance"])
+    odt, ovar = sew_oracle.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
+    assert close(dt, odt) and close(var, ovar)
+
+
+@pytest.mark.gpu
+def test_hip_spline_weighting_json_and_errors():
+    from openimucameracalibrator_amd import sew, synthetic
+    ds = synthetic.make_config("C2")
+    tel = dict(accelerometer=ds.accel.tolist(), gyroscope=ds.gyro.tolist(), timestamps_ns=(ds.imu_t_s * 1e9).round().astype(np.int64).tolist(), camera_fps=0.0)
+    sw = sew.spline_weighting_for_telemetry(tel)
+    assert set(sw) == {"so3", "r3", "camera_fps"} and sw["camera_fps"] == 30.0       # get_sew_for_dataset.py:46-51
+    assert close(sw["r3"]["knot_spacing"], GOLD["C2_accel_r3"]["dt"], 1e-6) and close(sw["so3"]["knot_spacing"], GOLD["C2_gyro_so3"]["dt"], 1e-6)
+    assert close(sw["r3"]["weighting_factor"], np.sqrt(GOLD["C2_accel_r3"]["variance"]), 1e-6)
+    with pytest.raises(RuntimeError):
+        sew.knot_spacing_and_variance(np.zeros((3, 4)), np.arange(4.0), 0.9)        # n < 8
+    with pytest.raises(ValueError):
+        sew.knot_spacing_and_variance(np.zeros((2, 2, 16)), np.arange(16.0), 0.9)   # more than 2-D (sew.py:173-174)
+
+
+@pytest.mark.gpu
+def test_hip_large_series_linearity_property():
+    """C5-size series (200 k samples): scaling the signal scales the variance by the square and
+    leaves the knot spacing unchanged (size-independent property, no oracle needed)."""
+    from openimucameracalibrator_amd import sew
+    rng = np.random.default_rng(3)
+    n = 200000
+    t = np.arange(n) / 200.0
+    sig = np.cumsum(rng.standard_normal((3, n)), axis=1) * 0.01 + 0.05 * rng.standard_normal((3, n))
+    d1, v1 = sew.knot_spacing_and_variance(sig, t, 0.97, min_dt=0.01, max_dt=0.3)
+    d2, v2 = sew.knot_spacing_and_variance(3.0 * sig, t, 0.97, min_dt=0.01, max_dt=0.3)
+    assert close(d1, d2, 1e-9) and close(9.0 * v1, v2, 1e-9) and 0.01 <= d1 <= 0.3
