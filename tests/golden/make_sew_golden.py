@@ -11,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, "/root/reference/python")
+sys.dont_write_bytecode = True   # never write a __pycache__ into the read-only reference tree
 import sew as reference_sew  # noqa: E402  (the reference module)
 import sew_cases  # noqa: E402
 
