@@ -245,3 +245,18 @@ def test_block_cyclic_reduction_deep_tree_c4():
         assert all(np.isfinite(steps))
     assert len(costs[0]) == len(costs[1]) >= 3
     assert np.allclose(costs[0], costs[1], rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("duration,views", [(0.3, 3), (0.75, 8)])
+def test_very_short_trajectories_single_and_two_block_band(algo, duration, views):
+    """Band of <= 64 columns (one block: only the last elimination runs) and of two blocks."""
+    ds = synthetic.make_config("tiny", duration=duration, num_views=views)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    gpu.trajectory_.SetOption("solver_algorithm", algo)
+    sg = gpu.trajectory_.Optimize(8, FLAGS1); sc = cpu.trajectory_.Optimize(8, FLAGS1)
+    assert sg["band_dim"] == sc["band_dim"] and sg["band_dim"] <= (64 if views == 3 else 128)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    for a, b in list(zip(ig, ic))[:3]:
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"] and a["step_is_successful"] == b["step_is_successful"]
