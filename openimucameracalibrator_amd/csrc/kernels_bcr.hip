@@ -57,13 +57,13 @@ __device__ __forceinline__ void tri10(int t, int& xt, int& yt) {
   yt = t - (xt * (xt + 1)) / 2;
 }
 
-template <bool LAST, bool PROF>
+template <int LD, bool LAST, bool PROF>
 __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int a = A.a, a1 = a + 1, LD = A.LD, rtf = A.rtf;
+  const int a = A.a, a1 = a + 1, rtf = A.rtf;
   const int Ru = 192 + a1;
   double* const W = lds;                 // [64][LD] column major: rows 0..63 pivot, 64.. left, 128.. right, 192.. border
   double* const dinvs = W + 64 * LD;     // [64]
@@ -130,14 +130,20 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
     if (wave < NAW) {
       const int rho = lane < 8 ? j0 + lane : 8 + wave * 56 + (lane - 8);
       const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru);
+      // eight reads off one base address (LD is a compile-time constant: immediate offsets); inactive lanes
+      // read row 0 and are masked afterwards
+      const double* colp = W + j0 * LD + (act ? rho : 0);
       double av[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) av[c] = (act && (lane >= 8 || lane >= c)) ? W[(j0 + c) * LD + rho] : 0.0;
+      for (int c = 0; c < 8; ++c) { const double v = colp[c * LD]; av[c] = (act && (lane >= 8 || lane >= c)) ? v : 0.0; }
+      if (PROF && prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      BCR_MARK(6);
       double rsd = 1.0;
+      bool bad = false;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        double piv = bcr_readlane(av[c], c);
-        if (!(piv > 0.0)) { if (lane == 0) *failp = 1; piv = 1.0; }
+        const double piv = bcr_readlane(av[c], c);
+        bad |= !(piv > 0.0);      // off the dependent chain: a non-positive pivot poisons the factor (NaN) and is reported below
         // 1/sqrt(piv) by two coupled (Goldschmidt) steps on the v_rsq_f64 seed (2^-24): the same
         // 2^-52 as two Newton steps, but the dependent chain piv -> l is 6 fp64 ops deep instead of 8
         const double y0 = __builtin_amdgcn_rsq(piv);
@@ -155,9 +161,16 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
           av[c2] = fma(-l, lc2, av[c2]);
         }
       }
+      if (PROF && prof) { asm volatile("s_nop 0" :: "v"(av[7])); }
+      BCR_MARK(7);
+      // the strictly upper part of the 8x8 diagonal block is written too (finite garbage, never read as data)
+      if (act && (lane >= 8 || wave == 0)) {
+        double* cp = W + j0 * LD + rho;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (act && (lane >= 8 || lane >= c) && (lane >= 8 || wave == 0)) W[(j0 + c) * LD + rho] = av[c];
+        for (int c = 0; c < 8; ++c) cp[c * LD] = av[c];
+      }
       if (wave == 0 && lane < 8) dinvs[j0 + lane] = rsd;
+      if (bad && lane == 0) *failp = 1;
     }
     BCR_MARK(1);
     bcr_lds_barrier();
@@ -497,9 +510,17 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     A.s = 1; A.offS_in = 0; A.offS_out = 0;
     hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_eliminate_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  using KernelFn = void (*)(BcrArgs);
+  KernelFn k_level = nullptr, k_last = nullptr, k_prof = nullptr;
+  switch (A.LD) {
+    case 209: k_level = bcr_eliminate_kernel<209, false, false>; k_last = bcr_eliminate_kernel<209, true, false>; k_prof = bcr_eliminate_kernel<209, false, true>; break;
+    case 241: k_level = bcr_eliminate_kernel<241, false, false>; k_last = bcr_eliminate_kernel<241, true, false>; k_prof = k_level; break;
+    case 273: k_level = bcr_eliminate_kernel<273, false, false>; k_last = bcr_eliminate_kernel<273, true, false>; k_prof = k_level; break;
+    default: return -1;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_last), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int schur_groups = (36 + 8 * A.rtf + (A.rtf * (A.rtf + 1)) / 2 + 3) / 4;
   // forward: levels while more than one block is active
   int strides[40]; int npivs[40]; int nlev = 0;
@@ -508,14 +529,13 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     const int m = (n + s - 1) / s;          // active blocks
     const int npiv = m / 2;
     A.s = s; A.offS_in = off; A.offS_out = off + (m - 1);
-    if (A.prof && s == 1) hipLaunchKernelGGL((bcr_eliminate_kernel<false, true>), dim3(npiv), dim3(kBcrThreads), lds, st, A);
-    else hipLaunchKernelGGL((bcr_eliminate_kernel<false, false>), dim3(npiv), dim3(kBcrThreads), lds, st, A);
+    hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(npiv), dim3(kBcrThreads), lds, st, A);
     hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, npiv), dim3(256), 0, st, A);
     strides[nlev] = s; npivs[nlev] = npiv; ++nlev;
     off += m - 1;
   }
   A.s = 0; A.offS_in = 0; A.offS_out = 0;
-  hipLaunchKernelGGL((bcr_eliminate_kernel<true, false>), dim3(1), dim3(kBcrThreads), lds, st, A);
+  hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
   for (int l = nlev - 1; l >= 0; --l) {
     A.s = strides[l];
     hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(256), 0, st, A);
