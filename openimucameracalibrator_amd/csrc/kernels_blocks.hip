@@ -230,9 +230,10 @@ __host__ __device__ inline ViewCols view_cols(const TangentLayout& tl, bool spli
 template <bool JAC>
 __device__ __forceinline__ void view_block(const EvalCtx& ctx, const ViewData& vd, const ViewCols& vc, int bid, int nblk, double* smem) {
   const int lane = threadIdx.x;
-  const int64_t c_begin = (int64_t)bid * kWave;
+  const int64_t c_begin = vd.chunk_c0[bid];
+  const int c_count = vd.chunk_n[bid];
   const int64_t c = c_begin + lane;
-  const bool valid = c < vd.n_corners;
+  const bool valid = lane < c_count;
   // LDS carve: knots | coloff | rows
   double* lds_so3 = smem;                              // 24*4
   double* lds_r3 = lds_so3 + kMaxStagedKnots * 4;      // 24*3
@@ -398,7 +399,7 @@ __device__ __forceinline__ void view_block(const EvalCtx& ctx, const ViewData& v
   if (prof) tp1 = clock64();
   // phase 2/3: one flush per view present in this chunk
   const int v_first = vd.corner_view[c_begin];
-  const int64_t c_last = (c_begin + kWave < vd.n_corners ? c_begin + kWave : vd.n_corners) - 1;
+  const int64_t c_last = c_begin + c_count - 1;
   const int v_last = vd.corner_view[c_last];
   for (int vv = v_first; vv <= v_last; ++vv) {
     int64_t a0 = vd.view_c0[vv], a1 = vd.view_c0[vv + 1];
@@ -455,9 +456,10 @@ constexpr int kImuChunk = 32;  // samples per wave (LDS rows = 3*32)
 template <int KIND, bool JAC>
 __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id, const ImuCols& ic, int bid, double* smem) {
   const int lane = threadIdx.x;
-  const int64_t i_begin = (int64_t)bid * kImuChunk;
+  const int64_t i_begin = id.chunk_i0[bid];
+  const int i_count = id.chunk_n[bid];
   const int64_t i = i_begin + lane;
-  const bool valid = lane < kImuChunk && i < id.n;
+  const bool valid = lane < i_count;
   double* lds_so3 = smem;
   double* lds_r3 = lds_so3 + kMaxStagedKnots * 4;
   int* coloff = reinterpret_cast<int*>(lds_r3 + kMaxStagedKnots * 3);
@@ -620,14 +622,23 @@ __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id,
     return;
   }
   __syncthreads();
-  // phase 2/3: samples of the chunk grouped into cells with identical knot windows
-  const int64_t i_end = i_begin + kImuChunk < id.n ? i_begin + kImuChunk : id.n;
-  int64_t a0 = i_begin;
-  while (a0 < i_end) {
-    const int ks0 = id.s_so3[a0], kb0 = id.s_b[a0];
-    const int kr0 = KIND == 0 ? id.s_r3[a0] : 0;
-    int64_t a1 = a0 + 1;
-    while (a1 < i_end && id.s_so3[a1] == ks0 && id.s_b[a1] == kb0 && (KIND != 0 || id.s_r3[a1] == kr0)) ++a1;
+  // phase 2/3: samples of the chunk grouped into cells with identical knot windows.  The cell
+  // boundaries come from the window indices the lanes already hold (one ballot), not from a
+  // scalar scan of global memory.
+  const int64_t i_end = i_begin + i_count;
+  // (re-read after the barrier instead of keeping three more registers live through phase 1: the kernel sits at 256 VGPRs)
+  const int c_so3 = valid ? id.s_so3[i] : 0x3fffffff, c_b = valid ? id.s_b[i] : 0x3fffffff;
+  const int c_r3 = (valid && KIND == 0) ? id.s_r3[i] : 0x3fffffff;
+  const int p_so3 = __shfl_up(c_so3, 1, 64), p_b = __shfl_up(c_b, 1, 64), p_r3 = __shfl_up(c_r3, 1, 64);   // all lanes take part
+  const bool starts_cell = valid && (lane == 0 || c_so3 != p_so3 || c_b != p_b || (KIND == 0 && c_r3 != p_r3));
+  unsigned long long starts = __ballot(starts_cell);
+  while (starts != 0ull) {
+    const int l0 = __builtin_ctzll(starts);
+    starts &= starts - 1ull;
+    const int l1 = starts != 0ull ? __builtin_ctzll(starts) : int(i_end - i_begin);
+    const int64_t a0 = i_begin + l0, a1 = i_begin + l1;
+    const int ks0 = __shfl(c_so3, l0, 64), kb0 = __shfl(c_b, l0, 64);
+    const int kr0 = KIND == 0 ? __shfl(c_r3, l0, 64) : 0;
     if (lane < ic.ncols) {
       int off = -1;
       if (ic.base_s >= 0 && lane >= ic.base_s && lane < ic.base_s + 18) { const int k = lane - ic.base_s; const int o = ctx.tl.so3[ks0 + k / 3]; off = o < 0 ? -1 : o + k % 3; }
@@ -640,7 +651,6 @@ __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id,
     __syncthreads();
     gram_flush_cell(rows, ic.stride, int(3 * (a0 - i_begin)), int(3 * (a1 - i_begin)), ic.ncols, ic.rescol, coloff, ctx, lane);
     __syncthreads();
-    a0 = a1;
   }
 }
 
@@ -673,7 +683,7 @@ size_t imu_lds_bytes(const ImuCols& ic) { return (kMaxStagedKnots * 7 + 32 + (si
 void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st) {
   if (vd.n_corners == 0) return;
   const ViewCols vc = view_cols(ctx.tl, spline_active);
-  const int grid = int((vd.n_corners + kWave - 1) / kWave);
+  const int grid = vd.n_chunks;
   if (jac) hipLaunchKernelGGL(view_blocks_kernel<true>, dim3(grid), dim3(64), view_lds_bytes(vc), st, ctx, vd, vc);
   else hipLaunchKernelGGL(view_blocks_kernel<false>, dim3(grid), dim3(64), (kMaxStagedKnots * 7 + 32) * sizeof(double), st, ctx, vd, vc);
 }
@@ -681,7 +691,7 @@ void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_acti
 void launch_imu_blocks(int kind, const EvalCtx& ctx, const ImuData& id, bool spline_active, bool bias_active, bool jac, hipStream_t st) {
   if (id.n == 0) return;
   const ImuCols ic = kind == 0 ? accel_cols(ctx.tl, spline_active, bias_active) : gyro_cols(ctx.tl, spline_active, bias_active);
-  const int grid = int((id.n + kImuChunk - 1) / kImuChunk);
+  const int grid = id.n_chunks;
   const size_t lds_cost = (kMaxStagedKnots * 7 + 32) * sizeof(double);
   if (kind == 0) {
     if (jac) hipLaunchKernelGGL((imu_blocks_kernel<0, true>), dim3(grid), dim3(64), imu_lds_bytes(ic), st, ctx, id, ic);
@@ -697,7 +707,7 @@ void launch_all_blocks(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia
                        bool gb_active, bool jac, hipStream_t st) {
   const ViewCols vc = view_cols(ctx.tl, spline_active);
   const ImuCols ica = accel_cols(ctx.tl, spline_active, ab_active), icg = gyro_cols(ctx.tl, spline_active, gb_active);
-  const int nb_view = int((vd.n_corners + kWave - 1) / kWave), nb_acc = int((ia.n + kImuChunk - 1) / kImuChunk), nb_gyr = int((ig.n + kImuChunk - 1) / kImuChunk);
+  const int nb_view = vd.n_corners > 0 ? vd.n_chunks : 0, nb_acc = ia.n > 0 ? ia.n_chunks : 0, nb_gyr = ig.n > 0 ? ig.n_chunks : 0;
   const int grid = nb_view + nb_acc + nb_gyr;
   if (grid == 0) return;
   size_t lds = (kMaxStagedKnots * 7 + 32) * sizeof(double);

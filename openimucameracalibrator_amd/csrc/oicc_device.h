@@ -47,6 +47,9 @@ struct ViewData {  // SoA over corners (sorted by view) and over views
   const int32_t* view_s_so3; const int32_t* view_s_r3;
   const double* view_u_so3; const double* view_u_r3;
   const uint8_t* view_rs;      // rolling-shutter functor (1) or global-shutter (0)
+  // work list: one wave per chunk = the corners of ONE view (split only above 64 corners), so that every view
+  // is reduced and scattered exactly once
+  const int64_t* chunk_c0; const int32_t* chunk_n; int32_t n_chunks;
 };
 
 struct ImuData {  // SoA over samples of one sensor (time sorted)
@@ -55,6 +58,8 @@ struct ImuData {  // SoA over samples of one sensor (time sorted)
   const double* u_so3; const double* u_r3; const double* u_b;
   const double* mx; const double* my; const double* mz;
   const double* w;       // per-sample weight 1/std
+  // work list: one wave per chunk = whole cells (runs of samples with identical knot windows), <= 32 samples
+  const int64_t* chunk_i0; const int32_t* chunk_n; int32_t n_chunks;
 };
 
 struct EvalCtx {

@@ -87,7 +87,8 @@ struct ImuHost {
   std::vector<double> u_so3, u_r3, u_b, mx, my, mz, w;
   size_t size() const { return s_so3.size(); }
 };
-struct ImuDev { DevBuf<int32_t> s_so3, s_r3, s_b; DevBuf<double> u_so3, u_r3, u_b, mx, my, mz, w; };
+struct ImuDev { DevBuf<int32_t> s_so3, s_r3, s_b; DevBuf<double> u_so3, u_r3, u_b, mx, my, mz, w; DevBuf<int64_t> chunk_i0; DevBuf<int32_t> chunk_n; int32_t n_chunks = 0;
+                std::vector<int64_t> h_chunk_i0; std::vector<int32_t> h_chunk_n; };
 
 struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g; };
 
@@ -145,6 +146,8 @@ struct oicc_problem {
   DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
   DevBuf<double> d_cu, d_cv, d_cisx, d_cisy, d_view_u_so3, d_view_u_r3;
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
+  DevBuf<int64_t> d_vchunk_c0; DevBuf<int32_t> d_vchunk_n; int32_t n_vchunks = 0;
+  std::vector<int64_t> h_vchunk_c0; std::vector<int32_t> h_vchunk_n;
   ImuDev d_acc, d_gyr;
   DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
   DevBuf<double> d_ws;
@@ -219,11 +222,34 @@ int sync_params_to_host(oicc_problem* p) {
   return OICC_OK;
 }
 
-bool upload_imu(oicc_problem* p, const ImuHost& h, ImuDev& d) {
+// Work lists of the residual kernels.  IMU: whole cells (runs of samples with identical knot windows, which
+// share every normal-equation target) are packed greedily into chunks of at most 32 samples; small problems
+// (latency bound) get at most `max_cells` cells per chunk so that more waves run side by side.
+void build_imu_chunks(const ImuHost& h, bool accel, int max_cells, std::vector<int64_t>& i0, std::vector<int32_t>& cnt) {
+  i0.clear(); cnt.clear();
+  const int64_t n = int64_t(h.size());
+  int64_t a = 0;
+  int64_t cur0 = 0; int cur_n = 0, cur_cells = 0;
+  while (a < n) {
+    int64_t b = a + 1;
+    while (b < n && b - a < 32 && h.s_so3[b] == h.s_so3[a] && h.s_b[b] == h.s_b[a] && (!accel || h.s_r3[b] == h.s_r3[a])) ++b;
+    const int len = int(b - a);
+    if (cur_n > 0 && (cur_n + len > 32 || cur_cells >= max_cells)) { i0.push_back(cur0); cnt.push_back(cur_n); cur_n = 0; cur_cells = 0; }
+    if (cur_n == 0) cur0 = a;
+    cur_n += len; ++cur_cells;
+    a = b;
+  }
+  if (cur_n > 0) { i0.push_back(cur0); cnt.push_back(cur_n); }
+}
+bool upload_imu(oicc_problem* p, const ImuHost& h, ImuDev& d, bool accel) {
   hipStream_t st = p->stream;
+  std::vector<int64_t>& i0 = d.h_chunk_i0; std::vector<int32_t>& cnt = d.h_chunk_n;   // outlive the asynchronous copies
+  const int max_cells = h.size() <= 65536 ? 2 : 32;
+  build_imu_chunks(h, accel, max_cells, i0, cnt);
+  d.n_chunks = int32_t(i0.size());
   return d.s_so3.upload(h.s_so3, st) && d.s_r3.upload(h.s_r3, st) && d.s_b.upload(h.s_b, st) && d.u_so3.upload(h.u_so3, st) &&
          d.u_r3.upload(h.u_r3, st) && d.u_b.upload(h.u_b, st) && d.mx.upload(h.mx, st) && d.my.upload(h.my, st) &&
-         d.mz.upload(h.mz, st) && d.w.upload(h.w, st);
+         d.mz.upload(h.mz, st) && d.w.upload(h.w, st) && d.chunk_i0.upload(i0, st) && d.chunk_n.upload(cnt, st);
 }
 
 int sync_measurements(oicc_problem* p) {
@@ -234,7 +260,14 @@ int sync_measurements(oicc_problem* p) {
             p->d_view_c0.upload(p->view_c0, st) && p->d_view_s_so3.upload(p->view_s_so3, st) &&
             p->d_view_s_r3.upload(p->view_s_r3, st) && p->d_view_u_so3.upload(p->view_u_so3, st) &&
             p->d_view_u_r3.upload(p->view_u_r3, st) && p->d_view_rs.upload(p->view_rs, st) && p->d_pts.upload(p->pts, st) &&
-            upload_imu(p, p->acc, p->d_acc) && upload_imu(p, p->gyr, p->d_gyr);
+            upload_imu(p, p->acc, p->d_acc, true) && upload_imu(p, p->gyr, p->d_gyr, false);
+  {
+    std::vector<int64_t>& c0 = p->h_vchunk_c0; std::vector<int32_t>& cn = p->h_vchunk_n; c0.clear(); cn.clear();
+    for (size_t v = 0; v + 1 < p->view_c0.size(); ++v)
+      for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; c += 64) { c0.push_back(c); cn.push_back(int32_t(std::min<int64_t>(64, p->view_c0[v + 1] - c))); }
+    p->n_vchunks = int32_t(c0.size());
+    ok = ok && p->d_vchunk_c0.upload(c0, st) && p->d_vchunk_n.upload(cn, st);
+  }
   std::vector<uint8_t> all(p->view_rs.size(), 1);
   ok = ok && p->d_view_rs_all.upload(all, st);
   if (!ok) { p->err = "device upload of measurements failed"; return OICC_ERR_HIP; }
@@ -353,12 +386,14 @@ ViewData view_data(oicc_problem* p, bool force_rs = false) {
   v.corner_isy = p->d_cisy.p; v.corner_pt = p->d_corner_pt.p; v.view_c0 = p->d_view_c0.p; v.view_s_so3 = p->d_view_s_so3.p;
   v.view_s_r3 = p->d_view_s_r3.p; v.view_u_so3 = p->d_view_u_so3.p; v.view_u_r3 = p->d_view_u_r3.p;
   v.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
+  v.chunk_c0 = p->d_vchunk_c0.p; v.chunk_n = p->d_vchunk_n.p; v.n_chunks = p->n_vchunks;
   return v;
 }
 ImuData imu_data(const ImuHost& h, const ImuDev& d) {
   ImuData i{};
   i.n = int64_t(h.size()); i.s_so3 = d.s_so3.p; i.s_r3 = d.s_r3.p; i.s_b = d.s_b.p; i.u_so3 = d.u_so3.p; i.u_r3 = d.u_r3.p;
   i.u_b = d.u_b.p; i.mx = d.mx.p; i.my = d.my.p; i.mz = d.mz.p; i.w = d.w.p;
+  i.chunk_i0 = d.chunk_i0.p; i.chunk_n = d.chunk_n.p; i.n_chunks = d.n_chunks;
   return i;
 }
 

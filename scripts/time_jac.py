@@ -1,0 +1,9 @@
+import sys
+sys.path.insert(0, '.')
+from openimucameracalibrator_amd import synthetic, estimator as E
+F = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
+for cfg in sys.argv[1:] or ["C2", "C5"]:
+    ds = synthetic.make_config(cfg)
+    cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    p, k = cal.trajectory_.TimeJacobianPass(F, repeats=10)
+    print(cfg, "pass ms %.4f" % p, "view/accel/gyro", [round(float(x), 4) for x in k], flush=True)
