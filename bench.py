@@ -171,8 +171,10 @@ def main():
         # dense on MI355X), not HBM; the HBM view of the same launch is given next to it.
         dom = "blocks"
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01h_pmc_hbm_C2.csv")
-        if world == 1 and os.path.exists(pmc):     # per-launch FETCH_SIZE + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_C2.csv")))
+        pmc = pmcs[-1] if pmcs else ""
+        if world == 1 and pmc:     # per-launch FETCH_SIZE + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes
             tot = 0.0
             for line in open(pmc):
                 if "all_blocks_kernel<true>" in line:
@@ -182,8 +184,8 @@ def main():
                         frac=kernels[dom]["fp64_TFLOPs"] / 78.6, traffic=traffic,
                         hbm=dict(achieved=kernels[dom]["hbm_GBps"], peak=8000.0, unit="GB/s", frac=kernels[dom]["hbm_GBps"] / 8000.0),
                         note="C2 is 8160 blocks (0.1 GFLOP, 1.5 MB): one launch of ~375 waves on 1024 SIMDs, latency bound; the same kernel on the C5-size "
-                             "problem is reported in extra_c5_single_gpu. traffic = HBM bytes per launch from profiles/r01h_pmc_hbm_C2.csv "
-                             "(fp64 atomics of the Gram scatter leave the XCD L2s: ~10x the algorithmic output).",
+                             "problem is reported in extra_c5_single_gpu. traffic = FETCH_SIZE + WRITE_SIZE per launch from the newest profiles/r*_pmc_hbm_C2.csv "
+                             "(%s): the fp64 atomics of the Gram scatter are counted as memory-side requests, ~10x the algorithmic output." % os.path.basename(pmc),
                         step_share=dict(blocks_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step),
                         kernels=kernels)
         out = {

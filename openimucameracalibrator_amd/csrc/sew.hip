@@ -78,22 +78,34 @@ extern "C" int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_
   if (!(max_dt > 0.0)) max_dt = (double(n) / 4.0) / sample_rate;         // sew.py:156-157
 
   const int64_t nh = n / 2 + 1;
-  double* d_sig = nullptr; hipfftDoubleComplex* d_spec = nullptr; SewDevice D; D.n = n; D.nh = nh; D.bin_hz = sample_rate / double(n);
-  hipfftHandle plan = 0; bool have_plan = false; int rc = OICC_OK;
-  auto cleanup = [&]() {
-    if (have_plan) (void)hipfftDestroy(plan);
-    if (d_sig) (void)hipFree(d_sig); if (d_spec) (void)hipFree(d_spec); if (D.pw) (void)hipFree(D.pw); if (D.acc) (void)hipFree(D.acc);
-    if (D.st) (void)hipStreamDestroy(D.st);
+  // device buffers, stream and the hipFFT plan are kept for the next call with the same (device, dims, n):
+  // get_sew_for_dataset.py calls this twice per data set (accelerometer, gyroscope) and plan creation costs milliseconds
+  struct Cache { int device = -1, dims = 0; int64_t n = 0; double* d_sig = nullptr; hipfftDoubleComplex* d_spec = nullptr;
+                 double* pw = nullptr; double* acc = nullptr; hipStream_t st = nullptr; hipfftHandle plan = 0; bool have_plan = false; };
+  static Cache C;   // not thread safe (the reference's pre-stage is a single-threaded script)
+  auto release = [&]() {
+    if (C.have_plan) (void)hipfftDestroy(C.plan);
+    if (C.d_sig) (void)hipFree(C.d_sig); if (C.d_spec) (void)hipFree(C.d_spec); if (C.pw) (void)hipFree(C.pw); if (C.acc) (void)hipFree(C.acc);
+    if (C.st) (void)hipStreamDestroy(C.st);
+    C = Cache();
   };
-  if (hipStreamCreateWithFlags(&D.st, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&d_sig, sizeof(double) * dims * n) != hipSuccess || hipMalloc(&d_spec, sizeof(hipfftDoubleComplex) * dims * nh) != hipSuccess ||
-      hipMalloc(&D.pw, sizeof(double) * nh) != hipSuccess || hipMalloc(&D.acc, 2 * sizeof(double)) != hipSuccess) { cleanup(); return OICC_ERR_HIP; }
-  if (hipMemcpyAsync(d_sig, signal, sizeof(double) * dims * n, hipMemcpyHostToDevice, D.st) != hipSuccess) { cleanup(); return OICC_ERR_HIP; }
-  int len = int(n);
-  if (hipfftPlanMany(&plan, 1, &len, nullptr, 1, len, nullptr, 1, int(nh), HIPFFT_D2Z, dims) != HIPFFT_SUCCESS) { cleanup(); return OICC_ERR_HIP; }
-  have_plan = true;
-  if (hipfftSetStream(plan, D.st) != HIPFFT_SUCCESS || hipfftExecD2Z(plan, d_sig, d_spec) != HIPFFT_SUCCESS) { cleanup(); return OICC_ERR_HIP; }
-  hipLaunchKernelGGL(sew_power_kernel, dim3(int((nh + 255) / 256)), dim3(256), 0, D.st, d_spec, dims, n, nh, D.pw);
+  if (C.device != device_ordinal || C.dims != dims || C.n != n) {
+    release();
+    if (hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&C.d_sig, sizeof(double) * dims * n) != hipSuccess || hipMalloc(&C.d_spec, sizeof(hipfftDoubleComplex) * dims * nh) != hipSuccess ||
+        hipMalloc(&C.pw, sizeof(double) * nh) != hipSuccess || hipMalloc(&C.acc, 2 * sizeof(double)) != hipSuccess) { release(); return OICC_ERR_HIP; }
+    int len = int(n);
+    if (hipfftPlanMany(&C.plan, 1, &len, nullptr, 1, len, nullptr, 1, int(nh), HIPFFT_D2Z, dims) != HIPFFT_SUCCESS) { release(); return OICC_ERR_HIP; }
+    C.have_plan = true;
+    if (hipfftSetStream(C.plan, C.st) != HIPFFT_SUCCESS) { release(); return OICC_ERR_HIP; }
+    C.device = device_ordinal; C.dims = dims; C.n = n;
+  }
+  SewDevice D; D.n = n; D.nh = nh; D.bin_hz = sample_rate / double(n); D.pw = C.pw; D.acc = C.acc; D.st = C.st;
+  int rc = OICC_OK;
+  auto cleanup = [&]() {};
+  if (hipMemcpyAsync(C.d_sig, signal, sizeof(double) * dims * n, hipMemcpyHostToDevice, D.st) != hipSuccess) { release(); return OICC_ERR_HIP; }
+  if (hipfftExecD2Z(C.plan, C.d_sig, C.d_spec) != HIPFFT_SUCCESS) { release(); return OICC_ERR_HIP; }
+  hipLaunchKernelGGL(sew_power_kernel, dim3(int((nh + 255) / 256)), dim3(256), 0, D.st, C.d_spec, dims, n, nh, D.pw);
 
   // quality_func(dt) = max_remove / removed(dt), max_remove = signal_energy(Xhat) (1 - quality)  (sew.py:146-151)
   bool ok = true;
