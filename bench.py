@@ -89,11 +89,28 @@ def main():
         base, num_views=base["num_views"] * world, duration=base["duration"] * world))
     cal = E.ImuCameraCalibrator(device=local_rank)
     tr = cal.trajectory_
-    if use_dist:   # share torch's stream so the RCCL all-reduce is ordered with the kernels
+    reduce_path = "none"
+    native = use_dist and os.environ.get("OICC_BENCH_TORCH_ALLREDUCE") != "1"
+    if use_dist and not native:   # torch staging path: share torch's stream so that the all-reduce is ordered with the kernels
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
     cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
 
-    if use_dist:
+    if native:
+        # native path: the library calls ncclAllReduce (RCCL over xGMI) in place on its own stream; torch.distributed only
+        # carries the 128-byte ncclUniqueId from rank 0 to the other ranks
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.tensor(list(tr.RcclUniqueId()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            tr.EnableRccl(world, rank, bytes(idt.cpu().tolist()))
+            reduce_path = "rccl-native"
+        except Exception as e:   # e.g. RCCL symbols not visible: fall back to the torch staging path
+            sys.stderr.write("native RCCL path unavailable (%s): falling back to torch.distributed staging\n" % e)
+            native = False
+            tr.SetStream(torch.cuda.current_stream().cuda_stream)
+    if use_dist and not native:
+        reduce_path = "torch-staging"
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         staging = {}
@@ -195,7 +212,7 @@ def main():
             "dtype": "f64", "data": "synthetic (seed 20241115)",
             "config": {"workload": "C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s%s"
                                    % (ds.num_views, n_corners, n_blocks - ds.num_views, "" if world == 1 else " (C2 x %d, time-sharded, all-reduce of JtJ/Jtr)" % world),
-                       "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR",
+                       "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR", "allreduce": reduce_path,
                        "step": "one LM iteration: Jacobian+assembly, block-cyclic-reduction solve, retraction, cost pass, one host read-back"},
             "corners_per_s": n_corners * args.steps / dt,
             "jacobian_pass_ms": pass_ms,

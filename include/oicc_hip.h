@@ -219,6 +219,14 @@ int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out,
 typedef int (*oicc_allreduce_fn)(void* user, void* device_ptr, int64_t count,
                                  void* hip_stream);
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user);
+/* Native RCCL reduction (preferred): the library binds the RCCL of the process at run time (dlsym / dlopen of
+ * librccl.so.1, no link-time dependency), builds a communicator from the 128-byte ncclUniqueId that rank 0 obtained
+ * with oicc_rccl_get_unique_id and the caller distributed (MPI / torch.distributed broadcast / a file), and from then
+ * on sums the packed normal-equation buffer IN PLACE with ncclAllReduce(ncclDouble, ncclSum) on the library's own
+ * stream: no staging copies, no host involvement.  nranks = 1 is allowed (single-GPU test of the path).
+ * Replaces any hook installed with oicc_set_allreduce; oicc_destroy releases the communicator. */
+int oicc_rccl_get_unique_id(uint8_t id[128]);
+int oicc_rccl_init(oicc_problem* p, int32_t nranks, int32_t rank, const uint8_t id[128]);
 /* Tell this rank about measurements held by OTHER ranks (timestamps only), so
  * that every rank derives the same tangent layout (which knots are in the
  * problem, bandwidth, which parameter blocks exist).

@@ -9,6 +9,8 @@
 // kernels_solve.hip; this file never computes residuals, Jacobians or solves on
 // the CPU (there is no CPU fallback).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: the entry points are bound with dlsym at run time
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -141,6 +143,7 @@ struct oicc_problem {
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
   oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
+  void* rccl_comm = nullptr;   // ncclComm_t of oicc_rccl_init
   // device
   DevBuf<double> d_x, d_xc, d_pts;
   DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
@@ -431,6 +434,38 @@ extern "C" {
 
 const char* oicc_version(void) { return "oicc-hip-gfx950-r1"; }
 
+// ---- native RCCL binding (no link-time dependency: the RCCL of the process is found at run time) ----
+namespace {
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  bool ok = false;
+};
+RcclApi& rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api;
+  tried = true;
+  void* handles[4] = {RTLD_DEFAULT, dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD), dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD), nullptr};
+  for (int k = 0; k < 5 && !api.ok; ++k) {
+    void* h = k < 3 ? handles[k] : (k == 3 ? dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL) : dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL));
+    if (k > 0 && h == nullptr) continue;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
+  }
+  return api;
+}
+int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stream) {
+  oicc_problem* p = static_cast<oicc_problem*>(user);
+  return rccl_api().AllReduce(device_ptr, device_ptr, size_t(count), ncclDouble, ncclSum, static_cast<ncclComm_t>(p->rccl_comm),
+                              static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : -1;
+}
+}  // namespace
 int oicc_create(oicc_problem** out, int device_ordinal) {
   if (!out) return OICC_ERR_INVALID_ARG;
   *out = nullptr;
@@ -454,6 +489,7 @@ void oicc_destroy(oicc_problem* p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->rccl_comm) { (void)rccl_api().CommDestroy(static_cast<ncclComm_t>(p->rccl_comm)); p->rccl_comm = nullptr; }
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->pin) (void)hipHostFree(p->pin);
   delete p;
@@ -467,6 +503,30 @@ int oicc_set_option(oicc_problem* p, const char* name, double value) {
   auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name); it->second = value; return OICC_OK;
 }
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user) { p->reduce = fn; p->reduce_user = user; return OICC_OK; }
+
+int oicc_rccl_get_unique_id(uint8_t id[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!id) return OICC_ERR_INVALID_ARG;
+  RcclApi& api = rccl_api();
+  if (!api.ok) return OICC_ERR_UNSUPPORTED;
+  ncclUniqueId u;
+  if (api.GetUniqueId(&u) != ncclSuccess) return OICC_ERR_HIP;
+  std::memcpy(id, &u, 128);
+  return OICC_OK;
+}
+int oicc_rccl_init(oicc_problem* p, int32_t nranks, int32_t rank, const uint8_t id[128]) {
+  ARG(p, id != nullptr && nranks >= 1 && rank >= 0 && rank < nranks, "bad RCCL rank / size");
+  RcclApi& api = rccl_api();
+  if (!api.ok) { p->err = "RCCL (librccl.so.1) not found in this process"; return OICC_ERR_UNSUPPORTED; }
+  (void)hipSetDevice(p->device);
+  if (p->rccl_comm) { (void)api.CommDestroy(static_cast<ncclComm_t>(p->rccl_comm)); p->rccl_comm = nullptr; }
+  ncclUniqueId u; std::memcpy(&u, id, 128);
+  ncclComm_t comm = nullptr;
+  if (api.CommInitRank(&comm, nranks, u, rank) != ncclSuccess) { p->err = "ncclCommInitRank failed"; return OICC_ERR_HIP; }
+  p->rccl_comm = comm;
+  p->reduce = rccl_reduce_in_place; p->reduce_user = p;
+  return OICC_OK;
+}
 
 int oicc_set_times(oicc_problem* p, int64_t dt_so3, int64_t dt_r3, int64_t start_ns, int64_t end_ns) {
   ARG(p, dt_so3 > 0 && dt_r3 > 0 && end_ns >= start_ns, "bad spline times");

@@ -241,6 +241,19 @@ class SplineTrajectoryEstimator:
         self._keep.append(cb)
         self._ck(self._b.set_allreduce(self._h, cb, None))
 
+    def RcclUniqueId(self):
+        """128-byte ncclUniqueId (call on rank 0, distribute to the other ranks)."""
+        buf = (C.c_uint8 * 128)()
+        rc = self._b.rccl_get_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("oicc_rccl_get_unique_id failed with status %d (RCCL not found in this process?)" % rc)
+        return bytes(buf)
+
+    def EnableRccl(self, nranks, rank, unique_id):
+        """Native in-place ncclAllReduce of the normal equations on the library's stream."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._ck(self._b.rccl_init(self._h, int(nranks), int(rank), buf))
+
     # ---- evaluation hooks ---------------------------------------------------
     def GetTangentLayout(self, flags):
         n_so3, n_r3 = self.GetNumSO3Knots(), self.GetNumR3Knots()

@@ -260,3 +260,16 @@ def test_very_short_trajectories_single_and_two_block_band(algo, duration, views
     ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     for a, b in list(zip(ig, ic))[:3]:
         assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"] and a["step_is_successful"] == b["step_is_successful"]
+
+
+def test_native_rccl_reduction_single_rank():
+    """oicc_rccl_init with a one-rank communicator: ncclAllReduce in place on the library's stream must leave the
+    normal equations and the LM iterates unchanged (the N > 1 logic is covered by tests/test_distributed_gloo.py)."""
+    ds = synthetic.make_config("tiny")
+    ref = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    par = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    par.trajectory_.EnableRccl(1, 0, par.trajectory_.RcclUniqueId())
+    c0, H0, g0 = ref.trajectory_.Evaluate(FLAGS1); c1, H1, g1 = par.trajectory_.Evaluate(FLAGS1)
+    assert abs(c0 - c1) <= 1e-12 * c0 and rel_err(H1, H0) < 1e-12 and rel_err(g1, g0) < 1e-12
+    s0 = ref.trajectory_.Optimize(20, FLAGS1); s1 = par.trajectory_.Optimize(20, FLAGS1)
+    assert s0["num_iterations"] == s1["num_iterations"] and abs(s0["final_cost"] - s1["final_cost"]) <= 1e-9 * s0["final_cost"]
