@@ -27,13 +27,9 @@ namespace oicc {
 constexpr int kWave = 64;
 constexpr int kMaxStagedKnots = 24;  // knots of one kind staged per wave
 
-#if defined(OICC_DBG_ATOMICS) && OICC_DBG_ATOMICS == 1
-__device__ __forceinline__ void atomic_add_f64(double* p, double v) { if (v == 1.2345e300) *p = v; }              // experiment: no scatter at all
-#elif defined(OICC_DBG_ATOMICS) && OICC_DBG_ATOMICS == 2
-__device__ __forceinline__ void atomic_add_f64(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // experiment: L2-local atomics
-#else
+// fp64 add without return value (global_atomic_add_f64).  Measured: workgroup scope costs the same as device scope on
+// MI355X and the whole scatter is ~45 % of a C5-size pass, so the lever is the number of atomics, not their scope.
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
-#endif
 
 __device__ __forceinline__ void ne_add(const NormalEq& ne, const TangentLayout& tl, int i, int j, double v) {
   if (i > j) { const int t = i; i = j; j = t; }
@@ -233,6 +229,18 @@ __device__ __forceinline__ void view_block(const EvalCtx& ctx, const ViewData& v
   const int lo_r = wave_min_i(s_r3), hi_r = wave_max_i(valid ? s_r3 + 6 : 0);
   const StagedKnots<4> ks = stage_knots<4>(ctx.x + ctx.pl.so3, ctx.pl.n_so3, lo_s, hi_s, lds_so3, lane);
   const StagedKnots<3> kr = stage_knots<3>(ctx.x + ctx.pl.r3, ctx.pl.n_r3, lo_r, hi_r, lds_r3, lane);
+  // tangent offsets of this view's columns: the dependent global loads (view -> knot window -> layout) are issued here,
+  // so that their latency is covered by the evaluation phase instead of standing in front of the Gram product
+  if (JAC && lane < vc.ncols) {
+    const int vv = vd.corner_view[c_begin];
+    int off = -1;
+    const int ss = vd.view_s_so3[vv], sr = vd.view_s_r3[vv];
+    if (vc.base_s >= 0 && lane >= vc.base_s && lane < vc.base_s + 18) { const int k = lane - vc.base_s; const int o = ctx.tl.so3[ss + k / 3]; off = o < 0 ? -1 : o + k % 3; }
+    else if (vc.base_r >= 0 && lane >= vc.base_r && lane < vc.base_r + 18) { const int k = lane - vc.base_r; const int o = ctx.tl.r3[sr + k / 3]; off = o < 0 ? -1 : o + k % 3; }
+    else if (vc.base_t >= 0 && lane >= vc.base_t && lane < vc.base_t + 6) off = ctx.tl.tic + (lane - vc.base_t);
+    else if (vc.base_l >= 0 && lane == vc.base_l) off = ctx.tl.ld;
+    coloff[lane] = off;
+  }
   __syncthreads();
   const bool prof = ctx.prof != nullptr && bid == nblk / 2;
   long long tp0 = prof ? clock64() : 0, tp1 = 0, tp3 = 0;
@@ -383,29 +391,8 @@ __device__ __forceinline__ void view_block(const EvalCtx& ctx, const ViewData& v
   }
   __syncthreads();
   if (prof) tp1 = clock64();
-  // phase 2/3: one flush per view present in this chunk
-  const int v_first = vd.corner_view[c_begin];
-  const int64_t c_last = c_begin + c_count - 1;
-  const int v_last = vd.corner_view[c_last];
-  for (int vv = v_first; vv <= v_last; ++vv) {
-    int64_t a0 = vd.view_c0[vv], a1 = vd.view_c0[vv + 1];
-    if (a0 < c_begin) a0 = c_begin;
-    if (a1 > c_last + 1) a1 = c_last + 1;
-    if (a1 <= a0) continue;
-    // column offsets of this view
-    if (lane < vc.ncols) {
-      int off = -1;
-      const int ss = vd.view_s_so3[vv], sr = vd.view_s_r3[vv];
-      if (vc.base_s >= 0 && lane >= vc.base_s && lane < vc.base_s + 18) { const int k = lane - vc.base_s; const int o = ctx.tl.so3[ss + k / 3]; off = o < 0 ? -1 : o + k % 3; }
-      else if (vc.base_r >= 0 && lane >= vc.base_r && lane < vc.base_r + 18) { const int k = lane - vc.base_r; const int o = ctx.tl.r3[sr + k / 3]; off = o < 0 ? -1 : o + k % 3; }
-      else if (vc.base_t >= 0 && lane >= vc.base_t && lane < vc.base_t + 6) off = ctx.tl.tic + (lane - vc.base_t);
-      else if (vc.base_l >= 0 && lane == vc.base_l) off = ctx.tl.ld;
-      coloff[lane] = off;
-    }
-    __syncthreads();
-    gram_flush_cell(rows, vc.stride, int(2 * (a0 - c_begin)), int(2 * (a1 - c_begin)), vc.ncols, vc.rescol, coloff, ctx, lane);
-    __syncthreads();
-  }
+  // phase 2/3: the chunk is (part of) ONE view, its column offsets were fetched before the evaluation phase
+  gram_flush_cell(rows, vc.stride, 0, 2 * c_count, vc.ncols, vc.rescol, coloff, ctx, lane);
   if (prof && lane == 0) { tp3 = clock64(); ctx.prof[0] = tp1 - tp0; ctx.prof[1] = tp3 - tp1; }
 }
 

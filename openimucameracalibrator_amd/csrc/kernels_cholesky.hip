@@ -381,9 +381,6 @@ __global__ void __launch_bounds__(kCholThreads) band_arrow_cholesky_kernel(CholA
         __builtin_amdgcn_s_setprio(0);
       }
     } else {
-#ifdef OICC_DBG_SKIP
-      if (!((OICC_DBG_SKIP >> wave) & 1))
-#endif
 #pragma unroll
       for (int i = 1; i <= TMAX; ++i) if (i <= n_rest) run_tile(tk_kind[i], tk_lpa[i], tk_lpb[i], tk_row[i], tk_col[i], tk_c1[i], tk_c2[i], tk_c3[i], tk_ok[i], LpC, j0);
       // global factor storage: band rows (lane = row, one panel column per wave slot), border rows
