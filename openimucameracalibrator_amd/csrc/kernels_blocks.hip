@@ -650,14 +650,17 @@ __global__ void __launch_bounds__(64) all_blocks_kernel(EvalCtx ctx, ViewData vd
 }
 
 // ---- launchers ---------------------------------------------------------------
-size_t view_lds_bytes(const ViewCols& vc) { return (kMaxStagedKnots * 7 + 32 + (size_t)2 * kWave * vc.stride + 64) * sizeof(double); }
+size_t view_lds_bytes(const ViewCols& vc, int max_corners) {
+  const int rows = 2 * (max_corners < 1 ? 1 : (max_corners > kWave ? kWave : max_corners));
+  return (kMaxStagedKnots * 7 + 32 + (size_t)(rows + 3) * vc.stride + 64) * sizeof(double);   // +3: the K loop reads up to 3 (masked) rows past the end
+}
 size_t imu_lds_bytes(const ImuCols& ic) { return (kMaxStagedKnots * 7 + 32 + (size_t)3 * kImuChunk * ic.stride + 64) * sizeof(double); }
 
 void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st) {
   if (vd.n_corners == 0) return;
   const ViewCols vc = view_cols(ctx.tl, spline_active);
   const int grid = vd.n_chunks;
-  if (jac) hipLaunchKernelGGL(view_blocks_kernel<true>, dim3(grid), dim3(64), view_lds_bytes(vc), st, ctx, vd, vc);
+  if (jac) hipLaunchKernelGGL(view_blocks_kernel<true>, dim3(grid), dim3(64), view_lds_bytes(vc, vd.max_chunk_n), st, ctx, vd, vc);
   else hipLaunchKernelGGL(view_blocks_kernel<false>, dim3(grid), dim3(64), (kMaxStagedKnots * 7 + 32) * sizeof(double), st, ctx, vd, vc);
 }
 
@@ -684,7 +687,7 @@ void launch_all_blocks(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia
   const int grid = nb_view + nb_acc + nb_gyr;
   if (grid == 0) return;
   size_t lds = (kMaxStagedKnots * 7 + 32) * sizeof(double);
-  if (jac) { lds = view_lds_bytes(vc); if (imu_lds_bytes(ica) > lds) lds = imu_lds_bytes(ica); if (imu_lds_bytes(icg) > lds) lds = imu_lds_bytes(icg); }
+  if (jac) { lds = view_lds_bytes(vc, vd.max_chunk_n); if (imu_lds_bytes(ica) > lds) lds = imu_lds_bytes(ica); if (imu_lds_bytes(icg) > lds) lds = imu_lds_bytes(icg); }
   if (jac) hipLaunchKernelGGL(all_blocks_kernel<true>, dim3(grid), dim3(64), lds, st, ctx, vd, vc, ia, ica, ig, icg, nb_view, nb_acc);
   else hipLaunchKernelGGL(all_blocks_kernel<false>, dim3(grid), dim3(64), lds, st, ctx, vd, vc, ia, ica, ig, icg, nb_view, nb_acc);
 }

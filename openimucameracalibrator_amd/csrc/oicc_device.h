@@ -50,6 +50,7 @@ struct ViewData {  // SoA over corners (sorted by view) and over views
   // work list: one wave per chunk = the corners of ONE view (split only above 64 corners), so that every view
   // is reduced and scattered exactly once
   const int64_t* chunk_c0; const int32_t* chunk_n; int32_t n_chunks;
+  int32_t max_chunk_n;   // largest chunk: sizes the LDS row buffer (2 rows per corner), hence the waves resident per CU
 };
 
 struct ImuData {  // SoA over samples of one sensor (time sorted)

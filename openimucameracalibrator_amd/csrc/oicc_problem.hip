@@ -150,7 +150,7 @@ struct oicc_problem {
   DevBuf<double> d_cu, d_cv, d_cisx, d_cisy, d_view_u_so3, d_view_u_r3;
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
   DevBuf<int64_t> d_vchunk_c0; DevBuf<int32_t> d_vchunk_n; int32_t n_vchunks = 0;
-  std::vector<int64_t> h_vchunk_c0; std::vector<int32_t> h_vchunk_n;
+  std::vector<int64_t> h_vchunk_c0; std::vector<int32_t> h_vchunk_n; int32_t max_vchunk_n = 64;
   ImuDev d_acc, d_gyr;
   DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
   DevBuf<double> d_ws;
@@ -170,7 +170,7 @@ struct oicc_problem {
     opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
-    opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0;
+    opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0; opt["imu_chunk_cells"] = 0;
   }
 };
 
@@ -227,7 +227,7 @@ int sync_params_to_host(oicc_problem* p) {
 
 // Work lists of the residual kernels.  IMU: whole cells (runs of samples with identical knot windows, which
 // share every normal-equation target) are packed greedily into chunks of at most 32 samples; small problems
-// (latency bound) get at most `max_cells` cells per chunk so that more waves run side by side.
+// (latency bound) get one cell per chunk (`max_cells`, option imu_chunk_cells) so that more waves run side by side.
 void build_imu_chunks(const ImuHost& h, bool accel, int max_cells, std::vector<int64_t>& i0, std::vector<int32_t>& cnt) {
   i0.clear(); cnt.clear();
   const int64_t n = int64_t(h.size());
@@ -247,7 +247,8 @@ void build_imu_chunks(const ImuHost& h, bool accel, int max_cells, std::vector<i
 bool upload_imu(oicc_problem* p, const ImuHost& h, ImuDev& d, bool accel) {
   hipStream_t st = p->stream;
   std::vector<int64_t>& i0 = d.h_chunk_i0; std::vector<int32_t>& cnt = d.h_chunk_n;   // outlive the asynchronous copies
-  const int max_cells = h.size() <= 65536 ? 2 : 32;
+  const int opt_cells = int(p->opt["imu_chunk_cells"]);   // 0: automatic
+  const int max_cells = opt_cells > 0 ? opt_cells : (h.size() <= 65536 ? 1 : 32);
   build_imu_chunks(h, accel, max_cells, i0, cnt);
   d.n_chunks = int32_t(i0.size());
   return d.s_so3.upload(h.s_so3, st) && d.s_r3.upload(h.s_r3, st) && d.s_b.upload(h.s_b, st) && d.u_so3.upload(h.u_so3, st) &&
@@ -269,6 +270,7 @@ int sync_measurements(oicc_problem* p) {
     for (size_t v = 0; v + 1 < p->view_c0.size(); ++v)
       for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; c += 64) { c0.push_back(c); cn.push_back(int32_t(std::min<int64_t>(64, p->view_c0[v + 1] - c))); }
     p->n_vchunks = int32_t(c0.size());
+    p->max_vchunk_n = 1; for (int32_t v : cn) p->max_vchunk_n = std::max(p->max_vchunk_n, v);
     ok = ok && p->d_vchunk_c0.upload(c0, st) && p->d_vchunk_n.upload(cn, st);
   }
   std::vector<uint8_t> all(p->view_rs.size(), 1);
@@ -389,7 +391,7 @@ ViewData view_data(oicc_problem* p, bool force_rs = false) {
   v.corner_isy = p->d_cisy.p; v.corner_pt = p->d_corner_pt.p; v.view_c0 = p->d_view_c0.p; v.view_s_so3 = p->d_view_s_so3.p;
   v.view_s_r3 = p->d_view_s_r3.p; v.view_u_so3 = p->d_view_u_so3.p; v.view_u_r3 = p->d_view_u_r3.p;
   v.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
-  v.chunk_c0 = p->d_vchunk_c0.p; v.chunk_n = p->d_vchunk_n.p; v.n_chunks = p->n_vchunks;
+  v.chunk_c0 = p->d_vchunk_c0.p; v.chunk_n = p->d_vchunk_n.p; v.n_chunks = p->n_vchunks; v.max_chunk_n = p->max_vchunk_n;
   return v;
 }
 ImuData imu_data(const ImuHost& h, const ImuDev& d) {
@@ -500,7 +502,9 @@ int oicc_set_stream(oicc_problem* p, void* s) {
   p->stream = reinterpret_cast<hipStream_t>(s); p->own_stream = false; return OICC_OK;
 }
 int oicc_set_option(oicc_problem* p, const char* name, double value) {
-  auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name); it->second = value; return OICC_OK;
+  auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name); it->second = value;
+  if (std::string(name) == "imu_chunk_cells") p->meas_dirty = true;   // the work lists are rebuilt at the next pass
+  return OICC_OK;
 }
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user) { p->reduce = fn; p->reduce_user = user; return OICC_OK; }
 
