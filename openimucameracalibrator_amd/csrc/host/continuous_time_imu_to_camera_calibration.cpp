@@ -213,9 +213,14 @@ int main(int argc, char* argv[]) {
   ThreeAxisSensorCalibParams acc_intr, gyr_intr;
   CHECK_MSG(ReadIMUIntrinsics(F.str("imu_intrinsics"), F.str("imu_bias_file"), &acc_intr, &gyr_intr), "Could not open " << F.str("imu_intrinsics"));
   std::cout << "Loaded IMU intrinsics.\n";
-  CHECK_MSG(!F.str("spline_error_weighting_json").empty(), "You need to provide spline error weighting factors. Create with get_sew_for_dataset.py.");
+  // The reference aborts without a spline-error-weighting file ("Create with get_sew_for_dataset.py", cc:166-170).
+  // Here --spline_error_weighting_json=device runs that pre-stage on the GPU instead (oicc_sew_knot_spacing_and_variance
+  // with the script's defaults q_r3 0.96 / q_so3 0.98 and knot-spacing bounds, get_sew_for_dataset.py:20-23,38-39).
+  CHECK_MSG(!F.str("spline_error_weighting_json").empty(), "You need to provide spline error weighting factors. Create with get_sew_for_dataset.py (or pass --spline_error_weighting_json=device).");
   SplineWeightingData weight_data;
-  CHECK_MSG(ReadSplineErrorWeighting(F.str("spline_error_weighting_json"), &weight_data), "Could not open " << F.str("spline_error_weighting_json"));
+  const bool sew_on_device = F.str("spline_error_weighting_json") == "device";
+  if (!sew_on_device)
+    CHECK_MSG(ReadSplineErrorWeighting(F.str("spline_error_weighting_json"), &weight_data), "Could not open " << F.str("spline_error_weighting_json"));
 
   double init_line_delay_us = 1. / fps / recon_calib_dataset.image_height;   // [s] despite the name (cc:186-189, quirk Q1)
   if (F.b("global_shutter")) init_line_delay_us = 0.0;
@@ -225,6 +230,23 @@ int main(int argc, char* argv[]) {
             << ", dt_r3/dt_so3 " << weight_data.dt_r3 << "/" << weight_data.dt_so3 << " s\n";
   CHECK_MSG(!recon_calib_dataset.views.empty(), "no view of the corner file is in the pose dataset");
   if (F.b("dry_run")) { std::cout << "dry run: inputs parsed, no solve.\n"; return 0; }
+  if (sew_on_device) {
+    const size_t n = telemetry_data.accelerometer.size();
+    std::vector<double> sig(3 * n), t(n);
+    auto run = [&](const std::vector<ImuReading>& r, double q, double lo, double hi, double* dt, double* sd) {
+      for (size_t i = 0; i < n; ++i) { t[i] = r[i].t_s; sig[i] = r[i].v[0]; sig[n + i] = r[i].v[1]; sig[2 * n + i] = r[i].v[2]; }
+      double var = 0.0; int32_t ev = 0;
+      const int rc = oicc_sew_knot_spacing_and_variance(int(F.d("device")), 3, int64_t(n), sig.data(), t.data(), q, lo, hi, dt, &var, &ev);
+      CHECK_MSG(rc == 0, "spline error weighting on the device failed with status " << rc);
+      *sd = std::sqrt(var);
+    };
+    CHECK_MSG(n >= 8 && telemetry_data.gyroscope.size() == n, "telemetry too short for spline error weighting");
+    run(telemetry_data.accelerometer, 0.96, 0.01, 0.15, &weight_data.dt_r3, &weight_data.std_r3);
+    run(telemetry_data.gyroscope, 0.98, 0.01, 0.2, &weight_data.dt_so3, &weight_data.std_so3);
+    weight_data.cam_fps = fps;
+    std::cout << "Spline error weighting on the device: dt_r3/dt_so3 " << weight_data.dt_r3 << "/" << weight_data.dt_so3 << " s, std_r3/std_so3 "
+              << weight_data.std_r3 << "/" << weight_data.std_so3 << "\n";
+  }
 
   ImuCameraCalibrator imu_cam_calibrator(int(F.d("device")));
   imu_cam_calibrator.trajectory_.SetOption("solver_partitions", F.d("solver_partitions"));

@@ -590,10 +590,12 @@ static void launch_sweep(const CholArgs& A, int grid, int br, hipStream_t st) {
   }
 }
 
+void launch_band_arrow_cholesky_global(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st);   // kernels_band_global.hip
+
 int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st) {
   const int ar = tl.a + 1;
   const int m = tl.hb + PW;
-  if (m > 128) return -1;
+  if (m > 128) { launch_band_arrow_cholesky_global(tl, sb, st); return 0; }   // any geometry: global-memory fallback
   const int mcap = m <= 64 ? 64 : 128;
   CholArgs A{};
   A.sys = CholSys{sb.Mb, sb.Mt, sb.Mc, tl.Pb, tl.W, tl.hb, tl.a};
@@ -606,8 +608,7 @@ int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, 
     if (L < tl.hb + PW) p = 1; else A.L = L;
   }
   if (p <= 1) {
-    if (lds_bytes(mcap, ar, m) > 160 * 1024 - 64) return -1;
-    if (!sweep_geometry_ok(m, ar)) return -1;
+    if (lds_bytes(mcap, ar, m) > 160 * 1024 - 64 || !sweep_geometry_ok(m, ar)) { launch_band_arrow_cholesky_global(tl, sb, st); return 0; }
     if (mcap == 64) launch_sweep<64, 0>(A, 1, ar, st); else launch_sweep<128, 0>(A, 1, ar, st);
     return 0;
   }

@@ -62,3 +62,25 @@ def test_cli_full_calibration_matches_python_mirror(tmp_path):
     first = next(iter(out["trajectory"].values()))
     assert set(first) == {"gyro_imu", "gyro_spline", "gyro_bias", "accl_imu", "accl_spline", "accl_bias"}
     assert len(out["trajectory"]) == int(cal.gyro_accepted.sum())
+
+
+@pytest.mark.gpu
+def test_cli_runs_spline_error_weighting_on_the_device(tmp_path):
+    """--spline_error_weighting_json=device: the pre-stage of get_sew_for_dataset.py runs inside the CLI on the GPU and
+    the knot spacings it finds (reported back as r3_dt / so3_dt) equal those of the Python mirror / numpy oracle."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import sew_oracle
+    ds = synthetic.make_config("C1", camera="gopro9_division")
+    flags = io_files.write_dataset_files(ds, str(tmp_path))
+    flags["spline_error_weighting_json"] = "device"
+    r = run_cli(flags, "--known_grav_dir_axis=UNKNOWN")
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Spline error weighting on the device" in r.stdout
+    out = json.load(open(flags["result_output_json"]))
+    tel = json.load(open(flags["telemetry_json"]))
+    t = np.asarray(tel["timestamps_ns"], dtype=np.float64) * 1e-9
+    r3_dt, _ = sew_oracle.knot_spacing_and_variance(np.asarray(tel["accelerometer"]).T, t, 0.96, 0.01, 0.15)
+    so3_dt, _ = sew_oracle.knot_spacing_and_variance(np.asarray(tel["gyroscope"]).T, t, 0.98, 0.01, 0.2)
+    assert abs(out["r3_dt"] - r3_dt) < 1e-6 * r3_dt and abs(out["so3_dt"] - so3_dt) < 1e-6 * so3_dt
+    assert out["final_reproj_error"] < 2.0

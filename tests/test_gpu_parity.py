@@ -347,3 +347,17 @@ def test_c5_time_shards_sum_to_the_whole():
     assert abs(c_sum - c_all) <= 1e-11 * c_all and rel_err(g_sum, g_all) < 1e-10
     s = whole.trajectory_.Optimize(1, FLAGS1)
     assert s["num_successful_steps"] == 1 and s["final_cost"] < 0.5 * s["initial_cost"] and s["band_dim"] > 85000
+
+
+def test_wide_band_falls_back_to_the_global_memory_solver():
+    """dt_r3 << dt_so3 (what the spline error weighting picks for noisy accelerometer data): half bandwidth > 200, beyond
+    both LDS solvers; the global-memory band Cholesky takes over and the LM iterates still equal the oracle's."""
+    ds = synthetic.make_config("tiny", dt_so3=0.2, dt_r3=0.017, duration=2.0, num_views=20)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    sg = gpu.trajectory_.Optimize(6, FLAGS1); sc = cpu.trajectory_.Optimize(6, FLAGS1)
+    assert sg["half_bandwidth"] == sc["half_bandwidth"] > 128
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert len(ig) == len(ic) >= 3
+    for a, b in list(zip(ig, ic))[:4]:
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"] and a["step_is_successful"] == b["step_is_successful"]
