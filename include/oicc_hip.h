@@ -200,7 +200,11 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  *   max_num_consecutive_invalid_steps 5,
  *   gs_unit_loss 0 (1: trivial loss on GS views instead of quirk Q2),
  *   rs_time_in_seconds 0 (1: documented fix of quirk Q1),
- *   verbose 0.
+ *   verbose 0;
+ * device-side choices (no effect on the result beyond rounding):
+ *   solver_algorithm 0 (0 auto, 1 LDS-window band sweep, 2 block cyclic reduction; any geometry neither takes
+ *   goes to a global-memory band Cholesky), solver_partitions 0 (time partitions of algorithm 1; 0 = heuristic),
+ *   imu_chunk_cells 0 (knot-window cells per IMU work-list chunk; 0 = 1 on small problems, as many as fit on large ones).
  * Inner iterations (impl.h:266) are NOT reproduced (DESIGN.md deviation D1). */
 int oicc_set_option(oicc_problem* p, const char* name, double value);
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,
