@@ -154,6 +154,7 @@ struct oicc_problem {
   ImuDev d_acc, d_gyr;
   DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
   DevBuf<double> d_ws;
+  DevBuf<double> d_ne2;   // second normal-equation buffer: the Jacobian pass at the candidate runs while the host decides
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
   DevBuf<LmState> d_state;
@@ -161,7 +162,7 @@ struct oicc_problem {
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // cached layout
-  int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{};
+  int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
   Active act{};
 
   oicc_problem() {
@@ -356,12 +357,13 @@ int make_layout(oicc_problem* p, int flags) {
   const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
   ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
   const int ar = tl.a + 1;
-  if (!p->d_ne.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
+  if (!p->d_ne.resize(ne.total) || !p->d_ne2.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
       !p->d_Mc.resize(int64_t(ar) * ar) || !p->d_scale.resize(std::max(tl.P, 1)) || !p->d_diag.resize(std::max(tl.P, 1)) ||
       !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1) ||
       !p->d_ws.resize(size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))))) {
     p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   ne.base = p->d_ne.p;
+  p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   p->layout_flags = flags;
   return OICC_OK;
 }
@@ -404,12 +406,14 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
-              bool cost_already_zero = false) {
+              bool cost_already_zero = false, const NormalEq* target = nullptr) {
   hipStream_t st = p->stream;
   EvalCtx ctx = make_ctx(p, x);
+  const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
+  ctx.ne = ne;
   ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac;
-  if (jac) HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), st));
-  else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), st));
+  if (jac) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
+  else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
   const Active& a = p->act;
   if (only_kind < 0) launch_all_blocks(ctx, view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
   if (only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
@@ -417,7 +421,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   if (only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
   HIPCK(p, hipGetLastError());
   if (p->reduce) {
-    int rc = jac ? p->reduce(p->reduce_user, p->ne.base, p->ne.total, st) : p->reduce(p->reduce_user, p->ne.cost(), 1, st);
+    int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, ne.cost(), 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   }
   return OICC_OK;
@@ -766,6 +770,13 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipStreamSynchronize(st)); return OICC_OK; };
+  // read-back without draining the stream: the host waits for an event recorded right after the two copies, so that
+  // work enqueued behind it (the Jacobian pass at the candidate) runs while the host takes the accept/reject decision
+  auto read_back_begin = [&]() -> int {
+    HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCK(p, hipEventRecord(ev[5], st)); return OICC_OK; };
+  auto read_back_wait = [&]() -> int { HIPCK(p, hipEventSynchronize(ev[5])); return OICC_OK; };
   auto elapsed_s = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? double(ms) * 1e-3 : 0.0; };
 
   double t0 = now_s();
@@ -803,7 +814,15 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipEventRecord(ev[2], st));
-    rc = read_back(); if (rc) return rc;
+    rc = read_back_begin(); if (rc) return rc;
+    // Jacobian pass + gradient norm at the CANDIDATE into the second buffer, before the host knows whether the step is
+    // accepted (it is, on 4 of 4 iterations of the C2 calibration): the read-back latency hides behind it.  A rejected
+    // step simply leaves the second buffer unused.
+    HIPCK(p, hipEventRecord(ev[3], st));
+    rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
+    launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+    HIPCK(p, hipEventRecord(ev[4], st));
+    rc = read_back_wait(); if (rc) return rc;
     const LmState hs = pin->st;
     const double cand_cost = pin->cost;
     S.seconds_linear_solver += elapsed_s(ev[0], ev[1]); S.seconds_residual += elapsed_s(ev[1], ev[2]);
@@ -836,12 +855,9 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       return finish(OICC_CONVERGENCE, "Function tolerance reached.");
     }
     if (rel_dec > min_rel_dec) {
-      std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current
+      std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current ...
+      std::swap(p->ne.base, p->ne2.base);      // ... and so do its normal equations (already being computed)
       cost = cand_cost;
-      HIPCK(p, hipEventRecord(ev[3], st));
-      rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
-      launch_lm_gradmax(p->ne, P, p->d_state.p, st);
-      HIPCK(p, hipEventRecord(ev[4], st));
       gmax_pending = true;
       ++S.num_successful_steps;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
@@ -871,18 +887,25 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   oicc_problem::HostPin* pin = p->pin;
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));
+  // Same pipeline as oicc_optimize with every step accepted: the Jacobian pass of the NEXT iteration (here: at x again)
+  // is enqueued into the second buffer right behind the read-back copies, the host waits for the copies only.
+  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+  launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
   for (int it = 0; it < steps; ++it) {
-    rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
-    if (it == 0) launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
-    launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
     if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCK(p, hipStreamSynchronize(st));
+    HIPCK(p, hipEventRecord(p->ev[5], st));
+    rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
+    launch_lm_gradmax(p->ne2, tl.P, p->d_state.p, st);
+    HIPCK(p, hipEventSynchronize(p->ev[5]));
     if (pin->st.chol_failed) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
+    std::swap(p->ne.base, p->ne2.base);
   }
+  HIPCK(p, hipStreamSynchronize(st));
   return OICC_OK;
 }
 
