@@ -8,7 +8,8 @@
 //    binary of theia::Reconstruction, unreadable without TheiaSfM):
 //      {"views": {"<name>": {"orientation_angle_axis": [3] (world->camera, as
 //       theia::Camera stores it), "position": [3]}}, "tracks": {"<id>": [x,y,z,w]}}
-//  * the two PLY files and the OpenCV debug overlay (:334-454) are not produced;
+//  * the two PLY files (:334-364) are written as plain ASCII point clouds (camera centres, and board points for the
+//    input data set) -- theia::WritePlyFile [EXT] is not available; the OpenCV debug overlay (:366-454) is not produced;
 //  * --dry_run parses and cross-checks every input without touching the GPU;
 //  * --device selects the HIP device.
 #include <cstdio>
@@ -308,6 +309,36 @@ int main(int argc, char* argv[]) {
     std::ofstream f(F.str("result_output_json"));
     CHECK_MSG(f.is_open(), "cannot write " << F.str("result_output_json"));
     oicc_json::dump(out, f, 4); f << std::endl;   // std::setw(4), cc:330
+  }
+  // cc:334-364: camera centres along the spline at the image timestamps (green) and the input pose data set (red,
+  // with the board points) as PLY files in --output_path
+  if (!F.str("output_path").empty()) {
+    auto write_ply = [](const std::string& path, const std::vector<Vec3>& pts, const std::vector<std::array<int, 3>>& rgb) {
+      std::ofstream f(path);
+      if (!f.is_open()) return false;
+      f << "ply\nformat ascii 1.0\nelement vertex " << pts.size() << "\nproperty float x\nproperty float y\nproperty float z\n"
+        << "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n";
+      for (size_t i = 0; i < pts.size(); ++i)
+        f << pts[i][0] << " " << pts[i][1] << " " << pts[i][2] << " " << rgb[i][0] << " " << rgb[i][1] << " " << rgb[i][2] << "\n";
+      return true;
+    };
+    std::vector<Vec3> pts; std::vector<std::array<int, 3>> rgb;
+    const SE3 T_i_c_final = imu_cam_calibrator.trajectory_.GetT_i_c();
+    for (const View& v : recon_calib_dataset.views) {
+      const int64_t t_ns = int64_t(v.timestamp_s * S_TO_NS);
+      SE3 T_w_i;
+      if (!imu_cam_calibrator.trajectory_.GetPose(t_ns, T_w_i)) continue;
+      const Vec3 r = quat_rotate(T_w_i.q, T_i_c_final.t);       // T_w_c = T_w_i * T_i_c
+      pts.push_back(Vec3{{T_w_i.t[0] + r[0], T_w_i.t[1] + r[1], T_w_i.t[2] + r[2]}}); rgb.push_back({{0, 255, 0}});
+    }
+    CHECK_MSG(write_ply(F.str("output_path") + "/sparse_recon_spline.ply", pts, rgb), "cannot write sparse_recon_spline.ply");
+    pts.clear(); rgb.clear();
+    for (const auto& kv : recon_calib_dataset.tracks) {
+      const auto& X = kv.second;
+      pts.push_back(Vec3{{X[0] / X[3], X[1] / X[3], X[2] / X[3]}}); rgb.push_back({{255, 255, 255}});
+    }
+    for (const View& v : recon_calib_dataset.views) { pts.push_back(v.position); rgb.push_back({{255, 0, 0}}); }
+    CHECK_MSG(write_ply(F.str("output_path") + "/sparse_recon_calib_dataset.ply", pts, rgb), "cannot write sparse_recon_calib_dataset.ply");
   }
   const oicc_summary& s = imu_cam_calibrator.last_summary_;
   std::cout << "done: P=" << s.num_parameters_tangent << " blocks=" << s.num_residual_blocks << "\n";

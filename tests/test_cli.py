@@ -46,9 +46,15 @@ def test_cli_rejects_unknown_flags_and_missing_files(tmp_path):
 def test_cli_full_calibration_matches_python_mirror(tmp_path):
     ds = synthetic.make_config("C1", camera="gopro9_division")
     flags = io_files.write_dataset_files(ds, str(tmp_path))
-    r = run_cli(flags, "--known_grav_dir_axis=UNKNOWN", "--calibrate_cam_line_delay")
+    r = run_cli(flags, "--known_grav_dir_axis=UNKNOWN", "--calibrate_cam_line_delay", "--output_path=" + str(tmp_path))
     assert r.returncode == 0, r.stderr + r.stdout
     out = json.load(open(flags["result_output_json"]))
+    # the two PLY files of the reference (cc:354-364): spline camera centres, input data set (board points + cameras)
+    for name, nvert in (("sparse_recon_spline.ply", None), ("sparse_recon_calib_dataset.ply", len(ds.points) + ds.num_views)):
+        lines = open(os.path.join(str(tmp_path), name)).read().splitlines()
+        assert lines[0] == "ply" and "end_header" in lines
+        n = int([ln for ln in lines if ln.startswith("element vertex")][0].split()[-1])
+        assert n == len(lines) - lines.index("end_header") - 1 and n > 0 and (nvert is None or n == nvert)
     for k in ("q_i_c", "t_i_c", "final_reproj_error", "r3_dt", "so3_dt", "init_line_delay_us", "calib_line_delay_us", "time_offset_imu_to_cam_s", "trajectory"):
         assert k in out
     # same problem through the Python mirror (file round trip quantises timestamps to ns/us)
