@@ -269,6 +269,15 @@ def main():
                     t1 = time.perf_counter(); o = sew_oracle.knot_spacing_and_variance(sig, tt, 0.96, min_dt=0.01, max_dt=0.15); to = time.perf_counter() - t1
                     res[nm] = dict(samples=int(sig.shape[1]), device_ms=1e3 * tg, numpy_oracle_ms=1e3 * to, dt=g[0], dt_oracle=o[0])
                 out["extra_sew_prestage"] = res
+                # gyro-to-camera initialisation on the C2 telemetry (view orientations of the data set), device vs numpy oracle
+                from openimucameracalibrator_amd import rotation_init as RI
+                import rotation_init_oracle as RO
+                q_cw = ds.view_q_wc * np.array([-1.0, -1.0, -1.0, 1.0])
+                RI.estimate_camera_imu_rotation(ds.view_t_s, q_cw, ds.imu_t_s, ds.gyro, 0.005)
+                t1 = time.perf_counter(); rg = RI.estimate_camera_imu_rotation(ds.view_t_s, q_cw, ds.imu_t_s, ds.gyro, 0.005); tg = time.perf_counter() - t1
+                t1 = time.perf_counter(); ro = RO.estimate_imu_to_camera_rotation(ds.view_t_s, q_cw, ds.imu_t_s, ds.gyro, 0.005, True); to = time.perf_counter() - t1
+                out["extra_rotation_init"] = dict(imu_samples=int(len(ds.imu_t_s)), device_ms=1e3 * tg, numpy_oracle_ms=1e3 * to,
+                                                   time_offset=rg["time_offset"], time_offset_oracle=ro[1], iterations=rg["iterations"])
             except Exception as e:
                 out["extra_sew_prestage"] = {"error": str(e)[:200]}
     if use_dist:

@@ -321,6 +321,28 @@ int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_t dims, int
                                        const double* times, double quality, double min_dt, double max_dt,
                                        double* dt, double* variance, int32_t* num_evaluations);
 
+
+/* ---- Gyroscope-to-camera rotation / time-offset initialisation ------------
+ * ImuToCameraRotationEstimator::EstimateCameraImuRotation + SolveClosedForm,
+ * src/core/imu_to_camera_rotation_estimator.cc:39-274, as driven by
+ * applications/estimate_imu_to_camera_rotation.cc:150-214; it produces the file
+ * continuous_time_imu_to_camera_calibration reads with --gyro_to_cam_initial_calibration.
+ *   t_vis_s / q_vis_xyzw  camera orientation samples, strictly increasing times; the quaternion of
+ *                         theia::Camera::GetOrientationAsRotationMatrix() (world -> camera), (x,y,z,w)
+ *   t_imu_s / gyro_xyz    gyroscope samples (rad/s, a known bias already removed), strictly increasing times
+ *   dt_imu                mean IMU sample spacing [s] (estimate_imu_to_camera_rotation.cc:118-124)
+ *   estimate_gyro_bias    EnableGyroBiasEstimation(): bias = mean_vis - R mean_imu of the best probe
+ * Outputs: R_imu_to_camera as a quaternion (x,y,z,w; Eigen::Quaterniond(R)), the time offset in [-1, 1] s found by the
+ * golden-section search (tolerance 1e-4), the gyro bias (untouched unless estimated), the Huber-type alignment error
+ * of the last accepted probe and the number of search iterations.  The preparation (common window, slerp to the IMU
+ * times, quaternion-difference rates, 15-tap moving averages) runs once on the host as in the reference; every probe of
+ * the search is two reduction launches over the IMU samples on the device.  OICC_ERR_INVALID_ARG for unsorted times or
+ * fewer than 16 IMU samples in the common window. */
+int oicc_estimate_imu_to_camera_rotation(int32_t device_ordinal, int64_t n_vis, const double* t_vis_s, const double* q_vis_xyzw,
+                                         int64_t n_imu, const double* t_imu_s, const double* gyro_xyz, double dt_imu,
+                                         int32_t estimate_gyro_bias, double q_imu_to_cam_xyzw[4], double* time_offset_imu_to_cam,
+                                         double gyro_bias[3], double* alignment_error, int32_t* iterations);
+
 #ifdef __cplusplus
 }
 #endif

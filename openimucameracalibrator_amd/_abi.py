@@ -102,6 +102,8 @@ DEVICE_ONLY = {
     "time_jacobian_pass": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_dp]),
     "time_linear_solve": (C.c_int, [H, C.c_int32, C.c_int32, c_dp]),
     "run_lm_iterations": (C.c_int, [H, C.c_int32, C.c_int32]),
+    "estimate_imu_to_camera_rotation": (C.c_int, [C.c_int32, C.c_int64, c_dp, c_dp, C.c_int64, c_dp, c_dp, C.c_double, C.c_int32,
+                                                  c_dp, c_dp, c_dp, c_dp, c_i32p]),
     "rccl_get_unique_id": (C.c_int, [c_u8p]),
     "rccl_init": (C.c_int, [H, C.c_int32, C.c_int32, c_u8p]),
     "sew_knot_spacing_and_variance": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, c_dp, c_dp, C.c_double, C.c_double, C.c_double,

@@ -1,0 +1,137 @@
+"""Gyroscope-to-camera rotation / time-offset initialisation (src/core/imu_to_camera_rotation_estimator.cc).
+
+* not gpu: the numpy oracle (oracle/rotation_init_oracle.py, parity unpinned -- the reference is unbuildable here) recovers
+  planted rotations, gyro biases and time offsets from synthetic data and has the properties the algorithm implies;
+* gpu: the device path (oicc_estimate_imu_to_camera_rotation) against the oracle: rotation 1e-9, offset identical
+  (same golden-section path), bias 1e-9, error 1e-9 relative.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import rotation_init_oracle as O  # noqa: E402
+
+
+def qconj(q):
+    return q * np.array([-1.0, -1.0, -1.0, 1.0])
+
+
+def qangle(a, b):
+    return 2.0 * np.arccos(min(1.0, abs(float(a @ b))))
+
+
+def _exp_so3(phi):
+    th = np.linalg.norm(phi, axis=1, keepdims=True)
+    k = np.where(th > 1e-12, np.sin(th / 2) / np.where(th > 1e-12, th, 1.0), 0.5)
+    return np.concatenate([k * phi, np.cos(th / 2)], axis=1)
+
+
+def _qmul(a, b):
+    return O.qmul(np.atleast_2d(a), np.atleast_2d(b))
+
+
+Q_IC = np.array([-0.0060003, -0.70763572, 0.70653566, 0.00480024])      # README-like T_i_c rotation (x, y, z, w)
+
+
+def make_case(td=0.0, bias=(0.0, 0.0, 0.0), fps=30.0, duration=40.0, drop_every=0, fmin=0.2, fmax=0.8, seed=3):
+    """Hand-held rotation with six incommensurate components per axis in [fmin, fmax] Hz (the golden-section search of
+    the reference needs one dominant basin in [-1, 1] s: slower motion makes the objective flat, a few fast components make
+    it periodic): R_wi(t) = exp(phi(t)); gyro = body rate in the IMU frame (numerical derivative at
+    the IMU rate) + bias; camera orientation world -> camera = (R_wi R_ic)^T at `fps`, time stamps shifted by td."""
+    rng = np.random.default_rng(seed)
+    fr = rng.uniform(fmin, fmax, (3, 6)); ph = rng.uniform(0, 2 * np.pi, (3, 6)); am = rng.uniform(0.05, 0.25, (3, 6))
+
+    def q_wi(t):
+        phi = np.stack([np.sum(am[a] * np.sin(2 * np.pi * fr[a] * t[:, None] + ph[a]), axis=1) for a in range(3)], axis=1)
+        return _exp_so3(phi)
+    t_imu = np.arange(int(duration * 200)) / 200.0
+    h = 1e-4
+    qa, qb = q_wi(t_imu - h), q_wi(t_imu + h)
+    dq = _qmul(qconj(qa), qb)                                   # q_a^-1 q_b = exp(w_body 2h)
+    gyro = 2.0 * dq[:, :3] / (2 * h) + np.asarray(bias)
+    t_true = np.arange(int(duration * fps)) / fps
+    q_wc = _qmul(q_wi(t_true), np.tile(Q_IC, (len(t_true), 1)))
+    q_cw = qconj(q_wc)                                          # GetOrientationAsRotationMatrix(): world -> camera
+    t_vis = t_true + td
+    if drop_every:
+        keep = np.arange(len(t_vis)) % drop_every != drop_every - 1
+        t_vis, q_cw = t_vis[keep], q_cw[keep]
+    return None, t_vis, q_cw, t_imu, gyro, 1.0 / 200.0
+
+
+def test_oracle_recovers_planted_rotation_bias_and_offset():
+    ds, tv, qv, ti, gy, dt = make_case(td=0.0, bias=(0.01, -0.02, 0.015))
+    q, td, b, err, it = O.estimate_imu_to_camera_rotation(tv, qv, ti, gy, dt, True)
+    assert qangle(q, qconj(Q_IC)) < np.deg2rad(2.0)      # R_imu_to_camera = R_i_c^T
+    assert abs(td) < 0.02 and it > 10
+    # vis = R imu_true and imu_measured = imu_true + bias: the estimated offset moves by -R bias when a bias is planted
+    # (the absolute value also carries the mean error of the finite-difference visual rates)
+    _, tv0, qv0, ti0, gy0, dt0 = make_case(td=0.0)
+    q0, _, b0, _, _ = O.estimate_imu_to_camera_rotation(tv0, qv0, ti0, gy0, dt0, True)
+    R = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[2] * q[3]), 2 * (q[0] * q[2] + q[1] * q[3])],
+                  [2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[0] * q[3])],
+                  [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+    assert np.abs((b - b0) + R @ np.array([0.01, -0.02, 0.015])).max() < 2e-3
+    # without bias estimation the bias output stays zero and the rotation is still found
+    q3, _, b3, _, _ = O.estimate_imu_to_camera_rotation(tv0, qv0, ti0, gy0, dt0, False)
+    assert np.all(b3 == 0.0) and qangle(q3, qconj(Q_IC)) < np.deg2rad(2.0)
+    found = []
+    for planted in (0.12, -0.2):
+        _, tv2, qv2, ti2, gy2, dt2 = make_case(td=planted)
+        q2, td2, _, _, _ = O.estimate_imu_to_camera_rotation(tv2, qv2, ti2, gy2, dt2, True)
+        found.append(td2)
+        assert qangle(q2, qconj(Q_IC)) < np.deg2rad(2.0)
+    # view time stamps shifted by +td: the estimator reports that shift (t_cam = t_imu + offset), up to the grid of the search
+    assert abs(found[0] - 0.12) < 0.02 and abs(found[1] + 0.2) < 0.02
+
+
+def test_oracle_pieces():
+    ts = np.array([0.0, 1.0, 2.0, 4.0])
+    k, d = O.nearest(ts, np.array([-1.0, 0.4, 0.5, 0.6, 3.0, 9.0]))
+    assert k.tolist() == [0, 0, 0, 1, 2, 3] and np.allclose(d, [1.0, 0.4, 0.5, 0.4, 1.0, 5.0])      # ties go to the earlier sample
+    a = np.array([[0.0, 0.0, 0.0, 1.0]]); b = np.array([[0.0, 0.0, np.sin(0.5), np.cos(0.5)]])
+    assert np.allclose(O.slerp(a, b, np.array([0.5])), [[0.0, 0.0, np.sin(0.25), np.cos(0.25)]])
+    assert np.allclose(O.slerp(a, -b, np.array([0.5])), [[0.0, 0.0, np.sin(0.25), np.cos(0.25)]])  # shortest path
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((3, 3)); Rq, _ = np.linalg.qr(A)
+    if np.linalg.det(Rq) < 0:
+        Rq[:, 0] *= -1
+    imu = rng.standard_normal((500, 3)); vis = imu @ Rq.T + np.array([0.1, -0.2, 0.3])
+    ts = np.arange(500) * 0.005
+    err, R, bb = O.solve_closed_form(ts, vis, imu, 0.0, True)
+    assert np.abs(R - Rq).max() < 1e-12 and np.abs(bb - [0.1, -0.2, 0.3]).max() < 1e-12 and err < 1e-20
+    q = O.quat_from_rotation(Rq)
+    assert abs(np.linalg.norm(q) - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [dict(), dict(td=0.15, bias=(0.01, -0.02, 0.015)), dict(td=-0.07, drop_every=7), dict(fps=10.0, duration=20.0, fmax=1.5)])
+def test_hip_matches_oracle(case):
+    from openimucameracalibrator_amd import rotation_init as RI
+    ds, tv, qv, ti, gy, dt = make_case(**case)
+    for est_bias in (True, False):
+        q, td, b, err, it = O.estimate_imu_to_camera_rotation(tv, qv, ti, gy, dt, est_bias)
+        r = RI.estimate_camera_imu_rotation(tv, qv, ti, gy, dt, est_bias)
+        assert r["iterations"] == it and abs(r["time_offset"] - td) < 1e-12
+        assert min(np.abs(r["q_imu_to_cam"] - q).max(), np.abs(r["q_imu_to_cam"] + q).max()) < 1e-9
+        assert abs(r["error"] - err) <= 1e-9 * max(err, 1e-12)
+        if est_bias:
+            assert np.abs(r["gyro_bias"] - b).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_application_twin_and_errors():
+    from openimucameracalibrator_amd import rotation_init as RI
+    ds, tv, qv, ti, gy, dt = make_case(td=0.0, drop_every=5)
+    tel = dict(gyroscope=gy.tolist(), timestamps_ns=(ti * 1e9).round().astype(np.int64).tolist())
+    out = RI.gyro_to_camera_init_for_dataset(tel, tv, qv)
+    assert set(out) == {"gyro_bias", "gyro_to_camera_rotation", "time_offset_gyro_to_cam"}           # estimate_imu_to_camera_rotation.cc:200-207
+    q = np.array([out["gyro_to_camera_rotation"][c] for c in "xyzw"])
+    assert qangle(q, qconj(Q_IC)) < np.deg2rad(2.0) and abs(out["time_offset_gyro_to_cam"]) < 0.03
+    with pytest.raises(RuntimeError):
+        RI.estimate_camera_imu_rotation(tv[::-1].copy(), qv, ti, gy, dt)                            # unsorted times
