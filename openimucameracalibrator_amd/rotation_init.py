@@ -84,8 +84,10 @@ def main(argv=None):
     ap.add_argument("--device", default=0, type=int)
     a = ap.parse_args(argv)
     tel = json.load(open(a.telemetry_json)); ds = json.load(open(a.input_pose_calibration_dataset))
-    names = sorted(ds["views"], key=lambda k: ds["views"][k]["timestamp_s"])
-    t = [ds["views"][k]["timestamp_s"] for k in names]
+    # view time: "timestamp_s" if the twin carries it, else the view name in microseconds (the corner-file convention)
+    vt = {k: (v["timestamp_s"] if "timestamp_s" in v else int(k) * 1e-6) for k, v in ds["views"].items()}
+    names = sorted(ds["views"], key=lambda k: vt[k])
+    t = [vt[k] for k in names]
     q = []
     for k in names:                                 # world -> camera rotation of the view as a quaternion
         aa = np.asarray(ds["views"][k]["orientation_angle_axis"], float); th = np.linalg.norm(aa)
