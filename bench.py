@@ -98,16 +98,32 @@ def main():
     if native:
         # native path: the library calls ncclAllReduce (RCCL over xGMI) in place on its own stream; torch.distributed only
         # carries the 128-byte ncclUniqueId from rank 0 to the other ranks
+        # Every step is agreed on by all ranks (MIN all-reduce of a success flag), so that a rank that cannot bind RCCL or
+        # build the communicator takes every other rank to the fallback with it instead of leaving them in a collective.
+        def all_ok(ok):
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return int(f[0]) == 1
+        my_id = None
         try:
-            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                idt.copy_(torch.tensor(list(tr.RcclUniqueId()), dtype=torch.uint8))
+            my_id = tr.RcclUniqueId()          # probes the binding on every rank; only rank 0's id is used
+        except Exception as e:
+            sys.stderr.write("rank %d: native RCCL binding unavailable (%s)\n" % (rank, e))
+        native = all_ok(my_id is not None)
+        if native:
+            idt = torch.tensor(list(my_id), dtype=torch.uint8, device="cuda")
             dist.broadcast(idt, src=0)
-            tr.EnableRccl(world, rank, bytes(idt.cpu().tolist()))
+            ok = True
+            try:
+                tr.EnableRccl(world, rank, bytes(idt.cpu().tolist()))
+            except Exception as e:
+                ok = False
+                sys.stderr.write("rank %d: ncclCommInitRank through the library failed (%s)\n" % (rank, e))
+            native = all_ok(ok)
+        if native:
             reduce_path = "rccl-native"
-        except Exception as e:   # e.g. RCCL symbols not visible: fall back to the torch staging path
-            sys.stderr.write("native RCCL path unavailable (%s): falling back to torch.distributed staging\n" % e)
-            native = False
+        else:
+            sys.stderr.write("falling back to the torch.distributed staging hook\n")
             tr.SetStream(torch.cuda.current_stream().cuda_stream)
     if use_dist and not native:
         reduce_path = "torch-staging"
