@@ -361,3 +361,27 @@ def test_wide_band_falls_back_to_the_global_memory_solver():
     assert len(ig) == len(ic) >= 3
     for a, b in list(zip(ig, ic))[:4]:
         assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"] and a["step_is_successful"] == b["step_is_successful"]
+
+
+@pytest.mark.parametrize("camera", ["gopro6_double_sphere", "gopro9_eucm"])
+def test_failed_projection_gives_1e10_residual_and_zero_jacobian(camera):
+    """ceres_calib_split_residuals.h:391-393: a corner whose projection fails (here: a board point moved behind the
+    camera of a model with a validity cone) contributes the residual (1e10, 1e10) and no derivative."""
+    if camera not in synthetic.CAMERAS:
+        pytest.skip("camera preset not defined")
+    ds = synthetic.make_config("tiny", camera=camera)
+    ds.points = ds.points.copy(); ds.points[0] = [0.0, 0.0, 5.0, 1.0]          # behind the camera that looks down -z at the board
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    n = 2 * gpu.num_corners
+    rg, Jg = gpu.trajectory_.EvaluateBlocks(FLAGS1, 0, n)
+    rc, Jc = cpu.trajectory_.EvaluateBlocks(FLAGS1, 0, n)
+    bad = np.abs(rc) >= 1e10
+    assert bad.sum() >= 2 and np.array_equal(np.abs(rg) >= 1e10, bad)
+    assert np.all(rg[bad] == 1e10) and np.all(Jg[bad] == 0.0) and np.all(Jc[bad] == 0.0)
+    ok = ~bad
+    assert np.abs(rg[ok] - rc[ok]).max() <= 1e-11 * (1 + np.abs(rc[ok]).max())
+    scale = np.abs(Jc[ok]).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc[ok]).max() + 1e-30
+    assert (np.abs(Jg[ok] - Jc[ok]) / scale).max() < 1e-8
+    cg = gpu.trajectory_.EvaluateCost(FLAGS1); cc = cpu.trajectory_.EvaluateCost(FLAGS1)
+    assert abs(cg - cc) <= 1e-12 * cc and cc > 1e19
