@@ -385,3 +385,24 @@ def test_failed_projection_gives_1e10_residual_and_zero_jacobian(camera):
     assert (np.abs(Jg[ok] - Jc[ok]) / scale).max() < 1e-8
     cg = gpu.trajectory_.EvaluateCost(FLAGS1); cc = cpu.trajectory_.EvaluateCost(FLAGS1)
     assert abs(cg - cc) <= 1e-12 * cc and cc > 1e19
+
+
+def test_ragged_views_empty_view_and_views_above_64_corners():
+    """Views with 80 corners (split into two work-list chunks of 64 + 16), a view with half of its corners and a view
+    with none: normal equations and LM iterates equal the oracle's; the empty view triggers quirk Q6
+    (GetMeanReprojectionError returns 0.0, impl.h:1002-1004)."""
+    ds = synthetic.make_config("tiny", board=(10, 8), corners_per_view=80)
+    assert ds.num_corners == 80 * ds.num_views
+    keep = np.ones(ds.num_corners, dtype=bool)
+    a3, b3 = ds.corner_offset[3], ds.corner_offset[4]; keep[a3:b3] = False                 # view 3: empty
+    a5, b5 = ds.corner_offset[5], ds.corner_offset[6]; keep[a5 + 40:b5] = False            # view 5: 40 corners
+    counts = np.array([keep[ds.corner_offset[v]:ds.corner_offset[v + 1]].sum() for v in range(ds.num_views)])
+    ds.corner_uv = ds.corner_uv[keep]; ds.corner_point = ds.corner_point[keep]
+    ds.corner_offset = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1); cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    sg = gpu.trajectory_.Optimize(10, FLAGS1); sc = cpu.trajectory_.Optimize(10, FLAGS1)
+    assert sg["num_iterations"] == sc["num_iterations"] and abs(sg["final_cost"] - sc["final_cost"]) <= 1e-8 * sc["final_cost"]
+    assert gpu.trajectory_.GetMeanReprojectionError() == 0.0 == cpu.trajectory_.GetMeanReprojectionError()
