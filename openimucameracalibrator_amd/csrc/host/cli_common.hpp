@@ -1,0 +1,76 @@
+// Pieces shared by the command-line applications of this directory: gflags-style flag parsing, CHECK, and the readers
+// of the input files both applications take (telemetry JSON, JSON twin of the TheiaSfM pose data set).
+#pragma once
+#include <array>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <string>
+#include <utility>
+
+#include "estimator.hpp"
+#include "json_min.hpp"
+
+namespace oicc_cli {
+using namespace OpenICC;
+using oicc_json::Value;
+
+// gflags-style command line: --name=value, --name value, --bool / --nobool; the table gives names and defaults
+struct Flags {
+  std::map<std::string, std::string> s;
+  explicit Flags(std::map<std::string, std::string> table) : s(std::move(table)) {}
+  bool parse(int argc, char** argv) {
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a.rfind("--", 0) != 0) { std::cerr << "unexpected argument " << a << "\n"; return false; }
+      a = a.substr(2);
+      std::string k = a, v; bool has = false;
+      const size_t eq = a.find('=');
+      if (eq != std::string::npos) { k = a.substr(0, eq); v = a.substr(eq + 1); has = true; }
+      bool neg = false;
+      if (!s.count(k) && k.rfind("no", 0) == 0 && s.count(k.substr(2))) { k = k.substr(2); neg = true; }
+      if (!s.count(k)) { std::cerr << "unknown flag --" << k << "\n"; return false; }
+      const bool is_bool = s[k] == "true" || s[k] == "false";
+      if (!has) { if (is_bool) v = neg ? "false" : "true"; else if (i + 1 < argc) v = argv[++i]; else { std::cerr << "flag --" << k << " needs a value\n"; return false; } }
+      s[k] = v;
+    }
+    return true;
+  }
+  std::string str(const std::string& k) const { return s.at(k); }
+  bool b(const std::string& k) const { const std::string& v = s.at(k); return v == "true" || v == "1"; }
+  double d(const std::string& k) const { return std::stod(s.at(k)); }
+};
+
+#define CHECK_MSG(cond, msg) do { if (!(cond)) { std::cerr << "Check failed: " #cond " " << msg << std::endl; std::exit(1); } } while (0)
+
+// src/io/read_telemetry.cc:29-68
+inline bool ReadTelemetryJSON(const std::string& path, CameraTelemetryData* t) {
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  const Value& accl = j.at("accelerometer"); const Value& gyro = j.at("gyroscope"); const Value& ts = j.at("timestamps_ns");
+  if (gyro.size() != ts.size() || accl.size() != ts.size()) { std::cerr << "Telemetry should have the same amount of timestamps, accelerometer and gyroscope values.\n"; return false; }
+  for (size_t i = 0; i < ts.size(); ++i) {
+    const double t_s = ts.at(i).as_double() * NS_TO_S;
+    t->accelerometer.push_back({t_s, Vec3{{accl.at(i).at(0).as_double(), accl.at(i).at(1).as_double(), accl.at(i).at(2).as_double()}}});
+    t->gyroscope.push_back({t_s, Vec3{{gyro.at(i).at(0).as_double(), gyro.at(i).at(1).as_double(), gyro.at(i).at(2).as_double()}}});
+  }
+  if (j.contains("img_timestamps_ns")) for (size_t i = 0; i < j.at("img_timestamps_ns").size(); ++i) t->img_timestamps_s.push_back(j.at("img_timestamps_ns").at(i).as_double() * NS_TO_S);
+  return true;
+}
+// JSON twin of the TheiaSfM pose dataset
+inline bool read_pose_dataset(const std::string& path, std::map<std::string, View>* views, std::map<int, std::array<double, 4>>* tracks) {
+  if (path.size() > 10 && path.substr(path.size() - 10) == ".calibdata") {
+    std::cerr << "TheiaSfM .calibdata (cereal binary) cannot be read without TheiaSfM; export it to the JSON twin described in this file's header.\n"; return false; }
+  Value j; if (!oicc_json::parse_file(path, &j)) return false;
+  for (const auto& kv : j.at("views").obj) {
+    View v; v.name = kv.first;
+    const Value& o = kv.second;
+    if (o.contains("orientation_angle_axis")) { const Value& a = o.at("orientation_angle_axis"); v.q_wc = quat_conj(quat_from_angle_axis(Vec3{{a.at(0).as_double(), a.at(1).as_double(), a.at(2).as_double()}})); }
+    else { const Value& q = o.at("q_wc"); v.q_wc = quat_normalized(Quat{q.at("x").as_double(), q.at("y").as_double(), q.at("z").as_double(), q.at("w").as_double()}); }
+    const Value& p = o.at("position"); v.position = Vec3{{p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double()}};
+    (*views)[v.name] = v;
+  }
+  for (const auto& kv : j.at("tracks").obj) { const Value& p = kv.second; (*tracks)[std::stoi(kv.first)] = {p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double(), p.size() > 3 ? p.at(3).as_double() : 1.0}; }
+  return true;
+}
+
+}  // namespace oicc_cli

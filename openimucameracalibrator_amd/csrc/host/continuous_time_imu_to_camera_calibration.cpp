@@ -20,45 +20,14 @@
 #include <map>
 #include <string>
 
-#include "estimator.hpp"
-#include "json_min.hpp"
+#include "cli_common.hpp"
 
 using namespace OpenICC;
 using namespace OpenICC::core;
 using oicc_json::Value;
+using namespace oicc_cli;
 
 namespace {
-
-struct Flags {
-  std::map<std::string, std::string> s = {
-      {"telemetry_json", ""}, {"input_pose_dataset", ""}, {"input_corners", ""}, {"camera_calibration_json", ""},
-      {"gyro_to_cam_initial_calibration", ""}, {"imu_intrinsics", ""}, {"imu_bias_file", ""}, {"global_shutter", "false"},
-      {"spline_error_weighting_json", ""}, {"output_path", ""}, {"calibrate_cam_line_delay", "false"}, {"result_output_json", ""},
-      {"max_t", "1000."}, {"reestimate_biases", "false"}, {"gravity_const", "9.81"}, {"known_grav_dir_axis", "Z"},
-      {"debug_video_path", ""}, {"dry_run", "false"}, {"device", "0"}, {"solver_partitions", "0"}, {"solver_algorithm", "0"}};
-  bool parse(int argc, char** argv) {
-    for (int i = 1; i < argc; ++i) {
-      std::string a = argv[i];
-      if (a.rfind("--", 0) != 0) { std::cerr << "unexpected argument " << a << "\n"; return false; }
-      a = a.substr(2);
-      std::string k = a, v; bool has = false;
-      const size_t eq = a.find('=');
-      if (eq != std::string::npos) { k = a.substr(0, eq); v = a.substr(eq + 1); has = true; }
-      bool neg = false;
-      if (!s.count(k) && k.rfind("no", 0) == 0 && s.count(k.substr(2))) { k = k.substr(2); neg = true; }
-      if (!s.count(k)) { std::cerr << "unknown flag --" << k << "\n"; return false; }
-      const bool is_bool = s[k] == "true" || s[k] == "false";
-      if (!has) { if (is_bool) v = neg ? "false" : "true"; else if (i + 1 < argc) v = argv[++i]; else { std::cerr << "flag --" << k << " needs a value\n"; return false; } }
-      s[k] = v;
-    }
-    return true;
-  }
-  std::string str(const std::string& k) const { return s.at(k); }
-  bool b(const std::string& k) const { const std::string& v = s.at(k); return v == "true" || v == "1"; }
-  double d(const std::string& k) const { return std::stod(s.at(k)); }
-};
-
-#define CHECK_MSG(cond, msg) do { if (!(cond)) { std::cerr << "Check failed: " #cond " " << msg << std::endl; std::exit(1); } } while (0)
 
 int model_from_string(const std::string& s) {   // theia::StringToCameraIntrinsicsModelType
   if (s == "PINHOLE") return OICC_CAM_PINHOLE;
@@ -94,19 +63,6 @@ bool read_camera_calibration(const std::string& path, CalibDataset* cam, double*
   return true;
 }
 
-// src/io/read_telemetry.cc:29-68
-bool ReadTelemetryJSON(const std::string& path, CameraTelemetryData* t) {
-  Value j; if (!oicc_json::parse_file(path, &j)) return false;
-  const Value& accl = j.at("accelerometer"); const Value& gyro = j.at("gyroscope"); const Value& ts = j.at("timestamps_ns");
-  if (gyro.size() != ts.size() || accl.size() != ts.size()) { std::cerr << "Telemetry should have the same amount of timestamps, accelerometer and gyroscope values.\n"; return false; }
-  for (size_t i = 0; i < ts.size(); ++i) {
-    const double t_s = ts.at(i).as_double() * NS_TO_S;
-    t->accelerometer.push_back({t_s, Vec3{{accl.at(i).at(0).as_double(), accl.at(i).at(1).as_double(), accl.at(i).at(2).as_double()}}});
-    t->gyroscope.push_back({t_s, Vec3{{gyro.at(i).at(0).as_double(), gyro.at(i).at(1).as_double(), gyro.at(i).at(2).as_double()}}});
-  }
-  if (j.contains("img_timestamps_ns")) for (size_t i = 0; i < j.at("img_timestamps_ns").size(); ++i) t->img_timestamps_s.push_back(j.at("img_timestamps_ns").at(i).as_double() * NS_TO_S);
-  return true;
-}
 // src/io/read_misc.cc:30-47
 bool ReadSplineErrorWeighting(const std::string& path, SplineWeightingData* w) {
   Value j; if (!oicc_json::parse_file(path, &j)) return false;
@@ -152,30 +108,17 @@ bool read_scene(const std::string& path, Value* scene) {
   *scene = text ? oicc_json::Parser::parse(bytes) : oicc_json::UbjsonReader::parse(bytes);
   return true;
 }
-// JSON twin of the TheiaSfM pose dataset
-bool read_pose_dataset(const std::string& path, std::map<std::string, View>* views, std::map<int, std::array<double, 4>>* tracks) {
-  if (path.size() > 10 && path.substr(path.size() - 10) == ".calibdata") {
-    std::cerr << "TheiaSfM .calibdata (cereal binary) cannot be read without TheiaSfM; export it to the JSON twin described in this file's header.\n"; return false; }
-  Value j; if (!oicc_json::parse_file(path, &j)) return false;
-  for (const auto& kv : j.at("views").obj) {
-    View v; v.name = kv.first;
-    const Value& o = kv.second;
-    if (o.contains("orientation_angle_axis")) { const Value& a = o.at("orientation_angle_axis"); v.q_wc = quat_conj(quat_from_angle_axis(Vec3{{a.at(0).as_double(), a.at(1).as_double(), a.at(2).as_double()}})); }
-    else { const Value& q = o.at("q_wc"); v.q_wc = quat_normalized(Quat{q.at("x").as_double(), q.at("y").as_double(), q.at("z").as_double(), q.at("w").as_double()}); }
-    const Value& p = o.at("position"); v.position = Vec3{{p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double()}};
-    (*views)[v.name] = v;
-  }
-  for (const auto& kv : j.at("tracks").obj) { const Value& p = kv.second; (*tracks)[std::stoi(kv.first)] = {p.at(0).as_double(), p.at(1).as_double(), p.at(2).as_double(), p.size() > 3 ? p.at(3).as_double() : 1.0}; }
-  return true;
-}
-
 Value xyz(const Vec3& v) { Value o; o["x"] = Value(v[0]); o["y"] = Value(v[1]); o["z"] = Value(v[2]); return o; }
 Value xyz(const double* v) { return xyz(Vec3{{v[0], v[1], v[2]}}); }
 
 }  // namespace
 
 int main(int argc, char* argv[]) {
-  Flags F;
+  Flags F({{"telemetry_json", ""}, {"input_pose_dataset", ""}, {"input_corners", ""}, {"camera_calibration_json", ""},
+           {"gyro_to_cam_initial_calibration", ""}, {"imu_intrinsics", ""}, {"imu_bias_file", ""}, {"global_shutter", "false"},
+           {"spline_error_weighting_json", ""}, {"output_path", ""}, {"calibrate_cam_line_delay", "false"}, {"result_output_json", ""},
+           {"max_t", "1000."}, {"reestimate_biases", "false"}, {"gravity_const", "9.81"}, {"known_grav_dir_axis", "Z"},
+           {"debug_video_path", ""}, {"dry_run", "false"}, {"device", "0"}, {"solver_partitions", "0"}, {"solver_algorithm", "0"}});
   if (!F.parse(argc, argv)) return 2;
 
   // pose dataset, corners, camera (cc:93-105)

@@ -90,3 +90,37 @@ def test_cli_runs_spline_error_weighting_on_the_device(tmp_path):
     so3_dt, _ = sew_oracle.knot_spacing_and_variance(np.asarray(tel["gyroscope"]).T, t, 0.98, 0.01, 0.2)
     assert abs(out["r3_dt"] - r3_dt) < 1e-6 * r3_dt and abs(out["so3_dt"] - so3_dt) < 1e-6 * so3_dt
     assert out["final_reproj_error"] < 2.0
+
+
+ROT_CLI = os.path.join(os.path.dirname(CLI), "estimate_imu_to_camera_rotation")
+
+
+def test_rotation_cli_flag_and_file_errors(tmp_path):
+    r = subprocess.run([ROT_CLI, "--not_a_flag"], capture_output=True, text=True)
+    assert r.returncode == 2
+    r = subprocess.run([ROT_CLI, "--input_pose_calibration_dataset", str(tmp_path / "none.json")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not read Reconstruction file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rotation_cli_matches_python_twin(tmp_path):
+    """estimate_imu_to_camera_rotation (C++ CLI) and python -m openimucameracalibrator_amd.rotation_init are twins of
+    applications/estimate_imu_to_camera_rotation.cc: same output keys, same numbers on the same files."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_rotation_init import make_case, Q_IC, qconj, qangle
+    from openimucameracalibrator_amd import rotation_init as RI, io_files
+    _, tv, q_cw, ti, gy, _ = make_case(td=0.05, drop_every=6)
+    tel = dict(accelerometer=np.zeros_like(gy).tolist(), gyroscope=gy.tolist(), timestamps_ns=np.round(ti * 1e9).astype(np.int64).tolist(), img_timestamps_ns=[])
+    views = {str(int(round(t * 1e6))): dict(orientation_angle_axis=io_files.angle_axis_from_quat(q).tolist(), position=[0.0, 0.0, 0.0]) for t, q in zip(tv, q_cw)}
+    json.dump(tel, open(tmp_path / "tel.json", "w")); json.dump(dict(views=views, tracks={}), open(tmp_path / "poses.json", "w"))
+    out_c, out_p = str(tmp_path / "c.json"), str(tmp_path / "p.json")
+    r = subprocess.run([ROT_CLI, "--input_pose_calibration_dataset", str(tmp_path / "poses.json"), "--telemetry_json", str(tmp_path / "tel.json"),
+                        "--imu_rotation_init_output", out_c], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    RI.main(["--input_pose_calibration_dataset", str(tmp_path / "poses.json"), "--telemetry_json", str(tmp_path / "tel.json"), "--imu_rotation_init_output", out_p])
+    c, p = json.load(open(out_c)), json.load(open(out_p))
+    assert set(c) == set(p) == {"gyro_bias", "gyro_to_camera_rotation", "time_offset_gyro_to_cam"}
+    qc = np.array([c["gyro_to_camera_rotation"][k] for k in "xyzw"]); qp = np.array([p["gyro_to_camera_rotation"][k] for k in "xyzw"])
+    assert min(np.abs(qc - qp).max(), np.abs(qc + qp).max()) < 1e-6 and abs(c["time_offset_gyro_to_cam"] - p["time_offset_gyro_to_cam"]) < 1e-6
+    assert qangle(qc, qconj(Q_IC)) < np.deg2rad(2.0) and abs(c["time_offset_gyro_to_cam"] - 0.05) < 0.03
