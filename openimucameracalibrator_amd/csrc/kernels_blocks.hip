@@ -433,6 +433,7 @@ __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id,
   const int i_count = id.chunk_n[bid];
   const int64_t i = i_begin + lane;
   const bool valid = lane < i_count;
+  const long long ip0 = ctx.prof != nullptr ? clock64() : 0;
   double* lds_so3 = smem;
   double* lds_r3 = lds_so3 + kMaxStagedKnots * 4;
   int* coloff = reinterpret_cast<int*>(lds_r3 + kMaxStagedKnots * 3);
@@ -595,6 +596,8 @@ __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id,
     return;
   }
   __syncthreads();
+  const bool iprof = ctx.prof != nullptr && bid == (int)gridDim.x / 2;
+  const long long ip1 = iprof ? clock64() : 0;
   // phase 2/3: samples of the chunk grouped into cells with identical knot windows.  The cell
   // boundaries come from the window indices the lanes already hold (one ballot), not from a
   // scalar scan of global memory.
@@ -625,6 +628,7 @@ __device__ __forceinline__ void imu_block(const EvalCtx& ctx, const ImuData& id,
     gram_flush_cell(rows, ic.stride, int(3 * (a0 - i_begin)), int(3 * (a1 - i_begin)), ic.ncols, ic.rescol, coloff, ctx, lane);
     __syncthreads();
   }
+  if (iprof && lane == 0) { const long long ip3 = clock64(); ctx.prof[0] = ip1 - ip0; ctx.prof[1] = ip3 - ip1; }
 }
 
 // ---- kernels: standalone (timing / debugging one block type) and fused (one launch for

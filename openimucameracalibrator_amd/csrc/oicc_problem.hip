@@ -981,6 +981,19 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
 }
 
 // Debug: cycle counters of one mid-grid view block: [phase 1 (spline+residual+Jacobian rows), phase 2+3 (Gram + atomic flush)]
+// kind 0: views, 1: accelerometer, 2: gyroscope -- [evaluation phase, Gram+scatter, MFMA part, scatter part] of the middle chunk
+int oicc_debug_block_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[4]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
+  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p;
+  HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), p->stream));
+  if (kind == 0) launch_view_blocks(ctx, view_data(p), p->act.spline, true, p->stream);
+  else launch_imu_blocks(kind - 1, ctx, kind == 1 ? imu_data(p->acc, p->d_acc) : imu_data(p->gyr, p->d_gyr), p->act.spline, kind == 1 ? p->act.ab : p->act.gb, true, p->stream);
+  HIPCK(p, hipMemcpyAsync(out, d.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  return OICC_OK;
+}
 int oicc_debug_view_profile(oicc_problem* p, int32_t flags, long long out[4]) {
   int rc = prepare(p, flags); if (rc) return rc;
   DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
