@@ -77,6 +77,7 @@ struct EvalCtx {
   double* dbg_res;        // optional per-row residual dump (parity tests)
   double* dbg_jac;        // optional per-row Jacobian dump in the fixed ABI layout
   long long* prof;        // optional: per-phase cycle counters of one block (debug)
+  int prof_repeat;        // debug: > 0 runs the profiled block once more, so that the counted pass sees warm caches
 };
 
 // device-resident scalars of one LM iteration (the only per-iteration read-back)

@@ -383,7 +383,7 @@ EvalCtx make_ctx(oicc_problem* p, const double* x) {
   c.inv_so3_dt = p->inv_so3_dt; c.inv_r3_dt = p->inv_r3_dt;
   std::memcpy(c.intr, p->intr, sizeof(c.intr)); c.cam_model = p->cam_model;
   c.gs_unit_loss = p->opt["gs_unit_loss"] != 0.0; c.rs_time_in_seconds = p->opt["rs_time_in_seconds"] != 0.0;
-  c.dbg_res = nullptr; c.dbg_jac = nullptr; c.prof = nullptr;
+  c.dbg_res = nullptr; c.dbg_jac = nullptr; c.prof = nullptr; c.prof_repeat = 0;
   return c;
 }
 ViewData view_data(oicc_problem* p, bool force_rs = false) {
@@ -986,7 +986,7 @@ int oicc_debug_block_profile(oicc_problem* p, int32_t flags, int32_t kind, long 
   int rc = prepare(p, flags); if (rc) return rc;
   DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
   HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
-  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p;
+  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p; ctx.prof_repeat = kind >= 10 ? 1 : 0; kind %= 10;
   HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), p->stream));
   if (kind == 0) launch_view_blocks(ctx, view_data(p), p->act.spline, true, p->stream);
   else launch_imu_blocks(kind - 1, ctx, kind == 1 ? imu_data(p->acc, p->d_acc) : imu_data(p->gyr, p->d_gyr), p->act.spline, kind == 1 ? p->act.ab : p->act.gb, true, p->stream);
