@@ -435,11 +435,6 @@ int read_cost(oicc_problem* p, double* cost) {
 
 }  // namespace
 
-// ================================= C API =======================================
-extern "C" {
-
-const char* oicc_version(void) { return "oicc-hip-gfx950-r1"; }
-
 // ---- native RCCL binding (no link-time dependency: the RCCL of the process is found at run time) ----
 namespace {
 struct RcclApi {
@@ -472,6 +467,11 @@ int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stre
                               static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : -1;
 }
 }  // namespace
+// ================================= C API =======================================
+extern "C" {
+
+const char* oicc_version(void) { return "oicc-hip-gfx950-r1"; }
+
 int oicc_create(oicc_problem** out, int device_ordinal) {
   if (!out) return OICC_ERR_INVALID_ARG;
   *out = nullptr;
