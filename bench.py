@@ -255,6 +255,27 @@ def main():
                                        sample="first %d LM iterations of the same C2 problem (forward-mode Jet autodiff in strides of 4, "
                                               "OpenMP over residual blocks, band+arrow Cholesky): %.2f s" % (cs["num_iterations"], cdt),
                                        ms_per_lm_iteration=1e3 * cdt / max(cs["num_iterations"], 1))
+            # second CPU baseline (SURVEY 8d ii): the same CPU LM loop with the closed-form Jacobians of the device kernels
+            # compiled for the host (oracle/cpu_analytic.hpp) instead of forward-mode Jets, i.e. a CPU code without autodiff
+            best = None
+            for nth in sorted({8, 16, 32, cores}):          # the CPU assembly keeps one partial system per thread: more threads is not always faster
+                if nth > cores:
+                    continue
+                acal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+                acal.trajectory_.SetOption("analytic_jacobians", 1); acal.trajectory_.SetOption("num_threads", nth)
+                acal.trajectory_.Optimize(1, flags)            # warm-up (thread pool, page faults)
+                acal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+                acal.trajectory_.SetOption("analytic_jacobians", 1); acal.trajectory_.SetOption("num_threads", nth)
+                t1 = time.perf_counter()
+                as_ = acal.trajectory_.Optimize(iters, flags)
+                adt = time.perf_counter() - t1
+                if best is None or adt / as_["num_iterations"] < best[0] / best[1]:
+                    best = (adt, as_["num_iterations"], nth)
+            adt, ait, nth = best
+            out["cpu_baseline"]["analytic"] = dict(value=n_blocks * ait / adt, unit="blocks/s", cores=nth, kind="port",
+                                                   sample="the same %d LM iterations with analytic Jacobians (formulas of the device kernels on the host, OpenMP, "
+                                                          "best of 8/16/32/%d threads): %.3f s" % (ait, cores, adt),
+                                                   ms_per_lm_iteration=1e3 * adt / max(ait, 1))
         # ---- extra: C5-size Jacobian pass on one GPU --------------------------------
         if not args.no_extra and world == 1:
             try:

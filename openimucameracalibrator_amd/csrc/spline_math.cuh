@@ -12,25 +12,33 @@
 // after LieLocalParameterization (basalt_spline/ceres_local_param.h:84-108).
 // Derivation: SURVEY.md Appendix A / DESIGN.md section 4.
 #pragma once
+// OICC_HOST_MATH: the same formulas compiled by a host compiler -- used only by oracle/cpu_analytic.hpp (the
+// "analytic CPU path" timing baseline of SURVEY 8d and a CPU cross-check of these formulas against forward-mode Jets).
+#if defined(OICC_HOST_MATH)
+#include <cmath>
+#define OICC_DEV inline
+#define OICC_TABLE static const
+#else
 #include <hip/hip_runtime.h>
+#define OICC_DEV __device__ __forceinline__
+#define OICC_TABLE __device__ __constant__ const
+#endif
 
 namespace oicc {
-
-#define OICC_DEV __device__ __forceinline__
 
 constexpr double kSophusEps = 1e-10;  // sophus/common.hpp:94
 
 // ---- order-6 blending matrices, exact rationals /120 (spline_common.h:67-98) ----
 // coeff_i(u) = sum_k M[i][k] u^k ; evaluated like the reference: p_k = B(D,k) u^(k-D),
 // coeff = M * p  (ceres_spline_helper.h:69-87,116-122,209-211).
-__device__ __constant__ const double kM6[36] = {
+OICC_TABLE double kM6[36] = {
     1.0 / 120, -5.0 / 120, 10.0 / 120, -10.0 / 120, 5.0 / 120, -1.0 / 120,
     26.0 / 120, -50.0 / 120, 20.0 / 120, 20.0 / 120, -20.0 / 120, 5.0 / 120,
     66.0 / 120, 0.0, -60.0 / 120, 0.0, 30.0 / 120, -10.0 / 120,
     26.0 / 120, 50.0 / 120, 20.0 / 120, -20.0 / 120, -20.0 / 120, 10.0 / 120,
     1.0 / 120, 5.0 / 120, 10.0 / 120, 10.0 / 120, 5.0 / 120, -5.0 / 120,
     0.0, 0.0, 0.0, 0.0, 0.0, 1.0 / 120};
-__device__ __constant__ const double kMc6[36] = {
+OICC_TABLE double kMc6[36] = {
     1.0, 0.0, 0.0, 0.0, 0.0, 0.0,
     119.0 / 120, 5.0 / 120, -10.0 / 120, 10.0 / 120, -5.0 / 120, 1.0 / 120,
     93.0 / 120, 55.0 / 120, -30.0 / 120, -10.0 / 120, 15.0 / 120, -4.0 / 120,
@@ -38,7 +46,7 @@ __device__ __constant__ const double kMc6[36] = {
     1.0 / 120, 5.0 / 120, 10.0 / 120, 10.0 / 120, 5.0 / 120, -4.0 / 120,
     0.0, 0.0, 0.0, 0.0, 0.0, 1.0 / 120};
 // order 3 (bias splines): M3*2 = [[1,-2,1],[1,2,-2],[0,0,1]]
-__device__ __constant__ const double kM3[9] = {0.5, -1.0, 0.5, 0.5, 1.0, -1.0, 0.0, 0.0, 0.5};
+OICC_TABLE double kM3[9] = {0.5, -1.0, 0.5, 0.5, 1.0, -1.0, 0.0, 0.0, 0.5};
 
 // powers-with-derivative vector p = baseCoeffsWithTime<D>(u), N = 6.
 template <int D>

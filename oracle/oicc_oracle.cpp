@@ -10,6 +10,7 @@
 // The LM loop restates Ceres 2.1.0's TrustRegionMinimizer +
 // LevenbergMarquardtStrategy [EXT] ("parity unpinned"), without inner
 // iterations (DESIGN.md deviation D1).
+#include "cpu_analytic.hpp"
 #include "oicc_oracle_math.hpp"
 #include "../include/oicc_hip.h"
 
@@ -65,7 +66,7 @@ struct Problem {
     opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
-    opt["verbose"] = 0; opt["num_threads"] = 0;
+    opt["verbose"] = 0; opt["num_threads"] = 0; opt["analytic_jacobians"] = 0;
   }
 };
 
@@ -187,7 +188,45 @@ void so3_cols(const double* Jamb, int nres, const double* q, double* Jt, int ld,
     Jt[r * ld + c0 + c] = s; }
 }
 
+// ---- analytic CPU path (option analytic_jacobians = 1): see cpu_analytic.hpp ----------------------------------------
+static cpu_analytic::Common analytic_common(const Problem& p) {
+  cpu_analytic::Common C{};
+  C.so3 = p.so3.data(); C.r3 = p.r3.data(); C.ab = p.ab.data(); C.gb = p.gb.data();
+  C.T_i_c = p.T_i_c; C.g = p.g; C.ld = p.ld; C.ai = p.acc_intr; C.gi = p.gyr_intr; C.pts = p.pts.data();
+  C.inv_so3_dt = p.inv_so3_dt; C.inv_r3_dt = p.inv_r3_dt; C.cam_model = p.cam_model; C.intr = p.intr;
+  C.gs_unit_loss = p.opt.at("gs_unit_loss") != 0.0; C.rs_time_in_seconds = p.opt.at("rs_time_in_seconds") != 0.0;
+  return C;
+}
+static void eval_view_analytic(const Problem& p, const Layout& L, const Active& a, const ViewBlk& v, BlockEval* out) {
+  const int n = int(v.c1 - v.c0);
+  out->nres = 2 * n; out->ncols = 43; out->r.assign(2 * n, 0.0); out->J.assign(size_t(2 * n) * 43, 0.0); out->col_off.assign(43, -1);
+  const cpu_analytic::Common C = analytic_common(p);
+  cpu_analytic::view_rows(C, v.s_so3, v.s_r3, v.u_so3, v.u_r3, v.rs, n, &p.uv[2 * v.c0], &p.cov[2 * v.c0], &p.pidx[v.c0], a.spline, a.tic, v.rs && a.ld,
+                          out->r.data(), out->J.data());
+  if (a.spline) for (int i = 0; i < kN; ++i) for (int c = 0; c < 3; ++c) { out->col_off[3 * i + c] = L.so3[v.s_so3 + i] + c; out->col_off[18 + 3 * i + c] = L.r3[v.s_r3 + i] + c; }
+  if (a.tic) for (int c = 0; c < 6; ++c) out->col_off[36 + c] = L.other[0] + c;
+  if (v.rs && a.ld) out->col_off[42] = L.other[2];
+}
+static void eval_accel_analytic(const Problem& p, const Layout& L, const Active& a, const ImuBlk& b, BlockEval* out) {
+  out->nres = 3; out->ncols = 54; out->r.assign(3, 0.0); out->J.assign(3 * 54, 0.0); out->col_off.assign(54, -1);
+  const cpu_analytic::Common C = analytic_common(p);
+  cpu_analytic::imu_rows<0>(C, b.s_so3, b.s_r3, b.s_b, b.u_so3, b.u_r3, b.u_b, b.m, b.w, a.spline, a.g, a.ab, a.intr_a, out->r.data(), out->J.data());
+  if (a.spline) for (int i = 0; i < kN; ++i) for (int c = 0; c < 3; ++c) { out->col_off[3 * i + c] = L.so3[b.s_so3 + i] + c; out->col_off[18 + 3 * i + c] = L.r3[b.s_r3 + i] + c; }
+  if (a.g) for (int c = 0; c < 3; ++c) out->col_off[36 + c] = L.other[1] + c;
+  if (a.ab) for (int i = 0; i < kNb; ++i) for (int c = 0; c < 3; ++c) out->col_off[39 + 3 * i + c] = L.ab[b.s_b + i] + c;
+  if (a.intr_a) for (int c = 0; c < 6; ++c) out->col_off[48 + c] = L.other[3] + c;
+}
+static void eval_gyro_analytic(const Problem& p, const Layout& L, const Active& a, const ImuBlk& b, BlockEval* out) {
+  out->nres = 3; out->ncols = 36; out->r.assign(3, 0.0); out->J.assign(3 * 36, 0.0); out->col_off.assign(36, -1);
+  const cpu_analytic::Common C = analytic_common(p);
+  cpu_analytic::imu_rows<1>(C, b.s_so3, 0, b.s_b, b.u_so3, 0.0, b.u_b, b.m, b.w, a.spline, false, a.gb, a.intr_g, out->r.data(), out->J.data());
+  if (a.spline) for (int i = 0; i < kN; ++i) for (int c = 0; c < 3; ++c) out->col_off[3 * i + c] = L.so3[b.s_so3 + i] + c;
+  if (a.gb) for (int i = 0; i < kNb; ++i) for (int c = 0; c < 3; ++c) out->col_off[18 + 3 * i + c] = L.gb[b.s_b + i] + c;
+  if (a.intr_g) for (int c = 0; c < 9; ++c) out->col_off[27 + c] = L.other[4] + c;
+}
+
 void eval_view(const Problem& p, const Layout& L, const Active& a, const ViewBlk& v, bool want_jac, BlockEval* out) {
+  if (want_jac && p.opt.at("analytic_jacobians") != 0.0) { eval_view_analytic(p, L, a, v, out); return; }
   const int n = int(v.c1 - v.c0);
   ReprojFunctor f;
   f.rolling_shutter = v.rs; f.n = n; f.obs = &p.uv[2 * v.c0]; f.cov = &p.cov[2 * v.c0];
@@ -224,6 +263,7 @@ void eval_view(const Problem& p, const Layout& L, const Active& a, const ViewBlk
 }
 
 void eval_accel(const Problem& p, const Layout& L, const Active& a, const ImuBlk& b, bool want_jac, BlockEval* out) {
+  if (want_jac && p.opt.at("analytic_jacobians") != 0.0) { eval_accel_analytic(p, L, a, b, out); return; }
   AccelFunctor f;
   for (int i = 0; i < 3; ++i) f.meas[i] = b.m[i];
   f.u_r3 = b.u_r3; f.inv_r3_dt = p.inv_r3_dt; f.u_so3 = b.u_so3; f.inv_so3_dt = p.inv_so3_dt;
@@ -254,6 +294,7 @@ void eval_accel(const Problem& p, const Layout& L, const Active& a, const ImuBlk
 }
 
 void eval_gyro(const Problem& p, const Layout& L, const Active& a, const ImuBlk& b, bool want_jac, BlockEval* out) {
+  if (want_jac && p.opt.at("analytic_jacobians") != 0.0) { eval_gyro_analytic(p, L, a, b, out); return; }
   GyroFunctor f;
   for (int i = 0; i < 3; ++i) f.meas[i] = b.m[i];
   f.u_so3 = b.u_so3; f.inv_so3_dt = p.inv_so3_dt; f.inv_std = b.w; f.u_bias = b.u_b; f.inv_bias_dt = p.inv_gb_dt;

@@ -88,3 +88,26 @@ def test_recovers_planted_calibration_on_a_longer_sequence():
     assert ang < np.deg2rad(1.0), np.rad2deg(ang)
     assert np.abs(cal.trajectory_.GetGravity() - ds.truth["gravity"]).max() < 0.2
     assert cal.trajectory_.GetMeanReprojectionError() < 1.0
+
+
+@pytest.mark.parametrize("flags", [E.SPLINE | E.T_I_C | E.GRAVITY_DIR, E.SPLINE | E.T_I_C | E.GRAVITY_DIR | E.IMU_BIASES | E.IMU_INTRINSICS | E.CAM_LINE_DELAY,
+                                   E.CAM_LINE_DELAY])
+@pytest.mark.parametrize("camera", ["gopro9_division", "gopro6_fisheye", "gopro6_double_sphere"])
+def test_analytic_cpu_path_equals_forward_mode_jets(flags, camera):
+    """oracle option analytic_jacobians: the closed-form Jacobians of the device kernels (spline_math.cuh compiled for the
+    host + the chain rules of kernels_blocks.hip, oracle/cpu_analytic.hpp) against forward-mode Jets, on the CPU: normal
+    equations, per-block Jacobians, and the LM iterate sequence."""
+    ds = synthetic.make_config("tiny", camera=camera)
+    jets = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    ana = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    ana.trajectory_.SetOption("analytic_jacobians", 1)
+    cj, Hj, gj = jets.trajectory_.Evaluate(flags); ca, Ha, ga = ana.trajectory_.Evaluate(flags)
+    assert abs(cj - ca) <= 1e-12 * cj
+    assert np.abs(Ha - Hj).max() <= 1e-9 * np.abs(Hj).max() and np.abs(ga - gj).max() <= 1e-9 * np.abs(gj).max()
+    for kind, n in ((0, 2 * jets.num_corners), (1, 3 * int(jets.accl_accepted.sum())), (2, 3 * int(jets.gyro_accepted.sum()))):
+        rj, Jj = jets.trajectory_.EvaluateBlocks(flags, kind, n); ra, Ja = ana.trajectory_.EvaluateBlocks(flags, kind, n)
+        assert np.abs(ra - rj).max() <= 1e-11 * (1 + np.abs(rj).max())
+        scale = np.abs(Jj).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jj).max() + 1e-30
+        assert (np.abs(Ja - Jj) / scale).max() < 1e-8
+    sj = jets.trajectory_.Optimize(10, flags); sa = ana.trajectory_.Optimize(10, flags)
+    assert sj["num_iterations"] == sa["num_iterations"] and abs(sj["final_cost"] - sa["final_cost"]) <= 1e-8 * sj["final_cost"]
