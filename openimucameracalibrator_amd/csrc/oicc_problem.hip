@@ -144,6 +144,7 @@ struct oicc_problem {
   std::vector<oicc_iteration> trace;
   oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
   void* rccl_comm = nullptr;   // ncclComm_t of oicc_rccl_init
+  int rccl_nranks = 1;
   // device
   DevBuf<double> d_x, d_xc, d_pts;
   DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
@@ -531,7 +532,7 @@ int oicc_rccl_init(oicc_problem* p, int32_t nranks, int32_t rank, const uint8_t 
   ncclUniqueId u; std::memcpy(&u, id, 128);
   ncclComm_t comm = nullptr;
   if (api.CommInitRank(&comm, nranks, u, rank) != ncclSuccess) { p->err = "ncclCommInitRank failed"; return OICC_ERR_HIP; }
-  p->rccl_comm = comm;
+  p->rccl_comm = comm; p->rccl_nranks = nranks;
   p->reduce = rccl_reduce_in_place; p->reduce_user = p;
   return OICC_OK;
 }
@@ -814,6 +815,12 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipEventRecord(ev[2], st));
+    // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave
+    // last-bit differences in the model cost change and the step norms.  Summing the three scalars over the ranks and
+    // dividing by their number gives every rank bit-identical inputs to the accept / reject / terminate decisions, so
+    // the ranks can never take different branches (and then wait in different collectives).
+    const bool rank_consistent = p->rccl_comm != nullptr && p->rccl_nranks > 1;
+    if (rank_consistent && rccl_reduce_in_place(p, &p->d_state.p->model_cost_change, 3, st) != 0) { p->err = "all-reduce of the step state failed"; return OICC_ERR_STATE; }
     rc = read_back_begin(); if (rc) return rc;
     // Jacobian pass + gradient norm at the CANDIDATE into the second buffer, before the host knows whether the step is
     // accepted (it is, on 4 of 4 iterations of the C2 calibration): the read-back latency hides behind it.  A rejected
@@ -823,7 +830,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
     HIPCK(p, hipEventRecord(ev[4], st));
     rc = read_back_wait(); if (rc) return rc;
-    const LmState hs = pin->st;
+    LmState hs = pin->st;
+    if (rank_consistent) { const double inv = 1.0 / double(p->rccl_nranks); hs.model_cost_change *= inv; hs.step_norm_sq *= inv; hs.x_norm_sq *= inv; }
     const double cand_cost = pin->cost;
     S.seconds_linear_solver += elapsed_s(ev[0], ev[1]); S.seconds_residual += elapsed_s(ev[1], ev[2]);
     if (gmax_pending) {   // gradient of the point accepted in the previous iteration
