@@ -343,6 +343,49 @@ int oicc_estimate_imu_to_camera_rotation(int32_t device_ordinal, int64_t n_vis, 
                                          int32_t estimate_gyro_bias, double q_imu_to_cam_xyzw[4], double* time_offset_imu_to_cam,
                                          double gyro_bias[3], double* alignment_error, int32_t* iterations);
 
+/* ---- View bundle adjustment: camera intrinsics calibration and per-view pose refinement ------
+ * What the reference does through TheiaSfM's bundle adjuster [EXT] in
+ *   CameraCalibrator::RunCalibration      src/core/camera_calibrator.cc:131-219  (theia::BundleAdjustViews, three stages)
+ *   PoseEstimator::EstimatePosePinhole    src/core/pose_estimator.cc:62-90       (theia::BundleAdjustView)
+ *   PoseEstimator::OptimizeAllPoses       src/core/pose_estimator.cc:226-236     (theia::BundleAdjustView for every view)
+ *   utils::GetReprojErrorOfView           src/utils/utils.cc:163-177
+ * One residual block per observation: r = CameraToPixelCoordinates(intr, R(w)(X.xyz - X.w C)) - feature, camera
+ * extrinsics [position C | angle axis w] updated by plain addition (no local parameterisation, as Theia), one shared
+ * intrinsics block with constant entries held by a subset mask, scene points constant, ceres::HuberLoss(huber_width)
+ * per block.  Tangent order of oicc_ba_evaluate: for every view [position 3 if active | angle axis 3 if active], then the
+ * active intrinsics in ascending parameter index.  Jacobians are analytic and the normal equations (block diagonal +
+ * intrinsics arrow) are assembled and solved on the device by the kernels of the spline path.
+ * Options (oicc_ba_set_option): the trust-region options of oicc_set_option with Theia's defaults (function_tolerance
+ * 1e-6, parameter_tolerance 1e-8, gradient_tolerance 1e-10, max_trust_region_radius 1e12), huber_width (1.345 as both
+ * reference call sites set it; <= 0: trivial loss). */
+typedef struct oicc_ba oicc_ba;
+enum { OICC_BA_POSITION = 1, OICC_BA_ORIENTATION = 2 };   /* !constant_camera_position / !constant_camera_orientation */
+int oicc_ba_create(oicc_ba** out, int32_t device_ordinal);
+void oicc_ba_destroy(oicc_ba* p);
+const char* oicc_ba_last_error(const oicc_ba* p);
+int oicc_ba_set_option(oicc_ba* p, const char* name, double value);
+/* model / parameter order as oicc_set_camera (theia::Camera intrinsics of the shared group) */
+int oicc_ba_set_camera(oicc_ba* p, int32_t model, const double* intrinsics, int32_t n);
+int oicc_ba_get_camera(const oicc_ba* p, double* intrinsics, int32_t n);
+int oicc_ba_set_scene_points(oicc_ba* p, const double* xyzw, int64_t n);
+/* views: pose6 [nv][6] = theia::Camera position and angle axis (world -> camera); the observations of view v are
+ * uv / point_ids [corner_offsets[v], corner_offsets[v+1]).  Replaces all views (the reference's RemoveView = resend). */
+int oicc_ba_set_views(oicc_ba* p, int64_t nv, const double* pose6, const int64_t* corner_offsets, const double* uv,
+                      const int32_t* point_ids);
+int oicc_ba_set_poses(oicc_ba* p, const double* pose6, int64_t nv);
+int oicc_ba_get_poses(const oicc_ba* p, double* pose6, int64_t nv);
+/* cost (with the loss), dense J^T J [P][Pcap] and J^T r of the robustified problem at the current parameters */
+int oicc_ba_evaluate(oicc_ba* p, int32_t flags, int32_t intrinsics_mask, double* cost, double* H, double* g, int32_t Pcap);
+/* theia::BundleAdjustViews over all views: flags = OICC_BA_*, intrinsics_mask bit k = intrinsics parameter k variable
+ * (theia's GetSubsetFromOptimizeIntrinsicsType, resolved by the host mirror per camera model). */
+int oicc_ba_optimize(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t intrinsics_mask, oicc_summary* summary);
+int oicc_ba_get_iterations(const oicc_ba* p, oicc_iteration* out, int32_t cap);
+/* theia::BundleAdjustView for EVERY view independently (intrinsics constant): one kernel launch, one wavefront per
+ * view runs that view's whole Levenberg-Marquardt loop.  iterations / final_cost: [nv] or NULL. */
+int oicc_ba_optimize_views(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t* iterations, double* final_cost);
+/* GetReprojErrorOfView for every view: mean pixel distance of its observations, [nv] */
+int oicc_ba_view_reprojection_errors(oicc_ba* p, double* mean_px);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,41 @@ DEVICE_ONLY = {
 }
 
 
+HB = C.c_void_p  # oicc_ba*
+
+# View bundle adjustment (oicc_ba_* in include/oicc_hip.h): name -> (restype, argtypes)
+BA_SIGNATURES = {
+    "create": (C.c_int, [C.POINTER(HB), C.c_int32]),
+    "destroy": (None, [HB]),
+    "last_error": (C.c_char_p, [HB]),
+    "set_option": (C.c_int, [HB, C.c_char_p, C.c_double]),
+    "set_camera": (C.c_int, [HB, C.c_int32, c_dp, C.c_int32]),
+    "get_camera": (C.c_int, [HB, c_dp, C.c_int32]),
+    "set_scene_points": (C.c_int, [HB, c_dp, C.c_int64]),
+    "set_views": (C.c_int, [HB, C.c_int64, c_dp, c_i64p, c_dp, c_i32p]),
+    "set_poses": (C.c_int, [HB, c_dp, C.c_int64]),
+    "get_poses": (C.c_int, [HB, c_dp, C.c_int64]),
+    "evaluate": (C.c_int, [HB, C.c_int32, C.c_int32, c_dp, c_dp, c_dp, C.c_int32]),
+    "optimize": (C.c_int, [HB, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Summary)]),
+    "get_iterations": (C.c_int, [HB, C.POINTER(Iteration), C.c_int32]),
+    "optimize_views": (C.c_int, [HB, C.c_int32, C.c_int32, c_i32p, c_dp]),
+    "view_reprojection_errors": (C.c_int, [HB, c_dp]),
+}
+
+
+class BoundBa:
+    """Bound oicc_ba_* entry points of one library + prefix (``oicc_ba_`` for liboicc_hip.so)."""
+
+    def __init__(self, lib, prefix):
+        self.lib = lib
+        self.prefix = prefix
+        for name, (res, args) in BA_SIGNATURES.items():
+            fn = getattr(lib, prefix + name)  # AttributeError = missing symbol: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
 class Bound:
     """Namespace of bound entry points for one library + prefix."""
 

@@ -7,11 +7,12 @@ fails when no HIP device is usable.
 import ctypes
 import os
 
-from ._abi import Bound
+from ._abi import Bound, BoundBa
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboicc_hip.so")
 _bound = None
+_bound_ba = None
 
 
 def load():
@@ -24,3 +25,11 @@ def load():
         lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         _bound = Bound(lib, "oicc_", device=True)
     return _bound
+
+
+def load_ba():
+    """oicc_ba_* entry points (view bundle adjustment) of the same library."""
+    global _bound_ba
+    if _bound_ba is None:
+        _bound_ba = BoundBa(load().lib, "oicc_ba_")
+    return _bound_ba

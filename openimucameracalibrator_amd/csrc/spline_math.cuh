@@ -290,20 +290,26 @@ OICC_DEV void so3_Jr_inv_c(const double phi[3], double c, double J[9]) {
   J[6] = -0.5 * y + c * x * z;      J[7] = 0.5 * x + c * y * z;       J[8] = 1.0 - c * (x * x + y * y);
 }
 
-template <bool WANT_VAL, bool WANT_VEL, bool WANT_JAC, bool WANT_JVEL, class KnotAcc>
-OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out& o) {
-  double p[6], k[6], dk[6];
-  base_coeffs6<0>(u, p);
-  matvec6(kMc6, p, 1.0, k);
-  if (WANT_VEL || WANT_JVEL) {
-    base_coeffs6<1>(u, p);
-    matvec6(kMc6, p, inv_dt, dk);
-  }
-  constexpr bool JAC = WANT_JAC || WANT_JVEL;
+// Forward pass of the cumulative spline: value, body rate, and (KEEP) everything the backward passes need.
+struct So3Fwd {
+  Quat R; double w[3];
+  double k[6], dk[6];
   double delta[5][3];
   double wpre[5][3];   // omega_{m-1}: angular velocity accumulated BEFORE segment m
   double cinv[5];      // coefficient of Jr^-1(delta_i), from the half-angle of R_i^-1 R_{i+1}
   double sh[5], ch[5]; // sin/cos of |k delta_i| / 2 (shared by exp, Rodrigues and Jr)
+};
+template <bool WANT_VAL, bool WANT_VEL, bool JAC, class KnotAcc>
+OICC_DEV void so3_spline_forward(const KnotAcc& K, double u, double inv_dt, So3Fwd& F) {
+  double p[6];
+  double (&k)[6] = F.k; double (&dk)[6] = F.dk;
+  base_coeffs6<0>(u, p);
+  matvec6(kMc6, p, 1.0, k);
+  if (WANT_VEL) {
+    base_coeffs6<1>(u, p);
+    matvec6(kMc6, p, inv_dt, dk);
+  }
+  double (&delta)[5][3] = F.delta; double (&wpre)[5][3] = F.wpre; double (&cinv)[5] = F.cinv; double (&sh)[5] = F.sh; double (&ch)[5] = F.ch;
   Quat acc = K(0);
   double wv[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -351,7 +357,7 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
       e = Quat{imag * kd[0], imag * kd[1], imag * kd[2], real};
     }
     if (WANT_VAL) acc = so3_mul(acc, e);
-    if (WANT_VEL || WANT_JVEL) {
+    if (WANT_VEL) {
       wpre[i][0] = wv[0]; wpre[i][1] = wv[1]; wpre[i][2] = wv[2];
       double A[9];
       so3_matrix(so3_inverse(e), A);  // Adj(exp(k d)^-1)
@@ -362,8 +368,20 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
       wv[2] = nv[2] + delta[i][2] * dk[i + 1];
     }
   }
-  if (WANT_VAL) o.R = acc;
-  if (WANT_VEL) { o.w[0] = wv[0]; o.w[1] = wv[1]; o.w[2] = wv[2]; }
+  if (WANT_VAL) F.R = acc;
+  if (WANT_VEL) { F.w[0] = wv[0]; F.w[1] = wv[1]; F.w[2] = wv[2]; }
+}
+
+template <bool WANT_VAL, bool WANT_VEL, bool WANT_JAC, bool WANT_JVEL, class KnotAcc>
+OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out& o) {
+  constexpr bool JAC = WANT_JAC || WANT_JVEL;
+  So3Fwd F;
+  so3_spline_forward<WANT_VAL, (WANT_VEL || WANT_JVEL), JAC>(K, u, inv_dt, F);
+  if (WANT_VAL) o.R = F.R;
+  if (WANT_VEL) { o.w[0] = F.w[0]; o.w[1] = F.w[1]; o.w[2] = F.w[2]; }
+  const double (&k)[6] = F.k; const double (&dk)[6] = F.dk;
+  const double (&delta)[5][3] = F.delta; const double (&wpre)[5][3] = F.wpre; const double (&cinv)[5] = F.cinv; const double (&sh)[5] = F.sh; const double (&ch)[5] = F.ch;
+  (void)dk; (void)wpre;
   if (!JAC) return;
 
   // Backward pass.  P_i = A_{i+1}...A_4 (P_4 = I), A_i = exp(k_{i+1} delta_i).
@@ -427,6 +445,45 @@ OICC_DEV void so3_spline_eval(const KnotAcc& K, double u, double inv_dt, So3Out&
 #pragma unroll
     for (int e = 0; e < 9; ++e) o.JW[0][e] = -Zw[e];
   }
+}
+
+// Backward pass for a caller that needs L * dR/deps_j (ROWS x 3 per knot) rather than the six 3x3 matrices themselves
+// (reprojection: L = S Jpi R_ic^T [q]x, 2 x 3; accelerometer: L = w [R^T(a+g)]x, 3 x 3).  N_i = L P_i^T is carried
+// instead of P_i, so every product is (ROWS x 3)(3 x 3) and the six 3x3 Jacobians are never materialised (108 registers):
+//   rows_{i+1} = N_i k Jr(k d_i) Jr^-1(d_i) - [same for i+1] Jl^-1,   rows_0 = L (A_0...A_4)^T - N_0 k Jr Jl^-1.
+template <int ROWS>
+OICC_DEV void so3_spline_backward_rows(const So3Fwd& F, const double* L, double (&rows)[6][ROWS * 3]) {
+  double N[ROWS * 3], Zr[ROWS * 3];
+#pragma unroll
+  for (int e = 0; e < ROWS * 3; ++e) { N[e] = L[e]; Zr[e] = 0.0; }
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    const double kd[3] = {F.delta[i][0] * F.k[i + 1], F.delta[i][1] * F.k[i + 1], F.delta[i][2] * F.k[i + 1]};
+    double Jr[9], Jri[9], A[9];
+    rodrigues_and_Jr(kd, kd[0] * kd[0] + kd[1] * kd[1] + kd[2] * kd[2], F.sh[i], F.ch[i], A, Jr);
+    so3_Jr_inv_c(F.delta[i], F.cinv[i], Jri);
+    double G[ROWS * 3], Nn[ROWS * 3];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        G[r * 3 + c] = F.k[i + 1] * (N[r * 3] * Jr[c] + N[r * 3 + 1] * Jr[3 + c] + N[r * 3 + 2] * Jr[6 + c]);           // N k Jr
+        Nn[r * 3 + c] = N[r * 3] * A[c * 3] + N[r * 3 + 1] * A[c * 3 + 1] + N[r * 3 + 2] * A[c * 3 + 2];               // N A^T
+      }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double x = G[r * 3] * Jri[c] + G[r * 3 + 1] * Jri[3 + c] + G[r * 3 + 2] * Jri[6 + c];                      // G Jr^-1
+        const double z = G[r * 3] * Jri[c * 3] + G[r * 3 + 1] * Jri[c * 3 + 1] + G[r * 3 + 2] * Jri[c * 3 + 2];          // G Jr^-T
+        rows[i + 1][r * 3 + c] = x - Zr[r * 3 + c];
+        Zr[r * 3 + c] = z;
+      }
+#pragma unroll
+    for (int e = 0; e < ROWS * 3; ++e) N[e] = Nn[e];
+  }
+#pragma unroll
+  for (int e = 0; e < ROWS * 3; ++e) rows[0][e] = N[e] - Zr[e];
 }
 
 // -----------------------------------------------------------------------------

@@ -1,0 +1,344 @@
+// ORACLE (test infrastructure, never the product path) -- CPU restatement of the view bundle adjustment the
+// reference runs through TheiaSfM [EXT, pyTheiaSfM 69c3d37, not vendored in /root/reference]:
+//   src/core/camera_calibrator.cc:131-219  (RunCalibration: three BundleAdjustViews stages, Huber 1.345)
+//   src/core/pose_estimator.cc:62-90,226-236 (BundleAdjustView per view, intrinsics constant)
+//   src/utils/utils.cc:163-177              (GetReprojErrorOfView: mean pixel distance of a view)
+// Restated from the published algorithm of theia::BundleAdjuster / theia::ReprojectionError [EXT] and of Ceres 2.1
+// [EXT] (forward-mode Jets, HuberLoss + Corrector, Levenberg-Marquardt trust region, Jacobi scaling):
+//   residual block (one per observation) = CameraToPixelCoordinates(intr, AngleAxisRotatePoint(w, X.xyz - X.w C)) - feature
+//   parameter blocks: camera extrinsics [C | w] (6, plain addition), shared intrinsics (SubsetParameterization for the
+//   constant entries), points constant (BundleAdjustViews adds tracks as constant blocks).
+// PARITY UNPINNED: neither Theia nor Ceres can be built here and the reference holds no golden vectors for this path;
+// the restatement is checked against closed-form cases and against synthetic ground truth only.
+//
+// Exports the C-ABI of include/oicc_hip.h's oicc_ba_* entry points under the prefix oicc_oracle_ba_.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../include/oicc_hip.h"
+#include "oicc_oracle_math.hpp"
+#define OICC_HOST_MATH 1
+#include "../openimucameracalibrator_amd/csrc/ba_math.cuh"   // product formulas, only for the *_analytic_rows cross-check hook
+
+using namespace oicc_oracle;
+
+namespace {
+
+constexpr int kMaxIntr = 10;
+
+struct Ba {
+  std::string err;
+  int model = 0, n_intr = 0; double intr[kMaxIntr] = {0};
+  std::vector<double> pts;                 // [np][4]
+  std::vector<double> pose;                // [nv][6]  position, angle axis
+  std::vector<int64_t> c0{0};              // [nv+1]
+  std::vector<double> uv; std::vector<int32_t> pid;
+  std::map<std::string, double> opt;
+  std::vector<oicc_iteration> trace;
+  Ba() {
+    // theia::BundleAdjustmentOptions defaults [EXT] + Ceres 2.1 defaults [EXT] for what Theia leaves alone
+    opt["function_tolerance"] = 1e-6; opt["parameter_tolerance"] = 1e-8; opt["gradient_tolerance"] = 1e-10;
+    opt["initial_trust_region_radius"] = 1e4; opt["max_trust_region_radius"] = 1e12;
+    opt["min_trust_region_radius"] = 1e-32; opt["min_relative_decrease"] = 1e-3;
+    opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
+    opt["max_num_consecutive_invalid_steps"] = 5; opt["huber_width"] = 1.345; opt["verbose"] = 0;
+    opt["solver_algorithm"] = 0; opt["num_threads"] = 0;
+  }
+  int64_t nv() const { return int64_t(pose.size() / 6); }
+};
+
+// ceres::AngleAxisRotatePoint [EXT, ceres/rotation.h]
+template <class T>
+void angle_axis_rotate_point(const T w[3], const T pt[3], T out[3]) {
+  const T theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (theta2 > std::numeric_limits<double>::epsilon()) {
+    const T theta = sqrt(theta2);
+    const T costheta = cos(theta), sintheta = sin(theta);
+    const T theta_inverse = T(1.0) / theta;
+    const T ax[3] = {w[0] * theta_inverse, w[1] * theta_inverse, w[2] * theta_inverse};
+    const T cross[3] = {ax[1] * pt[2] - ax[2] * pt[1], ax[2] * pt[0] - ax[0] * pt[2], ax[0] * pt[1] - ax[1] * pt[0]};
+    const T tmp = (ax[0] * pt[0] + ax[1] * pt[1] + ax[2] * pt[2]) * (T(1.0) - costheta);
+    for (int i = 0; i < 3; ++i) out[i] = pt[i] * costheta + cross[i] * sintheta + ax[i] * tmp;
+  } else {
+    const T cross[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+    for (int i = 0; i < 3; ++i) out[i] = pt[i] + cross[i];
+  }
+}
+
+// theia::ReprojectionError::operator() [EXT]; identity feature covariance (camera_calibrator.cc:80-84 adds plain points)
+template <class T>
+bool reprojection_error(int model, const T* ext, const T* intr, const T* X, const double* feat, T* res) {
+  T adj[3];
+  for (int i = 0; i < 3; ++i) adj[i] = X[i] - X[3] * ext[i];
+  if (value_of(adj[0] * adj[0] + adj[1] * adj[1] + adj[2] * adj[2]) < 1e-8) return false;
+  T rot[3];
+  angle_axis_rotate_point(ext + 3, adj, rot);
+  T px[2];
+  if (!camera_to_pixel<T>(model, intr, rot, px)) return false;
+  res[0] = px[0] - feat[0]; res[1] = px[1] - feat[1];
+  return true;
+}
+
+struct Layout { int pose_dim, Pb, a, P; int pose_off[2]; int intr_off[kMaxIntr]; };
+Layout make_layout(const Ba& b, int flags, int mask) {
+  Layout L{};
+  L.pose_off[0] = L.pose_off[1] = -1;
+  int d = 0;
+  if (flags & OICC_BA_POSITION) { L.pose_off[0] = d; d += 3; }
+  if (flags & OICC_BA_ORIENTATION) { L.pose_off[1] = d; d += 3; }
+  L.pose_dim = d; L.Pb = int(b.nv()) * d;
+  int a = 0;
+  for (int k = 0; k < kMaxIntr; ++k) L.intr_off[k] = (k < b.n_intr && (mask >> k & 1)) ? L.Pb + a++ : -1;
+  L.a = a; L.P = L.Pb + a;
+  return L;
+}
+
+// ceres::HuberLoss + Corrector [EXT]: rho'' <= 0 everywhere -> rows and residual scaled by sqrt(rho')
+void huber_eval(double a, double s, double* rho, double* srho1) {
+  const double b = a * a;
+  if (a <= 0.0 || s <= b) { *rho = s; *srho1 = 1.0; return; }
+  const double r = std::sqrt(s);
+  *rho = 2.0 * a * r - b;
+  *srho1 = std::sqrt(std::max(std::numeric_limits<double>::min(), a / r));
+}
+
+// residual + Jacobian of one observation in the block's own columns [pose 6 | intr n | point 4]
+constexpr int NJ = 6 + kMaxIntr + 4;
+bool eval_obs(const Ba& b, int64_t v, int64_t c, double r[2], double* J /*2 x NJ or null*/) {
+  const double* ext = &b.pose[6 * v]; const double* X = &b.pts[4 * (int64_t)b.pid[c]]; const double* f = &b.uv[2 * c];
+  if (!J) { return reprojection_error<double>(b.model, ext, b.intr, X, f, r); }
+  typedef Jet<NJ> JT;
+  JT e[6], in[kMaxIntr], x[4], res[2];
+  for (int i = 0; i < 6; ++i) { e[i] = JT(ext[i]); e[i].v[i] = 1.0; }
+  for (int i = 0; i < kMaxIntr; ++i) { in[i] = JT(i < b.n_intr ? b.intr[i] : 0.0); in[i].v[6 + i] = 1.0; }
+  for (int i = 0; i < 4; ++i) { x[i] = JT(X[i]); x[i].v[6 + kMaxIntr + i] = 1.0; }
+  if (!reprojection_error<JT>(b.model, e, in, x, f, res)) return false;
+  for (int k = 0; k < 2; ++k) { r[k] = res[k].a; for (int j = 0; j < NJ; ++j) J[k * NJ + j] = res[k].v[j]; }
+  return true;
+}
+
+struct Dense { int P = 0; std::vector<double> H, g; double cost = 0; bool ok = true; };
+void build(const Ba& b, const Layout& L, int64_t v0, int64_t v1, Dense* ne) {
+  ne->P = L.P; ne->H.assign(size_t(L.P) * L.P, 0.0); ne->g.assign(L.P, 0.0); ne->cost = 0; ne->ok = true;
+  const double hw = b.opt.at("huber_width");
+  for (int64_t v = v0; v < v1; ++v)
+    for (int64_t c = b.c0[v]; c < b.c0[v + 1]; ++c) {
+      double r[2], J[2 * NJ];
+      if (!eval_obs(b, v, c, r, J)) { ne->ok = false; continue; }
+      double rho, s1; huber_eval(hw, r[0] * r[0] + r[1] * r[1], &rho, &s1);
+      ne->cost += 0.5 * rho;
+      int col[16]; double jr[2][16]; int n = 0;
+      for (int g = 0; g < 2; ++g) if (L.pose_off[g] >= 0) for (int k = 0; k < 3; ++k) {
+        col[n] = int(v - v0) * L.pose_dim + L.pose_off[g] + k; jr[0][n] = s1 * J[3 * g + k]; jr[1][n] = s1 * J[NJ + 3 * g + k]; ++n; }
+      for (int k = 0; k < b.n_intr; ++k) if (L.intr_off[k] >= 0) { col[n] = L.intr_off[k]; jr[0][n] = s1 * J[6 + k]; jr[1][n] = s1 * J[NJ + 6 + k]; ++n; }
+      for (int i = 0; i < n; ++i) {
+        ne->g[col[i]] += jr[0][i] * s1 * r[0] + jr[1][i] * s1 * r[1];
+        for (int j = 0; j < n; ++j) ne->H[size_t(col[i]) * ne->P + col[j]] += jr[0][i] * jr[0][j] + jr[1][i] * jr[1][j];
+      }
+    }
+}
+double total_cost(const Ba& b, int64_t v0, int64_t v1, bool* ok) {
+  const double hw = b.opt.at("huber_width"); double cost = 0; *ok = true;
+  for (int64_t v = v0; v < v1; ++v)
+    for (int64_t c = b.c0[v]; c < b.c0[v + 1]; ++c) {
+      double r[2];
+      if (!eval_obs(b, v, c, r, nullptr)) { *ok = false; continue; }
+      double rho, s1; huber_eval(hw, r[0] * r[0] + r[1] * r[1], &rho, &s1); cost += 0.5 * rho;
+    }
+  return cost;
+}
+
+// dense Cholesky solve of (S H S + D2) d = -S g
+bool solve_damped(const Dense& ne, const std::vector<double>& scale, const std::vector<double>& D2, std::vector<double>* d) {
+  const int P = ne.P; std::vector<double> A(size_t(P) * P), rhs(P);
+  for (int i = 0; i < P; ++i) { for (int j = 0; j < P; ++j) A[size_t(i) * P + j] = ne.H[size_t(i) * P + j] * scale[i] * scale[j]; A[size_t(i) * P + i] += D2[i]; rhs[i] = -ne.g[i] * scale[i]; }
+  for (int j = 0; j < P; ++j) {
+    double s = A[size_t(j) * P + j];
+    for (int k = 0; k < j; ++k) s -= A[size_t(j) * P + k] * A[size_t(j) * P + k];
+    if (!(s > 0.0)) return false;
+    const double l = std::sqrt(s); A[size_t(j) * P + j] = l;
+    for (int i = j + 1; i < P; ++i) {
+      double t = A[size_t(i) * P + j];
+      for (int k = 0; k < j; ++k) t -= A[size_t(i) * P + k] * A[size_t(j) * P + k];
+      A[size_t(i) * P + j] = t / l;
+    }
+  }
+  for (int i = 0; i < P; ++i) { double t = rhs[i]; for (int k = 0; k < i; ++k) t -= A[size_t(i) * P + k] * rhs[k]; rhs[i] = t / A[size_t(i) * P + i]; }
+  for (int i = P - 1; i >= 0; --i) { double t = rhs[i]; for (int k = i + 1; k < P; ++k) t -= A[size_t(k) * P + i] * rhs[k]; rhs[i] = t / A[size_t(i) * P + i]; }
+  *d = rhs; return true;
+}
+
+// Ceres 2.1 TrustRegionMinimizer [EXT] with the LM strategy, on the views [v0, v1) (+ the shared intrinsics when active)
+int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_summary* sum, std::vector<oicc_iteration>* trace) {
+  Layout L = make_layout(b, flags, mask);   // columns relative to the view range: [poses of v0..v1 | active intrinsics]
+  const int nvs = int(v1 - v0);
+  L.Pb = nvs * L.pose_dim; { int a = 0; for (int k = 0; k < kMaxIntr; ++k) if (L.intr_off[k] >= 0) L.intr_off[k] = L.Pb + a++; L.P = L.Pb + L.a; }
+  const int P = L.P;
+  oicc_summary S; std::memset(&S, 0, sizeof(S));
+  S.num_parameters_tangent = P; S.band_dim = L.Pb; S.arrow_dim = L.a; S.half_bandwidth = L.pose_dim > 0 ? L.pose_dim - 1 : 0;
+  S.num_residual_blocks = b.c0[v1] - b.c0[v0]; S.num_residuals = 2 * S.num_residual_blocks;
+  if (trace) trace->clear();
+  const double ftol = b.opt["function_tolerance"], ptol = b.opt["parameter_tolerance"], gtol = b.opt["gradient_tolerance"];
+  double radius = b.opt["initial_trust_region_radius"]; const double max_radius = b.opt["max_trust_region_radius"];
+  const double min_radius = b.opt["min_trust_region_radius"], min_rel_dec = b.opt["min_relative_decrease"];
+  const double min_diag = b.opt["min_lm_diagonal"], max_diag = b.opt["max_lm_diagonal"];
+  const int max_invalid = int(b.opt["max_num_consecutive_invalid_steps"]);
+  double decrease_factor = 2.0; bool reuse_diagonal = false;
+  auto finish = [&](int term, const char* msg, double cost, double gmax) {
+    S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax; std::snprintf(S.message, sizeof(S.message), "%s", msg);
+    if (sum) *sum = S; return OICC_OK; };
+  auto build_range = [&](Dense* ne) { build(b, L, v0, v1, ne); };
+  bool okc = true;
+  if (P == 0) { const double c = total_cost(b, v0, v1, &okc); S.initial_cost = c; return finish(OICC_CONVERGENCE, "no variable parameters", c, 0.0); }
+  Dense ne; build_range(&ne);
+  if (!ne.ok) { b.err = "residual evaluation failed at the initial point"; return OICC_ERR_STATE; }
+  double cost = ne.cost; S.initial_cost = cost;
+  std::vector<double> scale(P, 1.0);
+  if (b.opt["jacobi_scaling"] != 0) for (int i = 0; i < P; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(ne.H[size_t(i) * P + i]));
+  auto grad_max = [&]() { double m = 0; for (double v : ne.g) m = std::max(m, std::fabs(v)); return m; };
+  double gmax = grad_max();
+  if (trace) trace->push_back(oicc_iteration{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius});
+  if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.", cost, gmax);
+  // ambient norm over the non-constant parameter blocks (whole blocks, SubsetParameterization keeps the ambient size)
+  auto x_sq = [&]() { double s = 0; if (L.pose_dim > 0) for (int64_t v = v0; v < v1; ++v) for (int k = 0; k < 6; ++k) s += b.pose[6 * v + k] * b.pose[6 * v + k];
+    if (L.a > 0) for (int k = 0; k < b.n_intr; ++k) s += b.intr[k] * b.intr[k]; return s; };
+  double x_norm = std::sqrt(x_sq());
+  std::vector<double> diag(P), D2(P), step_s(P);
+  int iter = 0, invalid = 0;
+  while (true) {
+    if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.", cost, gmax);
+    if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.", cost, gmax);
+    ++iter; S.num_iterations = iter;
+    if (!reuse_diagonal) for (int i = 0; i < P; ++i) diag[i] = std::min(std::max(ne.H[size_t(i) * P + i] * scale[i] * scale[i], min_diag), max_diag);
+    for (int i = 0; i < P; ++i) D2[i] = diag[i] / radius;
+    bool ok = solve_damped(ne, scale, D2, &step_s);
+    double model = 0.0;
+    if (ok) { for (int i = 0; i < P; ++i) model += 0.5 * step_s[i] * (D2[i] * step_s[i] - ne.g[i] * scale[i]); ok = model > 0.0; }
+    if (!ok) {
+      if (++invalid >= max_invalid) return finish(OICC_FAILURE, "Number of consecutive invalid steps more than max.", cost, gmax);
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; ++S.num_unsuccessful_steps;
+      if (trace) trace->push_back(oicc_iteration{iter, 0, cost, 0.0, gmax, 0.0, 0.0, radius});
+      continue;
+    }
+    invalid = 0;
+    const std::vector<double> pose0(b.pose.begin() + 6 * v0, b.pose.begin() + 6 * v1); double intr0[kMaxIntr]; std::memcpy(intr0, b.intr, sizeof(intr0));
+    double step_sq = 0.0;
+    for (int64_t v = v0; v < v1; ++v) for (int g = 0; g < 2; ++g) if (L.pose_off[g] >= 0) for (int k = 0; k < 3; ++k) {
+      const int col = int(v - v0) * L.pose_dim + L.pose_off[g] + k; const double d = step_s[col] * scale[col];
+      const double x0 = b.pose[6 * v + 3 * g + k]; const double x1 = x0 + d; b.pose[6 * v + 3 * g + k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
+    for (int k = 0; k < b.n_intr; ++k) if (L.intr_off[k] >= 0) { const int col = L.intr_off[k]; const double x0 = b.intr[k]; const double x1 = x0 + step_s[col] * scale[col]; b.intr[k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
+    auto restore = [&]() { std::copy(pose0.begin(), pose0.end(), b.pose.begin() + 6 * v0); std::memcpy(b.intr, intr0, sizeof(intr0)); };
+    bool cand_ok = true; double cand_cost = total_cost(b, v0, v1, &cand_ok);
+    if (!cand_ok) cand_cost = std::numeric_limits<double>::max();   // Ceres: failed evaluation = step rejected
+    const double step_norm = std::sqrt(step_sq), cost_change = cost - cand_cost, rel_dec = cost_change / model;
+    if (step_norm <= ptol * (x_norm + ptol)) { restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
+      return finish(OICC_CONVERGENCE, "Parameter tolerance reached.", cost, gmax); }
+    if (std::fabs(cost_change) <= ftol * cost) { restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
+      return finish(OICC_CONVERGENCE, "Function tolerance reached.", cost, gmax); }
+    if (rel_dec > min_rel_dec) {
+      cost = cand_cost; x_norm = std::sqrt(x_sq());
+      build_range(&ne); gmax = grad_max(); ++S.num_successful_steps;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
+      radius = std::min(max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
+      if (trace) trace->push_back(oicc_iteration{iter, 1, cost, cost_change, gmax, step_norm, rel_dec, radius});
+      if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.", cost, gmax);
+    } else {
+      restore(); ++S.num_unsuccessful_steps;
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+struct oicc_ba { Ba b; };
+#define B_ (prob->b)
+
+int oicc_oracle_ba_create(oicc_ba** out, int32_t) { *out = new oicc_ba(); return OICC_OK; }
+void oicc_oracle_ba_destroy(oicc_ba* prob) { delete prob; }
+const char* oicc_oracle_ba_last_error(const oicc_ba* prob) { return prob->b.err.c_str(); }
+int oicc_oracle_ba_set_option(oicc_ba* prob, const char* name, double value) {
+  auto it = B_.opt.find(name); if (it == B_.opt.end()) { B_.err = std::string("unknown option ") + name; return OICC_ERR_INVALID_ARG; }
+  it->second = value; return OICC_OK; }
+int oicc_oracle_ba_set_camera(oicc_ba* prob, int32_t model, const double* intr, int32_t n) {
+  if (n < 0 || n > kMaxIntr) { B_.err = "too many intrinsics"; return OICC_ERR_INVALID_ARG; }
+  B_.model = model; B_.n_intr = n; std::memset(B_.intr, 0, sizeof(B_.intr)); std::memcpy(B_.intr, intr, n * sizeof(double)); return OICC_OK; }
+int oicc_oracle_ba_get_camera(const oicc_ba* prob, double* intr, int32_t n) { std::memcpy(intr, prob->b.intr, std::min<int>(n, kMaxIntr) * sizeof(double)); return OICC_OK; }
+int oicc_oracle_ba_set_scene_points(oicc_ba* prob, const double* xyzw, int64_t n) { B_.pts.assign(xyzw, xyzw + 4 * n); return OICC_OK; }
+int oicc_oracle_ba_set_views(oicc_ba* prob, int64_t nv, const double* pose6, const int64_t* coff, const double* uv, const int32_t* pid) {
+  B_.pose.assign(pose6, pose6 + 6 * nv); B_.c0.assign(coff, coff + nv + 1);
+  const int64_t nc = coff[nv]; B_.uv.assign(uv, uv + 2 * nc); B_.pid.assign(pid, pid + nc);
+  for (int64_t c = 0; c < nc; ++c) if (pid[c] < 0 || size_t(pid[c]) * 4 >= B_.pts.size()) { B_.err = "point id out of range"; return OICC_ERR_INVALID_ARG; }
+  return OICC_OK; }
+int oicc_oracle_ba_set_poses(oicc_ba* prob, const double* pose6, int64_t nv) { if (nv != B_.nv()) return OICC_ERR_INVALID_ARG; B_.pose.assign(pose6, pose6 + 6 * nv); return OICC_OK; }
+int oicc_oracle_ba_get_poses(const oicc_ba* prob, double* pose6, int64_t nv) { std::copy(prob->b.pose.begin(), prob->b.pose.begin() + 6 * nv, pose6); return OICC_OK; }
+
+int oicc_oracle_ba_evaluate(oicc_ba* prob, int32_t flags, int32_t mask, double* cost, double* H, double* g, int32_t Pcap) {
+  const Layout L = make_layout(B_, flags, mask);
+  if (L.P > Pcap) { B_.err = "Pcap too small"; return OICC_ERR_INVALID_ARG; }
+  Dense ne; build(B_, L, 0, B_.nv(), &ne);
+  if (cost) *cost = ne.cost;
+  if (H) for (int i = 0; i < L.P; ++i) for (int j = 0; j < L.P; ++j) H[size_t(i) * Pcap + j] = ne.H[size_t(i) * L.P + j];
+  if (g) std::copy(ne.g.begin(), ne.g.end(), g);
+  return ne.ok ? OICC_OK : OICC_ERR_STATE;
+}
+int oicc_oracle_ba_optimize(oicc_ba* prob, int32_t max_iters, int32_t flags, int32_t mask, oicc_summary* sum) {
+  return lm(B_, flags, mask, 0, B_.nv(), max_iters, sum, &B_.trace); }
+int oicc_oracle_ba_get_iterations(const oicc_ba* prob, oicc_iteration* out, int32_t cap) {
+  const int n = std::min<int>(cap, int(prob->b.trace.size())); std::copy(prob->b.trace.begin(), prob->b.trace.begin() + n, out); return n; }
+// BundleAdjustView for every view on its own (pose_estimator.cc:226-236): intrinsics constant, one LM per view
+int oicc_oracle_ba_optimize_views(oicc_ba* prob, int32_t max_iters, int32_t flags, int32_t* iterations, double* final_cost) {
+  for (int64_t v = 0; v < B_.nv(); ++v) {
+    oicc_summary S; int rc = lm(B_, flags, 0, v, v + 1, max_iters, &S, nullptr);
+    if (rc) return rc;
+    if (iterations) iterations[v] = S.num_iterations;
+    if (final_cost) final_cost[v] = S.final_cost;
+  }
+  return OICC_OK;
+}
+// utils::GetReprojErrorOfView, src/utils/utils.cc:163-177
+int oicc_oracle_ba_view_reprojection_errors(oicc_ba* prob, double* mean_px) {
+  for (int64_t v = 0; v < B_.nv(); ++v) {
+    double s = 0;
+    for (int64_t c = B_.c0[v]; c < B_.c0[v + 1]; ++c) { double r[2]; if (!eval_obs(B_, v, c, r, nullptr)) { r[0] = r[1] = std::numeric_limits<double>::quiet_NaN(); } s += std::sqrt(r[0] * r[0] + r[1] * r[1]); }
+    mean_px[v] = s / double(B_.c0[v + 1] - B_.c0[v]);
+  }
+  return OICC_OK;
+}
+
+// ---- cross-check hooks (tests): per-observation residuals and Jacobians [pose 6 | intr 10], Jets vs the product's formulas
+int oicc_oracle_ba_rows(oicc_ba* prob, int32_t analytic, double* res /*2 nc*/, double* jac /*2 nc x 16*/) {
+  const int64_t nv = B_.nv();
+  for (int64_t v = 0; v < nv; ++v) {
+    double R[9], Jr[9];
+    if (analytic) { oicc::angle_axis_matrix(&B_.pose[6 * v + 3], R); oicc::so3_Jr(&B_.pose[6 * v + 3], Jr); }
+    for (int64_t c = B_.c0[v]; c < B_.c0[v + 1]; ++c) {
+      double r[2] = {0, 0}; double* Jo = jac + size_t(2 * c) * 16;
+      std::fill(Jo, Jo + 32, 0.0);
+      if (analytic) {
+        double px[2], Jp[12], Ji[2 * oicc::kBaMaxIntr];
+        if (!oicc::ba_observation<true>(B_.model, B_.intr, &B_.pose[6 * v], R, Jr, &B_.pts[4 * (int64_t)B_.pid[c]], px, Jp, Ji, nullptr)) return OICC_ERR_STATE;
+        r[0] = px[0] - B_.uv[2 * c]; r[1] = px[1] - B_.uv[2 * c + 1];
+        for (int k = 0; k < 2; ++k) { for (int j = 0; j < 6; ++j) Jo[k * 16 + j] = Jp[k * 6 + j]; for (int j = 0; j < B_.n_intr; ++j) Jo[k * 16 + 6 + j] = Ji[k * oicc::kBaMaxIntr + j]; }
+      } else {
+        double J[2 * NJ];
+        if (!eval_obs(B_, v, c, r, J)) return OICC_ERR_STATE;
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 16; ++j) Jo[k * 16 + j] = J[k * NJ + j];
+      }
+      res[2 * c] = r[0]; res[2 * c + 1] = r[1];
+    }
+  }
+  return OICC_OK;
+}
+
+}  // extern "C"

@@ -39,11 +39,11 @@ inline void view_rows(const Common& C, int64_t s_so3, int64_t s_r3, double u_so3
     const double tau = rs ? obs_v * C.ld : 0.0;
     const double sh_s = C.rs_time_in_seconds ? C.inv_so3_dt : 1.0, sh_r = C.rs_time_in_seconds ? C.inv_r3_dt : 1.0;
     const double u_s = u_so3 + tau * sh_s, u_r = u_r3 + tau * sh_r;
-    So3Out so;
+    So3Fwd so;
     QuatKnots acc{C.so3 + 4 * s_so3};
-    if (spline_active) { if (ld_active) so3_spline_eval<true, true, true, false>(acc, u_s, C.inv_so3_dt, so); else so3_spline_eval<true, false, true, false>(acc, u_s, C.inv_so3_dt, so); }
-    else if (ld_active) so3_spline_eval<true, true, false, false>(acc, u_s, C.inv_so3_dt, so);
-    else so3_spline_eval<true, false, false, false>(acc, u_s, C.inv_so3_dt, so);
+    if (spline_active) { if (ld_active) so3_spline_forward<true, true, true>(acc, u_s, C.inv_so3_dt, so); else so3_spline_forward<true, false, true>(acc, u_s, C.inv_so3_dt, so); }
+    else if (ld_active) so3_spline_forward<true, true, false>(acc, u_s, C.inv_so3_dt, so);
+    else so3_spline_forward<true, false, false>(acc, u_s, C.inv_so3_dt, so);
     double cf[6]; r3_coeffs<0>(u_r, C.inv_r3_dt, cf);
     double t_wi[3] = {0, 0, 0};
     for (int j = 0; j < 6; ++j) { const double* p = C.r3 + 3 * (s_r3 + j); t_wi[0] += cf[j] * p[0]; t_wi[1] += cf[j] * p[1]; t_wi[2] += cf[j] * p[2]; }
@@ -84,9 +84,11 @@ inline void view_rows(const Common& C, int64_t s_so3, int64_t s_r3, double u_so3
         MQ[rr * 3 + 0] = b * qv[2] - cz * qv[1]; MQ[rr * 3 + 1] = cz * qv[0] - a * qv[2]; MQ[rr * 3 + 2] = a * qv[1] - b * qv[0];
         for (int cc = 0; cc < 3; ++cc) B[rr * 3 + cc] = M1[rr * 3] * Rwi[cc * 3] + M1[rr * 3 + 1] * Rwi[cc * 3 + 1] + M1[rr * 3 + 2] * Rwi[cc * 3 + 2];
       }
+      double jr[6][6];
+      so3_spline_backward_rows<2>(so, MQ, jr);
       for (int j = 0; j < 6; ++j) for (int cc = 0; cc < 3; ++cc) {
-        row0[3 * j + cc] = MQ[0] * so.JR[j][cc] + MQ[1] * so.JR[j][3 + cc] + MQ[2] * so.JR[j][6 + cc];
-        row1[3 * j + cc] = MQ[3] * so.JR[j][cc] + MQ[4] * so.JR[j][3 + cc] + MQ[5] * so.JR[j][6 + cc];
+        row0[3 * j + cc] = jr[j][cc];
+        row1[3 * j + cc] = jr[j][3 + cc];
         row0[18 + 3 * j + cc] = -cf[j] * B[cc]; row1[18 + 3 * j + cc] = -cf[j] * B[3 + cc];
       }
     }

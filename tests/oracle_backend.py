@@ -18,7 +18,7 @@ _bound = None
 
 
 def build():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oicc_oracle.cpp", "oicc_oracle_math.hpp", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oicc_oracle.cpp", "ba_oracle.cpp", "oicc_oracle_math.hpp", "Makefile")]
     if (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
@@ -31,3 +31,16 @@ def load():
         _bound = _abi.Bound(lib, "oicc_oracle_", device=False)
         _bound.raw = lib
     return _bound
+
+
+_bound_ba = None
+
+
+def load_ba():
+    """The oracle's view-bundle-adjustment entry points (oracle/ba_oracle.cpp)."""
+    global _bound_ba
+    if _bound_ba is None:
+        b = load()
+        _bound_ba = _abi.BoundBa(b.raw, "oicc_oracle_ba_")
+        _bound_ba.raw = b.raw
+    return _bound_ba

@@ -37,6 +37,10 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds only declared functions
     for n in list(_abi.SIGNATURES) + list(_abi.DEVICE_ONLY):
         assert "oicc_" + n in names, n
+    for n in _abi.BA_SIGNATURES:
+        assert "oicc_ba_" + n in names, n
+    assert sorted(n for n in names if n.startswith("oicc_ba_")) == sorted("oicc_ba_" + n for n in _abi.BA_SIGNATURES)
+    _lib.load_ba()   # binds every oicc_ba_* entry point or raises
 
 
 def test_no_cpu_fallback_without_device():
@@ -48,6 +52,11 @@ def test_no_cpu_fallback_without_device():
     assert b.create(ctypes.byref(h), 0) == -2      # OICC_ERR_NO_DEVICE
     with pytest.raises(E.OiccError):
         E.SplineTrajectoryEstimator()
+    from openimucameracalibrator_amd import camera_calibrator as CC
+    hb = _abi.HB()
+    assert _lib.load_ba().create(ctypes.byref(hb), 0) == -2
+    with pytest.raises(RuntimeError):
+        CC.ViewBundleAdjuster()
 
 
 @pytest.fixture(scope="module")
