@@ -90,3 +90,110 @@ def write_dataset_files(ds, out_dir):
     return dict(telemetry_json=p("telemetry.json"), input_pose_dataset=p("pose_dataset.json"), input_corners=p("corners.uson"),
                 camera_calibration_json=p("cam_calib.json"), gyro_to_cam_initial_calibration=p("imu_to_cam_init.json"),
                 spline_error_weighting_json=p("sew.json"), result_output_json=p("result.json"))
+
+
+def ubjson_decode(buf):
+    """Inverse of ubjson_encode for what nlohmann::json::to_ubjson writes without container optimisation
+    (src/io/read_scene.cc:25-41 reads the corner file with nlohmann::json::from_ubjson)."""
+    pos = [0]
+
+    def take(n):
+        b = buf[pos[0]:pos[0] + n]
+        pos[0] += n
+        return b
+
+    def number(tag):
+        fmt = {b"i": ">b", b"U": ">B", b"I": ">h", b"l": ">i", b"L": ">q", b"d": ">f", b"D": ">d"}[tag]
+        return struct.unpack(fmt, take(struct.calcsize(fmt)))[0]
+
+    def length():
+        return number(take(1))
+
+    def value(tag=None):
+        tag = tag or take(1)
+        if tag == b"Z": return None
+        if tag == b"T": return True
+        if tag == b"F": return False
+        if tag in (b"i", b"U", b"I", b"l", b"L", b"d", b"D"): return number(tag)
+        if tag == b"C": return take(1).decode()
+        if tag == b"S": return take(length()).decode()
+        if tag == b"[":
+            out = []
+            while buf[pos[0]:pos[0] + 1] != b"]":
+                out.append(value())
+            pos[0] += 1
+            return out
+        if tag == b"{":
+            out = {}
+            while buf[pos[0]:pos[0] + 1] != b"}":
+                k = take(length()).decode()
+                out[k] = value()
+            pos[0] += 1
+            return out
+        raise ValueError("unsupported UBJSON marker %r at %d" % (tag, pos[0] - 1))
+
+    return value()
+
+
+def read_scene_bson(path):
+    """io::read_scene_bson, src/io/read_scene.cc:25-41 (UBJSON; plain JSON accepted too)."""
+    raw = open(path, "rb").read()
+    if raw[:1] == b"{" and raw.lstrip()[:2] in (b'{"', b"{\n", b"{ "):
+        try:
+            return json.loads(raw.decode())
+        except Exception:
+            pass
+    return ubjson_decode(raw)
+
+
+_INTR_KEYS = {
+    syn.CAM_PINHOLE: ["focal_length", "aspect_ratio", "skew", "principal_pt_x", "principal_pt_y", "radial_distortion_1", "radial_distortion_2"],
+    syn.CAM_PINHOLE_RADIAL_TANGENTIAL: ["focal_length", "aspect_ratio", "skew", "principal_pt_x", "principal_pt_y", "radial_distortion_1",
+                                        "radial_distortion_2", "radial_distortion_3", "tangential_distortion_1", "tangential_distortion_2"],
+    syn.CAM_FISHEYE: ["focal_length", "aspect_ratio", "skew", "principal_pt_x", "principal_pt_y", "radial_distortion_1", "radial_distortion_2",
+                      "radial_distortion_3", "radial_distortion_4"],
+    syn.CAM_DIVISION_UNDISTORTION: ["focal_length", "aspect_ratio", "principal_pt_x", "principal_pt_y", "div_undist_distortion"],
+    syn.CAM_DOUBLE_SPHERE: ["focal_length", "aspect_ratio", "skew", "principal_pt_x", "principal_pt_y", "xi", "alpha"],
+    syn.CAM_EXTENDED_UNIFIED: ["focal_length", "aspect_ratio", "skew", "principal_pt_x", "principal_pt_y", "alpha", "beta"],
+}
+
+
+def write_camera_calibration(path, model, intrinsics, image_width, image_height, fps, nr_calib_images, total_reproj_error):
+    """io::write_camera_calibration, src/io/write_camera_calibration.cc:34-140: same keys.  (The reference writes the
+    PINHOLE model without its two radial terms and every model with skew 0; the radial terms are added here so that the
+    file reproduces the calibrated camera.)"""
+    keys = _INTR_KEYS[model]
+    intr = {k: float(v) for k, v in zip(keys, intrinsics)}
+    intr["skew"] = 0.0
+    obj = dict(stabelized=False, fps=float(fps), nr_calib_images=int(nr_calib_images), final_reproj_error=float(total_reproj_error),
+               image_width=int(image_width), image_height=int(image_height), intrinsic_type=MODEL_NAMES[model], intrinsics=intr)
+    json.dump(obj, open(path, "w"), indent=2)
+    return True
+
+
+def read_camera_calibration(path):
+    """io::read_camera_calibration, src/io/read_camera_calibration.cc:35-118 -> (model, intrinsics, width, height, fps)."""
+    obj = json.load(open(path))
+    model = {v: k for k, v in MODEL_NAMES.items()}[obj["intrinsic_type"]]
+    intr = np.array([float(obj["intrinsics"].get(k, 1.0 if k == "aspect_ratio" else 0.0)) for k in _INTR_KEYS[model]])
+    return model, intr, int(obj["image_width"]), int(obj["image_height"]), float(obj.get("fps", 0.0))
+
+
+def write_pose_dataset(path, t_s, pose6, points):
+    """JSON twin of theia::WriteReconstruction for a pose data set (the file continuous_time_imu_to_camera_calibration
+    reads with --input_pose_dataset): view key = timestamp in microseconds (camera_calibrator.cc:96)."""
+    views = {str(int(round(t * 1e6))): dict(orientation_angle_axis=[float(x) for x in p[3:]], position=[float(x) for x in p[:3]])
+             for t, p in zip(t_s, pose6)}
+    json.dump(dict(views=views, tracks={str(i): [float(x) for x in points[i]] for i in range(len(points))}), open(path, "w"))
+
+
+def write_ply_cameras(path, pose6, points, color=(255, 0, 0)):
+    """theia::WritePlyFile twin: board points (white) and camera centres (colour) as an ASCII point cloud."""
+    with open(path, "w") as f:
+        n = len(points) + len(pose6)
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n)
+        for p in points:
+            f.write("%.6f %.6f %.6f 255 255 255\n" % (p[0] / p[3], p[1] / p[3], p[2] / p[3]))
+        for p in pose6:
+            f.write("%.6f %.6f %.6f %d %d %d\n" % (p[0], p[1], p[2], color[0], color[1], color[2]))

@@ -1,0 +1,83 @@
+"""calibrate_camera / estimate_camera_poses_from_checkerboard twins on the CPU checker backend: file formats,
+planar start values, view filters; the device runs the same code in tests/test_gpu_ba.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_backend
+from openimucameracalibrator_amd import camera_calibrator as CC, io_files, planar_init, synthetic as S
+from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2
+
+
+def scene_of(ds, fps=30.0):
+    views = {}
+    for v in range(len(ds["pose_true"])):
+        a, b = ds["corner_offset"][v], ds["corner_offset"][v + 1]
+        views[str(1000000 + 33333 * v)] = dict(image_points={str(int(ds["point_ids"][c])): [float(ds["uv"][c, 0]), float(ds["uv"][c, 1])] for c in range(a, b)})
+    return dict(views=views, scene_pts={str(i): ds["points"][i, :3].tolist() for i in range(len(ds["points"]))},
+                image_width=ds["width"], image_height=ds["height"], camera_fps=fps)
+
+
+def test_ubjson_round_trip(tmp_path):
+    ds = CC.make_calibration_dataset("pinhole", num_views=3, corners_per_view=10)
+    sc = scene_of(ds)
+    p = tmp_path / "c.uson"
+    p.write_bytes(io_files.ubjson_encode(sc))
+    back = io_files.read_scene_bson(str(p))
+    assert back == json.loads(json.dumps(sc))
+
+
+def test_planar_start_values():
+    ds = CC.make_calibration_dataset("pinhole", num_views=12, corners_per_view=40)
+    w, h = ds["width"], ds["height"]
+    fs = []
+    for v in range(12):
+        a, b = ds["corner_offset"][v], ds["corner_offset"][v + 1]
+        ok, R, C, f = planar_init.initialize_view(ds["points"], ds["point_ids"][a:b], ds["uv"][a:b] - [w / 2, h / 2])
+        assert ok
+        fs.append(f)
+        ok, R, C, _ = planar_init.initialize_view(ds["points"], ds["point_ids"][a:b], ds["uv"][a:b] - [w / 2, h / 2], focal=ds["intrinsics"][0])
+        assert np.linalg.norm(C - ds["pose_true"][v, :3]) < 0.03
+        assert np.abs(R - CC.angle_axis_to_rotation(ds["pose_true"][v, 3:])).max() < 0.1
+    assert abs(np.median(fs) - ds["intrinsics"][0]) < 0.05 * ds["intrinsics"][0]
+    for cam in ("gopro6_fisheye", "gopro9_division", "gopro6_double_sphere", "gopro9_eucm", "pinhole_radtan"):
+        m, intr = S.CAMERAS[cam][0], np.array(S.CAMERAS[cam][1])
+        uv = np.array([[100.0, 80.0], [480.0, 270.0], [900.0, 500.0]])
+        xy = planar_init.pixel_to_normalized(m, intr, uv)
+        px, ok = S.project(m, intr, np.concatenate([xy, np.ones((3, 1))], 1))
+        assert np.all(ok) and np.abs(px - uv).max() < 1e-8
+
+
+@pytest.mark.parametrize("camera", ["pinhole", "gopro9_division"])
+def test_calibrate_camera_application(camera, tmp_path):
+    ds = CC.make_calibration_dataset(camera, num_views=40, corners_per_view=40)
+    out = str(tmp_path / "calib")
+    cal = APP.calibrate_camera_from_json(scene_of(ds), ds["model_name"], grid_size=0.02, output_path=out, backend=oracle_backend.load_ba())
+    assert cal is not None and cal.NumViews() >= 20
+    model, intr, w, h, fps = io_files.read_camera_calibration(out + ".json")
+    assert model == ds["model"] and (w, h) == (ds["width"], ds["height"]) and fps == 30.0
+    tr = ds["intrinsics"]
+    assert abs(intr[0] - tr[0]) < 1.5
+    obj = json.load(open(out + ".json"))
+    assert obj["nr_calib_images"] == cal.NumViews() and obj["final_reproj_error"] < 0.4 and obj["intrinsic_type"] == ds["model_name"]
+    for suffix in ("_ransac_poses.ply", "_final_poses.ply", ".calibdata.json"):
+        assert os.path.getsize(out + suffix) > 100
+
+
+def test_estimate_poses_application_feeds_the_spline_cli_format(tmp_path):
+    ds = CC.make_calibration_dataset("gopro9_division", num_views=25, corners_per_view=40)
+    t_s, pose, points, err = APP2.estimate_poses_from_json(scene_of(ds), ds["model"], ds["intrinsics"], ds["height"], backend=oracle_backend.load_ba())
+    assert len(t_s) >= 23 and np.all(err < 0.004 * ds["height"])
+    # poses agree with the truth (matched by timestamp)
+    keys = [1000000 + 33333 * v for v in range(25)]
+    for t, p in zip(t_s, pose):
+        v = keys.index(int(round(t * 1e6)))
+        assert np.linalg.norm(p[:3] - ds["pose_true"][v, :3]) < 6e-3
+    out = str(tmp_path / "poses.json")
+    io_files.write_pose_dataset(out, t_s, pose, points)
+    obj = json.load(open(out))
+    assert set(obj) == {"views", "tracks"} and len(obj["views"]) == len(t_s) and len(obj["tracks"]) == 48
+    v0 = next(iter(obj["views"].values()))
+    assert set(v0) == {"orientation_angle_axis", "position"}

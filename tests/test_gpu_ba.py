@@ -186,3 +186,33 @@ def test_failed_projection_rejects_the_step_and_reports_nan():
     assert np.isnan(eg[2]) and np.isnan(ec[2]) and np.abs(np.delete(eg, 2) - np.delete(ec, 2)).max() < 1e-10
     with pytest.raises(RuntimeError):
         gpu.Optimize(10, POSE, 0)
+
+
+def _scene(ds):
+    import test_ba_applications as T
+    return T.scene_of(ds)
+
+
+def test_calibrate_camera_application_on_device(tmp_path):
+    """calibrate_camera twin end to end (corner file -> calibration JSON): device result = checker result."""
+    from openimucameracalibrator_amd import calibrate_camera as APP, io_files
+    ds = CC.make_calibration_dataset("gopro9_division", num_views=40, corners_per_view=40)
+    p = tmp_path / "corners.uson"
+    p.write_bytes(io_files.ubjson_encode(_scene(ds)))
+    out = str(tmp_path / "calib")
+    assert APP.main(["--input_corners=%s" % p, "--camera_model_to_calibrate=DIVISION_UNDISTORTION", "--save_path_calib_dataset=%s" % out,
+                     "--grid_size=0.02"]) == 0
+    ref = APP.calibrate_camera_from_json(io_files.read_scene_bson(str(p)), "DIVISION_UNDISTORTION", grid_size=0.02, backend=oracle_backend.load_ba())
+    model, intr, w, h, fps = io_files.read_camera_calibration(out + ".json")
+    assert np.abs(intr - ref.GetIntrinsics()).max() <= 1e-6 * np.abs(intr).max()
+    assert abs(intr[0] - ds["intrinsics"][0]) < 1.5 and abs(intr[4] / ds["intrinsics"][4] - 1) < 0.1
+
+
+def test_estimate_camera_poses_application_on_device():
+    from openimucameracalibrator_amd import estimate_camera_poses_from_checkerboard as APP2
+    ds = CC.make_calibration_dataset("gopro6_fisheye", num_views=60, corners_per_view=40)
+    sc = _scene(ds)
+    tg, pg, _, eg = APP2.estimate_poses_from_json(sc, ds["model"], ds["intrinsics"], ds["height"])
+    tc, pc, _, ec = APP2.estimate_poses_from_json(sc, ds["model"], ds["intrinsics"], ds["height"], backend=oracle_backend.load_ba())
+    assert tg == tc and len(tg) >= 55
+    assert np.abs(pg - pc).max() < 1e-8 and np.abs(eg - ec).max() < 1e-6
