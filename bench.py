@@ -317,6 +317,50 @@ def main():
                                                    time_offset=rg["time_offset"], time_offset_oracle=ro[1], iterations=rg["iterations"])
             except Exception as e:
                 out["extra_sew_prestage"] = {"error": str(e)[:200]}
+        # ---- extra: view bundle adjustment: BASELINE config 0 (pinhole intrinsics, 30 frames) through the
+        # three RunCalibration stages, and the per-view pose refinement of a 2000-frame corner file in one launch; the oracle
+        # (CPU restatement of Theia's bundle adjuster, Jets, one core) timed beside it
+        if not args.no_extra and world == 1:
+            try:
+                from openimucameracalibrator_amd import camera_calibrator as CC
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_backend
+                ob_ba = oracle_backend.load_ba()
+                dsc = CC.make_calibration_dataset("pinhole", num_views=30, corners_per_view=40)
+
+                def run_calibration(backend):
+                    cal_ = CC.CameraCalibrator("PINHOLE", device=local_rank, backend=backend)
+                    cal_.SetScenePoints(dsc["points"])
+                    for v in range(len(dsc["pose_init"])):
+                        vid = cal_.AddView(CC.angle_axis_to_rotation(dsc["pose_init"][v, 3:]), dsc["pose_init"][v, :3], dsc["intrinsics"][0] * 1.05, 0.0,
+                                           dsc["width"], dsc["height"], 0.1 * v)
+                        for c in range(dsc["corner_offset"][v], dsc["corner_offset"][v + 1]):
+                            cal_.AddObservation(vid, dsc["point_ids"][c], dsc["uv"][c])
+                    t1_ = time.perf_counter(); ok_ = cal_.RunCalibration(); return cal_, ok_, time.perf_counter() - t1_
+                run_calibration(None)                                  # warm-up (code load)
+                cg, okg, tg = run_calibration(None)
+                cc_, okc, tc = run_calibration(ob_ba)
+                dsp = CC.make_calibration_dataset("gopro6_fisheye", num_views=2000, corners_per_view=40, pose_noise=(0.01, 0.01))
+
+                def refine(backend):
+                    ba_ = CC.ViewBundleAdjuster(device=local_rank, backend=backend)
+                    ba_.SetCamera(dsp["model"], dsp["intrinsics"]); ba_.SetScenePoints(dsp["points"])
+                    ba_.SetViews(dsp["pose_init"], dsp["corner_offset"], dsp["uv"], dsp["point_ids"])
+                    ba_.ViewReprojectionErrors()                       # uploads done before the timed call
+                    t1_ = time.perf_counter(); it_, _ = ba_.OptimizeViews(50); return ba_.GetPoses(), it_, time.perf_counter() - t1_
+                refine(None)
+                pg, itg, tpg = refine(None)
+                pc, itc, tpc = refine(ob_ba)
+                out["extra_view_bundle_adjustment"] = dict(
+                    config0_calibration=dict(views=30, observations=int(dsc["corner_offset"][-1]), device_ms=1e3 * tg, oracle_ms=1e3 * tc, oracle_cores=1,
+                                             lm_iterations=[s_["num_iterations"] for s_ in cg.summaries],
+                                             focal_length=float(cg.GetIntrinsics()[0]), focal_length_oracle=float(cc_.GetIntrinsics()[0]),
+                                             focal_length_truth=float(dsc["intrinsics"][0])),
+                    pose_refinement=dict(views=2000, observations=int(dsp["corner_offset"][-1]), device_ms=1e3 * tpg, oracle_ms=1e3 * tpc, oracle_cores=1,
+                                         lm_iterations_total=int(itg.sum()), same_iteration_counts=bool(np.array_equal(itg, itc)),
+                                         max_pose_difference=float(np.abs(pg - pc).max())))
+            except Exception as e:
+                out["extra_view_bundle_adjustment"] = {"error": str(e)[:200]}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
