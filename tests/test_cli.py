@@ -124,3 +124,33 @@ def test_rotation_cli_matches_python_twin(tmp_path):
     qc = np.array([c["gyro_to_camera_rotation"][k] for k in "xyzw"]); qp = np.array([p["gyro_to_camera_rotation"][k] for k in "xyzw"])
     assert min(np.abs(qc - qp).max(), np.abs(qc + qp).max()) < 1e-6 and abs(c["time_offset_gyro_to_cam"] - p["time_offset_gyro_to_cam"]) < 1e-6
     assert qangle(qc, qconj(Q_IC)) < np.deg2rad(2.0) and abs(c["time_offset_gyro_to_cam"] - 0.05) < 0.03
+
+
+@pytest.mark.gpu
+def test_whole_chain_from_the_corner_file(tmp_path):
+    """corner file -> calibrate_camera -> estimate_camera_poses_from_checkerboard -> device spline error weighting ->
+    continuous_time_imu_to_camera_calibration: every program of the chain is this repository's, every heavy step runs
+    on the GPU, and the planted camera intrinsics and IMU-to-camera rotation come back."""
+    from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2
+    ds = synthetic.make_config("C2")
+    flags = io_files.write_dataset_files(ds, str(tmp_path))
+    calib = str(tmp_path / "chain_cam")
+    assert APP.main(["--input_corners=" + flags["input_corners"], "--camera_model_to_calibrate=DIVISION_UNDISTORTION",
+                     "--save_path_calib_dataset=" + calib, "--grid_size=0.02"]) == 0
+    model, intr, w, h, fps = io_files.read_camera_calibration(calib + ".json")
+    tr = ds.intrinsics
+    assert abs(intr[0] - tr[0]) < 0.01 * tr[0] and np.abs(intr[2:4] - tr[2:4]).max() < 4.0 and abs(intr[4] / tr[4] - 1) < 0.1
+    poses = str(tmp_path / "chain_poses.json")
+    assert APP2.main(["--input_corners=" + flags["input_corners"], "--camera_calibration_json=" + calib + ".json",
+                      "--output_pose_dataset=" + poses]) == 0
+    assert len(json.load(open(poses))["views"]) >= 190
+    flags = dict(flags, camera_calibration_json=calib + ".json", input_pose_dataset=poses, spline_error_weighting_json="device",
+                 result_output_json=str(tmp_path / "chain_result.json"))
+    r = run_cli(flags, "--known_grav_dir_axis=UNKNOWN", "--calibrate_cam_line_delay")
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = json.load(open(flags["result_output_json"]))
+    q = np.array([out["q_i_c"][c] for c in "xyzw"])
+    qt = np.asarray(ds.truth["q_i_c"])
+    ang = 2 * np.degrees(np.arccos(min(1.0, abs(float(q @ qt)) / (np.linalg.norm(q) * np.linalg.norm(qt)))))
+    assert ang < 0.5, (q, qt)
+    assert out["final_reproj_error"] < 0.6
