@@ -30,14 +30,14 @@ def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path=
     w, h = int(scene["image_width"]), int(scene["image_height"])
     px, py = w / 2.0, h / 2.0                                        # initial principal point, camera_calibrator.cc:228-230
     views = []
-    for key in sorted(scene["views"], key=lambda s: float(s)):       # nlohmann::json iterates keys in sorted order
+    for key in sorted(scene["views"]):                                 # nlohmann::json (std::map) iterates the keys in string order
         ip = scene["views"][key]["image_points"]
         if len(ip) < 4:
             continue
         pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
         uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
         ok, R, C, f = planar_init.initialize_view(points, pid, uv - [px, py])
-        if ok:
+        if ok:       # success_init of the reference (camera_calibrator.cc:327): a view that does not determine a focal length is skipped
             views.append([float(key) * 1e-6, pid, uv, f])
     if not views:
         return None

@@ -29,40 +29,6 @@ using namespace oicc_cli;
 
 namespace {
 
-int model_from_string(const std::string& s) {   // theia::StringToCameraIntrinsicsModelType
-  if (s == "PINHOLE") return OICC_CAM_PINHOLE;
-  if (s == "PINHOLE_RADIAL_TANGENTIAL") return OICC_CAM_PINHOLE_RADIAL_TANGENTIAL;
-  if (s == "FISHEYE") return OICC_CAM_FISHEYE;
-  if (s == "DIVISION_UNDISTORTION") return OICC_CAM_DIVISION_UNDISTORTION;
-  if (s == "DOUBLE_SPHERE") return OICC_CAM_DOUBLE_SPHERE;
-  if (s == "EXTENDED_UNIFIED") return OICC_CAM_EXTENDED_UNIFIED;
-  return -1;
-}
-
-// src/io/read_camera_calibration.cc:35-118
-bool read_camera_calibration(const std::string& path, CalibDataset* cam, double* fps) {
-  Value j; if (!oicc_json::parse_file(path, &j)) { std::cerr << "Could not open: " << path << "\n"; return false; }
-  const std::string type = j.at("intrinsic_type").as_string();
-  cam->camera_model = model_from_string(type);
-  if (cam->camera_model < 0) { std::cerr << "unsupported intrinsic_type " << type << "\n"; return false; }
-  cam->image_width = int(j.at("image_width").as_double()); cam->image_height = int(j.at("image_height").as_double());
-  const Value& in = j.at("intrinsics");
-  const double f = in.at("focal_length").as_double(), cx = in.at("principal_pt_x").as_double(), cy = in.at("principal_pt_y").as_double();
-  const double ar = in.contains("aspect_ratio") ? in.at("aspect_ratio").as_double() : 1.0;
-  *fps = j.at("fps").as_double();
-  auto g = [&](const char* k) { return in.at(k).as_double(); };
-  std::vector<double>& v = cam->intrinsics;
-  switch (cam->camera_model) {
-    case OICC_CAM_DIVISION_UNDISTORTION: v = {f, ar, cx, cy, g("div_undist_distortion")}; break;
-    case OICC_CAM_DOUBLE_SPHERE: v = {f, ar, 0.0, cx, cy, g("xi"), g("alpha")}; break;
-    case OICC_CAM_EXTENDED_UNIFIED: v = {f, ar, 0.0, cx, cy, g("alpha"), g("beta")}; break;
-    case OICC_CAM_FISHEYE: v = {f, ar, 0.0, cx, cy, g("radial_distortion_1"), g("radial_distortion_2"), g("radial_distortion_3"), g("radial_distortion_4")}; break;
-    case OICC_CAM_PINHOLE_RADIAL_TANGENTIAL: v = {f, ar, 0.0, cx, cy, g("radial_distortion_1"), g("radial_distortion_2"), g("radial_distortion_3"), g("tangential_distortion_1"), g("tangential_distortion_2")}; break;
-    case OICC_CAM_PINHOLE: v = {f, ar, 0.0, cx, cy, 0.0, 0.0}; break;   // the reference reads only the aspect ratio (:110-112)
-  }
-  return true;
-}
-
 // src/io/read_misc.cc:30-47
 bool ReadSplineErrorWeighting(const std::string& path, SplineWeightingData* w) {
   Value j; if (!oicc_json::parse_file(path, &j)) return false;
@@ -98,14 +64,6 @@ bool ReadIMUIntrinsics(const std::string& path_intr, const std::string& path_bia
     gyr->mis[0] = -M(mg, 0, 1); gyr->mis[1] = M(mg, 0, 2); gyr->mis[2] = -M(mg, 1, 2); gyr->mis[3] = M(mg, 1, 0); gyr->mis[4] = -M(mg, 2, 0); gyr->mis[5] = M(mg, 2, 1);
     for (int i = 0; i < 3; ++i) gyr->scale[i] = M(sg, i, i);
   }
-  return true;
-}
-// corner file: UBJSON (src/io/read_scene.cc:25-41) -- a .json text file is accepted too
-bool read_scene(const std::string& path, Value* scene) {
-  std::string bytes; if (!oicc_json::read_file(path, &bytes)) { std::cerr << "Can not open " << path << "\n"; return false; }
-  size_t i = 0; while (i < bytes.size() && (bytes[i] == ' ' || bytes[i] == '\n')) ++i;
-  const bool text = path.size() > 5 && path.substr(path.size() - 5) == ".json";
-  *scene = text ? oicc_json::Parser::parse(bytes) : oicc_json::UbjsonReader::parse(bytes);
   return true;
 }
 Value xyz(const Vec3& v) { Value o; o["x"] = Value(v[0]); o["y"] = Value(v[1]); o["z"] = Value(v[2]); return o; }

@@ -28,7 +28,7 @@ def estimate_poses_from_json(scene, model, intrinsics, image_height, device=0, b
     pe = CC.PoseEstimator(device=device, backend=backend)
     pe.SetScenePoints(points)
     t_s, px_obs = [], []
-    for key in sorted(scene["views"], key=lambda s: float(s)):
+    for key in sorted(scene["views"]):                                   # nlohmann::json (std::map) key order
         ip = scene["views"][key]["image_points"]
         if len(ip) < min_num_points:                                   # pose_estimator.cc:131-135
             continue

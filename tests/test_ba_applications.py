@@ -81,3 +81,58 @@ def test_estimate_poses_application_feeds_the_spline_cli_format(tmp_path):
     assert set(obj) == {"views", "tracks"} and len(obj["views"]) == len(t_s) and len(obj["tracks"]) == 48
     v0 = next(iter(obj["views"].values()))
     assert set(v0) == {"orientation_angle_axis", "position"}
+
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openimucameracalibrator_amd", "csrc")
+
+
+@pytest.mark.parametrize("camera", ["pinhole", "gopro6_fisheye"])
+def test_cpp_applications_start_values_match_the_python_twins(camera, tmp_path):
+    """--dry_run of the two C++ applications (no device needed): UBJSON reader, board frame, DLT homography, Zhang focal
+    length, pose from homography, Newton undistortion -- against planar_init.py on the same corner file."""
+    import subprocess
+    if not os.path.exists(os.path.join(CSRC, "calibrate_camera")):
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
+    ds = CC.make_calibration_dataset(camera, num_views=9, corners_per_view=40)
+    sc = scene_of(ds)
+    corners = tmp_path / "corners.uson"
+    corners.write_bytes(io_files.ubjson_encode(sc))
+    r = subprocess.run([os.path.join(CSRC, "calibrate_camera"), "--input_corners=%s" % corners, "--camera_model_to_calibrate=" + ds["model_name"], "--dry_run"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    w, h = ds["width"], ds["height"]
+    idx = {i: i for i in range(48)}
+    fs, views = [], []
+    for key in sorted(sc["views"]):
+        ip = sc["views"][key]["image_points"]
+        pid = np.array([int(k) for k in sorted(ip)], dtype=np.int32)       # the C++ side iterates a std::map: string order
+        uv = np.array([ip[k] for k in sorted(ip)])
+        ok, R, C, f = planar_init.initialize_view(ds["points"], pid, uv - [w / 2, h / 2])
+        if ok:
+            fs.append(f)
+        views.append((key, pid, uv, ok))
+    f0 = float(np.median(fs))
+    assert abs(out["focal_length"] - f0) < 1e-6 * f0
+    assert sorted(out["poses"]) == sorted(k for k, _, _, ok in views if ok)      # views without an own focal estimate are skipped
+    for key, pid, uv, ok in views:
+        if not ok:
+            continue
+        ok, R, C, _ = planar_init.initialize_view(ds["points"], pid, uv - [w / 2, h / 2], focal=f0)
+        got = np.array(out["poses"][key])
+        assert np.abs(got[:3] - C).max() < 1e-7 and np.abs(got[3:] - CC.rotation_to_angle_axis(R)).max() < 1e-7
+    calib = tmp_path / "cam.json"
+    io_files.write_camera_calibration(str(calib), ds["model"], ds["intrinsics"], w, h, 30.0, 9, 0.1)
+    r = subprocess.run([os.path.join(CSRC, "estimate_camera_poses_from_checkerboard"), "--input_corners=%s" % corners,
+                        "--camera_calibration_json=%s" % calib, "--output_pose_dataset=%s" % (tmp_path / "p.json"), "--dry_run"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    intr = ds["intrinsics"].copy()
+    if camera == "pinhole":
+        intr[5:] = 0.0        # the reference's reader drops the PINHOLE radial terms (src/io/read_camera_calibration.cc:110-112)
+    for key, pid, uv, _ in views:
+        xy = planar_init.pixel_to_normalized(ds["model"], intr, uv)
+        ok, R, C, _ = planar_init.initialize_view(ds["points"], pid, xy, focal=1.0)
+        got = np.array(out["poses"][key])
+        assert np.abs(got[6:8] - xy[0]).max() < 1e-9
+        assert np.abs(got[:3] - C).max() < 1e-7 and np.abs(got[3:6] - CC.rotation_to_angle_axis(R)).max() < 1e-7

@@ -154,3 +154,37 @@ def test_whole_chain_from_the_corner_file(tmp_path):
     ang = 2 * np.degrees(np.arccos(min(1.0, abs(float(q @ qt)) / (np.linalg.norm(q) * np.linalg.norm(qt)))))
     assert ang < 0.5, (q, qt)
     assert out["final_reproj_error"] < 0.6
+
+
+@pytest.mark.gpu
+def test_cpp_camera_calibration_and_pose_estimation_match_the_python_twins(tmp_path):
+    """calibrate_camera and estimate_camera_poses_from_checkerboard as C++ programs (reference flags, corner file in,
+    calibration JSON / pose data set out) against the Python twins driving the same device kernels."""
+    from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2, camera_calibrator as CC
+    import test_ba_applications as T
+    csrc = os.path.dirname(CLI)
+    ds = CC.make_calibration_dataset("gopro9_division", num_views=40, corners_per_view=40)
+    corners = str(tmp_path / "corners.uson")
+    open(corners, "wb").write(io_files.ubjson_encode(T.scene_of(ds)))
+    out = str(tmp_path / "cpp_calib")
+    r = subprocess.run([os.path.join(csrc, "calibrate_camera"), "--input_corners=" + corners, "--camera_model_to_calibrate=DIVISION_UNDISTORTION",
+                        "--save_path_calib_dataset=" + out, "--grid_size=0.02", "--verbose"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Final camera calibration reprojection error" in r.stdout and "Focal Length:" in r.stdout
+    cal = APP.calibrate_camera_from_json(io_files.read_scene_bson(corners), "DIVISION_UNDISTORTION", grid_size=0.02)
+    model, intr, w, h, fps = io_files.read_camera_calibration(out + ".json")
+    assert json.load(open(out + ".json"))["nr_calib_images"] == cal.NumViews()
+    assert np.abs(intr - cal.GetIntrinsics()).max() <= 1e-6 * np.abs(intr).max()
+    for suffix in ("_ransac_poses.ply", "_final_poses.ply", ".calibdata.json"):
+        assert os.path.getsize(out + suffix) > 100
+    poses = str(tmp_path / "cpp_poses.json")
+    r = subprocess.run([os.path.join(csrc, "estimate_camera_poses_from_checkerboard"), "--input_corners=" + corners,
+                        "--camera_calibration_json=" + out + ".json", "--output_pose_dataset=" + poses], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    t_s, pose, _, err = APP2.estimate_poses_from_json(io_files.read_scene_bson(corners), model, intr, h)
+    got = json.load(open(poses))["views"]
+    assert len(got) == len(t_s) >= 38
+    for t, p in zip(t_s, pose):
+        g = got[str(int(round(t * 1e6)))]
+        assert np.abs(np.array(g["position"]) - p[:3]).max() < 1e-7 and np.abs(np.array(g["orientation_angle_axis"]) - p[3:]).max() < 1e-7
+    assert open(poses + ".ply").read().startswith("ply")
