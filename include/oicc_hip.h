@@ -359,7 +359,12 @@ int oicc_estimate_imu_to_camera_rotation(int32_t device_ordinal, int64_t n_vis, 
  * 1e-6, parameter_tolerance 1e-8, gradient_tolerance 1e-10, max_trust_region_radius 1e12), huber_width (1.345 as both
  * reference call sites set it; <= 0: trivial loss). */
 typedef struct oicc_ba oicc_ba;
-enum { OICC_BA_POSITION = 1, OICC_BA_ORIENTATION = 2 };   /* !constant_camera_position / !constant_camera_orientation */
+enum { OICC_BA_POSITION = 1, OICC_BA_ORIENTATION = 2,   /* !constant_camera_position / !constant_camera_orientation */
+       /* theia::BundleAdjustTracks (camera_calibrator.cc:207-213, pose_estimator.cc:192-224): the board points are the
+        * variables (homogeneous 4-vectors under ceres::HomogeneousVectorParameterization: 3 tangent dimensions each, as
+        * use_homogeneous_point_parametrization selects), every camera constant; not combinable with the other flags or
+        * with an intrinsics mask.  Tangent order: 3 per variable point in point order. */
+       OICC_BA_POINTS = 4 };
 int oicc_ba_create(oicc_ba** out, int32_t device_ordinal);
 void oicc_ba_destroy(oicc_ba* p);
 const char* oicc_ba_last_error(const oicc_ba* p);
@@ -368,6 +373,10 @@ int oicc_ba_set_option(oicc_ba* p, const char* name, double value);
 int oicc_ba_set_camera(oicc_ba* p, int32_t model, const double* intrinsics, int32_t n);
 int oicc_ba_get_camera(const oicc_ba* p, double* intrinsics, int32_t n);
 int oicc_ba_set_scene_points(oicc_ba* p, const double* xyzw, int64_t n);
+int oicc_ba_get_scene_points(const oicc_ba* p, double* xyzw, int64_t n);
+/* which points OICC_BA_POINTS may move (1) -- PoseEstimator::OptimizeBoardPoints adjusts only tracks with more than 30
+ * observations (pose_estimator.cc:201-208); default after oicc_ba_set_scene_points: all */
+int oicc_ba_set_variable_points(oicc_ba* p, const uint8_t* variable, int64_t n);
 /* views: pose6 [nv][6] = theia::Camera position and angle axis (world -> camera); the observations of view v are
  * uv / point_ids [corner_offsets[v], corner_offsets[v+1]).  Replaces all views (the reference's RemoveView = resend). */
 int oicc_ba_set_views(oicc_ba* p, int64_t nv, const double* pose6, const int64_t* corner_offsets, const double* uv,

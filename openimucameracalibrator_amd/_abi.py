@@ -122,6 +122,8 @@ BA_SIGNATURES = {
     "set_camera": (C.c_int, [HB, C.c_int32, c_dp, C.c_int32]),
     "get_camera": (C.c_int, [HB, c_dp, C.c_int32]),
     "set_scene_points": (C.c_int, [HB, c_dp, C.c_int64]),
+    "get_scene_points": (C.c_int, [HB, c_dp, C.c_int64]),
+    "set_variable_points": (C.c_int, [HB, c_u8p, C.c_int64]),
     "set_views": (C.c_int, [HB, C.c_int64, c_dp, c_i64p, c_dp, c_i32p]),
     "set_poses": (C.c_int, [HB, c_dp, C.c_int64]),
     "get_poses": (C.c_int, [HB, c_dp, C.c_int64]),

@@ -10,8 +10,8 @@ The reference stores views, tracks and the camera in a theia::Reconstruction [EX
 flat numpy arrays in the layout the C-ABI takes.  What stays outside (named, not silently skipped):
 the RANSAC pose / focal-length initialisation of CalibrateCameraFromJson (camera_calibrator.cc:247-316,
 theia::EstimateUncalibratedAbsolutePose / EstimateRadialDistUncalibratedAbsolutePose [EXT]) -- views enter
-through AddView with an initial pose, exactly as the reference's own AddView is fed -- and the optional
-board-point refinement (theia::BundleAdjustTracks, camera_calibrator.cc:207-216).
+through AddView with an initial pose, exactly as the reference's own AddView is fed -- and the empirical point
+covariances PoseEstimator::OptimizeBoardPoints prints (ceres::Covariance, pose_estimator.cc:209-223).
 """
 import ctypes as C
 
@@ -23,6 +23,7 @@ from .synthetic import (CAM_PINHOLE, CAM_PINHOLE_RADIAL_TANGENTIAL, CAM_FISHEYE,
 
 BA_POSITION = 1
 BA_ORIENTATION = 2
+BA_POINTS = 4       # theia::BundleAdjustTracks: board points variable, cameras constant
 
 # theia::OptimizeIntrinsicsType [EXT, theia/sfm/types.h]
 NONE = 0x00
@@ -140,7 +141,20 @@ class ViewBundleAdjuster:
 
     def SetScenePoints(self, xyzw):
         p = np.ascontiguousarray(xyzw, dtype=np.float64).reshape(-1, 4)
+        self.np_ = len(p)
+        self.nvar_ = len(p)
         self._ck(self.b.set_scene_points(self.h, _dp(p), len(p)))
+
+    def GetScenePoints(self):
+        out = np.zeros((self.np_, 4))
+        self._ck(self.b.get_scene_points(self.h, _dp(out), self.np_))
+        return out
+
+    def SetVariablePoints(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert len(m) == self.np_
+        self.nvar_ = int(m.astype(bool).sum())
+        self._ck(self.b.set_variable_points(self.h, m.ctypes.data_as(_abi.c_u8p), len(m)))
 
     def SetViews(self, pose6, corner_offsets, uv, point_ids):
         pose6 = np.ascontiguousarray(pose6, dtype=np.float64).reshape(-1, 6)
@@ -162,6 +176,8 @@ class ViewBundleAdjuster:
         return out
 
     def NumTangent(self, flags, mask):
+        if flags & BA_POINTS:
+            return 3 * self.nvar_
         d = 3 * bool(flags & BA_POSITION) + 3 * bool(flags & BA_ORIENTATION)
         return self.nv * d + bin(mask & ((1 << self.n_intr) - 1)).count("1")
 
@@ -222,8 +238,7 @@ class CameraCalibrator:
     def __init__(self, camera_model, optimize_board_pts=False, device=0, backend=None):
         if camera_model not in MODEL_IDS:
             raise ValueError("unknown camera model %s" % camera_model)
-        if optimize_board_pts:
-            raise NotImplementedError("board point refinement (theia::BundleAdjustTracks) is not part of this path")
+        self.optimize_board_pts_ = bool(optimize_board_pts)
         self.camera_model_ = camera_model
         self.model = MODEL_IDS[camera_model]
         self.views = _Views()
@@ -322,7 +337,20 @@ class CameraCalibrator:
         self.RemoveViewsReprojError(2.0)
         if self.NumViews() < self.min_num_view_:
             return False
+        if self.optimize_board_pts_:                                 # camera_calibrator.cc:207-216
+            self._bundle_adjust_tracks()
+            self._bundle_adjust_views(False, opt)
         return True
+
+    def _bundle_adjust_tracks(self):
+        """theia::BundleAdjustTracks over all tracks: board points variable (homogeneous), cameras constant."""
+        self._upload()
+        s = self.ba.Optimize(self.max_num_iterations, BA_POINTS, 0)
+        self.points = self.ba.GetScenePoints()
+        self.summaries.append(s)
+        if self.verbose_:
+            print("BundleAdjustTracks: cost %.6f -> %.6f in %d iterations (%s)" % (s["initial_cost"], s["final_cost"], s["num_iterations"], s["message"]))
+        return s
 
     def TotalReprojectionError(self):
         """camera_calibrator.cc:352-366: mean over the views of GetReprojErrorOfView."""
@@ -373,6 +401,19 @@ class PoseEstimator:
         out = self.ba.GetPoses()
         self.views.pose = [out[i].copy() for i in range(len(out))]
         return it, fc
+
+    def OptimizeBoardPoints(self, min_num_obs_for_optim=30):
+        """pose_estimator.cc:192-224: BundleAdjustTracks over the tracks seen in more than 30 views, cameras constant
+        (the empirical covariances the reference prints afterwards are not computed)."""
+        pose, off, uv, pid = self.views.flat()
+        counts = np.bincount(pid, minlength=len(self.points))
+        self.ba.SetCamera(self.model, self.intr)
+        self.ba.SetScenePoints(self.points)
+        self.ba.SetViews(pose, off, uv, pid)
+        self.ba.SetVariablePoints((counts > min_num_obs_for_optim).astype(np.uint8))
+        s = self.ba.Optimize(self.max_num_iterations, BA_POINTS, 0)
+        self.points = self.ba.GetScenePoints()
+        return s
 
     def Poses(self):
         return np.asarray(self.views.pose).reshape(-1, 6)

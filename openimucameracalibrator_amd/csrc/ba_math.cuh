@@ -160,6 +160,44 @@ OICC_DEV bool ba_observation(int model, const double* intr, const double pose[6]
   return true;
 }
 
+// ceres::HomogeneousVectorParameterization(4) [EXT, ceres/local_parameterization.cc, internal/householder_vector.h]: the board
+// points of theia::BundleAdjustTracks under use_homogeneous_point_parametrization.  H = I - beta v v^T maps x to |x| e_4;
+// x (+) d = |x| H [sin(|d|/2)/|d| d ; cos(|d|/2)],  d(x (+) d)/dd at 0 = |x|/2 H[:, 0:3].
+OICC_DEV void householder_vector4(const double x[4], double v[4], double* beta) {
+  const double sigma = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = 1.0; *beta = 0.0;
+  const double xp = x[3];
+  if (sigma <= 2.220446049250313e-16) { if (xp < 0.0) *beta = 2.0; return; }
+  const double mu = sqrt(xp * xp + sigma);
+  const double vp = xp <= 0.0 ? xp - mu : -sigma / (xp + mu);
+  *beta = 2.0 * vp * vp / (sigma + vp * vp);
+  v[0] /= vp; v[1] /= vp; v[2] /= vp;
+}
+OICC_DEV void homogeneous_plus4(const double x[4], const double d[3], double out[4]) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  const double h = 0.5 * nd;
+  double sh, ch; sincos(h, &sh, &ch);
+  const double sbd = sh / h;
+  const double y[4] = {0.5 * sbd * d[0], 0.5 * sbd * d[1], 0.5 * sbd * d[2], ch};
+  double v[4], beta; householder_vector4(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  const double vy = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vy));
+}
+// rows of a 2 x 4 Jacobian w.r.t. the homogeneous point -> 2 x 3 w.r.t. the tangent increment
+OICC_DEV void homogeneous_tangent_rows(const double x[4], const double JX[8], double Jt[6]) {
+  double v[4], beta; householder_vector4(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double jv = JX[r * 4] * v[0] + JX[r * 4 + 1] * v[1] + JX[r * 4 + 2] * v[2] + JX[r * 4 + 3] * v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Jt[r * 3 + c] = nx * (0.5 * JX[r * 4 + c] - 0.5 * beta * v[c] * jv);
+  }
+}
+
 // ceres::HuberLoss(a) [EXT]: rho(s) = s (s <= a^2), 2 a sqrt(s) - a^2 otherwise; rho'' <= 0, so Ceres' Corrector
 // scales residual and Jacobian rows by sqrt(rho') and nothing else.  a <= 0: trivial loss.
 OICC_DEV void huber(double a, double s, double* rho, double* sqrt_rho1) {

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) ba_blocks_kernel(const double* x, BaData d
     double R[9], Jr[9];
     angle_axis_matrix(pose + 3, R);
     if (JAC) so3_Jr(pose + 3, Jr);
-    const double* X = d.pts + 4 * (int64_t)d.pid[c];
+    const double* X = x + d.pts_off + 4 * (int64_t)d.pid[c];
     double px[2], Jp[12], Ji[2 * kBaMaxIntr];
     const bool ok = ba_observation<JAC>(d.model, intr, pose, R, Jr, X, px, Jp, Ji, nullptr);
     if (!ok) {
@@ -153,6 +153,101 @@ __global__ void ba_retract_kernel(const double* x, double* xc, BaData d, Tangent
   }
 }
 
+// ---- OICC_BA_POINTS: theia::BundleAdjustTracks (board points variable, cameras constant).  One wave = observations of ONE
+// point (chunks of <= 64, gathered through the by-point permutation); rows [tangent 3 | r] under the homogeneous-vector
+// parameterisation; the point's 3x3 block lands on the band diagonal (half bandwidth 2).
+template <bool JAC>
+__global__ void __launch_bounds__(64) ba_point_blocks_kernel(const double* x, BaData d, TangentLayout tl, NormalEq ne) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  int* coloff = reinterpret_cast<int*>(smem);
+  double* rows = smem + 16;
+  const int lane = threadIdx.x, bid = blockIdx.x;
+  const int64_t c_begin = d.pchunk_c0[bid];
+  const int c_count = d.pchunk_n[bid];
+  const int pt = d.pchunk_point[bid];
+  const bool valid = lane < c_count;
+  const int toff = d.point_tangent[pt];
+  if (JAC && lane < 32) coloff[lane] = (lane < 3 && toff >= 0) ? toff + lane : -1;
+  const double* intr = x + 6 * d.n_views;
+  const double* X = x + d.pts_off + 4 * (int64_t)pt;
+  double cost_local = 0.0;
+  if (JAC) { double* row0 = rows + (2 * lane) * kBaStride; for (int k = 0; k < 2 * kBaStride; ++k) row0[k] = 0.0; }
+  if (valid) {
+    const int64_t c = d.pobs[c_begin + lane];
+    const double* pose = x + 6 * (int64_t)d.corner_view[c];
+    double R[9], Jr[9];
+    angle_axis_matrix(pose + 3, R);
+    if (JAC) so3_Jr(pose + 3, Jr);
+    double px[2], Jp[12], Ji[2 * kBaMaxIntr], JX[8];
+    const bool ok = ba_observation<JAC>(d.model, intr, pose, R, Jr, X, px, Jp, Ji, JAC ? JX : nullptr);
+    if (!ok) cost_local = 1e300;
+    else {
+      const double r0 = px[0] - d.u[c], r1 = px[1] - d.v[c];
+      double rho, s1;
+      huber(d.huber, r0 * r0 + r1 * r1, &rho, &s1);
+      cost_local = 0.5 * rho;
+      if (JAC) {
+        double Jt[6];
+        homogeneous_tangent_rows(X, JX, Jt);
+        double* row0 = rows + (2 * lane) * kBaStride;
+        double* row1 = row0 + kBaStride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { row0[k] = s1 * Jt[k]; row1[k] = s1 * Jt[3 + k]; }
+        row0[3] = s1 * r0; row1[3] = s1 * r1;
+      }
+    }
+  }
+  if (!JAC) {
+    const double s = wave_sum(cost_local);
+    if (lane == 0 && s != 0.0) atomic_add_f64(ne.cost(), s);
+    return;
+  }
+  __syncthreads();
+  EvalCtx ctx{};
+  ctx.ne = ne; ctx.tl = tl; ctx.prof = nullptr;
+  {
+    double quad = 0.0;
+    if (valid) { const double* row0 = rows + (2 * lane) * kBaStride; const double a = row0[3], b = row0[kBaStride + 3]; quad = 0.5 * (a * a + b * b); }
+    const double diff = wave_sum(cost_local - quad);
+    if (lane == 0 && diff != 0.0) atomic_add_f64(ne.cost(), diff);
+  }
+  gram_flush_cell(rows, kBaStride, 0, 2 * c_count, 4, 3, coloff, ctx, lane);
+}
+
+__global__ void ba_point_retract_kernel(const double* x, double* xc, BaData d, TangentLayout tl, SolveBuffers sb, NormalEq ne) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  double step_sq = 0.0, x_sq = 0.0, model = 0.0;
+  if (tid == 0) *ne.cost() = 0.0;
+  for (int64_t i = tid; i < tl.P; i += nthreads) {
+    const double s = sb.step_s[i];
+    model += 0.5 * s * (sb.D2[i] * s - ne.g()[i] * sb.scale[i]);
+  }
+  for (int64_t i = tid; i < d.n_points; i += nthreads) {
+    const int o = d.point_tangent[i];
+    if (o < 0) continue;
+    const double* X0 = x + d.pts_off + 4 * i;
+    double* X1 = xc + d.pts_off + 4 * i;
+    const double dl[3] = {sb.step_s[o] * sb.scale[o], sb.step_s[o + 1] * sb.scale[o + 1], sb.step_s[o + 2] * sb.scale[o + 2]};
+    double out[4];
+    homogeneous_plus4(X0, dl, out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { X1[k] = out[k]; step_sq += (out[k] - X0[k]) * (out[k] - X0[k]); x_sq += X0[k] * X0[k]; }
+  }
+  __shared__ double red[3][256];
+  red[0][threadIdx.x] = step_sq; red[1][threadIdx.x] = x_sq; red[2][threadIdx.x] = model;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(&sb.st->step_norm_sq, red[0][0]);
+    unsafeAtomicAdd(&sb.st->x_norm_sq, red[1][0]);
+    unsafeAtomicAdd(&sb.st->model_cost_change, red[2][0]);
+  }
+}
+
 __global__ void __launch_bounds__(64) ba_view_errors_kernel(const double* x, BaData d, double* mean_px) {
   const int v = blockIdx.x, lane = threadIdx.x;
   const double* pose = x + 6 * (int64_t)v;
@@ -163,7 +258,7 @@ __global__ void __launch_bounds__(64) ba_view_errors_kernel(const double* x, BaD
   const int64_t c0 = d.view_c0[v], c1 = d.view_c0[v + 1];
   for (int64_t c = c0 + lane; c < c1; c += 64) {
     double px[2];
-    const bool ok = ba_observation<false>(d.model, intr, pose, R, nullptr, d.pts + 4 * (int64_t)d.pid[c], px, nullptr, nullptr, nullptr);
+    const bool ok = ba_observation<false>(d.model, intr, pose, R, nullptr, x + d.pts_off + 4 * (int64_t)d.pid[c], px, nullptr, nullptr, nullptr);
     const double r0 = px[0] - d.u[c], r1 = px[1] - d.v[c];
     s += ok ? sqrt(r0 * r0 + r1 * r1) : nan("");
   }
@@ -173,7 +268,7 @@ __global__ void __launch_bounds__(64) ba_view_errors_kernel(const double* x, BaD
 
 // ---- one wave = one view's whole LM loop (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy [EXT], 3 or 6 unknowns)
 template <int D>
-__device__ __forceinline__ bool ba_view_normal_eq(const BaData& d, const double* intr, const double pose[6], int64_t c0, int64_t c1, int lane,
+__device__ __forceinline__ bool ba_view_normal_eq(const BaData& d, const double* intr, const double* pts, const double pose[6], int64_t c0, int64_t c1, int lane,
                                                   const int idx[6], bool jac, double* cost, double H[21], double g[6]) {
   double R[9], Jr[9];
   angle_axis_matrix(pose + 3, R);
@@ -187,8 +282,8 @@ __device__ __forceinline__ bool ba_view_normal_eq(const BaData& d, const double*
   for (int64_t c = c0 + lane; c < c1; c += 64) {
     double px[2], Jp[12], Ji[2 * kBaMaxIntr];
     bool ok;
-    if (jac) ok = ba_observation<true>(d.model, intr, pose, R, Jr, d.pts + 4 * (int64_t)d.pid[c], px, Jp, Ji, nullptr);
-    else ok = ba_observation<false>(d.model, intr, pose, R, Jr, d.pts + 4 * (int64_t)d.pid[c], px, Jp, Ji, nullptr);
+    if (jac) ok = ba_observation<true>(d.model, intr, pose, R, Jr, pts + 4 * (int64_t)d.pid[c], px, Jp, Ji, nullptr);
+    else ok = ba_observation<false>(d.model, intr, pose, R, Jr, pts + 4 * (int64_t)d.pid[c], px, Jp, Ji, nullptr);
     if (!ok) { bad = 1; continue; }
     const double r0 = px[0] - d.u[c], r1 = px[1] - d.v[c];
     double rho, s1;
@@ -264,6 +359,7 @@ template <int D>
 __global__ void __launch_bounds__(64) ba_optimize_views_kernel(double* x, BaData d, BaLmOptions o, int32_t* iterations, double* final_cost) {
   const int v = blockIdx.x, lane = threadIdx.x;
   const double* intr = x + 6 * d.n_views;
+  const double* pts = x + d.pts_off;
   double* pose_g = x + 6 * (int64_t)v;
   const int64_t c0 = d.view_c0[v], c1 = d.view_c0[v + 1];
   int idx[6]; { int n = 0; for (int g = 0; g < 2; ++g) if (d.pose_off[g] >= 0) for (int k = 0; k < 3; ++k) idx[n++] = 3 * g + k; for (; n < 6; ++n) idx[n] = 0; }
@@ -272,7 +368,7 @@ __global__ void __launch_bounds__(64) ba_optimize_views_kernel(double* x, BaData
   for (int k = 0; k < 6; ++k) pose[k] = pose_g[k];
   double cost, H[21], g[6];
   int iter = 0;
-  bool ok0 = ba_view_normal_eq<D>(d, intr, pose, c0, c1, lane, idx, true, &cost, H, g);
+  bool ok0 = ba_view_normal_eq<D>(d, intr, pts, pose, c0, c1, lane, idx, true, &cost, H, g);
   if (!ok0 || c1 <= c0) { if (lane == 0) { if (iterations) iterations[v] = -1; if (final_cost) final_cost[v] = nan(""); } return; }
   double scale[6], diag[6], D2[6], step[6];
   { int e = 0;
@@ -316,7 +412,7 @@ __global__ void __launch_bounds__(64) ba_optimize_views_kernel(double* x, BaData
 #pragma unroll
     for (int i = 0; i < D; ++i) { const int ii = D == 6 ? i : idx[i]; const double x0 = pose[ii]; const double x1 = x0 + step[i] * scale[i]; cand[ii] = x1; step_sq += (x1 - x0) * (x1 - x0); }
     double cand_cost, Hd[21], gd[6];
-    const bool cok = ba_view_normal_eq<D>(d, intr, cand, c0, c1, lane, idx, false, &cand_cost, Hd, gd);
+    const bool cok = ba_view_normal_eq<D>(d, intr, pts, cand, c0, c1, lane, idx, false, &cand_cost, Hd, gd);
     if (!cok) cand_cost = DBL_MAX;
     const double step_norm = sqrt(step_sq), cost_change = cost - cand_cost, rel_dec = cost_change / model;
     if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) break;
@@ -325,7 +421,7 @@ __global__ void __launch_bounds__(64) ba_optimize_views_kernel(double* x, BaData
 #pragma unroll
       for (int k = 0; k < 6; ++k) pose[k] = cand[k];
       x_norm = x_norm_of(pose);
-      ba_view_normal_eq<D>(d, intr, pose, c0, c1, lane, idx, true, &cost, H, g);
+      ba_view_normal_eq<D>(d, intr, pts, pose, c0, c1, lane, idx, true, &cost, H, g);
       radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel_dec - 1.0, 3.0));
       radius = fmin(o.max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
       if (grad_max() <= o.gradient_tolerance) break;
@@ -353,6 +449,18 @@ void launch_ba_retract(const double* x, double* xc, const BaData& d, const Tange
   int64_t work = 6 * d.n_views + tl.P;
   int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(ba_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, d, tl, sb, ne);
+}
+void launch_ba_point_blocks(const double* x, const BaData& d, const TangentLayout& tl, const NormalEq& ne, bool jac, hipStream_t st) {
+  if (d.n_pchunks == 0) return;
+  const size_t lds = (16 + (size_t)(2 * 64 + 3) * kBaStride + 64) * sizeof(double);
+  if (jac) hipLaunchKernelGGL(ba_point_blocks_kernel<true>, dim3(d.n_pchunks), dim3(64), lds, st, x, d, tl, ne);
+  else hipLaunchKernelGGL(ba_point_blocks_kernel<false>, dim3(d.n_pchunks), dim3(64), 256, st, x, d, tl, ne);
+}
+void launch_ba_point_retract(const double* x, double* xc, const BaData& d, const TangentLayout& tl, const SolveBuffers& sb, const NormalEq& ne,
+                             hipStream_t st) {
+  int64_t work = d.n_points + tl.P;
+  int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(ba_point_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, d, tl, sb, ne);
 }
 void launch_ba_view_errors(const double* x, const BaData& d, double* mean_px, hipStream_t st) {
   if (d.n_views == 0) return;

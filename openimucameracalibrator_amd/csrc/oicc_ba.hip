@@ -29,7 +29,10 @@ struct oicc_ba {
   hipStream_t stream = nullptr;
   std::string err;
   int model = 0, n_intr = 0;
-  std::vector<double> x;                 // [pose 6 nv | intrinsics 10]
+  std::vector<double> x;                 // device mirror [pose 6 nv | intrinsics 10 | points 4 np], assembled by sync()
+  std::vector<double> pose;              // [nv][6]
+  std::vector<uint8_t> var_pts;          // [np] variable under OICC_BA_POINTS (empty: all)
+  std::vector<int32_t> corner_view, pobs, pchunk_n, pchunk_point, point_tangent; std::vector<int64_t> pchunk_c0;
   int64_t nv = 0;
   std::vector<double> pts, u, v; std::vector<int32_t> pid; std::vector<int64_t> c0{0};
   std::vector<int64_t> chunk_c0; std::vector<int32_t> chunk_n, chunk_view;
@@ -37,9 +40,9 @@ struct oicc_ba {
   bool meas_dirty = true, x_dirty = true;
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
-  DevBuf<double> d_x, d_xc, d_pts, d_u, d_v, d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_ws, d_out;
-  DevBuf<int32_t> d_pid, d_chunk_n, d_chunk_view, d_iters;
-  DevBuf<int64_t> d_c0, d_chunk_c0;
+  DevBuf<double> d_x, d_xc, d_u, d_v, d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_ws, d_out;
+  DevBuf<int32_t> d_pid, d_chunk_n, d_chunk_view, d_iters, d_corner_view, d_pobs, d_pchunk_n, d_pchunk_point, d_point_tangent;
+  DevBuf<int64_t> d_c0, d_chunk_c0, d_pchunk_c0;
   DevBuf<LmState> d_state;
   struct HostPin { LmState st; double cost; };
   HostPin* pin = nullptr;
@@ -68,7 +71,7 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-struct Prepared { BaData d; TangentLayout tl; NormalEq ne; };
+struct Prepared { BaData d; TangentLayout tl; NormalEq ne; bool points = false; };
 
 int sync(oicc_ba* p) {
   HIPCK(p, hipSetDevice(p->device));
@@ -77,15 +80,31 @@ int sync(oicc_ba* p) {
     p->chunk_c0.clear(); p->chunk_n.clear(); p->chunk_view.clear();
     for (int64_t v = 0; v < p->nv; ++v)
       for (int64_t c = p->c0[v]; c < p->c0[v + 1]; c += 64) { p->chunk_c0.push_back(c); p->chunk_n.push_back(int32_t(std::min<int64_t>(64, p->c0[v + 1] - c))); p->chunk_view.push_back(int32_t(v)); }
-    const bool ok = p->d_pts.upload(p->pts, st) && p->d_u.upload(p->u, st) && p->d_v.upload(p->v, st) && p->d_pid.upload(p->pid, st) &&
+    // OICC_BA_POINTS: the same observations regrouped by board point (stable by-point permutation, one point per chunk)
+    const int64_t nc = int64_t(p->pid.size()), np = int64_t(p->pts.size() / 4);
+    p->corner_view.assign(size_t(nc), 0);
+    for (int64_t v = 0; v < p->nv; ++v) for (int64_t c = p->c0[v]; c < p->c0[v + 1]; ++c) p->corner_view[size_t(c)] = int32_t(v);
+    std::vector<int64_t> start(size_t(np) + 1, 0);
+    for (int64_t c = 0; c < nc; ++c) ++start[size_t(p->pid[size_t(c)]) + 1];
+    for (int64_t i = 0; i < np; ++i) start[size_t(i) + 1] += start[size_t(i)];
+    p->pobs.assign(size_t(nc), 0);
+    { std::vector<int64_t> fill(start.begin(), start.end() - 1); for (int64_t c = 0; c < nc; ++c) p->pobs[size_t(fill[size_t(p->pid[size_t(c)])]++)] = int32_t(c); }
+    p->pchunk_c0.clear(); p->pchunk_n.clear(); p->pchunk_point.clear();
+    for (int64_t i = 0; i < np; ++i)
+      for (int64_t c = start[size_t(i)]; c < start[size_t(i) + 1]; c += 64) { p->pchunk_c0.push_back(c); p->pchunk_n.push_back(int32_t(std::min<int64_t>(64, start[size_t(i) + 1] - c))); p->pchunk_point.push_back(int32_t(i)); }
+    const bool ok = p->d_u.upload(p->u, st) && p->d_v.upload(p->v, st) && p->d_pid.upload(p->pid, st) &&
                     p->d_c0.upload(p->c0, st) && p->d_chunk_c0.upload(p->chunk_c0, st) && p->d_chunk_n.upload(p->chunk_n, st) &&
-                    p->d_chunk_view.upload(p->chunk_view, st);
+                    p->d_chunk_view.upload(p->chunk_view, st) && p->d_corner_view.upload(p->corner_view, st) && p->d_pobs.upload(p->pobs, st) &&
+                    p->d_pchunk_c0.upload(p->pchunk_c0, st) && p->d_pchunk_n.upload(p->pchunk_n, st) && p->d_pchunk_point.upload(p->pchunk_point, st);
     if (!ok) { p->err = "device upload of observations failed"; return OICC_ERR_HIP; }
     HIPCK(p, hipStreamSynchronize(st));
     p->meas_dirty = false;
   }
   if (p->x_dirty) {
+    p->x.assign(size_t(6 * p->nv + kBaIntr) + p->pts.size(), 0.0);
+    std::copy(p->pose.begin(), p->pose.end(), p->x.begin());
     std::memcpy(p->x.data() + 6 * p->nv, p->intr, sizeof(p->intr));
+    std::copy(p->pts.begin(), p->pts.end(), p->x.begin() + 6 * p->nv + kBaIntr);
     if (!p->d_x.resize(p->x.size()) || !p->d_xc.resize(p->x.size())) { p->err = "hipMalloc parameters"; return OICC_ERR_HIP; }
     HIPCK(p, hipMemcpyAsync(p->d_x.p, p->x.data(), p->x.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCK(p, hipStreamSynchronize(st));
@@ -97,17 +116,22 @@ int sync(oicc_ba* p) {
 int download(oicc_ba* p) {
   HIPCK(p, hipMemcpyAsync(p->x.data(), p->d_x.p, p->x.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIPCK(p, hipStreamSynchronize(p->stream));
+  std::copy(p->x.begin(), p->x.begin() + 6 * p->nv, p->pose.begin());
   std::memcpy(p->intr, p->x.data() + 6 * p->nv, sizeof(p->intr));
+  std::copy(p->x.begin() + 6 * p->nv + kBaIntr, p->x.end(), p->pts.begin());
   return OICC_OK;
 }
 
 int prepare(oicc_ba* p, int flags, int mask, Prepared* out) {
   ARG(p, p->n_intr > 0, "oicc_ba_set_camera has not been called");
-  ARG(p, (flags & ~(OICC_BA_POSITION | OICC_BA_ORIENTATION)) == 0, "unknown flag");
+  ARG(p, (flags & ~(OICC_BA_POSITION | OICC_BA_ORIENTATION | OICC_BA_POINTS)) == 0, "unknown flag");
+  const bool points = (flags & OICC_BA_POINTS) != 0;
+  ARG(p, !points || (flags == OICC_BA_POINTS && mask == 0), "OICC_BA_POINTS cannot be combined with other flags or an intrinsics mask");
   int rc = sync(p); if (rc) return rc;
+  out->points = points;
   BaData& d = out->d; std::memset(&d, 0, sizeof(d));
   d.n_views = p->nv; d.n_corners = int64_t(p->pid.size());
-  d.pts = p->d_pts.p; d.u = p->d_u.p; d.v = p->d_v.p; d.pid = p->d_pid.p; d.view_c0 = p->d_c0.p;
+  d.pts_off = 6 * p->nv + kBaIntr; d.u = p->d_u.p; d.v = p->d_v.p; d.pid = p->d_pid.p; d.view_c0 = p->d_c0.p;
   d.chunk_c0 = p->d_chunk_c0.p; d.chunk_n = p->d_chunk_n.p; d.chunk_view = p->d_chunk_view.p; d.n_chunks = int32_t(p->chunk_c0.size());
   d.model = p->model; d.n_intr = p->n_intr;
   int dim = 0;
@@ -120,9 +144,20 @@ int prepare(oicc_ba* p, int flags, int mask, Prepared* out) {
   d.n_arrow = a;
   d.huber = p->opt["huber_width"];
   d.dbg_res = nullptr;
+  d.corner_view = p->d_corner_view.p; d.pobs = p->d_pobs.p; d.pchunk_c0 = p->d_pchunk_c0.p; d.pchunk_n = p->d_pchunk_n.p;
+  d.pchunk_point = p->d_pchunk_point.p; d.n_pchunks = int32_t(p->pchunk_c0.size()); d.n_points = int64_t(p->pts.size() / 4);
+  int n_var3 = 0;
+  if (points) {
+    p->point_tangent.assign(size_t(d.n_points), -1);
+    for (int64_t i = 0; i < d.n_points; ++i) if (p->var_pts.empty() || p->var_pts[size_t(i)]) { p->point_tangent[size_t(i)] = n_var3; n_var3 += 3; }
+    if (!p->d_point_tangent.upload(p->point_tangent, p->stream)) { p->err = "device upload failed"; return OICC_ERR_HIP; }
+    HIPCK(p, hipStreamSynchronize(p->stream));
+  }
+  d.point_tangent = p->d_point_tangent.p;
   TangentLayout& tl = out->tl; std::memset(&tl, 0, sizeof(tl));
   tl.tic = tl.g = tl.ld = tl.ai = tl.gi = -1;
   tl.Pb = int32_t(p->nv) * dim; tl.a = a; tl.P = tl.Pb + a; tl.hb = dim > 0 ? dim - 1 : 0; tl.W = tl.hb + 1;
+  if (points) { tl.Pb = n_var3; tl.a = 0; tl.P = n_var3; tl.hb = n_var3 > 0 ? 2 : 0; tl.W = tl.hb + 1; }
   NormalEq& ne = out->ne;
   const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
   ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
@@ -140,7 +175,8 @@ int eval_pass(oicc_ba* p, const Prepared& P, const double* x, bool jac, bool cos
   hipStream_t st = p->stream;
   if (jac) HIPCK(p, hipMemsetAsync(P.ne.base, 0, P.ne.total * sizeof(double), st));
   else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(P.ne.cost(), 0, sizeof(double), st));
-  launch_ba_blocks(x, P.d, P.tl, P.ne, jac, st);
+  if (P.points) launch_ba_point_blocks(x, P.d, P.tl, P.ne, jac, st);
+  else launch_ba_blocks(x, P.d, P.tl, P.ne, jac, st);
   HIPCK(p, hipGetLastError());
   return OICC_OK;
 }
@@ -160,7 +196,6 @@ int oicc_ba_create(oicc_ba** out, int32_t device_ordinal) {
   if (hipStreamCreate(&p->stream) != hipSuccess) { delete p; return OICC_ERR_HIP; }
   if (hipHostMalloc(reinterpret_cast<void**>(&p->pin), sizeof(*p->pin), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(p->stream); delete p; return OICC_ERR_HIP; }
   std::memset(p->pin, 0, sizeof(*p->pin));
-  p->x.assign(kBaIntr, 0.0);
   *out = p;
   return OICC_OK;
 }
@@ -179,18 +214,24 @@ int oicc_ba_set_camera(oicc_ba* p, int32_t model, const double* intrinsics, int3
   p->model = model; p->n_intr = n; std::memset(p->intr, 0, sizeof(p->intr)); std::memcpy(p->intr, intrinsics, n * sizeof(double));
   p->x_dirty = true; return OICC_OK; }
 int oicc_ba_get_camera(const oicc_ba* p, double* intrinsics, int32_t n) { std::memcpy(intrinsics, p->intr, std::min<int>(n, kBaIntr) * sizeof(double)); return OICC_OK; }
-int oicc_ba_set_scene_points(oicc_ba* p, const double* xyzw, int64_t n) { ARG(p, n >= 0, "bad count"); p->pts.assign(xyzw, xyzw + 4 * n); p->meas_dirty = true; return OICC_OK; }
+int oicc_ba_set_scene_points(oicc_ba* p, const double* xyzw, int64_t n) {
+  ARG(p, n >= 0, "bad count");
+  for (size_t c = 0; c < p->pid.size(); ++c) ARG(p, p->pid[c] < n, "fewer points than the views reference");
+  p->pts.assign(xyzw, xyzw + 4 * n); p->var_pts.clear(); p->meas_dirty = true; p->x_dirty = true; return OICC_OK; }
+int oicc_ba_get_scene_points(const oicc_ba* p, double* xyzw, int64_t n) { std::copy(p->pts.begin(), p->pts.begin() + 4 * std::min<int64_t>(n, int64_t(p->pts.size() / 4)), xyzw); return OICC_OK; }
+int oicc_ba_set_variable_points(oicc_ba* p, const uint8_t* variable, int64_t n) {
+  ARG(p, n * 4 == int64_t(p->pts.size()), "point count mismatch"); p->var_pts.assign(variable, variable + n); return OICC_OK; }
 int oicc_ba_set_views(oicc_ba* p, int64_t nv, const double* pose6, const int64_t* coff, const double* uv, const int32_t* point_ids) {
   ARG(p, nv >= 0 && coff && coff[0] == 0, "bad view table");
   for (int64_t v = 0; v < nv; ++v) ARG(p, coff[v + 1] >= coff[v], "corner offsets must not decrease");
   const int64_t nc = coff[nv];
   for (int64_t c = 0; c < nc; ++c) ARG(p, point_ids[c] >= 0 && size_t(point_ids[c]) * 4 < p->pts.size(), "point id out of range (call oicc_ba_set_scene_points first)");
-  p->nv = nv; p->x.assign(6 * nv + kBaIntr, 0.0); std::copy(pose6, pose6 + 6 * nv, p->x.begin());
+  p->nv = nv; p->pose.assign(pose6, pose6 + 6 * nv);
   p->c0.assign(coff, coff + nv + 1); p->u.resize(nc); p->v.resize(nc); p->pid.assign(point_ids, point_ids + nc);
   for (int64_t c = 0; c < nc; ++c) { p->u[c] = uv[2 * c]; p->v[c] = uv[2 * c + 1]; }
   p->meas_dirty = true; p->x_dirty = true; return OICC_OK; }
-int oicc_ba_set_poses(oicc_ba* p, const double* pose6, int64_t nv) { ARG(p, nv == p->nv, "view count mismatch"); std::copy(pose6, pose6 + 6 * nv, p->x.begin()); p->x_dirty = true; return OICC_OK; }
-int oicc_ba_get_poses(const oicc_ba* p, double* pose6, int64_t nv) { std::copy(p->x.begin(), p->x.begin() + 6 * std::min(nv, p->nv), pose6); return OICC_OK; }
+int oicc_ba_set_poses(oicc_ba* p, const double* pose6, int64_t nv) { ARG(p, nv == p->nv, "view count mismatch"); p->pose.assign(pose6, pose6 + 6 * nv); p->x_dirty = true; return OICC_OK; }
+int oicc_ba_get_poses(const oicc_ba* p, double* pose6, int64_t nv) { std::copy(p->pose.begin(), p->pose.begin() + 6 * std::min(nv, p->nv), pose6); return OICC_OK; }
 
 int oicc_ba_evaluate(oicc_ba* p, int32_t flags, int32_t mask, double* cost, double* H, double* g, int32_t Pcap) {
   Prepared P; int rc = prepare(p, flags, mask, &P); if (rc) return rc;
@@ -222,7 +263,7 @@ int oicc_ba_optimize(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t mask,
   const int P = tl.P;
   oicc_summary S; std::memset(&S, 0, sizeof(S));
   S.num_parameters_tangent = P; S.band_dim = tl.Pb; S.arrow_dim = tl.a; S.half_bandwidth = tl.hb;
-  S.num_residual_blocks = int64_t(p->pid.size()); S.num_residuals = 2 * S.num_residual_blocks;
+  S.num_residual_blocks = int64_t(p->pid.size()); S.num_residuals = 2 * S.num_residual_blocks;   // constant points keep their blocks (cost)
   p->trace.clear();
   const double ftol = p->opt["function_tolerance"], ptol = p->opt["parameter_tolerance"], gtol = p->opt["gradient_tolerance"];
   double radius = p->opt["initial_trust_region_radius"]; const double max_radius = p->opt["max_trust_region_radius"];
@@ -263,7 +304,8 @@ int oicc_ba_optimize(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t mask,
     if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
     t0 = now_s();
     if (launch_lm_solve(ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) { p->err = "linear solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
-    launch_ba_retract(p->d_x.p, p->d_xc.p, PR.d, tl, sb, ne, st);
+    if (PR.points) launch_ba_point_retract(p->d_x.p, p->d_xc.p, PR.d, tl, sb, ne, st);
+    else launch_ba_retract(p->d_x.p, p->d_xc.p, PR.d, tl, sb, ne, st);
     HIPCK(p, hipGetLastError());
     rc = eval_pass(p, PR, p->d_xc.p, false, true); if (rc) return rc;   // ba_retract_kernel cleared the cost slot
     rc = read_back(); if (rc) return rc;
@@ -321,7 +363,7 @@ int oicc_ba_get_iterations(const oicc_ba* p, oicc_iteration* out, int32_t cap) {
 
 int oicc_ba_optimize_views(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t* iterations, double* final_cost) {
   Prepared PR; int rc = prepare(p, flags, 0, &PR); if (rc) return rc;
-  ARG(p, PR.d.pose_dim > 0, "no pose component is variable");
+  ARG(p, !PR.points && PR.d.pose_dim > 0, "no pose component is variable");
   BaLmOptions o{p->opt["function_tolerance"], p->opt["parameter_tolerance"], p->opt["gradient_tolerance"], p->opt["initial_trust_region_radius"],
                 p->opt["max_trust_region_radius"], p->opt["min_trust_region_radius"], p->opt["min_relative_decrease"], p->opt["min_lm_diagonal"],
                 p->opt["max_lm_diagonal"], p->opt["jacobi_scaling"] != 0 ? 1 : 0, int32_t(p->opt["max_num_consecutive_invalid_steps"]), max_iters};

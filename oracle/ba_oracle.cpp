@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <string>
@@ -37,6 +38,7 @@ struct Ba {
   std::string err;
   int model = 0, n_intr = 0; double intr[kMaxIntr] = {0};
   std::vector<double> pts;                 // [np][4]
+  std::vector<uint8_t> var_pts;            // [np] 1 = variable in BundleAdjustTracks (empty: all)
   std::vector<double> pose;                // [nv][6]  position, angle axis
   std::vector<int64_t> c0{0};              // [nv+1]
   std::vector<double> uv; std::vector<int32_t> pid;
@@ -175,15 +177,49 @@ bool solve_damped(const Dense& ne, const std::vector<double>& scale, const std::
   *d = rhs; return true;
 }
 
-// Ceres 2.1 TrustRegionMinimizer [EXT] with the LM strategy, on the views [v0, v1) (+ the shared intrinsics when active)
-int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_summary* sum, std::vector<oicc_iteration>* trace) {
-  Layout L = make_layout(b, flags, mask);   // columns relative to the view range: [poses of v0..v1 | active intrinsics]
-  const int nvs = int(v1 - v0);
-  L.Pb = nvs * L.pose_dim; { int a = 0; for (int k = 0; k < kMaxIntr; ++k) if (L.intr_off[k] >= 0) L.intr_off[k] = L.Pb + a++; L.P = L.Pb + L.a; }
-  const int P = L.P;
+// ---- ceres::HomogeneousVectorParameterization(4) [EXT, ceres/local_parameterization.cc + internal/householder_vector.h]
+void householder_vector(const double x[4], double v[4], double* beta) {
+  const double sigma = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  for (int i = 0; i < 3; ++i) v[i] = x[i];
+  v[3] = 1.0; *beta = 0.0;
+  const double x_pivot = x[3];
+  if (sigma <= std::numeric_limits<double>::epsilon()) { if (x_pivot < 0.0) *beta = 2.0; return; }
+  const double mu = std::sqrt(x_pivot * x_pivot + sigma);
+  double v_pivot = 1.0;
+  if (x_pivot <= 0.0) v_pivot = x_pivot - mu; else v_pivot = -sigma / (x_pivot + mu);
+  *beta = 2.0 * v_pivot * v_pivot / (sigma + v_pivot * v_pivot);
+  for (int i = 0; i < 3; ++i) v[i] /= v_pivot;
+}
+void homogeneous_plus(const double x[4], const double d[3], double out[4]) {
+  const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { for (int i = 0; i < 4; ++i) out[i] = x[i]; return; }
+  const double h = 0.5 * nd, sbd = std::sin(h) / h;
+  const double y[4] = {0.5 * sbd * d[0], 0.5 * sbd * d[1], 0.5 * sbd * d[2], std::cos(h)};
+  double v[4], beta; householder_vector(x, v, &beta);
+  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  const double vy = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
+  for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vy));
+}
+void homogeneous_plus_jacobian(const double x[4], double J[12] /*4x3 row major*/) {
+  double v[4], beta; householder_vector(x, v, &beta);
+  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 3; ++c) J[r * 3 + c] = nx * (-0.5 * beta * v[c] * v[r] + (r == c ? 0.5 : 0.0));
+}
+
+// Ceres 2.1 TrustRegionMinimizer [EXT] with the LM strategy over an abstract problem
+struct LmProblem {
+  int P = 0, band = 0, arrow = 0, hb = 0; int64_t blocks = 0;
+  std::function<void(Dense*)> build;                               // normal equations + cost at the current point
+  std::function<double(bool*)> cost;                               // cost at the current point
+  std::function<double(const std::vector<double>&)> apply;         // x <- x (+) step; returns |x_new - x|^2 (ambient)
+  std::function<void()> save, restore;
+  std::function<double()> x_sq;                                    // ambient squared norm over the non-constant blocks
+};
+int lm_run(Ba& b, LmProblem& pr, int max_iters, oicc_summary* sum, std::vector<oicc_iteration>* trace) {
+  const int P = pr.P;
   oicc_summary S; std::memset(&S, 0, sizeof(S));
-  S.num_parameters_tangent = P; S.band_dim = L.Pb; S.arrow_dim = L.a; S.half_bandwidth = L.pose_dim > 0 ? L.pose_dim - 1 : 0;
-  S.num_residual_blocks = b.c0[v1] - b.c0[v0]; S.num_residuals = 2 * S.num_residual_blocks;
+  S.num_parameters_tangent = P; S.band_dim = pr.band; S.arrow_dim = pr.arrow; S.half_bandwidth = pr.hb;
+  S.num_residual_blocks = pr.blocks; S.num_residuals = 2 * pr.blocks;
   if (trace) trace->clear();
   const double ftol = b.opt["function_tolerance"], ptol = b.opt["parameter_tolerance"], gtol = b.opt["gradient_tolerance"];
   double radius = b.opt["initial_trust_region_radius"]; const double max_radius = b.opt["max_trust_region_radius"];
@@ -194,10 +230,9 @@ int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_s
   auto finish = [&](int term, const char* msg, double cost, double gmax) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax; std::snprintf(S.message, sizeof(S.message), "%s", msg);
     if (sum) *sum = S; return OICC_OK; };
-  auto build_range = [&](Dense* ne) { build(b, L, v0, v1, ne); };
   bool okc = true;
-  if (P == 0) { const double c = total_cost(b, v0, v1, &okc); S.initial_cost = c; return finish(OICC_CONVERGENCE, "no variable parameters", c, 0.0); }
-  Dense ne; build_range(&ne);
+  if (P == 0) { const double c = pr.cost(&okc); S.initial_cost = c; return finish(OICC_CONVERGENCE, "no variable parameters", c, 0.0); }
+  Dense ne; pr.build(&ne);
   if (!ne.ok) { b.err = "residual evaluation failed at the initial point"; return OICC_ERR_STATE; }
   double cost = ne.cost; S.initial_cost = cost;
   std::vector<double> scale(P, 1.0);
@@ -206,11 +241,8 @@ int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_s
   double gmax = grad_max();
   if (trace) trace->push_back(oicc_iteration{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius});
   if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.", cost, gmax);
-  // ambient norm over the non-constant parameter blocks (whole blocks, SubsetParameterization keeps the ambient size)
-  auto x_sq = [&]() { double s = 0; if (L.pose_dim > 0) for (int64_t v = v0; v < v1; ++v) for (int k = 0; k < 6; ++k) s += b.pose[6 * v + k] * b.pose[6 * v + k];
-    if (L.a > 0) for (int k = 0; k < b.n_intr; ++k) s += b.intr[k] * b.intr[k]; return s; };
-  double x_norm = std::sqrt(x_sq());
-  std::vector<double> diag(P), D2(P), step_s(P);
+  double x_norm = std::sqrt(pr.x_sq());
+  std::vector<double> diag(P), D2(P), step_s(P), step(P);
   int iter = 0, invalid = 0;
   while (true) {
     if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.", cost, gmax);
@@ -228,33 +260,102 @@ int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_s
       continue;
     }
     invalid = 0;
-    const std::vector<double> pose0(b.pose.begin() + 6 * v0, b.pose.begin() + 6 * v1); double intr0[kMaxIntr]; std::memcpy(intr0, b.intr, sizeof(intr0));
-    double step_sq = 0.0;
-    for (int64_t v = v0; v < v1; ++v) for (int g = 0; g < 2; ++g) if (L.pose_off[g] >= 0) for (int k = 0; k < 3; ++k) {
-      const int col = int(v - v0) * L.pose_dim + L.pose_off[g] + k; const double d = step_s[col] * scale[col];
-      const double x0 = b.pose[6 * v + 3 * g + k]; const double x1 = x0 + d; b.pose[6 * v + 3 * g + k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
-    for (int k = 0; k < b.n_intr; ++k) if (L.intr_off[k] >= 0) { const int col = L.intr_off[k]; const double x0 = b.intr[k]; const double x1 = x0 + step_s[col] * scale[col]; b.intr[k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
-    auto restore = [&]() { std::copy(pose0.begin(), pose0.end(), b.pose.begin() + 6 * v0); std::memcpy(b.intr, intr0, sizeof(intr0)); };
-    bool cand_ok = true; double cand_cost = total_cost(b, v0, v1, &cand_ok);
+    for (int i = 0; i < P; ++i) step[i] = step_s[i] * scale[i];
+    pr.save();
+    const double step_sq = pr.apply(step);
+    bool cand_ok = true; double cand_cost = pr.cost(&cand_ok);
     if (!cand_ok) cand_cost = std::numeric_limits<double>::max();   // Ceres: failed evaluation = step rejected
     const double step_norm = std::sqrt(step_sq), cost_change = cost - cand_cost, rel_dec = cost_change / model;
-    if (step_norm <= ptol * (x_norm + ptol)) { restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
+    if (step_norm <= ptol * (x_norm + ptol)) { pr.restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
       return finish(OICC_CONVERGENCE, "Parameter tolerance reached.", cost, gmax); }
-    if (std::fabs(cost_change) <= ftol * cost) { restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
+    if (std::fabs(cost_change) <= ftol * cost) { pr.restore(); if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
       return finish(OICC_CONVERGENCE, "Function tolerance reached.", cost, gmax); }
     if (rel_dec > min_rel_dec) {
-      cost = cand_cost; x_norm = std::sqrt(x_sq());
-      build_range(&ne); gmax = grad_max(); ++S.num_successful_steps;
+      cost = cand_cost; x_norm = std::sqrt(pr.x_sq());
+      pr.build(&ne); gmax = grad_max(); ++S.num_successful_steps;
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel_dec - 1.0, 3));
       radius = std::min(max_radius, radius); decrease_factor = 2.0; reuse_diagonal = false;
       if (trace) trace->push_back(oicc_iteration{iter, 1, cost, cost_change, gmax, step_norm, rel_dec, radius});
       if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.", cost, gmax);
     } else {
-      restore(); ++S.num_unsuccessful_steps;
+      pr.restore(); ++S.num_unsuccessful_steps;
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
       if (trace) trace->push_back(oicc_iteration{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius});
     }
   }
+}
+
+// theia::BundleAdjustViews / BundleAdjustView over the views [v0, v1) (+ the shared intrinsics when active)
+int lm(Ba& b, int flags, int mask, int64_t v0, int64_t v1, int max_iters, oicc_summary* sum, std::vector<oicc_iteration>* trace) {
+  Layout L = make_layout(b, flags, mask);   // columns relative to the view range: [poses of v0..v1 | active intrinsics]
+  const int nvs = int(v1 - v0);
+  L.Pb = nvs * L.pose_dim; { int a = 0; for (int k = 0; k < kMaxIntr; ++k) if (L.intr_off[k] >= 0) L.intr_off[k] = L.Pb + a++; L.P = L.Pb + L.a; }
+  LmProblem pr;
+  pr.P = L.P; pr.band = L.Pb; pr.arrow = L.a; pr.hb = L.pose_dim > 0 ? L.pose_dim - 1 : 0; pr.blocks = b.c0[v1] - b.c0[v0];
+  std::vector<double> pose0; double intr0[kMaxIntr];
+  pr.build = [&](Dense* ne) { build(b, L, v0, v1, ne); };
+  pr.cost = [&](bool* ok) { return total_cost(b, v0, v1, ok); };
+  pr.save = [&]() { pose0.assign(b.pose.begin() + 6 * v0, b.pose.begin() + 6 * v1); std::memcpy(intr0, b.intr, sizeof(intr0)); };
+  pr.restore = [&]() { std::copy(pose0.begin(), pose0.end(), b.pose.begin() + 6 * v0); std::memcpy(b.intr, intr0, sizeof(intr0)); };
+  pr.apply = [&](const std::vector<double>& step) {
+    double step_sq = 0.0;
+    for (int64_t v = v0; v < v1; ++v) for (int g = 0; g < 2; ++g) if (L.pose_off[g] >= 0) for (int k = 0; k < 3; ++k) {
+      const int col = int(v - v0) * L.pose_dim + L.pose_off[g] + k;
+      const double x0 = b.pose[6 * v + 3 * g + k]; const double x1 = x0 + step[col]; b.pose[6 * v + 3 * g + k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
+    for (int k = 0; k < b.n_intr; ++k) if (L.intr_off[k] >= 0) { const double x0 = b.intr[k]; const double x1 = x0 + step[L.intr_off[k]]; b.intr[k] = x1; step_sq += (x1 - x0) * (x1 - x0); }
+    return step_sq; };
+  // ambient norm over the non-constant parameter blocks (whole blocks, SubsetParameterization keeps the ambient size)
+  pr.x_sq = [&]() { double s = 0; if (L.pose_dim > 0) for (int64_t v = v0; v < v1; ++v) for (int k = 0; k < 6; ++k) s += b.pose[6 * v + k] * b.pose[6 * v + k];
+    if (L.a > 0) for (int k = 0; k < b.n_intr; ++k) s += b.intr[k] * b.intr[k]; return s; };
+  return lm_run(b, pr, max_iters, sum, trace);
+}
+
+// theia::BundleAdjustTracks [EXT]: the variable board points (homogeneous, HomogeneousVectorParameterization), every camera
+// constant (camera_calibrator.cc:207-213, pose_estimator.cc:192-224)
+struct PointLayout { std::vector<int> off; int P = 0; };
+PointLayout point_layout(const Ba& b) {
+  PointLayout L; const int64_t np = int64_t(b.pts.size() / 4); L.off.assign(np, -1);
+  for (int64_t i = 0; i < np; ++i) if (b.var_pts.empty() || b.var_pts[i]) { L.off[i] = L.P; L.P += 3; }
+  return L;
+}
+void build_points(const Ba& b, const PointLayout& L, Dense* ne) {
+  ne->P = L.P; ne->H.assign(size_t(L.P) * L.P, 0.0); ne->g.assign(L.P, 0.0); ne->cost = 0; ne->ok = true;
+  const double hw = b.opt.at("huber_width");
+  for (int64_t v = 0; v < b.nv(); ++v)
+    for (int64_t c = b.c0[v]; c < b.c0[v + 1]; ++c) {
+      double r[2], J[2 * NJ];
+      if (!eval_obs(b, v, c, r, J)) { ne->ok = false; continue; }
+      double rho, s1; huber_eval(hw, r[0] * r[0] + r[1] * r[1], &rho, &s1);
+      ne->cost += 0.5 * rho;
+      const int o = L.off[b.pid[c]];
+      if (o < 0) continue;
+      double Jp[12]; homogeneous_plus_jacobian(&b.pts[4 * (int64_t)b.pid[c]], Jp);
+      double jr[2][3];
+      for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) { double t = 0; for (int m = 0; m < 4; ++m) t += J[k * NJ + 6 + kMaxIntr + m] * Jp[m * 3 + j]; jr[k][j] = s1 * t; }
+      for (int i = 0; i < 3; ++i) {
+        ne->g[o + i] += jr[0][i] * s1 * r[0] + jr[1][i] * s1 * r[1];
+        for (int j = 0; j < 3; ++j) ne->H[size_t(o + i) * ne->P + o + j] += jr[0][i] * jr[0][j] + jr[1][i] * jr[1][j];
+      }
+    }
+}
+int lm_points(Ba& b, int max_iters, oicc_summary* sum, std::vector<oicc_iteration>* trace) {
+  const PointLayout L = point_layout(b);
+  LmProblem pr;
+  pr.P = L.P; pr.band = L.P; pr.arrow = 0; pr.hb = L.P > 0 ? 2 : 0; pr.blocks = b.c0[b.nv()];
+  std::vector<double> pts0;
+  pr.build = [&](Dense* ne) { build_points(b, L, ne); };
+  pr.cost = [&](bool* ok) { return total_cost(b, 0, b.nv(), ok); };
+  pr.save = [&]() { pts0 = b.pts; };
+  pr.restore = [&]() { b.pts = pts0; };
+  pr.apply = [&](const std::vector<double>& step) {
+    double step_sq = 0.0;
+    for (size_t i = 0; i < L.off.size(); ++i) if (L.off[i] >= 0) {
+      double out[4]; homogeneous_plus(&b.pts[4 * i], &step[L.off[i]], out);
+      for (int k = 0; k < 4; ++k) { step_sq += (out[k] - b.pts[4 * i + k]) * (out[k] - b.pts[4 * i + k]); b.pts[4 * i + k] = out[k]; }
+    }
+    return step_sq; };
+  pr.x_sq = [&]() { double s = 0; for (size_t i = 0; i < L.off.size(); ++i) if (L.off[i] >= 0) for (int k = 0; k < 4; ++k) s += b.pts[4 * i + k] * b.pts[4 * i + k]; return s; };
+  return lm_run(b, pr, max_iters, sum, trace);
 }
 
 }  // namespace
@@ -274,7 +375,11 @@ int oicc_oracle_ba_set_camera(oicc_ba* prob, int32_t model, const double* intr, 
   if (n < 0 || n > kMaxIntr) { B_.err = "too many intrinsics"; return OICC_ERR_INVALID_ARG; }
   B_.model = model; B_.n_intr = n; std::memset(B_.intr, 0, sizeof(B_.intr)); std::memcpy(B_.intr, intr, n * sizeof(double)); return OICC_OK; }
 int oicc_oracle_ba_get_camera(const oicc_ba* prob, double* intr, int32_t n) { std::memcpy(intr, prob->b.intr, std::min<int>(n, kMaxIntr) * sizeof(double)); return OICC_OK; }
-int oicc_oracle_ba_set_scene_points(oicc_ba* prob, const double* xyzw, int64_t n) { B_.pts.assign(xyzw, xyzw + 4 * n); return OICC_OK; }
+int oicc_oracle_ba_set_scene_points(oicc_ba* prob, const double* xyzw, int64_t n) { B_.pts.assign(xyzw, xyzw + 4 * n); B_.var_pts.clear(); return OICC_OK; }
+int oicc_oracle_ba_get_scene_points(const oicc_ba* prob, double* xyzw, int64_t n) { std::copy(prob->b.pts.begin(), prob->b.pts.begin() + 4 * n, xyzw); return OICC_OK; }
+int oicc_oracle_ba_set_variable_points(oicc_ba* prob, const uint8_t* mask, int64_t n) {
+  if (n * 4 != int64_t(B_.pts.size())) { B_.err = "point count mismatch"; return OICC_ERR_INVALID_ARG; }
+  B_.var_pts.assign(mask, mask + n); return OICC_OK; }
 int oicc_oracle_ba_set_views(oicc_ba* prob, int64_t nv, const double* pose6, const int64_t* coff, const double* uv, const int32_t* pid) {
   B_.pose.assign(pose6, pose6 + 6 * nv); B_.c0.assign(coff, coff + nv + 1);
   const int64_t nc = coff[nv]; B_.uv.assign(uv, uv + 2 * nc); B_.pid.assign(pid, pid + nc);
@@ -284,6 +389,16 @@ int oicc_oracle_ba_set_poses(oicc_ba* prob, const double* pose6, int64_t nv) { i
 int oicc_oracle_ba_get_poses(const oicc_ba* prob, double* pose6, int64_t nv) { std::copy(prob->b.pose.begin(), prob->b.pose.begin() + 6 * nv, pose6); return OICC_OK; }
 
 int oicc_oracle_ba_evaluate(oicc_ba* prob, int32_t flags, int32_t mask, double* cost, double* H, double* g, int32_t Pcap) {
+  if (flags & OICC_BA_POINTS) {
+    if (flags != OICC_BA_POINTS || mask != 0) { B_.err = "OICC_BA_POINTS cannot be combined"; return OICC_ERR_INVALID_ARG; }
+    const PointLayout PL = point_layout(B_);
+    if (PL.P > Pcap) { B_.err = "Pcap too small"; return OICC_ERR_INVALID_ARG; }
+    Dense ne; build_points(B_, PL, &ne);
+    if (cost) *cost = ne.cost;
+    if (H) for (int i = 0; i < PL.P; ++i) for (int j = 0; j < PL.P; ++j) H[size_t(i) * Pcap + j] = ne.H[size_t(i) * PL.P + j];
+    if (g) std::copy(ne.g.begin(), ne.g.end(), g);
+    return ne.ok ? OICC_OK : OICC_ERR_STATE;
+  }
   const Layout L = make_layout(B_, flags, mask);
   if (L.P > Pcap) { B_.err = "Pcap too small"; return OICC_ERR_INVALID_ARG; }
   Dense ne; build(B_, L, 0, B_.nv(), &ne);
@@ -293,6 +408,10 @@ int oicc_oracle_ba_evaluate(oicc_ba* prob, int32_t flags, int32_t mask, double* 
   return ne.ok ? OICC_OK : OICC_ERR_STATE;
 }
 int oicc_oracle_ba_optimize(oicc_ba* prob, int32_t max_iters, int32_t flags, int32_t mask, oicc_summary* sum) {
+  if (flags & OICC_BA_POINTS) {
+    if (flags != OICC_BA_POINTS || mask != 0) { B_.err = "OICC_BA_POINTS cannot be combined"; return OICC_ERR_INVALID_ARG; }
+    return lm_points(B_, max_iters, sum, &B_.trace);
+  }
   return lm(B_, flags, mask, 0, B_.nv(), max_iters, sum, &B_.trace); }
 int oicc_oracle_ba_get_iterations(const oicc_ba* prob, oicc_iteration* out, int32_t cap) {
   const int n = std::min<int>(cap, int(prob->b.trace.size())); std::copy(prob->b.trace.begin(), prob->b.trace.begin() + n, out); return n; }
@@ -315,6 +434,32 @@ int oicc_oracle_ba_view_reprojection_errors(oicc_ba* prob, double* mean_px) {
   }
   return OICC_OK;
 }
+
+// tangent rows of every observation w.r.t. its board point (2 x 3): Jets * plus-Jacobian vs the product's closed forms; and (+) itself
+int oicc_oracle_ba_point_rows(oicc_ba* prob, int32_t analytic, double* jac /*2 nc x 3*/) {
+  for (int64_t v = 0; v < B_.nv(); ++v) {
+    double R[9], Jr[9];
+    oicc::angle_axis_matrix(&B_.pose[6 * v + 3], R); oicc::so3_Jr(&B_.pose[6 * v + 3], Jr);
+    for (int64_t c = B_.c0[v]; c < B_.c0[v + 1]; ++c) {
+      const double* X = &B_.pts[4 * (int64_t)B_.pid[c]];
+      double* Jo = jac + size_t(2 * c) * 3;
+      if (analytic) {
+        double px[2], Jp[12], Ji[2 * oicc::kBaMaxIntr], JX[8];
+        if (!oicc::ba_observation<true>(B_.model, B_.intr, &B_.pose[6 * v], R, Jr, X, px, Jp, Ji, JX)) return OICC_ERR_STATE;
+        oicc::homogeneous_tangent_rows(X, JX, Jo);
+      } else {
+        double r[2], J[2 * NJ], P[12];
+        if (!eval_obs(B_, v, c, r, J)) return OICC_ERR_STATE;
+        homogeneous_plus_jacobian(X, P);
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) { double t = 0; for (int m = 0; m < 4; ++m) t += J[k * NJ + 6 + kMaxIntr + m] * P[m * 3 + j]; Jo[k * 3 + j] = t; }
+      }
+    }
+  }
+  return OICC_OK;
+}
+void oicc_oracle_ba_plus_product(const double* x, const double* d, double* out) { oicc::homogeneous_plus4(x, d, out); }
+
+void oicc_oracle_ba_plus(const double* x, const double* d, double* out) { homogeneous_plus(x, d, out); }
 
 // ---- cross-check hooks (tests): per-observation residuals and Jacobians [pose 6 | intr 10], Jets vs the product's formulas
 int oicc_oracle_ba_rows(oicc_ba* prob, int32_t analytic, double* res /*2 nc*/, double* jac /*2 nc x 16*/) {

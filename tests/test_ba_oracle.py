@@ -140,3 +140,112 @@ def test_optimize_views_refines_every_pose_independently():
     assert np.abs(ba2.GetPoses() - p_ind).max() < 1e-4
     err = ba.ViewReprojectionErrors()
     assert err.shape == (8,) and np.all(err < 0.5)
+
+
+def test_householder_parameterization_of_the_board_points():
+    """HomogeneousVectorParameterization: x (+) 0 = x, |x (+) d| = |x|, the tangent Jacobian is the derivative of
+    (+) at 0; normal equations of OICC_BA_POINTS are the Gram matrix of J_X * that Jacobian."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=6, corners_per_view=30)
+    pts = ds["points"].copy()
+    pts[:, 2] += 0.002 * np.sin(np.arange(48))          # a slightly warped board
+    pts *= np.linspace(0.5, 2.0, 48)[:, None]            # arbitrary homogeneous scales
+    ba = _adjuster(dict(ds, points=pts), pose=ds["pose_true"])
+    ba.SetOption("huber_width", 0.0)
+    cost, H, g = ba.Evaluate(CC.BA_POINTS, 0)
+    assert H.shape == (144, 144)
+    for i in range(48):                                   # block diagonal: points do not interact
+        blk = H[3 * i:3 * i + 3]
+        assert np.all(np.delete(blk, slice(3 * i, 3 * i + 3), axis=1) == 0.0)
+    # finite differences of the cost along the tangent of point 7 through (+): g = d cost / d delta
+    lib = ba.b.raw
+    lib.oicc_oracle_ba_plus.argtypes = [_abi.c_dp, _abi.c_dp, _abi.c_dp]
+    x = pts[7].copy(); out = np.zeros(4)
+    for k in range(3):
+        d = np.zeros(3); d[k] = 1e-6
+        cs = []
+        for sgn in (+1, -1):
+            lib.oicc_oracle_ba_plus(x.ctypes.data_as(_abi.c_dp), (sgn * d).ctypes.data_as(_abi.c_dp), out.ctypes.data_as(_abi.c_dp))
+            assert abs(np.linalg.norm(out) - np.linalg.norm(x)) < 1e-12
+            p2 = pts.copy(); p2[7] = out
+            b2 = _adjuster(dict(ds, points=p2), pose=ds["pose_true"]); b2.SetOption("huber_width", 0.0)
+            cs.append(b2.Evaluate(CC.BA_POINTS, 0)[0])
+        assert abs((cs[0] - cs[1]) / 2e-6 - g[21 + k]) < 1e-5 * (abs(g[21 + k]) + 1.0)
+
+
+def test_bundle_adjust_tracks_flattens_a_warped_board_estimate():
+    """BundleAdjustTracks: observations of the true (planar) board, board estimate perturbed by 0.5 mm -> points return."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=40, corners_per_view=40, noise_px=0.05)
+    rng = np.random.default_rng(3)
+    pts = ds["points"].copy()
+    pts[:, :3] += rng.normal(0, 5e-4, (48, 3))
+    ba = _adjuster(dict(ds, points=pts), pose=ds["pose_true"])
+    mask = np.ones(48, dtype=np.uint8); mask[:4] = 0
+    ba.SetVariablePoints(mask)
+    s = ba.Optimize(50, CC.BA_POINTS, 0)
+    assert s["termination"] == 0 and s["num_parameters_tangent"] == 3 * 44 and s["final_cost"] < 0.2 * s["initial_cost"]
+    out = ba.GetScenePoints()
+    assert np.array_equal(out[:4], pts[:4])                                   # constant points untouched
+    e0 = np.linalg.norm(pts[4:, :3] / pts[4:, 3:] - ds["points"][4:, :3], axis=1)
+    e1 = np.linalg.norm(out[4:, :3] / out[4:, 3:] - ds["points"][4:, :3], axis=1)
+    assert e1.mean() < 0.3 * e0.mean()
+    with pytest.raises(RuntimeError):
+        ba.Optimize(5, CC.BA_POINTS | CC.BA_POSITION, 0)
+
+
+def test_point_tangent_rows_and_plus_of_the_product_match_the_oracle():
+    ds = CC.make_calibration_dataset("gopro6_double_sphere", num_views=5, corners_per_view=30)
+    pts = ds["points"].copy()
+    pts[:, 2] += 0.003 * np.cos(np.arange(48)); pts *= np.linspace(0.5, 2.0, 48)[:, None]
+    ba = _adjuster(dict(ds, points=pts), pose=ds["pose_true"])
+    lib = ba.b.raw
+    lib.oicc_oracle_ba_point_rows.argtypes = [_abi.HB, _abi.C.c_int32, _abi.c_dp]
+    nc = len(ds["uv"])
+    Jj = np.zeros((2 * nc, 3)); Ja = np.zeros((2 * nc, 3))
+    assert lib.oicc_oracle_ba_point_rows(ba.h, 0, Jj.ctypes.data_as(_abi.c_dp)) == 0
+    assert lib.oicc_oracle_ba_point_rows(ba.h, 1, Ja.ctypes.data_as(_abi.c_dp)) == 0
+    assert np.abs(Jj - Ja).max() < 1e-9 * np.abs(Jj).max()
+    for f in (lib.oicc_oracle_ba_plus, lib.oicc_oracle_ba_plus_product):
+        f.argtypes = [_abi.c_dp, _abi.c_dp, _abi.c_dp]
+    rng = np.random.default_rng(1)
+    for x in list(pts[[0, 5, 47]]) + [np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 0.0, -2.0]), np.array([0.3, -0.2, 0.1, -1.5])]:   # incl. the x_pivot <= 0 branches
+        for d in (rng.normal(0, 0.1, 3), np.zeros(3), rng.normal(0, 1e-9, 3)):
+            a = np.zeros(4); b = np.zeros(4); x = np.ascontiguousarray(x); d = np.ascontiguousarray(d)
+            lib.oicc_oracle_ba_plus(x.ctypes.data_as(_abi.c_dp), d.ctypes.data_as(_abi.c_dp), a.ctypes.data_as(_abi.c_dp))
+            lib.oicc_oracle_ba_plus_product(x.ctypes.data_as(_abi.c_dp), d.ctypes.data_as(_abi.c_dp), b.ctypes.data_as(_abi.c_dp))
+            assert np.abs(a - b).max() < 1e-14 * max(1.0, np.abs(x).max())
+
+
+def test_camera_calibrator_with_board_point_refinement():
+    """optimize_board_pts (camera_calibrator.cc:207-216): a board that is really bowed by 1 mm, modelled as flat -> the
+    point refinement recovers the bow (up to the gauge the fixed cameras leave) and lowers the reprojection error."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=30, corners_per_view=40, noise_px=0.05)
+    true_pts = ds["points"].copy()
+    xy = true_pts[:, :2] - true_pts[:, :2].mean(0)
+    true_pts[:, 2] = 0.15 * (xy ** 2).sum(1)                    # ~1.2 mm sag at the corners of the 0.15 m board
+    # re-project the observations from the bowed board
+    from openimucameracalibrator_amd import synthetic as S
+    uv = ds["uv"].copy()
+    rng = np.random.default_rng(0)
+    for v in range(30):
+        a, b = ds["corner_offset"][v], ds["corner_offset"][v + 1]
+        R = CC.angle_axis_to_rotation(ds["pose_true"][v, 3:])
+        pc = (true_pts[ds["point_ids"][a:b], :3] - ds["pose_true"][v, :3]) @ R.T
+        uv[a:b] = S.project(ds["model"], ds["intrinsics"], pc)[0] + rng.normal(0, 0.05, (b - a, 2))
+    res = {}
+    for refine in (False, True):
+        cal = CC.CameraCalibrator("PINHOLE", optimize_board_pts=refine, backend=oracle_backend.load_ba())
+        cal.SetScenePoints(ds["points"])                          # the flat model
+        for v in range(30):
+            vid = cal.AddView(CC.angle_axis_to_rotation(ds["pose_init"][v, 3:]), ds["pose_init"][v, :3], ds["intrinsics"][0] * 1.03, 0.0,
+                              ds["width"], ds["height"], 0.1 * v)
+            for c in range(ds["corner_offset"][v], ds["corner_offset"][v + 1]):
+                cal.AddObservation(vid, ds["point_ids"][c], uv[c])
+        assert cal.RunCalibration()
+        res[refine] = (cal.TotalReprojectionError(), cal.points.copy(), len(cal.summaries))
+    assert res[True][2] == res[False][2] + 2
+    assert res[True][0] < 0.6 * res[False][0]
+    z = res[True][1][:, 2] / res[True][1][:, 3]
+    A = np.c_[xy, np.ones(48)]                                    # remove the plane the gauge leaves free
+    zr = z - A @ np.linalg.lstsq(A, z, rcond=None)[0]
+    tr = true_pts[:, 2] - A @ np.linalg.lstsq(A, true_pts[:, 2], rcond=None)[0]
+    assert np.corrcoef(zr, tr)[0, 1] > 0.95 and np.abs(zr - tr).max() < 0.6 * np.abs(tr).max()   # a bowl trades off with radial distortion: the shape comes back, not all of its depth

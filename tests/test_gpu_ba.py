@@ -216,3 +216,86 @@ def test_estimate_camera_poses_application_on_device():
     tc, pc, _, ec = APP2.estimate_poses_from_json(sc, ds["model"], ds["intrinsics"], ds["height"], backend=oracle_backend.load_ba())
     assert tg == tc and len(tg) >= 55
     assert np.abs(pg - pc).max() < 1e-8 and np.abs(eg - ec).max() < 1e-6
+
+
+def _warped(ds, seed=3, sigma=5e-4):
+    rng = np.random.default_rng(seed)
+    pts = ds["points"].copy()
+    pts[:, :3] += rng.normal(0, sigma, (48, 3))
+    pts *= np.linspace(0.7, 1.6, 48)[:, None]            # arbitrary homogeneous scales
+    return dict(ds, points=pts)
+
+
+def test_bundle_adjust_tracks_normal_equations_and_lm():
+    """OICC_BA_POINTS (theia::BundleAdjustTracks): board points variable under the homogeneous-vector parameterisation,
+    cameras constant; normal equations (3x3 blocks on the band) and the whole LM run against the oracle, with a subset of
+    the points held constant and with points seen in more than 64 views (several chunks per point)."""
+    ds = _warped(CC.make_calibration_dataset("gopro9_eucm", num_views=90, corners_per_view=40, noise_px=0.05, outlier_fraction=0.03))
+    gpu, cpu = pair(ds, pose=ds["pose_true"])
+    assert np.bincount(ds["point_ids"]).max() > 64
+    mask = np.ones(48, dtype=np.uint8); mask[[0, 7, 47]] = 0
+    for b in (gpu, cpu):
+        b.SetVariablePoints(mask)
+    cg, Hg, gg = gpu.Evaluate(CC.BA_POINTS, 0)
+    cc, Hc, gc = cpu.Evaluate(CC.BA_POINTS, 0)
+    assert Hg.shape == (135, 135)
+    assert abs(cg - cc) <= 1e-12 * cc
+    d = np.sqrt(np.abs(np.diag(Hc))) + 1e-300
+    assert (np.abs(Hg - Hc) / np.outer(d, d)).max() < 1e-10
+    assert (np.abs(gg - gc) / (d * np.sqrt(2 * cc))).max() < 1e-10
+    sg = gpu.Optimize(50, CC.BA_POINTS, 0); sc = cpu.Optimize(50, CC.BA_POINTS, 0)
+    assert sg["num_iterations"] == sc["num_iterations"] and sg["termination"] == sc["termination"] == 0
+    assert [i["step_is_successful"] for i in gpu.Iterations()] == [i["step_is_successful"] for i in cpu.Iterations()]
+    assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-9 * sc["final_cost"]
+    pg, pc = gpu.GetScenePoints(), cpu.GetScenePoints()
+    assert np.abs(pg - pc).max() < 1e-9
+    assert np.array_equal(pg[[0, 7, 47]], ds["points"][[0, 7, 47]])
+    assert sg["final_cost"] < 0.8 * sg["initial_cost"] and sg["half_bandwidth"] == 2 and sg["arrow_dim"] == 0
+    with pytest.raises(RuntimeError):
+        gpu.Optimize(5, CC.BA_POINTS | CC.BA_ORIENTATION, 0)
+
+
+def test_calibration_with_board_point_refinement_matches_oracle():
+    """CameraCalibrator(optimize_board_pts=True): stages 1-3, BundleAdjustTracks, BundleAdjustViews (camera_calibrator.cc:207-216)."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=30, corners_per_view=40, noise_px=0.1)
+    ds = dict(ds, points=_warped(ds, sigma=3e-4)["points"] / np.linspace(0.7, 1.6, 48)[:, None])    # w = 1 again
+    cals = []
+    for backend in (None, oracle_backend.load_ba()):
+        cal = CC.CameraCalibrator("PINHOLE", optimize_board_pts=True, backend=backend)
+        cal.SetScenePoints(ds["points"])
+        for v in range(30):
+            vid = cal.AddView(CC.angle_axis_to_rotation(ds["pose_init"][v, 3:]), ds["pose_init"][v, :3], ds["intrinsics"][0] * 1.04, 0.0,
+                              ds["width"], ds["height"], 0.1 * v)
+            for c in range(ds["corner_offset"][v], ds["corner_offset"][v + 1]):
+                cal.AddObservation(vid, ds["point_ids"][c], ds["uv"][c])
+        assert cal.RunCalibration()
+        cals.append(cal)
+    g, c = cals
+    assert len(g.summaries) == 5 and [s["num_iterations"] for s in g.summaries] == [s["num_iterations"] for s in c.summaries]
+    assert np.abs(g.GetIntrinsics() - c.GetIntrinsics()).max() <= 1e-6 * np.abs(c.GetIntrinsics()).max()
+    assert np.abs(g.points - c.points).max() < 1e-8
+    assert g.summaries[3]["final_cost"] < g.summaries[3]["initial_cost"]
+
+
+def test_pose_estimator_board_point_refinement():
+    """PoseEstimator::OptimizeBoardPoints (tracks with more than 30 observations) followed by OptimizeAllPoses."""
+    ds = _warped(CC.make_calibration_dataset("pinhole", num_views=45, corners_per_view=36, noise_px=0.05, pose_noise=(0.003, 0.003)), sigma=3e-4)
+    pts = ds["points"] / ds["points"][:, 3:]
+    f, cx, cy = ds["intrinsics"][0], ds["intrinsics"][3], ds["intrinsics"][4]
+    out = []
+    for backend in (None, oracle_backend.load_ba()):
+        pe = CC.PoseEstimator(backend=backend)
+        pe.SetScenePoints(pts)
+        for v in range(45):
+            a, b = ds["corner_offset"][v], ds["corner_offset"][v + 1]
+            pe.AddView(CC.angle_axis_to_rotation(ds["pose_init"][v, 3:]), ds["pose_init"][v, :3], 0.1 * v, ds["point_ids"][a:b], (ds["uv"][a:b] - [cx, cy]) / f)
+        pe.OptimizeAllPoses()
+        s = pe.OptimizeBoardPoints()
+        it, fc = pe.OptimizeAllPoses()
+        out.append((s, pe.points.copy(), pe.Poses().copy(), it))
+    (sg, pg, qg, ig), (sc, pc, qc, ic) = out
+    counts = np.bincount(ds["point_ids"], minlength=48)
+    assert sg["num_parameters_tangent"] == 3 * int((counts > 30).sum()) > 0
+    assert sg["num_iterations"] == sc["num_iterations"]
+    assert np.abs(pg - pc).max() < 1e-9 and np.abs(qg - qc).max() < 1e-8 and np.array_equal(ig, ic)
+    assert np.array_equal(pg[counts <= 30], pts[counts <= 30])
