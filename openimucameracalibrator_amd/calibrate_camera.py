@@ -22,7 +22,8 @@ def str2bool(v):
     return str(v).lower() in ("1", "true", "yes", "on", "")
 
 
-def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path="", verbose=False, device=0, backend=None):
+def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path="", verbose=False, device=0, backend=None,
+                               optimize_board_points=False):
     """CalibrateCameraFromJson, camera_calibrator.cc:221-377.  Returns the CameraCalibrator (or None on failure)."""
     ids = sorted(int(k) for k in scene["scene_pts"])
     index = {k: i for i, k in enumerate(ids)}
@@ -42,7 +43,7 @@ def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path=
     if not views:
         return None
     f0 = float(np.median([v[3] for v in views]))
-    cal = CC.CameraCalibrator(camera_model, device=device, backend=backend)
+    cal = CC.CameraCalibrator(camera_model, optimize_board_pts=optimize_board_points, device=device, backend=backend)
     if verbose:
         cal.SetVerbose()
     cal.SetScenePoints(points)
@@ -69,10 +70,10 @@ def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path=
     total = cal.TotalReprojectionError()
     print("Final camera calibration reprojection error: %s from %d view." % (total, cal.NumViews()))
     if output_path:
-        io_files.write_pose_dataset(output_path + ".calibdata.json", cal.views.t_s, cal.views.pose, points)
+        io_files.write_pose_dataset(output_path + ".calibdata.json", cal.views.t_s, cal.views.pose, cal.points)
         io_files.write_camera_calibration(output_path + ".json", cal.model, cal.GetIntrinsics(), w, h, scene.get("camera_fps", 0.0),
                                           cal.NumViews(), total)
-        io_files.write_ply_cameras(output_path + "_final_poses.ply", cal.views.pose, points)
+        io_files.write_ply_cameras(output_path + "_final_poses.ply", cal.views.pose, cal.points)
     return cal
 
 
@@ -85,11 +86,9 @@ def main(argv=None):
     ap.add_argument("--optimize_board_points", type=str2bool, nargs="?", const=True, default=False)
     ap.add_argument("--verbose", type=str2bool, nargs="?", const=True, default=False)
     a = ap.parse_args(argv)
-    if a.optimize_board_points:
-        print("--optimize_board_points (theia::BundleAdjustTracks) is not part of this path", file=sys.stderr)
-        return 2
     scene = io_files.read_scene_bson(a.input_corners)
-    cal = calibrate_camera_from_json(scene, a.camera_model_to_calibrate, a.grid_size, a.save_path_calib_dataset, a.verbose)
+    cal = calibrate_camera_from_json(scene, a.camera_model_to_calibrate, a.grid_size, a.save_path_calib_dataset, a.verbose,
+                                     optimize_board_points=a.optimize_board_points)
     if cal is None:
         return 1
     cal.PrintResult()

@@ -19,7 +19,6 @@ int main(int argc, char* argv[]) {
   Flags F({{"input_corners", ""}, {"camera_model_to_calibrate", "DOUBLE_SPHERE"}, {"save_path_calib_dataset", ""}, {"grid_size", "0.04"},
            {"optimize_board_points", "false"}, {"verbose", "false"}, {"dry_run", "false"}});   // dry_run: print the start values, no device
   if (!F.parse(argc, argv)) return 2;
-  if (F.b("optimize_board_points")) { std::cerr << "--optimize_board_points (theia::BundleAdjustTracks) is not part of this path\n"; return 2; }
   Scene sc;
   CHECK_MSG(load_scene(F.str("input_corners"), &sc), "Failed to load " << F.str("input_corners"));
   const std::string model_name = F.str("camera_model_to_calibrate");
@@ -50,7 +49,7 @@ int main(int argc, char* argv[]) {
     o["poses"] = P; oicc_json::dump(o, std::cout, 0); std::cout << std::endl;
     return 0;
   }
-  CameraCalibrator cal(model_name, model, false);
+  CameraCalibrator cal(model_name, model, F.b("optimize_board_points"));
   if (F.b("verbose")) cal.SetVerbose();
   cal.SetScenePoints(sc.points);
   // a zero division-model coefficient sits on the model's identity branch, whose derivative w.r.t. the coefficient is zero
@@ -74,10 +73,10 @@ int main(int argc, char* argv[]) {
   const double total = cal.TotalReprojectionError();
   std::cout << "Final camera calibration reprojection error: " << total << " from " << cal.NumViews() << " view." << std::endl;
   if (!out.empty()) {
-    CHECK_MSG(write_pose_dataset(out + ".calibdata.json", cal.Views(), sc.points), "Could not write " << out << ".calibdata.json");
+    CHECK_MSG(write_pose_dataset(out + ".calibdata.json", cal.Views(), cal.Points()), "Could not write " << out << ".calibdata.json");
     CHECK_MSG(write_camera_calibration(out + ".json", model, model_name, cal.Intrinsics(), sc.width, sc.height, sc.fps, cal.NumViews(), total),
               "Could not write calibration file.");
-    write_ply_cameras(out + "_final_poses.ply", cal.Views().pose, sc.points);
+    write_ply_cameras(out + "_final_poses.ply", cal.Views().pose, cal.Points());
   }
   cal.PrintResult();
   return 0;

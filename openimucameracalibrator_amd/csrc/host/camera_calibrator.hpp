@@ -98,6 +98,12 @@ class ViewBundleAdjuster {   // theia::BundleAdjuster for one shared camera and 
     for (int64_t v = 0; v < nv_; ++v) std::copy(p6.begin() + 6 * v, p6.begin() + 6 * v + 6, views->pose[size_t(v)].begin());
     if (intr) { intr->resize(size_t(n_intr_)); Check(oicc_ba_get_camera(h_, intr->data(), n_intr_)); }
   }
+  void DownloadPoints(std::vector<std::array<double, 4>>* points) const {
+    std::vector<double> flat(points->size() * 4, 0.0);
+    Check(oicc_ba_get_scene_points(h_, flat.data(), int64_t(points->size())));
+    for (size_t i = 0; i < points->size(); ++i) std::copy(flat.begin() + 4 * i, flat.begin() + 4 * i + 4, (*points)[i].begin());
+  }
+  void SetVariablePoints(const std::vector<uint8_t>& mask) { Check(oicc_ba_set_variable_points(h_, mask.data(), int64_t(mask.size()))); }
   oicc_summary Optimize(int max_iters, int flags, int mask) { oicc_summary s; Check(oicc_ba_optimize(h_, max_iters, flags, mask, &s)); return s; }
   void OptimizeViews(int max_iters, std::vector<int32_t>* it, std::vector<double>* cost) {
     it->resize(size_t(nv_)); cost->resize(size_t(nv_));
@@ -111,9 +117,7 @@ class ViewBundleAdjuster {   // theia::BundleAdjuster for one shared camera and 
 class CameraCalibrator {
  public:
   CameraCalibrator(const std::string& camera_model, int model_id, bool optimize_board_pts, int device = 0)
-      : camera_model_(camera_model), model_(model_id), ba_(device) {
-    if (optimize_board_pts) { std::cerr << "board point refinement (theia::BundleAdjustTracks) is not part of this path\n"; std::exit(2); }
-  }
+      : camera_model_(camera_model), model_(model_id), ba_(device), optimize_board_pts_(optimize_board_pts) {}
   void SetVerbose() { verbose_ = true; }
   void SetScenePoints(const std::vector<std::array<double, 4>>& pts) { points_ = pts; }
   // camera_calibrator.cc:86-129: principal point at the image centre, model-specific start values
@@ -158,6 +162,13 @@ class CameraCalibrator {
     BundleAdjustViews(false, opt);
     RemoveViewsReprojError(2.0);
     if (NumViews() < min_num_view_) { std::cout << "Not enough views left for proper calibration!\n"; return false; }
+    if (optimize_board_pts_) {   // camera_calibrator.cc:207-216
+      ba_.Upload(model_, intr_, points_, views_);
+      const oicc_summary s = ba_.Optimize(max_num_iterations_, OICC_BA_POINTS, 0);   // theia::BundleAdjustTracks
+      ba_.DownloadPoints(&points_);
+      if (verbose_) std::cout << "BundleAdjustTracks: cost " << s.initial_cost << " -> " << s.final_cost << " in " << s.num_iterations << " iterations (" << s.message << ")\n";
+      BundleAdjustViews(false, opt);
+    }
     return true;
   }
   double TotalReprojectionError() {   // camera_calibrator.cc:352-366
@@ -178,7 +189,7 @@ class CameraCalibrator {
   }
   std::string camera_model_; int model_; ViewBundleAdjuster ba_;
   BaViews views_; std::vector<std::array<double, 4>> points_; std::vector<double> intr_;
-  int min_num_view_ = 10, max_num_iterations_ = 100; bool verbose_ = false;
+  int min_num_view_ = 10, max_num_iterations_ = 100; bool verbose_ = false, optimize_board_pts_ = false;
 };
 
 class PoseEstimator {   // bundle-adjustment half of pose_estimator.cc: poses of a calibrated camera, normalised PINHOLE f = 1
@@ -197,6 +208,20 @@ class PoseEstimator {   // bundle-adjustment half of pose_estimator.cc: poses of
     std::vector<int32_t> it; std::vector<double> cost;
     ba_.OptimizeViews(100, &it, &cost);
     ba_.Download(nullptr, &views_);
+  }
+  // pose_estimator.cc:192-224: BundleAdjustTracks over the tracks with more than 30 observations, cameras constant (the
+  // empirical covariances the reference prints afterwards are not computed)
+  void OptimizeBoardPoints(size_t min_num_obs_for_optim = 30) {
+    if (views_.pose.empty()) return;
+    std::vector<size_t> nobs(points_.size(), 0);
+    for (const auto& o : views_.obs) for (const auto& e : o) ++nobs[size_t(e[0])];
+    std::vector<uint8_t> mask(points_.size(), 0);
+    for (size_t i = 0; i < points_.size(); ++i) mask[i] = nobs[i] > min_num_obs_for_optim ? 1 : 0;
+    ba_.Upload(OICC_CAM_PINHOLE, {1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0}, points_, views_);
+    ba_.SetVariablePoints(mask);
+    const oicc_summary s = ba_.Optimize(100, OICC_BA_POINTS, 0);
+    ba_.DownloadPoints(&points_);
+    std::cout << "Board point optimization: cost " << s.initial_cost << " -> " << s.final_cost << " in " << s.num_iterations << " iterations\n";
   }
   BaViews& Views() { return views_; }
   const std::vector<std::array<double, 4>>& Points() const { return points_; }

@@ -18,7 +18,6 @@ using namespace OpenICC::core;
 int main(int argc, char* argv[]) {
   Flags F({{"input_corners", ""}, {"camera_calibration_json", ""}, {"output_pose_dataset", ""}, {"optimize_board_points", "false"}, {"dry_run", "false"}});   // dry_run: print the start poses, no device
   if (!F.parse(argc, argv)) return 2;
-  if (F.b("optimize_board_points")) { std::cerr << "--optimize_board_points (theia::BundleAdjustTracks) is not part of this path\n"; return 2; }
   Scene sc;
   CHECK_MSG(load_scene(F.str("input_corners"), &sc), "Failed to load " << F.str("input_corners"));
   OpenICC::CalibDataset cam; double fps = 0.0;
@@ -57,6 +56,7 @@ int main(int argc, char* argv[]) {
     src.push_back(v);
   }
   pe.OptimizeAllPoses();
+  if (F.b("optimize_board_points")) { pe.OptimizeBoardPoints(); pe.OptimizeAllPoses(); }   // estimate_camera_poses_from_checkerboard.cc:60-64
   // back projection in pixels with the calibrated camera (pose_estimator.cc:154-180), then FilterBadPoses
   BaViews& V = pe.Views();
   std::vector<int> bad; std::vector<double> z_kept; double err_sum = 0.0; int err_n = 0;
@@ -65,8 +65,8 @@ int main(int argc, char* argv[]) {
     const SceneView& sv = sc.views[src[i]];
     double e = 0.0; bool ok = true;
     for (size_t c = 0; c < sv.pid.size(); ++c) {
-      const auto& X = sc.points[size_t(sv.pid[c])];
-      const double a[3] = {X[0] - V.pose[i][0], X[1] - V.pose[i][1], X[2] - V.pose[i][2]};
+      const auto& X = pe.Points()[size_t(sv.pid[c])];
+      const double a[3] = {X[0] / X[3] - V.pose[i][0], X[1] / X[3] - V.pose[i][1], X[2] / X[3] - V.pose[i][2]};
       double p[3], px[2], J[6]; oicc::mat3_vec(R, a, p);
       if (!oicc::camera_project<false>(cam.camera_model, intr.data(), p, px, J)) { ok = false; break; }
       e += std::sqrt((px[0] - sv.uv[c][0]) * (px[0] - sv.uv[c][0]) + (px[1] - sv.uv[c][1]) * (px[1] - sv.uv[c][1]));
@@ -83,7 +83,7 @@ int main(int argc, char* argv[]) {
     V.remove(bad);
   }
   std::cout << "Estimated " << V.pose.size() << " camera poses, mean reprojection error " << (err_n ? err_sum / err_n : 0.0) << " px\n";
-  CHECK_MSG(write_pose_dataset(F.str("output_pose_dataset"), V, sc.points), "Could not write " << F.str("output_pose_dataset"));
-  write_ply_cameras(F.str("output_pose_dataset") + ".ply", V.pose, sc.points);
+  CHECK_MSG(write_pose_dataset(F.str("output_pose_dataset"), V, pe.Points()), "Could not write " << F.str("output_pose_dataset"));
+  write_ply_cameras(F.str("output_pose_dataset") + ".ply", V.pose, pe.Points());
   return 0;
 }

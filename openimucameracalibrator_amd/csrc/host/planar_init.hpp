@@ -136,7 +136,7 @@ inline void pose_from_homography(const Mat3& H, double f, const BoardFrame& bf, 
 // one view; focal <= 0: estimate it.  features relative to the principal point (or normalised coordinates with focal = 1)
 inline bool initialize_view(const std::vector<std::array<double, 4>>& points, const BoardFrame& bf, const std::vector<int>& point_index,
                             const std::vector<std::array<double, 2>>& features, double focal, Mat3* R, Vec3* C, double* f_out) {
-  if (bf.planarity > 1e-3 || point_index.size() < 4) return false;
+  if (bf.planarity > 0.05 || point_index.size() < 4) return false;   // a slightly bowed board still gives a usable start value
   std::vector<std::array<double, 2>> ab;
   for (int i : point_index) {
     double d[3]; for (int k = 0; k < 3; ++k) d[k] = points[i][k] / points[i][3] - bf.c[k];

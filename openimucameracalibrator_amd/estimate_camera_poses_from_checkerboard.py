@@ -19,7 +19,7 @@ from . import camera_calibrator as CC
 from . import io_files, planar_init
 
 
-def estimate_poses_from_json(scene, model, intrinsics, image_height, device=0, backend=None, min_num_points=8):
+def estimate_poses_from_json(scene, model, intrinsics, image_height, device=0, backend=None, min_num_points=8, optimize_board_points=False):
     """EstimatePosesFromJson + FilterBadPoses.  Returns (t_s, pose6, points, per-view mean reprojection error [px])."""
     ids = sorted(int(k) for k in scene["scene_pts"])
     index = {k: i for i, k in enumerate(ids)}
@@ -43,13 +43,17 @@ def estimate_poses_from_json(scene, model, intrinsics, image_height, device=0, b
     if not t_s:
         return [], np.zeros((0, 6)), points, np.zeros(0)
     pe.OptimizeAllPoses()
+    if optimize_board_points:                                          # estimate_camera_poses_from_checkerboard.cc:60-64
+        pe.OptimizeBoardPoints()
+        pe.OptimizeAllPoses()
+        points = pe.points
     pose = pe.Poses()
     # back projection test in pixels (pose_estimator.cc:154-180) with the calibrated camera
     from . import synthetic as S
     err = np.zeros(len(t_s))
     for v, (pid, uv) in enumerate(px_obs):
         R = CC.angle_axis_to_rotation(pose[v, 3:])
-        pc = (points[pid, :3] - pose[v, :3]) @ R.T
+        pc = (points[pid, :3] / points[pid, 3:] - pose[v, :3]) @ R.T
         px, ok = S.project(model, intrinsics, pc)
         err[v] = np.mean(np.linalg.norm(px - uv, axis=1)) if np.all(ok) else np.inf
     keep = err <= max_reproj_error
@@ -67,14 +71,12 @@ def main(argv=None):
     ap.add_argument("--input_corners", required=True)
     ap.add_argument("--camera_calibration_json", required=True)
     ap.add_argument("--output_pose_dataset", required=True)
-    ap.add_argument("--optimize_board_points", default="false")
+    ap.add_argument("--optimize_board_points", nargs="?", const="true", default="false")
     a = ap.parse_args(argv)
-    if str(a.optimize_board_points).lower() in ("1", "true", "yes"):
-        print("--optimize_board_points (theia::BundleAdjustTracks) is not part of this path", file=sys.stderr)
-        return 2
     scene = io_files.read_scene_bson(a.input_corners)
     model, intr, w, h, _ = io_files.read_camera_calibration(a.camera_calibration_json)
-    t_s, pose, points, err = estimate_poses_from_json(scene, model, intr, h)
+    t_s, pose, points, err = estimate_poses_from_json(scene, model, intr, h,
+                                                      optimize_board_points=str(a.optimize_board_points).lower() in ("1", "true", "yes", ""))
     print("Estimated %d camera poses, mean reprojection error %.4f px" % (len(t_s), float(np.mean(err)) if len(err) else float("nan")))
     io_files.write_pose_dataset(a.output_pose_dataset, t_s, pose, points)
     io_files.write_ply_cameras(a.output_pose_dataset + ".ply", pose, points)

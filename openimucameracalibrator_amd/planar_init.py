@@ -81,7 +81,7 @@ def initialize_view(points_xyzw, point_ids, features_centered, focal=None):
     """One view: (success, R, position, focal).  focal=None estimates it (uncalibrated), otherwise features are in the
     units of that focal length (1.0 for normalised image coordinates)."""
     c, E, planarity = board_frame(points_xyzw)
-    if planarity > 1e-3:
+    if planarity > 0.05:       # a slightly bowed board still gives a usable start value
         return False, None, None, None
     X = np.asarray(points_xyzw, dtype=np.float64)[np.asarray(point_ids)]
     X = X[:, :3] / X[:, 3:4]

@@ -86,14 +86,17 @@ def test_estimate_poses_application_feeds_the_spline_cli_format(tmp_path):
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openimucameracalibrator_amd", "csrc")
 
 
-@pytest.mark.parametrize("camera", ["pinhole", "gopro6_fisheye"])
-def test_cpp_applications_start_values_match_the_python_twins(camera, tmp_path):
+@pytest.mark.parametrize("camera,warp", [("pinhole", 0.0), ("gopro6_fisheye", 0.0), ("pinhole", 4e-4)])
+def test_cpp_applications_start_values_match_the_python_twins(camera, warp, tmp_path):
     """--dry_run of the two C++ applications (no device needed): UBJSON reader, board frame, DLT homography, Zhang focal
     length, pose from homography, Newton undistortion -- against planar_init.py on the same corner file."""
     import subprocess
     if not os.path.exists(os.path.join(CSRC, "calibrate_camera")):
         subprocess.check_call(["make", "-C", CSRC, "-s"])
     ds = CC.make_calibration_dataset(camera, num_views=9, corners_per_view=40)
+    if warp:      # board not in z = 0: both sides fit the board plane (PCA) and must agree on the resulting pose
+        pts = ds["points"].copy(); pts[:, 2] += 0.01 + warp * np.sin(np.arange(48)); pts[:, :3] = pts[:, :3] @ CC.angle_axis_to_rotation([0.2, -0.1, 0.3]).T
+        ds = dict(ds, points=pts)
     sc = scene_of(ds)
     corners = tmp_path / "corners.uson"
     corners.write_bytes(io_files.ubjson_encode(sc))
@@ -136,3 +139,21 @@ def test_cpp_applications_start_values_match_the_python_twins(camera, tmp_path):
         got = np.array(out["poses"][key])
         assert np.abs(got[6:8] - xy[0]).max() < 1e-9
         assert np.abs(got[:3] - C).max() < 1e-7 and np.abs(got[3:6] - CC.rotation_to_angle_axis(R)).max() < 1e-7
+
+
+def test_applications_with_board_point_refinement(tmp_path):
+    """--optimize_board_points of both applications (BundleAdjustTracks after the view stages): the refined board enters
+    the written pose data set / calibration archive."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=45, corners_per_view=40, noise_px=0.05)
+    pts = ds["points"].copy(); pts[:, 2] += 4e-4 * np.sin(np.arange(48))       # the corner file's board model is slightly wrong
+    sc = scene_of(dict(ds, points=pts))
+    out = str(tmp_path / "calib")
+    cal = APP.calibrate_camera_from_json(sc, "PINHOLE", grid_size=0.01, output_path=out, backend=oracle_backend.load_ba(), optimize_board_points=True)
+    assert cal is not None and len(cal.summaries) == 5
+    arch = json.load(open(out + ".calibdata.json"))
+    got = np.array([arch["tracks"][str(i)] for i in range(48)])
+    assert np.abs(got - cal.points).max() < 1e-12 and np.abs(got[:, :3] / got[:, 3:] - pts[:, :3]).max() > 1e-5
+    a = APP2.estimate_poses_from_json(sc, ds["model"], ds["intrinsics"], ds["height"], backend=oracle_backend.load_ba())
+    b = APP2.estimate_poses_from_json(sc, ds["model"], ds["intrinsics"], ds["height"], backend=oracle_backend.load_ba(), optimize_board_points=True)
+    assert len(a[0]) == len(b[0]) and b[3].mean() < a[3].mean()                # lower reprojection error with the refined board
+    assert np.abs(b[2] - a[2]).max() > 1e-5

@@ -188,3 +188,39 @@ def test_cpp_camera_calibration_and_pose_estimation_match_the_python_twins(tmp_p
         g = got[str(int(round(t * 1e6)))]
         assert np.abs(np.array(g["position"]) - p[:3]).max() < 1e-7 and np.abs(np.array(g["orientation_angle_axis"]) - p[3:]).max() < 1e-7
     assert open(poses + ".ply").read().startswith("ply")
+
+
+@pytest.mark.gpu
+def test_cpp_applications_with_board_point_refinement(tmp_path):
+    """--optimize_board_points of the two C++ applications against the Python twins on the same device kernels."""
+    from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2, camera_calibrator as CC
+    import test_ba_applications as T
+    csrc = os.path.dirname(CLI)
+    ds = CC.make_calibration_dataset("pinhole", num_views=45, corners_per_view=40, noise_px=0.05)
+    pts = ds["points"].copy(); pts[:, 2] += 4e-4 * np.sin(np.arange(48))
+    corners = str(tmp_path / "corners.uson")
+    open(corners, "wb").write(io_files.ubjson_encode(T.scene_of(dict(ds, points=pts))))
+    out = str(tmp_path / "calib")
+    r = subprocess.run([os.path.join(csrc, "calibrate_camera"), "--input_corners=" + corners, "--camera_model_to_calibrate=PINHOLE",
+                        "--save_path_calib_dataset=" + out, "--grid_size=0.01", "--optimize_board_points", "--verbose"], capture_output=True, text=True)
+    assert r.returncode == 0 and "BundleAdjustTracks" in r.stdout, r.stderr + r.stdout
+    cal = APP.calibrate_camera_from_json(io_files.read_scene_bson(corners), "PINHOLE", grid_size=0.01, optimize_board_points=True)
+    _, intr, _, _, _ = io_files.read_camera_calibration(out + ".json")
+    assert np.abs(intr - cal.GetIntrinsics()).max() <= 1e-6 * np.abs(intr).max()
+    tracks = json.load(open(out + ".calibdata.json"))["tracks"]
+    got = np.array([tracks[str(i)] for i in range(48)])
+    assert np.abs(got - cal.points).max() < 1e-8
+    poses = str(tmp_path / "poses.json")
+    r = subprocess.run([os.path.join(csrc, "estimate_camera_poses_from_checkerboard"), "--input_corners=" + corners,
+                        "--camera_calibration_json=" + out + ".json", "--output_pose_dataset=" + poses, "--optimize_board_points"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Board point optimization" in r.stdout, r.stderr + r.stdout
+    model, intr, w, h, _ = io_files.read_camera_calibration(out + ".json")
+    intr_cpp = intr.copy(); intr_cpp[5:] = 0.0      # the reference's reader drops the PINHOLE radial terms (read_camera_calibration.cc:110-112)
+    t_s, pose, points, err = APP2.estimate_poses_from_json(io_files.read_scene_bson(corners), model, intr_cpp, h, optimize_board_points=True)
+    obj = json.load(open(poses))
+    assert len(obj["views"]) == len(t_s)
+    gp = np.array([obj["tracks"][str(i)] for i in range(48)])
+    assert np.abs(gp - points).max() < 1e-8
+    for t, p in zip(t_s, pose):
+        g = obj["views"][str(int(round(t * 1e6)))]
+        assert np.abs(np.array(g["position"]) - p[:3]).max() < 1e-7
