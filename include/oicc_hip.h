@@ -390,7 +390,8 @@ int oicc_ba_evaluate(oicc_ba* p, int32_t flags, int32_t intrinsics_mask, double*
 int oicc_ba_optimize(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t intrinsics_mask, oicc_summary* summary);
 int oicc_ba_get_iterations(const oicc_ba* p, oicc_iteration* out, int32_t cap);
 /* theia::BundleAdjustView for EVERY view independently (intrinsics constant): one kernel launch, one wavefront per
- * view runs that view's whole Levenberg-Marquardt loop.  iterations / final_cost: [nv] or NULL. */
+ * view runs that view's whole Levenberg-Marquardt loop.  iterations / final_cost: [nv] or NULL; a view without
+ * observations, or whose residuals cannot be evaluated at the start, is left untouched and reports -1 / NaN. */
 int oicc_ba_optimize_views(oicc_ba* p, int32_t max_iters, int32_t flags, int32_t* iterations, double* final_cost);
 /* GetReprojErrorOfView for every view: mean pixel distance of its observations, [nv] */
 int oicc_ba_view_reprojection_errors(oicc_ba* p, double* mean_px);

@@ -419,6 +419,21 @@ class PoseEstimator:
         return np.asarray(self.views.pose).reshape(-1, 6)
 
 
+def shard_views(ds, rank, world):
+    """Contiguous view shard of a calibration data set for one process per GPU: every rank keeps ALL poses (so that the
+    tangent layout is the same everywhere) but only the observations of its own views.  Per-view refinement
+    (OptimizeViews) then needs no collective at all -- every view is its own problem; a joint bundle adjustment sums the
+    packed normal equations over the ranks exactly like the spline path."""
+    nv = len(ds["pose_init"])
+    lo, hi = nv * rank // world, nv * (rank + 1) // world
+    off = ds["corner_offset"]
+    new_off = np.zeros(nv + 1, dtype=np.int64)
+    for v in range(nv):
+        new_off[v + 1] = new_off[v] + ((off[v + 1] - off[v]) if lo <= v < hi else 0)
+    sel = slice(off[lo], off[hi])
+    return dict(ds, corner_offset=new_off, uv=ds["uv"][sel], point_ids=ds["point_ids"][sel], shard=(lo, hi))
+
+
 def make_calibration_dataset(camera="pinhole", num_views=30, corners_per_view=40, seed=20241115, noise_px=0.2,
                              pose_noise=(0.004, 0.004), outlier_fraction=0.0):
     """Synthetic input of calibrate_camera (BASELINE config 0): a 9x7 board (0.021 m squares, docs/gopro_calibration.md:8)

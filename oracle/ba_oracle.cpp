@@ -418,8 +418,13 @@ int oicc_oracle_ba_get_iterations(const oicc_ba* prob, oicc_iteration* out, int3
 // BundleAdjustView for every view on its own (pose_estimator.cc:226-236): intrinsics constant, one LM per view
 int oicc_oracle_ba_optimize_views(oicc_ba* prob, int32_t max_iters, int32_t flags, int32_t* iterations, double* final_cost) {
   for (int64_t v = 0; v < B_.nv(); ++v) {
-    oicc_summary S; int rc = lm(B_, flags, 0, v, v + 1, max_iters, &S, nullptr);
-    if (rc) return rc;
+    oicc_summary S;
+    // a view without observations, or one whose residuals cannot be evaluated at the start, is left alone (-1, NaN)
+    if (B_.c0[v + 1] == B_.c0[v] || lm(B_, flags, 0, v, v + 1, max_iters, &S, nullptr) != OICC_OK) {
+      if (iterations) iterations[v] = -1;
+      if (final_cost) final_cost[v] = std::numeric_limits<double>::quiet_NaN();
+      continue;
+    }
     if (iterations) iterations[v] = S.num_iterations;
     if (final_cost) final_cost[v] = S.final_cost;
   }

@@ -49,3 +49,53 @@ def test_two_rank_sharded_normal_equations_sum_to_whole(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def _ba_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_backend
+    from openimucameracalibrator_amd import camera_calibrator as CC
+
+    def adjuster(d):
+        ba = CC.ViewBundleAdjuster(backend=oracle_backend.load_ba())
+        ba.SetCamera(d["model"], d["intrinsics"]); ba.SetScenePoints(d["points"])
+        ba.SetViews(d["pose_init"], d["corner_offset"], d["uv"], d["point_ids"])
+        return ba
+    ds = CC.make_calibration_dataset("gopro9_division", num_views=13, corners_per_view=30, outlier_fraction=0.05)
+    mine = CC.shard_views(ds, rank, world)
+    flags, mask = CC.BA_POSITION | CC.BA_ORIENTATION, CC.intrinsics_mask(ds["model"], CC.FOCAL_LENGTH | CC.RADIAL_DISTORTION)
+    # joint bundle adjustment: packed normal equations summed over the ranks = the whole problem's
+    cost, H, g = adjuster(mine).Evaluate(flags, mask)
+    packed = torch.from_numpy(np.concatenate([H.ravel(), g, [cost]]))
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    # per-view refinement: no collective in the data path; the poses of the shards are gathered afterwards
+    ba = adjuster(mine)
+    lo, hi = mine["shard"]
+    it, fc = ba.OptimizeViews(50)
+    pose = torch.from_numpy(ba.GetPoses().copy())
+    own = torch.zeros(len(pose), dtype=torch.float64); own[lo:hi] = 1.0
+    merged = pose * own[:, None]
+    dist.all_reduce(merged, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        whole = adjuster(ds)
+        c1, H1, g1 = whole.Evaluate(flags, mask)
+        P = len(g1)
+        Hs = packed[:P * P].numpy().reshape(P, P); gs = packed[P * P:P * P + P].numpy(); cs = float(packed[-1])
+        whole.OptimizeViews(50)
+        ok = (np.abs(Hs - H1).max() <= 1e-10 * np.abs(H1).max() and np.abs(gs - g1).max() <= 1e-10 * np.abs(g1).max()
+              and abs(cs - c1) <= 1e-12 * c1 and np.abs(merged.numpy() - whole.GetPoses()).max() == 0.0
+              and np.all(it[hi:] == -1) and np.all(it[lo:hi] > 0))       # views without observations are left alone
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_view_bundle_adjustment_shards(tmp_path):
+    """View bundle adjustment over 2 ranks: joint normal equations sum to the whole; per-view refinement needs no collective."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "result_ba.txt")
+    mp.spawn(_ba_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
