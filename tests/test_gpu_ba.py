@@ -75,6 +75,10 @@ def test_views_with_more_than_64_and_with_no_observations():
     eg, ec = gpu.ViewReprojectionErrors(), cpu.ViewReprojectionErrors()
     assert np.isnan(eg[2]) and np.isnan(ec[2])
     assert np.abs(np.delete(eg, 2) - np.delete(ec, 2)).max() < 1e-10
+    ig, fg = gpu.OptimizeViews(30); ic, fc = cpu.OptimizeViews(30)
+    assert ig[2] == ic[2] == -1 and np.isnan(fg[2]) and np.isnan(fc[2])            # the empty view is left alone
+    assert np.array_equal(gpu.GetPoses()[2], ds["pose_init"][2])
+    assert np.array_equal(ig[:2], ic[:2]) and np.abs(gpu.GetPoses()[:2] - cpu.GetPoses()[:2]).max() < 1e-8
 
 
 @pytest.mark.parametrize("camera", ["pinhole", "gopro9_division", "gopro6_fisheye"])
