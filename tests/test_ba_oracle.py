@@ -249,3 +249,23 @@ def test_camera_calibrator_with_board_point_refinement():
     zr = z - A @ np.linalg.lstsq(A, z, rcond=None)[0]
     tr = true_pts[:, 2] - A @ np.linalg.lstsq(A, true_pts[:, 2], rcond=None)[0]
     assert np.corrcoef(zr, tr)[0, 1] > 0.95 and np.abs(zr - tr).max() < 0.6 * np.abs(tr).max()   # a bowl trades off with radial distortion: the shape comes back, not all of its depth
+
+
+@pytest.mark.parametrize("camera", ["pinhole_radtan", "gopro6_double_sphere"])
+def test_gradient_is_the_finite_difference_of_the_cost(camera):
+    """Independent of the autodiff: central differences of the (Huber) cost in every pose and intrinsics parameter."""
+    ds = CC.make_calibration_dataset(camera, num_views=3, corners_per_view=25, outlier_fraction=0.1)
+    n = CC.NUM_INTRINSICS[ds["model"]]
+    mask = (1 << n) - 1
+    flags = CC.BA_POSITION | CC.BA_ORIENTATION
+    cost, H, g = _adjuster(ds).Evaluate(flags, mask)
+    x0 = np.concatenate([ds["pose_init"].ravel(), ds["intrinsics"]])
+
+    def cost_at(x):
+        ba = _adjuster(ds, pose=x[:18].reshape(3, 6), intr=x[18:])
+        return ba.Evaluate(0, 0)[0]
+    for k in range(len(x0)):
+        h = 1e-6 * max(1.0, abs(x0[k])) if k < 18 or abs(x0[k]) > 1e-3 else 1e-7
+        xp, xm = x0.copy(), x0.copy(); xp[k] += h; xm[k] -= h
+        fd = (cost_at(xp) - cost_at(xm)) / (2 * h)
+        assert abs(fd - g[k]) <= 2e-5 * (abs(g[k]) + 1e-3 * np.abs(g).max()), (k, fd, g[k])
