@@ -40,3 +40,35 @@ def test_oracle_reproduces_fixture():
 def test_hip_reproduces_fixture():
     ds = synthetic.make_config("tiny")
     check(E.ImuCameraCalibrator().BatchInitSpline(ds), 1e-10)
+
+
+# ---- view bundle adjustment fixture (tests/golden/ba_problem.json, made by tests/golden/make_ba_golden.py from the oracle) ----
+import sys as _sys
+_sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_ba_golden as BAG  # noqa: E402
+
+BA_GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_problem.json")))
+
+
+def check_ba(backend, tol):
+    got = BAG.answers(BAG.load_inputs(BA_GOLD), backend)
+    ref = BA_GOLD["answers"]
+    for k in ("P", "lm_iterations", "message", "view_iterations", "points_iterations"):
+        assert got[k] == ref[k], k
+    for k in ("initial_cost", "grad_norm", "H_trace", "points_final_cost"):
+        assert abs(got[k] - ref[k]) <= tol * abs(ref[k]), k
+    assert np.abs(np.array(got["grad_tail"]) - ref["grad_tail"]).max() <= tol * ref["grad_norm"]
+    assert np.allclose(got["lm_costs"], ref["lm_costs"], rtol=max(tol, 1e-9), atol=0)
+    assert np.allclose(got["view_costs"], ref["view_costs"], rtol=max(tol, 1e-9), atol=0)
+    assert np.abs(np.array(got["final_intrinsics"]) - ref["final_intrinsics"]).max() <= 1e-7 * abs(ref["final_intrinsics"][0])
+    for k in ("final_pose0", "view_pose5", "point7"):
+        assert np.abs(np.array(got[k]) - ref[k]).max() < 1e-7, k
+
+
+def test_oracle_reproduces_ba_fixture():
+    check_ba(oracle_backend.load_ba(), 1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_ba_fixture():
+    check_ba(None, 1e-10)
