@@ -15,7 +15,8 @@ CLI = os.path.join(ROOT, "openimucameracalibrator_amd", "csrc", "continuous_time
 
 
 def ensure_cli():
-    if not os.path.exists(CLI):
+    names = ("continuous_time_imu_to_camera_calibration", "estimate_imu_to_camera_rotation", "calibrate_camera", "estimate_camera_poses_from_checkerboard")
+    if not all(os.path.exists(os.path.join(os.path.dirname(CLI), n)) for n in names):
         subprocess.check_call(["make", "-C", os.path.dirname(CLI), "-s"])
 
 
@@ -162,6 +163,7 @@ def test_cpp_camera_calibration_and_pose_estimation_match_the_python_twins(tmp_p
     calibration JSON / pose data set out) against the Python twins driving the same device kernels."""
     from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2, camera_calibrator as CC
     import test_ba_applications as T
+    ensure_cli()
     csrc = os.path.dirname(CLI)
     ds = CC.make_calibration_dataset("gopro9_division", num_views=40, corners_per_view=40)
     corners = str(tmp_path / "corners.uson")
@@ -195,6 +197,7 @@ def test_cpp_applications_with_board_point_refinement(tmp_path):
     """--optimize_board_points of the two C++ applications against the Python twins on the same device kernels."""
     from openimucameracalibrator_amd import calibrate_camera as APP, estimate_camera_poses_from_checkerboard as APP2, camera_calibrator as CC
     import test_ba_applications as T
+    ensure_cli()
     csrc = os.path.dirname(CLI)
     ds = CC.make_calibration_dataset("pinhole", num_views=45, corners_per_view=40, noise_px=0.05)
     pts = ds["points"].copy(); pts[:, 2] += 4e-4 * np.sin(np.arange(48))
