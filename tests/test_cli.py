@@ -97,6 +97,7 @@ ROT_CLI = os.path.join(os.path.dirname(CLI), "estimate_imu_to_camera_rotation")
 
 
 def test_rotation_cli_flag_and_file_errors(tmp_path):
+    ensure_cli()
     r = subprocess.run([ROT_CLI, "--not_a_flag"], capture_output=True, text=True)
     assert r.returncode == 2
     r = subprocess.run([ROT_CLI, "--input_pose_calibration_dataset", str(tmp_path / "none.json")], capture_output=True, text=True)
@@ -107,6 +108,7 @@ def test_rotation_cli_flag_and_file_errors(tmp_path):
 def test_rotation_cli_matches_python_twin(tmp_path):
     """estimate_imu_to_camera_rotation (C++ CLI) and python -m openimucameracalibrator_amd.rotation_init are twins of
     applications/estimate_imu_to_camera_rotation.cc: same output keys, same numbers on the same files."""
+    ensure_cli()
     import sys as _sys
     _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_rotation_init import make_case, Q_IC, qconj, qangle
