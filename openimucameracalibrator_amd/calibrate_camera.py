@@ -12,10 +12,8 @@ BundleAdjustViews stages and the view filters of RunCalibration run on the devic
 import argparse
 import sys
 
-import numpy as np
-
 from . import camera_calibrator as CC
-from . import io_files, planar_init
+from . import io_files
 
 
 def str2bool(v):
@@ -24,57 +22,13 @@ def str2bool(v):
 
 def calibrate_camera_from_json(scene, camera_model, grid_size=0.04, output_path="", verbose=False, device=0, backend=None,
                                optimize_board_points=False):
-    """CalibrateCameraFromJson, camera_calibrator.cc:221-377.  Returns the CameraCalibrator (or None on failure)."""
-    ids = sorted(int(k) for k in scene["scene_pts"])
-    index = {k: i for i, k in enumerate(ids)}
-    points = np.array([[*scene["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64)
-    w, h = int(scene["image_width"]), int(scene["image_height"])
-    px, py = w / 2.0, h / 2.0                                        # initial principal point, camera_calibrator.cc:228-230
-    views = []
-    for key in sorted(scene["views"]):                                 # nlohmann::json (std::map) iterates the keys in string order
-        ip = scene["views"][key]["image_points"]
-        if len(ip) < 4:
-            continue
-        pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
-        uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
-        ok, R, C, f = planar_init.initialize_view(points, pid, uv - [px, py])
-        if ok:       # success_init of the reference (camera_calibrator.cc:327): a view that does not determine a focal length is skipped
-            views.append([float(key) * 1e-6, pid, uv, f])
-    if not views:
-        return None
-    f0 = float(np.median([v[3] for v in views]))
+    """applications/calibrate_camera.cc:50-59: CameraCalibrator(model, optimize_board_points), SetGridSize, SetVerbose,
+    CalibrateCameraFromJson.  Returns the CameraCalibrator (or None on failure)."""
     cal = CC.CameraCalibrator(camera_model, optimize_board_pts=optimize_board_points, device=device, backend=backend)
+    cal.SetGridSize(grid_size)
     if verbose:
         cal.SetVerbose()
-    cal.SetScenePoints(points)
-    saved = []
-    init_poses = []
-    # division model: a zero distortion coefficient sits on the identity branch of the model, whose derivative w.r.t. the
-    # coefficient is zero (it could never leave it); the reference's solver delivers a non-zero estimate
-    k0 = -1e-8 if camera_model == "DIVISION_UNDISTORTION" else 0.0
-    for t_s, pid, uv, _ in views:
-        ok, R, C, _ = planar_init.initialize_view(points, pid, uv - [px, py], focal=f0)
-        if not ok or any(np.linalg.norm(C - s) < grid_size for s in saved):   # camera_calibrator.cc:318-329
-            continue
-        saved.append(C)
-        vid = cal.AddView(R, C, f0, k0, w, h, t_s)
-        for k, p in zip(pid, uv):
-            cal.AddObservation(vid, int(k), p)
-        init_poses.append(np.concatenate([C, CC.rotation_to_angle_axis(R)]))
-    print("Using %d views for camera calibration." % cal.NumViews())
-    if output_path:
-        io_files.write_ply_cameras(output_path + "_ransac_poses.ply", init_poses, points)
-    if not cal.RunCalibration():
-        print("Calibration failed.", file=sys.stderr)
-        return None
-    total = cal.TotalReprojectionError()
-    print("Final camera calibration reprojection error: %s from %d view." % (total, cal.NumViews()))
-    if output_path:
-        io_files.write_pose_dataset(output_path + ".calibdata.json", cal.views.t_s, cal.views.pose, cal.points)
-        io_files.write_camera_calibration(output_path + ".json", cal.model, cal.GetIntrinsics(), w, h, scene.get("camera_fps", 0.0),
-                                          cal.NumViews(), total)
-        io_files.write_ply_cameras(output_path + "_final_poses.ply", cal.views.pose, cal.points)
-    return cal
+    return cal if cal.CalibrateCameraFromJson(scene, output_path) else None
 
 
 def main(argv=None):

@@ -245,6 +245,7 @@ class CameraCalibrator:
         self.points = None
         self.intr = None
         self.min_num_view_ = 10        # camera_calibrator.h
+        self.grid_size_ = 0.04
         self.verbose_ = False
         self.ba = ViewBundleAdjuster(device=device, backend=backend)
         self.max_num_iterations = 100  # theia::BundleAdjustmentOptions default [EXT]
@@ -252,6 +253,65 @@ class CameraCalibrator:
 
     def SetVerbose(self):
         self.verbose_ = True
+
+    def SetGridSize(self, grid_size=0.04):
+        """camera poses are only used if no other pose lies within grid_size (camera_calibrator.h:61-63)."""
+        self.grid_size_ = float(grid_size)
+
+    def SetRansacErrorThresh(self, error_thresh=0.1):
+        """kept for interface parity: the start values here are closed forms, not RANSAC (planar_init.py)."""
+        self.ransac_error_thresh_ = float(error_thresh)
+
+    def CalibrateCameraFromJson(self, scene_json, output_path=""):
+        """camera_calibrator.cc:221-377: views from the corner file (start pose and focal length per view, voxel filter),
+        RunCalibration, outputs (`<out>.json`, `<out>.calibdata.json`, two PLY files)."""
+        from . import io_files, planar_init
+        ids = sorted(int(k) for k in scene_json["scene_pts"])
+        index = {k: i for i, k in enumerate(ids)}
+        points = np.array([[*scene_json["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64)
+        w, h = int(scene_json["image_width"]), int(scene_json["image_height"])
+        px, py = w / 2.0, h / 2.0                                          # initial principal point, camera_calibrator.cc:228-230
+        views = []
+        for key in sorted(scene_json["views"]):                            # nlohmann::json (std::map) iterates the keys in string order
+            ip = scene_json["views"][key]["image_points"]
+            if len(ip) < 4:
+                continue
+            pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
+            uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
+            ok, R, C, f = planar_init.initialize_view(points, pid, uv - [px, py])
+            if ok:   # success_init of the reference (camera_calibrator.cc:327): a view that does not determine a focal length is skipped
+                views.append([float(key) * 1e-6, pid, uv, f])
+        if not views:
+            return False
+        f0 = float(np.median([v[3] for v in views]))
+        self.SetScenePoints(points)
+        saved, init_poses = [], []
+        # division model: a zero distortion coefficient sits on the identity branch of the model, whose derivative w.r.t. the
+        # coefficient is zero (it could never leave it); the reference's solver delivers a non-zero estimate
+        k0 = -1e-8 if self.camera_model_ == "DIVISION_UNDISTORTION" else 0.0
+        for t_s, pid, uv, _ in views:
+            ok, R, C, _ = planar_init.initialize_view(points, pid, uv - [px, py], focal=f0)
+            if not ok or any(np.linalg.norm(C - s) < self.grid_size_ for s in saved):   # camera_calibrator.cc:318-329
+                continue
+            saved.append(C)
+            vid = self.AddView(R, C, f0, k0, w, h, t_s)
+            for k, p in zip(pid, uv):
+                self.AddObservation(vid, int(k), p)
+            init_poses.append(np.concatenate([C, rotation_to_angle_axis(R)]))
+        print("Using %d views for camera calibration." % self.NumViews())
+        if output_path:
+            io_files.write_ply_cameras(output_path + "_ransac_poses.ply", init_poses, points)
+        if not self.RunCalibration():
+            print("Calibration failed.")
+            return False
+        total = self.TotalReprojectionError()
+        print("Final camera calibration reprojection error: %s from %d view." % (total, self.NumViews()))
+        if output_path:
+            io_files.write_pose_dataset(output_path + ".calibdata.json", self.views.t_s, self.views.pose, self.points)
+            io_files.write_camera_calibration(output_path + ".json", self.model, self.GetIntrinsics(), w, h, scene_json.get("camera_fps", 0.0),
+                                              self.NumViews(), total)
+            io_files.write_ply_cameras(output_path + "_final_poses.ply", self.views.pose, self.points)
+        return True
 
     def SetScenePoints(self, xyzw):
         """io::scene_points_to_calib_dataset: the board points as homogeneous tracks."""
@@ -401,6 +461,67 @@ class PoseEstimator:
         out = self.ba.GetPoses()
         self.views.pose = [out[i].copy() for i in range(len(out))]
         return it, fc
+
+    def EstimatePosesFromJson(self, scene_json, model, intrinsics, image_height, min_num_points=8):
+        """pose_estimator.cc:92-190: every frame of the corner file -> normalised features, start pose, BundleAdjustView
+        (all frames in one launch), back-projection test in pixels with the calibrated camera."""
+        from . import planar_init
+        ids = sorted(int(k) for k in scene_json["scene_pts"])
+        index = {k: i for i, k in enumerate(ids)}
+        self.SetScenePoints(np.array([[*scene_json["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64))
+        self.calib_ = (int(model), np.asarray(intrinsics, dtype=np.float64))
+        self.max_reproj_error_ = 0.004 * image_height                        # pose_estimator.cc:97
+        self.px_obs_ = []
+        for key in sorted(scene_json["views"]):                              # nlohmann::json (std::map) key order
+            ip = scene_json["views"][key]["image_points"]
+            if len(ip) < min_num_points:                                     # pose_estimator.cc:131-135
+                continue
+            pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
+            uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
+            xy = planar_init.pixel_to_normalized(model, intrinsics, uv)      # camera.PixelToNormalizedCoordinates, :119-121
+            ok, R, C, _ = planar_init.initialize_view(self.points, pid, xy, focal=1.0)
+            if not ok:
+                continue
+            self.AddView(R, C, float(key) * 1e-6, pid, xy)
+            self.px_obs_.append((pid, uv))
+        if self.views.pose:
+            self.OptimizeAllPoses()
+        return True
+
+    def PixelReprojectionErrors(self):
+        """mean pixel distance per view with the calibrated camera (pose_estimator.cc:154-180)."""
+        from . import synthetic as S
+        model, intr = self.calib_
+        pose = self.Poses()
+        err = np.zeros(len(pose))
+        for v, (pid, uv) in enumerate(self.px_obs_):
+            R = angle_axis_to_rotation(pose[v, 3:])
+            pc = (self.points[pid, :3] / self.points[pid, 3:] - pose[v, :3]) @ R.T
+            px, ok = S.project(model, intr, pc)
+            err[v] = np.mean(np.linalg.norm(px - uv, axis=1)) if np.all(ok) else np.inf
+        return err
+
+    def FilterBadPoses(self):
+        """views above the back-projection threshold (pose_estimator.cc:176-183) and views whose z differs from the
+        median z by more than |median z| (FilterBadPoses, :238-261) are removed.  Returns the errors of the kept views."""
+        if not self.views.pose:
+            return np.zeros(0)
+        err = self.PixelReprojectionErrors()
+        pose = self.Poses()
+        keep = err <= self.max_reproj_error_
+        z = pose[:, 2]
+        if keep.any():
+            med = float(np.median(z[keep]))
+            keep &= ~(np.abs(z - med) > abs(med))
+        bad = [i for i in range(len(keep)) if not keep[i]]
+        self.views.remove(bad)
+        self.px_obs_ = [o for i, o in enumerate(self.px_obs_) if keep[i]]
+        return err[keep]
+
+    def GetPoseDataset(self):
+        """(timestamps [s], poses [n,6] = position | angle axis, homogeneous board points): what the reference hands to
+        theia::WriteReconstruction."""
+        return list(self.views.t_s), self.Poses(), self.points
 
     def OptimizeBoardPoints(self, min_num_obs_for_optim=30):
         """pose_estimator.cc:192-224: BundleAdjustTracks over the tracks seen in more than 30 views, cameras constant

@@ -16,54 +16,20 @@ import sys
 import numpy as np
 
 from . import camera_calibrator as CC
-from . import io_files, planar_init
+from . import io_files
 
 
 def estimate_poses_from_json(scene, model, intrinsics, image_height, device=0, backend=None, min_num_points=8, optimize_board_points=False):
-    """EstimatePosesFromJson + FilterBadPoses.  Returns (t_s, pose6, points, per-view mean reprojection error [px])."""
-    ids = sorted(int(k) for k in scene["scene_pts"])
-    index = {k: i for i, k in enumerate(ids)}
-    points = np.array([[*scene["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64)
-    max_reproj_error = 0.004 * image_height                            # pose_estimator.cc:97
+    """applications/estimate_camera_poses_from_checkerboard.cc:55-70: EstimatePosesFromJson, optionally OptimizeBoardPoints +
+    OptimizeAllPoses, FilterBadPoses, GetPoseDataset.  Returns (t_s, pose6, points, per-view mean reprojection error [px])."""
     pe = CC.PoseEstimator(device=device, backend=backend)
-    pe.SetScenePoints(points)
-    t_s, px_obs = [], []
-    for key in sorted(scene["views"]):                                   # nlohmann::json (std::map) key order
-        ip = scene["views"][key]["image_points"]
-        if len(ip) < min_num_points:                                   # pose_estimator.cc:131-135
-            continue
-        pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
-        uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
-        xy = planar_init.pixel_to_normalized(model, intrinsics, uv)    # camera.PixelToNormalizedCoordinates, :119-121
-        ok, R, C, _ = planar_init.initialize_view(points, pid, xy, focal=1.0)
-        if not ok:
-            continue
-        pe.AddView(R, C, float(key) * 1e-6, pid, xy)
-        t_s.append(float(key) * 1e-6); px_obs.append((pid, uv))
-    if not t_s:
-        return [], np.zeros((0, 6)), points, np.zeros(0)
-    pe.OptimizeAllPoses()
-    if optimize_board_points:                                          # estimate_camera_poses_from_checkerboard.cc:60-64
+    pe.EstimatePosesFromJson(scene, model, intrinsics, image_height, min_num_points=min_num_points)
+    if optimize_board_points and pe.views.pose:
         pe.OptimizeBoardPoints()
         pe.OptimizeAllPoses()
-        points = pe.points
-    pose = pe.Poses()
-    # back projection test in pixels (pose_estimator.cc:154-180) with the calibrated camera
-    from . import synthetic as S
-    err = np.zeros(len(t_s))
-    for v, (pid, uv) in enumerate(px_obs):
-        R = CC.angle_axis_to_rotation(pose[v, 3:])
-        pc = (points[pid, :3] / points[pid, 3:] - pose[v, :3]) @ R.T
-        px, ok = S.project(model, intrinsics, pc)
-        err[v] = np.mean(np.linalg.norm(px - uv, axis=1)) if np.all(ok) else np.inf
-    keep = err <= max_reproj_error
-    # FilterBadPoses: views whose z differs from the median z by more than |median z|
-    z = pose[:, 2]
-    if keep.any():
-        med = float(np.median(z[keep]))
-        keep &= ~(np.abs(z - med) > abs(med))
-    sel = np.where(keep)[0]
-    return [t_s[i] for i in sel], pose[sel], points, err[sel]
+    err = pe.FilterBadPoses()
+    t_s, pose, points = pe.GetPoseDataset()
+    return t_s, pose, points, err
 
 
 def main(argv=None):
