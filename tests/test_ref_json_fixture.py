@@ -1,0 +1,74 @@
+"""File formats pinned by the REFERENCE's own JSON library: tests/golden/ref_corners.* were written by
+oracle/_ref/ref_json_tool (= include/OpenCameraCalibrator/utils/json.h of the reference, nlohmann::json 3.7.0, built from
+the reference tree by `make -C oracle ref`; tests/golden/make_ubjson_golden.py).  The corner file is the input of the
+whole chain (src/io/read_scene.cc:25-41), so its reader must agree with the reference's serializer byte for byte."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from openimucameracalibrator_amd import io_files, planar_init, camera_calibrator as CC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+CSRC = os.path.join(ROOT, "openimucameracalibrator_amd", "csrc")
+TOOL = os.path.join(ROOT, "oracle", "_ref", "ref_json_tool")
+
+
+def _sorted(o):
+    if isinstance(o, dict):
+        return {k: _sorted(o[k]) for k in sorted(o)}      # nlohmann's object type is a std::map
+    if isinstance(o, list):
+        return [_sorted(x) for x in o]
+    return o
+
+
+def test_python_decoder_and_encoder_match_the_reference_serializer():
+    src = json.load(open(os.path.join(G, "ref_corners.json")))
+    raw = open(os.path.join(G, "ref_corners.uson"), "rb").read()
+    assert io_files.ubjson_decode(raw) == src
+    assert io_files.read_scene_bson(os.path.join(G, "ref_corners.uson")) == src
+    assert io_files.ubjson_encode(_sorted(src)) == raw            # byte for byte, every integer width included
+    assert json.load(open(os.path.join(G, "ref_roundtrip.json"))) == src
+
+
+def test_cpp_reader_parses_the_reference_bytes():
+    """calibrate_camera --dry_run on the reference-made corner file: host/json_min.hpp's UbjsonReader feeds the same
+    start values as the Python path computes from the decoded scene."""
+    if not os.path.exists(os.path.join(CSRC, "calibrate_camera")):
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
+    r = subprocess.run([os.path.join(CSRC, "calibrate_camera"), "--input_corners=" + os.path.join(G, "ref_corners.uson"),
+                        "--camera_model_to_calibrate=DIVISION_UNDISTORTION", "--dry_run"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    sc = json.load(open(os.path.join(G, "ref_corners.json")))
+    pts = np.array([[*sc["scene_pts"][str(i)], 1.0] for i in range(len(sc["scene_pts"]))])
+    w, h = sc["image_width"], sc["image_height"]
+    fs, views = [], []
+    for key in sorted(sc["views"]):
+        ip = sc["views"][key]["image_points"]
+        pid = np.array([int(k) for k in sorted(ip)], dtype=np.int32)
+        uv = np.array([ip[k] for k in sorted(ip)])
+        ok, R, C, f = planar_init.initialize_view(pts, pid, uv - [w / 2, h / 2])
+        if ok:
+            fs.append(f); views.append((key, pid, uv))
+    f0 = float(np.median(fs))
+    assert abs(out["focal_length"] - f0) < 1e-6 * f0 and sorted(out["poses"]) == sorted(k for k, _, _ in views)
+    for key, pid, uv in views:
+        ok, R, C, _ = planar_init.initialize_view(pts, pid, uv - [w / 2, h / 2], focal=f0)
+        got = np.array(out["poses"][key])
+        assert np.abs(got[:3] - C).max() < 1e-7 and np.abs(got[3:] - CC.rotation_to_angle_axis(R)).max() < 1e-7
+
+
+@pytest.mark.skipif(not os.path.exists(TOOL), reason="oracle/_ref/ref_json_tool is only built where /root/reference is mounted")
+def test_reference_library_reads_what_this_repository_writes(tmp_path):
+    """live: files of io_files.ubjson_encode (synthetic corner files of the tests) through the reference's from_ubjson."""
+    ds = CC.make_calibration_dataset("pinhole", num_views=4, corners_per_view=12, seed=5)
+    import test_ba_applications as T
+    sc = T.scene_of(ds)
+    a, b = str(tmp_path / "mine.uson"), str(tmp_path / "back.json")
+    open(a, "wb").write(io_files.ubjson_encode(sc))
+    subprocess.check_call([TOOL, "from_ubjson", a, b])
+    assert json.load(open(b)) == json.loads(json.dumps(sc))
