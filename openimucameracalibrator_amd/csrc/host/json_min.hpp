@@ -76,7 +76,8 @@ class Parser {
   void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
   [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json parse error: ") + m); }
   std::string parse_string() {
-    if (*p != '"') fail("expected string"); ++p;
+    if (*p != '"') fail("expected string");
+    ++p;
     std::string s;
     while (p < e && *p != '"') {
       if (*p == '\\') {
@@ -92,7 +93,8 @@ class Parser {
         ++p;
       } else s += *p++;
     }
-    if (p >= e) fail("unterminated string"); ++p;
+    if (p >= e) fail("unterminated string");
+    ++p;
     return s;
   }
   Value parse_value() {
