@@ -91,3 +91,38 @@ def test_cpp_reader_and_writer_reproduce_the_reference_dump(tmp_path):
     # text JSON in: the parser reads the reference's own dump back to the same document
     subprocess.check_call([exe, os.path.join(G, "ref_roundtrip.json"), out, "4"])
     assert json.load(open(out)) == json.load(open(os.path.join(G, "ref_corners.json")))
+
+
+def _documents():
+    from hypothesis import strategies as st
+    keys = st.text(alphabet="abcdefghijklmnopqrstuvwxyz0123456789_", min_size=1, max_size=8)
+    ints = st.one_of(st.integers(-2**63, 2**63 - 1), st.sampled_from([0, 127, 128, 255, 256, -128, -129, 32767, 32768, -32768, -32769,
+                                                                        2**31 - 1, 2**31, -2**31, -2**31 - 1]))
+    leaves = st.one_of(st.none(), st.booleans(), ints, st.floats(allow_nan=False, allow_infinity=False), keys)
+    return st.recursive(leaves, lambda c: st.one_of(st.lists(c, max_size=5), st.dictionaries(keys, c, max_size=5)), max_leaves=25)
+
+
+@pytest.mark.skipif(not os.path.exists(TOOL), reason="oracle/_ref/ref_json_tool is only built where /root/reference is mounted")
+def test_random_documents_against_the_reference_serializer(tmp_path):
+    """property test with the reference library as the judge: for random documents the encoder's bytes equal
+    nlohmann::json::to_ubjson's, the Python and C++ decoders read the reference's bytes, from_ubjson reads the encoder's."""
+    from hypothesis import given, settings, HealthCheck
+    a, b, c = str(tmp_path / "d.json"), str(tmp_path / "d.uson"), str(tmp_path / "back.json")
+    exe = str(tmp_path / "json_roundtrip")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(CSRC, "host", "json_roundtrip.cpp"), "-o", exe])
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(_documents())
+    def run(doc):
+        doc = {"doc": doc}
+        json.dump(doc, open(a, "w"))
+        subprocess.check_call([TOOL, "to_ubjson", a, b])
+        raw = open(b, "rb").read()
+        assert io_files.ubjson_encode(_sorted(doc)) == raw
+        assert io_files.ubjson_decode(raw) == doc
+        subprocess.check_call([exe, b, c, "2"])                      # the C++ reader (host/json_min.hpp) on the reference's bytes
+        assert json.load(open(c)) == doc
+        open(b, "wb").write(io_files.ubjson_encode(doc))
+        subprocess.check_call([TOOL, "from_ubjson", b, c])
+        assert json.load(open(c)) == doc
+    run()
