@@ -6,9 +6,11 @@
 // nlohmann's default object type, so iteration order and the key order of the
 // output file match the reference's.
 #pragma once
+#include <cerrno>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -120,7 +122,10 @@ class Parser {
       if (p == s) fail("unexpected character");
       std::string t(s, p);
       v.type = Value::Number; v.num = std::stod(t);
-      if (isint && t.size() < 19) { v.is_int = true; v.inum = std::stoll(t); }
+      if (isint) {   // every int64 exactly (ns timestamps exceed 2^53); beyond int64 the double stands in
+        errno = 0; char* endp = nullptr; const long long ll = std::strtoll(t.c_str(), &endp, 10);
+        if (errno == 0 && endp && *endp == '\0') { v.is_int = true; v.inum = ll; }
+      }
     }
     return v;
   }

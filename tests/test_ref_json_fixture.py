@@ -122,6 +122,8 @@ def test_random_documents_against_the_reference_serializer(tmp_path):
         assert io_files.ubjson_decode(raw) == doc
         subprocess.check_call([exe, b, c, "2"])                      # the C++ reader (host/json_min.hpp) on the reference's bytes
         assert json.load(open(c)) == doc
+        subprocess.check_call([exe, a, c, "0"])                      # ... and its text parser on the JSON text
+        assert json.load(open(c)) == doc
         open(b, "wb").write(io_files.ubjson_encode(doc))
         subprocess.check_call([TOOL, "from_ubjson", b, c])
         assert json.load(open(c)) == doc
