@@ -87,9 +87,18 @@ class Parser {
         switch (*p) {
           case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'r': s += '\r'; break;
           case 'b': s += '\b'; break; case 'f': s += '\f'; break;
-          case 'u': { if (e - p < 5) fail("bad \\u"); unsigned cp = std::stoul(std::string(p + 1, p + 5), nullptr, 16); p += 4;
-            if (cp < 0x80) s += char(cp); else if (cp < 0x800) { s += char(0xC0 | (cp >> 6)); s += char(0x80 | (cp & 0x3F)); }
-            else { s += char(0xE0 | (cp >> 12)); s += char(0x80 | ((cp >> 6) & 0x3F)); s += char(0x80 | (cp & 0x3F)); } break; }
+          case 'u': {
+            auto hex4 = [&](const char* q) -> unsigned { if (e - q < 4) fail("bad \\u"); return unsigned(std::stoul(std::string(q, q + 4), nullptr, 16)); };
+            unsigned cp = hex4(p + 1); p += 4;
+            if (cp >= 0xD800 && cp < 0xDC00 && e - p > 6 && p[1] == '\\' && p[2] == 'u') {   // surrogate pair
+              const unsigned lo = hex4(p + 3);
+              if (lo >= 0xDC00 && lo < 0xE000) { cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); p += 6; }
+            }
+            if (cp < 0x80) s += char(cp);
+            else if (cp < 0x800) { s += char(0xC0 | (cp >> 6)); s += char(0x80 | (cp & 0x3F)); }
+            else if (cp < 0x10000) { s += char(0xE0 | (cp >> 12)); s += char(0x80 | ((cp >> 6) & 0x3F)); s += char(0x80 | (cp & 0x3F)); }
+            else { s += char(0xF0 | (cp >> 18)); s += char(0x80 | ((cp >> 12) & 0x3F)); s += char(0x80 | ((cp >> 6) & 0x3F)); s += char(0x80 | (cp & 0x3F)); }
+            break; }
           default: s += *p;
         }
         ++p;
@@ -151,19 +160,31 @@ inline std::string number_to_string(double v) {
   for (int prec = 1; prec <= 17; ++prec) { snprintf(b, sizeof(b), "%.*g", prec, v); if (std::strtod(b, nullptr) == v) break; }
   return b;
 }
+// JSON string escapes as nlohmann's dump writes them (ensure_ascii = false): quote, backslash, control characters
+inline void dump_string(const std::string& str, std::ostream& os) {
+  os << '"';
+  for (unsigned char c : str) {
+    switch (c) {
+      case '"': os << "\\\""; break; case '\\': os << "\\\\"; break; case '\n': os << "\\n"; break; case '\t': os << "\\t"; break;
+      case '\r': os << "\\r"; break; case '\b': os << "\\b"; break; case '\f': os << "\\f"; break;
+      default: if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", unsigned(c)); os << b; } else os << char(c);
+    }
+  }
+  os << '"';
+}
 inline void dump(const Value& v, std::ostream& os, int indent, int level = 0) {
   const std::string pad(size_t(indent * (level + 1)), ' '), padc(size_t(indent * level), ' ');
   switch (v.type) {
     case Value::Null: os << "null"; break;
     case Value::Bool: os << (v.b ? "true" : "false"); break;
     case Value::Number: if (v.is_int) os << v.inum; else os << number_to_string(v.num); break;
-    case Value::String: { os << '"'; for (char c : v.str) { if (c == '"' || c == '\\') os << '\\' << c; else if (c == '\n') os << "\\n"; else os << c; } os << '"'; break; }
+    case Value::String: dump_string(v.str, os); break;
     case Value::Array: {
       if (v.arr.empty()) { os << "[]"; break; }
       os << "[\n"; for (size_t i = 0; i < v.arr.size(); ++i) { os << pad; dump(v.arr[i], os, indent, level + 1); os << (i + 1 < v.arr.size() ? ",\n" : "\n"); } os << padc << "]"; break; }
     case Value::Object: {
       if (v.obj.empty()) { os << "{}"; break; }
-      os << "{\n"; size_t i = 0; for (const auto& kv : v.obj) { os << pad << '"' << kv.first << "\": "; dump(kv.second, os, indent, level + 1); os << (++i < v.obj.size() ? ",\n" : "\n"); } os << padc << "}"; break; }
+      os << "{\n"; size_t i = 0; for (const auto& kv : v.obj) { os << pad; dump_string(kv.first, os); os << ": "; dump(kv.second, os, indent, level + 1); os << (++i < v.obj.size() ? ",\n" : "\n"); } os << padc << "}"; break; }
   }
 }
 

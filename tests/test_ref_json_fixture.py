@@ -98,8 +98,9 @@ def _documents():
     keys = st.text(alphabet="abcdefghijklmnopqrstuvwxyz0123456789_", min_size=1, max_size=8)
     ints = st.one_of(st.integers(-2**63, 2**63 - 1), st.sampled_from([0, 127, 128, 255, 256, -128, -129, 32767, 32768, -32768, -32769,
                                                                         2**31 - 1, 2**31, -2**31, -2**31 - 1]))
-    leaves = st.one_of(st.none(), st.booleans(), ints, st.floats(allow_nan=False, allow_infinity=False), keys)
-    return st.recursive(leaves, lambda c: st.one_of(st.lists(c, max_size=5), st.dictionaries(keys, c, max_size=5)), max_leaves=25)
+    texts = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=12)      # any unicode incl. controls, quotes, astral
+    leaves = st.one_of(st.none(), st.booleans(), ints, st.floats(allow_nan=False, allow_infinity=False), keys, texts)
+    return st.recursive(leaves, lambda c: st.one_of(st.lists(c, max_size=5), st.dictionaries(st.one_of(keys, texts), c, max_size=5)), max_leaves=25)
 
 
 @pytest.mark.skipif(not os.path.exists(TOOL), reason="oracle/_ref/ref_json_tool is only built where /root/reference is mounted")
@@ -111,7 +112,7 @@ def test_random_documents_against_the_reference_serializer(tmp_path):
     exe = str(tmp_path / "json_roundtrip")
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(CSRC, "host", "json_roundtrip.cpp"), "-o", exe])
 
-    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
     @given(_documents())
     def run(doc):
         doc = {"doc": doc}
