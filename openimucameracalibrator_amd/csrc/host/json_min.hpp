@@ -130,7 +130,7 @@ class Parser {
       while (p < e && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) { if (*p == '.' || *p == 'e' || *p == 'E') isint = false; ++p; }
       if (p == s) fail("unexpected character");
       std::string t(s, p);
-      v.type = Value::Number; v.num = std::stod(t);
+      v.type = Value::Number; v.num = std::strtod(t.c_str(), nullptr);   // (std::stod throws on subnormal results)
       if (isint) {   // every int64 exactly (ns timestamps exceed 2^53); beyond int64 the double stands in
         errno = 0; char* endp = nullptr; const long long ll = std::strtoll(t.c_str(), &endp, 10);
         if (errno == 0 && endp && *endp == '\0') { v.is_int = true; v.inum = ll; }

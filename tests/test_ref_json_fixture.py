@@ -112,7 +112,7 @@ def test_random_documents_against_the_reference_serializer(tmp_path):
     exe = str(tmp_path / "json_roundtrip")
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(CSRC, "host", "json_roundtrip.cpp"), "-o", exe])
 
-    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=150, derandomize=True, deadline=None, suppress_health_check=list(HealthCheck))
     @given(_documents())
     def run(doc):
         doc = {"doc": doc}
