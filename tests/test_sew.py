@@ -102,3 +102,46 @@ def test_hip_large_series_linearity_property():
     d1, v1 = sew.knot_spacing_and_variance(sig, t, 0.97, min_dt=0.01, max_dt=0.3)
     d2, v2 = sew.knot_spacing_and_variance(3.0 * sig, t, 0.97, min_dt=0.01, max_dt=0.3)
     assert close(d1, d2, 1e-9) and close(9.0 * v1, v2, 1e-9) and 0.01 <= d1 <= 0.3
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/python/sew.py"), reason="live comparison: only where the reference tree is mounted")
+def test_oracle_matches_the_reference_module_on_many_random_signals():
+    """beyond the seven committed goldens: 60 seeded signals (random walk + oscillations + noise; odd and even lengths;
+    one or three axes; several quality targets and spacing ranges) through the reference's python/sew.py and through
+    oracle/sew_oracle.py, live."""
+    import subprocess
+    import sys as _sys
+    # the reference module is imported in a child interpreter that never writes bytecode into the read-only tree
+    code = r'''
+import sys, json, numpy as np
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/python")
+import sew
+out = []
+for seed in range(60):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(400, 3000)); axes = 1 if seed % 5 == 0 else 3
+    rate = float(rng.choice([100.0, 200.0, 400.0]))
+    t = np.arange(n) / rate
+    sig = np.cumsum(rng.standard_normal((axes, n)), axis=1) * rng.uniform(0.002, 0.05) + rng.uniform(0.0, 0.3) * rng.standard_normal((axes, n))
+    for k in range(3):
+        sig += rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.2, 15.0) * t + rng.uniform(0, 6.28))
+    q = float(rng.choice([0.9, 0.96, 0.99, 0.999])); lo = float(rng.choice([0.005, 0.01, 0.02])); hi = float(rng.choice([0.1, 0.15, 0.4]))
+    dt, var = sew.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
+    out.append(dict(seed=seed, dt=float(dt), var=float(var)))
+print(json.dumps(out))
+'''
+    ref = json.loads(subprocess.check_output([_sys.executable, "-c", code], env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1")).decode().splitlines()[-1])
+    for r in ref:
+        seed = r["seed"]
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(400, 3000)); axes = 1 if seed % 5 == 0 else 3
+        rate = float(rng.choice([100.0, 200.0, 400.0]))
+        t = np.arange(n) / rate
+        sig = np.cumsum(rng.standard_normal((axes, n)), axis=1) * rng.uniform(0.002, 0.05) + rng.uniform(0.0, 0.3) * rng.standard_normal((axes, n))
+        for k in range(3):
+            sig += rng.uniform(0.1, 1.0) * np.sin(2 * np.pi * rng.uniform(0.2, 15.0) * t + rng.uniform(0, 6.28))
+        q = float(rng.choice([0.9, 0.96, 0.99, 0.999])); lo = float(rng.choice([0.005, 0.01, 0.02])); hi = float(rng.choice([0.1, 0.15, 0.4]))
+        dt, var = sew_oracle.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
+        assert abs(dt - r["dt"]) <= 1e-9 * r["dt"], (seed, dt, r["dt"])
+        assert abs(var - r["var"]) <= 1e-8 * abs(r["var"]) + 1e-300, (seed, var, r["var"])
