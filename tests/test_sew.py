@@ -145,3 +145,50 @@ print(json.dumps(out))
         dt, var = sew_oracle.knot_spacing_and_variance(sig, t, q, min_dt=lo, max_dt=hi)
         assert abs(dt - r["dt"]) <= 1e-9 * r["dt"], (seed, dt, r["dt"])
         assert abs(var - r["var"]) <= 1e-8 * abs(r["var"]) + 1e-300, (seed, var, r["var"])
+
+
+class _OracleSewBackend:
+    """test-only: the numpy oracle behind the C-ABI call shape openimucameracalibrator_amd.sew binds (no GPU here)."""
+
+    def sew_knot_spacing_and_variance(self, device, dims, n, sig_p, t_p, q, lo, hi, dt_ref, var_ref, ev_ref):
+        sig = np.ctypeslib.as_array(sig_p, shape=(dims, n)); t = np.ctypeslib.as_array(t_p, shape=(n,))
+        dt, var = sew_oracle.knot_spacing_and_variance(sig, t, q, min_dt=lo if lo > 0 else None, max_dt=hi if hi > 0 else None)
+        dt_ref._obj.value = dt; var_ref._obj.value = var; ev_ref._obj.value = 0
+        return 0
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/python/get_sew_for_dataset.py"), reason="live comparison: only where the reference tree is mounted")
+def test_twin_application_writes_what_the_reference_script_writes(tmp_path):
+    """python -m openimucameracalibrator_amd.sew is the twin of python/get_sew_for_dataset.py: the REFERENCE SCRIPT ITSELF is run
+    on a telemetry file (child interpreter, bytecode writing off; its unused imports cv2 / matplotlib, absent here, are
+    stubbed) and its output JSON is compared with the twin's (host logic of the twin + numpy oracle instead of the device)."""
+    import subprocess
+    import sys as _sys
+    from openimucameracalibrator_amd import synthetic, io_files, sew as twin
+    ds = synthetic.make_config("C1", camera="gopro9_division")
+    files = io_files.write_dataset_files(ds, str(tmp_path))
+    tel = json.load(open(files["telemetry_json"]))
+    tel["camera_fps"] = 59.94                                   # read_generic_json requires the key (telemetry_converter.py:237)
+    json.dump(tel, open(files["telemetry_json"], "w"))
+    out_ref = str(tmp_path / "sew_ref.json")
+    code = r'''
+import sys, types
+sys.dont_write_bytecode = True
+for name in ("cv2", "matplotlib", "matplotlib.pyplot", "natsort"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+sys.path.insert(0, "/root/reference/python")
+sys.argv = ["get_sew_for_dataset.py", "--input_json_path", sys.argv[1], "--output_path", sys.argv[2]]
+import get_sew_for_dataset
+get_sew_for_dataset.main()
+'''
+    subprocess.check_call([_sys.executable, "-c", code, files["telemetry_json"], out_ref], env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"),
+                          stdout=subprocess.DEVNULL)
+    ref = json.load(open(out_ref))
+    mine = twin.spline_weighting_for_telemetry(tel, backend=_OracleSewBackend())
+    assert set(mine) == set(ref) == {"so3", "r3", "camera_fps"} and mine["camera_fps"] == ref["camera_fps"] == 59.94
+    for k in ("so3", "r3"):
+        assert set(mine[k]) == set(ref[k]) == {"knot_spacing", "weighting_factor", "quality_factor"}
+        assert mine[k]["quality_factor"] == ref[k]["quality_factor"]
+        assert abs(mine[k]["knot_spacing"] - ref[k]["knot_spacing"]) <= 1e-9 * ref[k]["knot_spacing"]
+        assert abs(mine[k]["weighting_factor"] - ref[k]["weighting_factor"]) <= 1e-8 * ref[k]["weighting_factor"]
