@@ -129,3 +129,30 @@ def test_random_documents_against_the_reference_serializer(tmp_path):
         subprocess.check_call([TOOL, "from_ubjson", b, c])
         assert json.load(open(c)) == doc
     run()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/io"), reason="reads the reference sources: only where the tree is mounted")
+def test_every_json_key_of_the_reference_io_layer_is_known_to_the_host_code():
+    """Drop-in at the file level: every JSON key the reference's readers / writers of this path use (string literals in
+    json["..."] accesses of src/io/*.cc, the three applications' mains and the calibrator / pose estimator sources) appears in
+    this repository's host code (C++ applications + Python twins).  Out of scope, listed: the raw GoPro telemetry importer
+    (vendor format) and two board-description fields only the board extractor writes."""
+    import glob
+    import re
+    ref = glob.glob("/root/reference/src/io/*.cc") + ["/root/reference/applications/continuous_time_imu_to_camera_calibration.cc",
+                                                       "/root/reference/applications/estimate_imu_to_camera_rotation.cc",
+                                                       "/root/reference/applications/calibrate_camera.cc",
+                                                       "/root/reference/applications/estimate_camera_poses_from_checkerboard.cc",
+                                                       "/root/reference/src/core/board_extractor.cc", "/root/reference/src/core/camera_calibrator.cc",
+                                                       "/root/reference/src/core/pose_estimator.cc"]
+    keys = set()
+    for f in ref:
+        keys |= set(re.findall(r'\[\s*"([A-Za-z0-9_ /]+)"\s*\]', open(f).read()))
+    mine = ""
+    for f in glob.glob(os.path.join(CSRC, "host", "*")) + glob.glob(os.path.join(ROOT, "openimucameracalibrator_amd", "*.py")):
+        mine += open(f).read()
+    literals = set(re.findall(r'"([A-Za-z0-9_ /]+)"', mine))
+    out_of_scope = {"ACCL", "CORI", "GPS5", "GYRO", "cts", "precision", "samples", "streams", "value",      # read_gopro_imu_json.cc
+                    "calibration_board_type", "square_size_meter"}                                               # board_extractor.cc
+    assert len(keys) > 50
+    assert keys - literals == out_of_scope
