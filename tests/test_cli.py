@@ -229,3 +229,17 @@ def test_cpp_applications_with_board_point_refinement(tmp_path):
     for t, p in zip(t_s, pose):
         g = obj["views"][str(int(round(t * 1e6)))]
         assert np.abs(np.array(g["position"]) - p[:3]).max() < 1e-7
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/applications"), reason="reads the reference sources: only where the tree is mounted")
+def test_every_gflag_of_the_reference_applications_is_accepted():
+    """The four applications of this path keep the reference's command line: every DEFINE_<type>(name, ...) of the
+    reference's main is a flag of the C++ application here (extra flags: device selection, --dry_run, solver options)."""
+    import re
+    host = os.path.join(os.path.dirname(CLI), "host")
+    extras = {"device", "dry_run", "solver_algorithm", "solver_partitions"}
+    for app in ("continuous_time_imu_to_camera_calibration", "estimate_imu_to_camera_rotation", "calibrate_camera",
+                "estimate_camera_poses_from_checkerboard"):
+        ref = set(re.findall(r"DEFINE_\w+\(\s*(\w+)", open("/root/reference/applications/%s.cc" % app).read()))
+        mine = set(re.findall(r'\{"(\w+)",\s*"', open(os.path.join(host, app + ".cpp")).read()))
+        assert ref and ref <= mine and mine - ref <= extras, (app, ref - mine, mine - ref)
