@@ -184,6 +184,50 @@ class SplineTrajectoryEstimator {
   bool GetAcceleration(const int64_t& t_ns, Vec3& v) { uint8_t ok = 0; double o[3] = {0, 0, 0}; ck(oicc_get_trajectory(h_, 1, &t_ns, nullptr, nullptr, o, nullptr, nullptr, &ok)); if (ok) v = Vec3{{o[0], o[1], o[2]}}; return ok != 0; }
   Vec3 GetGyroBias(const int64_t& t_ns) { double o[3]; uint8_t ok; ck(oicc_get_trajectory(h_, 1, &t_ns, nullptr, nullptr, nullptr, o, nullptr, &ok)); return Vec3{{o[0], o[1], o[2]}}; }
   Vec3 GetAcclBias(const int64_t& t_ns) { double o[3]; uint8_t ok; ck(oicc_get_trajectory(h_, 1, &t_ns, nullptr, nullptr, nullptr, nullptr, o, &ok)); return Vec3{{o[0], o[1], o[2]}}; }
+  bool GetPosition(const int64_t& t_ns, Vec3& position) { SE3 T; if (!GetPose(t_ns, T)) return false; position = T.t; return true; }   // impl.h:879-897
+  // spline_trajectory_estimator.h:118; never called by the reference and not part of the device read-back: the six knots of
+  // the window are combined on the host (order-6 blending matrix, spline_common.h:67-98, first derivative)
+  bool GetVelocity(const int64_t& t_ns, Vec3& velocity) {
+    const int64_t st = t_ns - GetMinTimeNs(); const int64_t n = int64_t(GetNumR3Knots());
+    if (st < 0 || dt_r3_ns_ <= 0) return false;
+    const int64_t s = st / dt_r3_ns_; const double u = double(st % dt_r3_ns_) / double(dt_r3_ns_);
+    if (s + 6 > n) return false;
+    auto binom = [](int a, int b) { double r = 1; for (int i = 0; i < b; ++i) r = r * double(a - i) / double(i + 1); return r; };
+    std::vector<double> r3(size_t(3 * n)); ck(oicc_get_r3_knots(h_, r3.data(), n));
+    velocity = Vec3{{0, 0, 0}};
+    for (int j = 0; j < 6; ++j) {
+      double c = 0.0;
+      for (int i = 1; i < 6; ++i) {   // coefficient of u^i in basis j, times d/du
+        double sum = 0.0;
+        for (int k = j; k < 6; ++k) sum += ((k - j) % 2 ? -1.0 : 1.0) * binom(6, k - j) * std::pow(double(6 - k - 1), double(5 - i));
+        c += binom(5, i) * sum / 120.0 * double(i) * std::pow(u, double(i - 1));
+      }
+      c /= double(dt_r3_ns_) * NS_TO_S;
+      for (int d = 0; d < 3; ++d) velocity[size_t(d)] += c * r3[size_t(3 * (s + j) + d)];
+    }
+    return true;
+  }
+  SE3 GetKnot(int i) const {   // impl.h:805-807
+    std::vector<double> q(size_t(4 * GetNumSO3Knots())), r(size_t(3 * GetNumR3Knots()));
+    oicc_get_so3_knots(h_, q.data(), int64_t(GetNumSO3Knots())); oicc_get_r3_knots(h_, r.data(), int64_t(GetNumR3Knots()));
+    SE3 T; T.q = Quat{q[size_t(4 * i)], q[size_t(4 * i + 1)], q[size_t(4 * i + 2)], q[size_t(4 * i + 3)]}; T.t = Vec3{{r[size_t(3 * i)], r[size_t(3 * i + 1)], r[size_t(3 * i + 2)]}};
+    return T;
+  }
+  ThreeAxisSensorCalibParams GetAcclIntrinsics(const int64_t& t_ns) {   // impl.h:1143-1160
+    double a[6], g[9]; ck(oicc_get_imu_intrinsics(h_, a, g));
+    ThreeAxisSensorCalibParams c; c.mis[0] = a[0]; c.mis[1] = a[1]; c.mis[2] = a[2]; for (int k = 0; k < 3; ++k) c.scale[k] = a[3 + k];
+    c.bias = GetAcclBias(t_ns); return c;
+  }
+  ThreeAxisSensorCalibParams GetGyroIntrinsics(const int64_t& t_ns) {   // impl.h:1162-1180 (the bias is the ACCELEROMETER bias there, :1164)
+    double a[6], g[9]; ck(oicc_get_imu_intrinsics(h_, a, g));
+    ThreeAxisSensorCalibParams c; for (int k = 0; k < 6; ++k) c.mis[k] = g[k]; for (int k = 0; k < 3; ++k) c.scale[k] = g[6 + k];
+    c.bias = GetAcclBias(t_ns); return c;
+  }
+  void SetFixedParams(int flags) {   // impl.h:93-252 (runs inside Optimize, impl.h:268): fixes the active set of a following evaluation
+    int32_t nt = 0, other[5]; std::vector<int32_t> a(GetNumSO3Knots()), b(GetNumR3Knots()), c(size_t(oicc_get_num_accl_bias_knots(h_))), d(size_t(oicc_get_num_gyro_bias_knots(h_)));
+    ck(oicc_get_tangent_layout(h_, flags, &nt, a.data(), b.data(), c.data(), d.data(), other));
+  }
+  void SetImuToCameraTimeOffset(double imu_to_camera_time_offset_s) { imu_to_camera_time_offset_s_ = imu_to_camera_time_offset_s; }   // impl.h:867-870: stored, read by no residual
   // whole trajectory dump in one call (continuous_time_imu_to_camera_calibration.cc:274-327)
   void GetTrajectory(const std::vector<int64_t>& t_ns, std::vector<double>* gyro3, std::vector<double>* accel3, std::vector<double>* gb3,
                      std::vector<double>* ab3, std::vector<uint8_t>* valid) {
@@ -212,6 +256,7 @@ class SplineTrajectoryEstimator {
   }
   oicc_problem* h_ = nullptr;
   int64_t dt_so3_ns_ = 0, dt_r3_ns_ = 0;
+  double imu_to_camera_time_offset_s_ = 0.0;
   SE3 T_i_c_;
   CalibDataset image_data_;
   std::map<int, int32_t> track_index_;

@@ -376,6 +376,59 @@ class SplineTrajectoryEstimator:
         o = self.GetTrajectory([time_ns])
         return bool(o["valid"][0]), o["accel"][0]
 
+    def GetPosition(self, time_ns):
+        """impl.h:879-897: the R3 spline value (= translation of GetPose)."""
+        o = self.GetTrajectory([time_ns])
+        return bool(o["valid"][0]), o["pose"][0][4:7].copy()
+
+    def GetVelocity(self, time_ns):
+        """spline_trajectory_estimator.h:118: first derivative of the R3 spline.  Never called by the reference's own code and
+        not part of the device read-back (oicc_get_trajectory: pose, angular velocity, acceleration, biases), so the six
+        knots of the window are combined on the host (basalt_spline/spline_common.h:67-133 blending, order 6)."""
+        dt = self.dt_r3_ns
+        st = int(time_ns) - self.GetMinTimeNs()
+        n = self.GetNumR3Knots()
+        if st < 0 or dt <= 0:
+            return False, np.zeros(3)
+        s, u = st // dt, (st % dt) / float(dt)
+        if s + SPLINE_N > n:
+            return False, np.zeros(3)
+        from math import comb
+        N = SPLINE_N
+        M = np.zeros((N, N))          # blending matrix, spline_common.h:67-98 (non-cumulative)
+        for i in range(N):
+            for j in range(N):
+                M[j, i] = comb(N - 1, i) * sum((-1) ** (k - j) * comb(N, k - j) * (N - k - 1) ** (N - 1 - i) for k in range(j, N)) / float(np.prod(range(1, N)))
+        p = np.array([k * u ** (k - 1) if k >= 1 else 0.0 for k in range(N)])
+        coeff = (M @ p) / (dt * 1e-9)
+        _, r3 = self.GetKnots()
+        return True, coeff @ r3[s:s + N]
+
+    def GetKnot(self, i):
+        """impl.h:805-807: SE3 of (so3 knot i, r3 knot i) as (q_xyzw, p)."""
+        so3, r3 = self.GetKnots()
+        return so3[i].copy(), r3[i].copy()
+
+    def GetAcclIntrinsics(self, time_ns):
+        """impl.h:1143-1160: ThreeAxisSensorCalibParams of the accelerometer at a time (misalignment yz, zy, zx; scales; the
+        accelerometer bias spline's value) as a dict."""
+        a, _ = self.GetIMUIntrinsics()
+        return dict(misalignment=(a[0], a[1], a[2], 0.0, 0.0, 0.0), scale=tuple(a[3:6]), bias=self.GetAcclBias(time_ns))
+
+    def GetGyroIntrinsics(self, time_ns):
+        """impl.h:1162-1180.  As in the reference the bias comes from GetAcclBias (:1164), not from the gyroscope bias spline."""
+        _, g = self.GetIMUIntrinsics()
+        return dict(misalignment=tuple(g[0:6]), scale=tuple(g[6:9]), bias=self.GetAcclBias(time_ns))
+
+    def SetFixedParams(self, flags):
+        """impl.h:93-252 runs inside Optimize (impl.h:268); on its own it only fixes the active set a following Evaluate uses."""
+        self.GetTangentLayout(flags)
+
+    def SetImuToCameraTimeOffset(self, imu_to_camera_time_offset_s):
+        """impl.h:867-870 stores the value; no residual reads it (the applications shift the telemetry timestamps instead,
+        continuous_time_imu_to_camera_calibration.cc:188-196), and neither does anything here."""
+        self.imu_to_camera_time_offset_s_ = float(imu_to_camera_time_offset_s)
+
     def GetGyroBias(self, time_ns):
         return self.GetTrajectory([time_ns])["gyro_bias"][0]
 

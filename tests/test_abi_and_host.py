@@ -133,3 +133,24 @@ def test_shards_cover_every_measurement_once():
     assert (imu[keep] == 1).all()
     nc = sum(int(ds.shard(r, world).shard_corner_offset[-1]) for r in range(world))
     assert nc == ds.num_corners
+
+
+def test_remaining_reference_getters(cpu):
+    """GetPosition / GetVelocity / GetKnot / GetAcclIntrinsics / GetGyroIntrinsics (spline_trajectory_estimator.h:110-144)."""
+    ds, cal = cpu
+    tr = cal.trajectory_
+    t = tr.GetMinTimeNs() + int(0.37e9)
+    ok, pose = tr.GetPose(t)
+    ok2, pos = tr.GetPosition(t)
+    assert ok and ok2 and np.array_equal(pos, pose[4:7])
+    h = 20000                                      # ns
+    okv, vel = tr.GetVelocity(t)
+    _, p1 = tr.GetPosition(t + h); _, p0 = tr.GetPosition(t - h)
+    assert okv and np.abs(vel - (p1 - p0) / (2 * h * 1e-9)).max() < 1e-6 * max(1.0, np.abs(vel).max())
+    assert not tr.GetVelocity(tr.GetMinTimeNs() - 5)[0] and not tr.GetVelocity(tr.GetMaxTimeNs() + int(1e9))[0]
+    q, p = tr.GetKnot(3)
+    so3, r3 = tr.GetKnots()
+    assert np.array_equal(q, so3[3]) and np.array_equal(p, r3[3])
+    a = tr.GetAcclIntrinsics(t); g = tr.GetGyroIntrinsics(t)
+    assert a["scale"] == (1.0, 1.0, 1.0) and len(g["misalignment"]) == 6 and np.array_equal(g["bias"], tr.GetAcclBias(t))   # the reference's own mix-up
+    tr.SetImuToCameraTimeOffset(0.01); tr.SetFixedParams(E.SPLINE | E.T_I_C)
