@@ -335,6 +335,21 @@ class ImuCameraCalibrator {
   }
   double GetCalibratedRSLineDelay() { return trajectory_.GetRSLineDelay(); }
   double GetInitialRSLineDelay() const { return inital_cam_line_delay_s_; }
+  void SetCalibrateRSLineDelay() { calibrate_cam_line_delay_ = true; }          // imu_camera_calibrator.h:65-70
+  bool GetCalibrateRSLineDelay() const { return calibrate_cam_line_delay_; }
+  void SetRSLineDelay(double line_delay) { inital_cam_line_delay_s_ = line_delay; }
+  void ClearSpline() { cam_timestamps_.clear(); gyro_measurements_.clear(); accl_measurements_.clear(); }   // imu_camera_calibrator.cc:188-192
+  void GetIMUIntrinsics(ThreeAxisSensorCalibParams& acc_intrinsics, ThreeAxisSensorCalibParams& gyr_intrinsics, int64_t time_ns = 0) {   // :194-200
+    acc_intrinsics = trajectory_.GetAcclIntrinsics(time_ns); gyr_intrinsics = trajectory_.GetGyroIntrinsics(time_ns); }
+  // imu_camera_calibrator.cc:170-186: the spline pose at every camera timestamp as views (name = t_ns, world -> camera rotation)
+  void ToTheiaReconDataset(CalibDataset& output_recon) {
+    for (double t_s : cam_timestamps_) {
+      const int64_t t_ns = int64_t(t_s * S_TO_NS);
+      SE3 pose; if (!trajectory_.GetPose(t_ns, pose)) continue;
+      View v; v.name = std::to_string(t_ns); v.timestamp_s = t_s; v.q_wc = pose.q; v.position = pose.t;
+      output_recon.views.push_back(v);
+    }
+  }
   const std::vector<double>& GetCamTimestamps() const { return cam_timestamps_; }
   const std::map<double, Vec3>& GetGyroMeasurements() const { return gyro_measurements_; }
   const std::map<double, Vec3>& GetAcclMeasurements() const { return accl_measurements_; }
@@ -348,6 +363,7 @@ class ImuCameraCalibrator {
   std::vector<double> cam_timestamps_;
   std::map<double, Vec3> gyro_measurements_, accl_measurements_;
   double t0_s_ = 0, tend_s_ = 0, inital_cam_line_delay_s_ = 0;
+  bool calibrate_cam_line_delay_ = false;
   bool gravity_initialized_ = false;
   Vec3 gravity_init_{{0, 0, GRAVITY_MAGN}};
 };

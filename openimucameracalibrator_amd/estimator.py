@@ -492,6 +492,10 @@ class ImuCameraCalibrator:
         self.accl_accepted = tr.AddAccelerometerMeasurements(ds.accel[keep], ti, 1.0 / ds.std_r3)
         self.gyro_accepted = tr.AddGyroscopeMeasurements(ds.gyro[keep], ti, 1.0 / ds.std_so3)
         self.imu_t_ns = ti
+        # bookkeeping of imu_camera_calibrator.cc:49-52,105-107: view timestamps, every IMU sample inside [t0, tend)
+        self.cam_timestamps_ = [float(x) for x in vt]
+        self.gyro_measurements_ = {float(x): g for x, g in zip(t[keep], ds.gyro[keep])}
+        self.accl_measurements_ = {float(x): a for x, a in zip(t[keep], ds.accel[keep])}
         if shard is not None and shard[1] > 1:
             # other ranks' measurements: timestamps only, so that every rank derives the same tangent layout
             mine = np.zeros(ds.num_views, bool); mine[d.shard_view_index] = True
@@ -511,3 +515,49 @@ class ImuCameraCalibrator:
 
     def GetCalibratedRSLineDelay(self):
         return self.trajectory_.GetRSLineDelay()
+
+    # ---- the rest of core/imu_camera_calibrator.h:44-79 ------------------------------------------
+    def SetCalibrateRSLineDelay(self):
+        self.calibrate_cam_line_delay_ = True
+
+    def GetCalibrateRSLineDelay(self):
+        return bool(getattr(self, "calibrate_cam_line_delay_", False))
+
+    def SetRSLineDelay(self, line_delay):
+        self.inital_cam_line_delay_s_ = float(line_delay)
+
+    def GetInitialRSLineDelay(self):
+        return float(getattr(self, "inital_cam_line_delay_s_", 0.0))
+
+    def SetKnownGravityDir(self, gravity):
+        """imu_camera_calibrator.cc:126-128: trajectory_.SetGravity(gravity)."""
+        self.trajectory_.SetGravity(np.asarray(gravity, dtype=np.float64))
+
+    def GetCamTimestamps(self):
+        return list(getattr(self, "cam_timestamps_", []))
+
+    def GetGyroMeasurements(self):
+        return dict(getattr(self, "gyro_measurements_", {}))
+
+    def GetAcclMeasurements(self):
+        return dict(getattr(self, "accl_measurements_", {}))
+
+    def ClearSpline(self):
+        """imu_camera_calibrator.cc:188-192."""
+        self.cam_timestamps_ = []; self.gyro_measurements_ = {}; self.accl_measurements_ = {}
+
+    def GetIMUIntrinsics(self, time_ns=0):
+        """imu_camera_calibrator.cc:194-200 -> (accelerometer, gyroscope) ThreeAxisSensorCalibParams as dicts."""
+        return self.trajectory_.GetAcclIntrinsics(time_ns), self.trajectory_.GetGyroIntrinsics(time_ns)
+
+    def ToTheiaReconDataset(self):
+        """imu_camera_calibrator.cc:170-186: the spline pose at every camera timestamp as (name = t_ns, R_cw = R^T, position);
+        returned as the view table of the pose-data-set twin (io_files.write_pose_dataset)."""
+        out = {}
+        t_ns = [int(t * S_TO_NS) for t in self.GetCamTimestamps()]
+        tr = self.trajectory_.GetTrajectory(t_ns) if t_ns else None
+        for i, t in enumerate(t_ns):
+            if tr["valid"][i]:
+                q = tr["pose"][i][:4] * np.array([-1.0, -1.0, -1.0, 1.0])       # rotationMatrix().transpose()
+                out[str(t)] = dict(q_cw=q, position=tr["pose"][i][4:7].copy())
+        return out
