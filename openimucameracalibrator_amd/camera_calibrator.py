@@ -451,6 +451,21 @@ class PoseEstimator:
         self.views.obs.append([(int(k), float(f[0]), float(f[1])) for k, f in zip(point_ids, features)])
         return len(self.views.pose) - 1
 
+    def EstimatePosePinhole(self, timestamp_s, correspondences_undist, board_pts3_ids):
+        """pose_estimator.cc:62-90 for one frame: start pose from the normalised correspondences (closed forms instead of the
+        reference's RANSAC PnP), the frame is added with its observations; its BundleAdjustView runs together with every other
+        frame's in the next OptimizeAllPoses (one launch).  correspondences_undist: [n,2] normalised image points."""
+        from . import planar_init
+        pid = np.asarray(board_pts3_ids, dtype=np.int32)
+        xy = np.asarray(correspondences_undist, dtype=np.float64).reshape(-1, 2)
+        if len(pid) < 6:                                                      # ransac_summary.inliers.size() < 6, :72-74
+            return False
+        ok, R, C, _ = planar_init.initialize_view(self.points, pid, xy, focal=1.0)
+        if not ok:
+            return False
+        self.AddView(R, C, timestamp_s, pid, xy)
+        return True
+
     def OptimizeAllPoses(self):
         """pose_estimator.cc:226-236: BundleAdjustView per view -- here ONE launch, one wavefront per view."""
         pose, off, uv, pid = self.views.flat()

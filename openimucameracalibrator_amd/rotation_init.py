@@ -28,6 +28,47 @@ def estimate_camera_imu_rotation(t_vis_s, q_vis_xyzw, t_imu_s, gyro, dt_imu, est
     return dict(q_imu_to_cam=np.array(q[:]), time_offset=td.value, gyro_bias=np.array(bias[:]), error=err.value, iterations=it.value)
 
 
+def _quat_to_matrix(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class ImuToCameraRotationEstimator:
+    """Class mirror of OpenICC::core::ImuToCameraRotationEstimator (core/imu_to_camera_rotation_estimator.h:23-70): same
+    method names, maps keyed by time in seconds.  SolveClosedForm (one probe of the time-offset search) runs inside the device
+    entry point and is not exposed on its own."""
+
+    def __init__(self, visual_rotations=None, imu_angular_vel=None, device=0, backend=None):
+        self.visual_rotations_ = dict(visual_rotations or {})
+        self.imu_angular_vel_ = dict(imu_angular_vel or {})
+        self.estimate_gyro_bias_ = False
+        self.device, self.backend = device, backend
+
+    def SetVisualRotations(self, visual_rotations):
+        """time [s] -> camera orientation quaternion (x, y, z, w)."""
+        self.visual_rotations_ = dict(visual_rotations)
+
+    def SetAngularVelocities(self, imu_angular_vel):
+        """time [s] -> gyroscope sample (rad/s)."""
+        self.imu_angular_vel_ = dict(imu_angular_vel)
+
+    def EnableGyroBiasEstimation(self):
+        self.estimate_gyro_bias_ = True
+
+    def EstimateCameraImuRotation(self, dt_imu):
+        """-> (success, R_imu_to_camera [3,3], time_offset_imu_to_camera, gyro_bias [3]); the reference's two debug
+        outputs (smoothed angular velocities) stay on the device."""
+        tv = np.array(sorted(self.visual_rotations_)); ti = np.array(sorted(self.imu_angular_vel_))
+        if len(tv) < 2 or len(ti) < 16:
+            return False, np.eye(3), 0.0, np.zeros(3)
+        qv = np.array([self.visual_rotations_[t] for t in tv]); gy = np.array([self.imu_angular_vel_[t] for t in ti])
+        r = estimate_camera_imu_rotation(tv, qv, ti, gy, dt_imu, self.estimate_gyro_bias_, device=self.device, backend=self.backend)
+        self.last_ = r
+        return True, _quat_to_matrix(r["q_imu_to_cam"]), r["time_offset"], r["gyro_bias"]
+
+
 def _slerp(a, b, f):
     d = float(a @ b); ad = abs(d)
     if ad >= 1.0 - np.finfo(float).eps:

@@ -198,3 +198,21 @@ def test_mirrors_carry_every_defined_method_of_the_reference_classes():
     private_helper = {"InitializeGravity"}          # private in the reference; part of BatchInitSpline here
     assert names - private_helper <= py_names, sorted(names - private_helper - py_names)
     assert names - private_helper <= cpp_names, sorted(names - private_helper - cpp_names)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/OpenCameraCalibrator/core"), reason="reads the reference headers: only where the tree is mounted")
+def test_calibrator_pose_estimator_and_rotation_mirrors_carry_the_reference_names():
+    core = "/root/reference/include/OpenCameraCalibrator/core/"
+    pkg = os.path.join(ROOT, "openimucameracalibrator_amd")
+
+    def public_methods(header, cls):
+        h = open(core + header).read()
+        body = h[h.index("class " + cls):]
+        body = body[body.index("public:"):body.index("private:")]
+        return set(re.findall(r"\b([A-Z][A-Za-z0-9_]+)\s*\(", body)) - {cls, "EIGEN_MAKE_ALIGNED_OPERATOR_NEW"}
+    cc = open(os.path.join(pkg, "camera_calibrator.py")).read()
+    names = set(re.findall(r"def ([A-Z][A-Za-z0-9_]+)\(", cc))
+    assert public_methods("camera_calibrator.h", "CameraCalibrator") - {"WriteCalibration"} <= names      # declared, never defined
+    assert public_methods("pose_estimator.h", "PoseEstimator") <= names
+    ri = set(re.findall(r"def ([A-Z][A-Za-z0-9_]+)\(", open(os.path.join(pkg, "rotation_init.py")).read()))
+    assert public_methods("imu_to_camera_rotation_estimator.h", "ImuToCameraRotationEstimator") - {"SolveClosedForm"} <= ri   # one probe: inside the device call

@@ -135,3 +135,14 @@ def test_hip_application_twin_and_errors():
     assert qangle(q, qconj(Q_IC)) < np.deg2rad(2.0) and abs(out["time_offset_gyro_to_cam"]) < 0.03
     with pytest.raises(RuntimeError):
         RI.estimate_camera_imu_rotation(tv[::-1].copy(), qv, ti, gy, dt)                            # unsorted times
+
+
+def test_class_mirror_has_the_reference_interface():
+    """core/imu_to_camera_rotation_estimator.h:23-70 names on the class mirror; without data it reports failure."""
+    from openimucameracalibrator_amd import rotation_init as RI
+    est = RI.ImuToCameraRotationEstimator()
+    est.SetVisualRotations({0.0: [0, 0, 0, 1.0]}); est.SetAngularVelocities({0.0: [0.0, 0.0, 0.0]}); est.EnableGyroBiasEstimation()
+    ok, R, td, bias = est.EstimateCameraImuRotation(0.005)
+    assert not ok and np.array_equal(R, np.eye(3)) and td == 0.0
+    R90 = RI._quat_to_matrix(np.array([0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)]))
+    assert np.allclose(R90 @ [1.0, 0.0, 0.0], [0.0, 1.0, 0.0])
