@@ -39,7 +39,7 @@ def main(argv=None):
     ap.add_argument("--grid_size", type=float, default=0.04)
     ap.add_argument("--optimize_board_points", type=str2bool, nargs="?", const=True, default=False)
     ap.add_argument("--verbose", type=str2bool, nargs="?", const=True, default=False)
-    a = ap.parse_args(argv)
+    a = io_files.parse_reference_flags(ap, argv)
     scene = io_files.read_scene_bson(a.input_corners)
     cal = calibrate_camera_from_json(scene, a.camera_model_to_calibrate, a.grid_size, a.save_path_calib_dataset, a.verbose,
                                      optimize_board_points=a.optimize_board_points)

@@ -29,7 +29,19 @@ struct Flags {
       if (eq != std::string::npos) { k = a.substr(0, eq); v = a.substr(eq + 1); has = true; }
       bool neg = false;
       if (!s.count(k) && k.rfind("no", 0) == 0 && s.count(k.substr(2))) { k = k.substr(2); neg = true; }
-      if (!s.count(k)) { std::cerr << "unknown flag --" << k << "\n"; return false; }
+      if (!s.count(k)) {
+        // glog / gflags built-ins: the reference's binaries accept them (its python drivers pass --logtostderr=1 to every
+        // application, python/run_gopro_calibration.py:300-317); they are accepted and ignored here
+        static const char* const kIgnoredBool[] = {"logtostderr", "alsologtostderr", "colorlogtostderr", "stop_logging_if_full_disk", "log_prefix",
+                                                   "help", "helpfull", "helpshort", "version"};
+        static const char* const kIgnoredValue[] = {"v", "vmodule", "minloglevel", "stderrthreshold", "log_dir", "logbuflevel", "logbufsecs",
+                                                    "max_log_size", "flagfile", "fromenv", "tryfromenv", "undefok"};
+        bool ignored = false;
+        for (const char* n : kIgnoredBool) if (k == n || k == std::string("no") + n) ignored = true;
+        if (!ignored) for (const char* n : kIgnoredValue) if (k == n) { ignored = true; if (!has && i + 1 < argc) ++i; }
+        if (ignored) continue;
+        std::cerr << "unknown flag --" << k << "\n"; return false;
+      }
       const bool is_bool = s[k] == "true" || s[k] == "false";
       if (!has) { if (is_bool) v = neg ? "false" : "true"; else if (i + 1 < argc) v = argv[++i]; else { std::cerr << "flag --" << k << " needs a value\n"; return false; } }
       s[k] = v;

@@ -38,7 +38,7 @@ def main(argv=None):
     ap.add_argument("--camera_calibration_json", required=True)
     ap.add_argument("--output_pose_dataset", required=True)
     ap.add_argument("--optimize_board_points", nargs="?", const="true", default="false")
-    a = ap.parse_args(argv)
+    a = io_files.parse_reference_flags(ap, argv)
     scene = io_files.read_scene_bson(a.input_corners)
     model, intr, w, h, _ = io_files.read_camera_calibration(a.camera_calibration_json)
     t_s, pose, points, err = estimate_poses_from_json(scene, model, intr, h,

@@ -197,3 +197,23 @@ def write_ply_cameras(path, pose6, points, color=(255, 0, 0)):
             f.write("%.6f %.6f %.6f 255 255 255\n" % (p[0] / p[3], p[1] / p[3], p[2] / p[3]))
         for p in pose6:
             f.write("%.6f %.6f %.6f %d %d %d\n" % (p[0], p[1], p[2], color[0], color[1], color[2]))
+
+
+GLOG_FLAGS = ("logtostderr", "alsologtostderr", "colorlogtostderr", "stop_logging_if_full_disk", "log_prefix", "v", "vmodule", "minloglevel",
+              "stderrthreshold", "log_dir", "logbuflevel", "logbufsecs", "max_log_size", "flagfile", "fromenv", "tryfromenv", "undefok")
+
+
+def parse_reference_flags(parser, argv=None):
+    """argparse with the reference's command-line habits: its python drivers pass glog's --logtostderr=1 to every application
+    (python/run_gopro_calibration.py:300-317); glog / gflags built-ins are accepted and ignored, anything else unknown is an error."""
+    args, rest = parser.parse_known_args(argv)
+    i = 0
+    while i < len(rest):
+        name = rest[i].lstrip("-").split("=")[0]
+        if not rest[i].startswith("--") or (name not in GLOG_FLAGS and not (name.startswith("no") and name[2:] in GLOG_FLAGS)):
+            parser.error("unrecognized arguments: %s" % rest[i])
+        if "=" not in rest[i] and name in ("v", "vmodule", "minloglevel", "stderrthreshold", "log_dir", "logbuflevel", "logbufsecs", "max_log_size",
+                                           "flagfile", "fromenv", "tryfromenv", "undefok") and i + 1 < len(rest):
+            i += 1
+        i += 1
+    return args

@@ -9,6 +9,7 @@ import json
 import numpy as np
 
 from . import _lib
+from . import io_files
 
 
 def estimate_camera_imu_rotation(t_vis_s, q_vis_xyzw, t_imu_s, gyro, dt_imu, estimate_gyro_bias=True, device=0, backend=None):
@@ -123,7 +124,7 @@ def main(argv=None):
     ap.add_argument("--imu_bias_estimate", default="", help="bias JSON; if empty the gyro bias is estimated here")
     ap.add_argument("--imu_rotation_init_output", default="gyro_to_cam_calibration.json")
     ap.add_argument("--device", default=0, type=int)
-    a = ap.parse_args(argv)
+    a = io_files.parse_reference_flags(ap, argv)
     tel = json.load(open(a.telemetry_json)); ds = json.load(open(a.input_pose_calibration_dataset))
     # view time: "timestamp_s" if the twin carries it, else the view name in microseconds (the corner-file convention)
     vt = {k: (v["timestamp_s"] if "timestamp_s" in v else int(k) * 1e-6) for k, v in ds["views"].items()}

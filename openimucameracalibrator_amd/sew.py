@@ -9,6 +9,7 @@ import json
 import numpy as np
 
 from . import _lib
+from . import io_files
 
 
 def knot_spacing_and_variance(signal, times, quality, min_dt=None, max_dt=None, verbose=False, device=0, backend=None):
@@ -55,7 +56,7 @@ def main(argv=None):
     ap.add_argument("--q_so3", default=0.98, type=float, help="quality value for the rotational component (gyro)")
     ap.add_argument("--q_r3", default=0.96, type=float, help="quality value for the translational component (accelerometer)")
     ap.add_argument("--device", default=0, type=int)
-    args = ap.parse_args(argv)
+    args = io_files.parse_reference_flags(ap, argv)
     with open(args.input_json_path) as f:
         tel = json.load(f)
     sw = spline_weighting_for_telemetry(tel, args.q_so3, args.q_r3, device=args.device)

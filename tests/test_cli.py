@@ -243,3 +243,36 @@ def test_every_gflag_of_the_reference_applications_is_accepted():
         ref = set(re.findall(r"DEFINE_\w+\(\s*(\w+)", open("/root/reference/applications/%s.cc" % app).read()))
         mine = set(re.findall(r'\{"(\w+)",\s*"', open(os.path.join(host, app + ".cpp")).read()))
         assert ref and ref <= mine and mine - ref <= extras, (app, ref - mine, mine - ref)
+
+
+def test_glog_flags_of_the_reference_drivers_are_accepted(tmp_path):
+    """python/run_gopro_calibration.py:300-317 (and the other run_*.py drivers) start every application with glog's
+    --logtostderr=1: accepted and ignored, unknown flags still fail."""
+    ds = synthetic.make_config("C1", camera="gopro9_division")
+    flags = io_files.write_dataset_files(ds, str(tmp_path))
+    r = run_cli(flags, "--dry_run", "--logtostderr=1", "--v", "2", "--nologtostderr")
+    assert r.returncode == 0, r.stderr
+    assert run_cli(flags, "--dry_run", "--logtostderr=1", "--not_a_flag").returncode == 2
+    import argparse
+    ap = argparse.ArgumentParser(); ap.add_argument("--input_corners", default="")
+    a = io_files.parse_reference_flags(ap, ["--input_corners=x", "--logtostderr=1", "--v", "3", "--minloglevel=0"])
+    assert a.input_corners == "x"
+    with pytest.raises(SystemExit):
+        io_files.parse_reference_flags(ap, ["--input_corners=x", "--bogus=1"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python"), reason="reads the reference's driver scripts: only where the tree is mounted")
+def test_every_flag_the_reference_drivers_pass_is_accepted():
+    """the command lines python/run_*_calibration.py build for the four applications of this path."""
+    import glob
+    import re
+    host = os.path.join(os.path.dirname(CLI), "host")
+    apps = ("continuous_time_imu_to_camera_calibration", "estimate_imu_to_camera_rotation", "calibrate_camera", "estimate_camera_poses_from_checkerboard")
+    used = {a: set() for a in apps}
+    for f in glob.glob("/root/reference/python/run_*.py"):
+        for m in re.finditer(r"Popen\(\[pjoin\(bin_path,\s*['\"](\w+)['\"]\)(.*?)\]\)", open(f).read(), flags=re.S):
+            if m.group(1) in used:
+                used[m.group(1)] |= set(re.findall(r"--(\w+)", m.group(2)))
+    for a in apps:
+        mine = set(re.findall(r'\{"(\w+)",\s*"', open(os.path.join(host, a + ".cpp")).read()))
+        assert used[a] and used[a] - mine <= set(io_files.GLOG_FLAGS), (a, used[a] - mine)
