@@ -2,6 +2,7 @@
 // of the input files both applications take (telemetry JSON, JSON twin of the TheiaSfM pose data set).
 #pragma once
 #include <array>
+#include <cctype>
 #include <cstdlib>
 #include <iostream>
 #include <map>
@@ -49,7 +50,11 @@ struct Flags {
     return true;
   }
   std::string str(const std::string& k) const { return s.at(k); }
-  bool b(const std::string& k) const { const std::string& v = s.at(k); return v == "true" || v == "1"; }
+  // gflags' boolean spellings: true/false, t/f, yes/no, y/n, 1/0, any case
+  bool b(const std::string& k) const {
+    std::string v = s.at(k); for (char& c : v) c = char(std::tolower(static_cast<unsigned char>(c)));
+    return v == "true" || v == "t" || v == "yes" || v == "y" || v == "1";
+  }
   double d(const std::string& k) const { return std::stod(s.at(k)); }
 };
 
