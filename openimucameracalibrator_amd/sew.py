@@ -55,8 +55,12 @@ def main(argv=None):
     ap.add_argument("--output_path", help="output path")
     ap.add_argument("--q_so3", default=0.98, type=float, help="quality value for the rotational component (gyro)")
     ap.add_argument("--q_r3", default=0.96, type=float, help="quality value for the translational component (accelerometer)")
+    ap.add_argument("--use_gopro_importer", default=0, help="raw GoPro telemetry (get_sew_for_dataset.py:24-31); not supported here: convert it to the generic telemetry JSON first")
     ap.add_argument("--device", default=0, type=int)
     args = io_files.parse_reference_flags(ap, argv)
+    if str(args.use_gopro_importer) not in ("0", "", "False", "false"):
+        raise SystemExit("--use_gopro_importer: the raw GoPro telemetry importer (python/telemetry_converter.py) is outside this path; "
+                         "pass the generic telemetry JSON {accelerometer, gyroscope, timestamps_ns, camera_fps}")
     with open(args.input_json_path) as f:
         tel = json.load(f)
     sw = spline_weighting_for_telemetry(tel, args.q_so3, args.q_r3, device=args.device)
