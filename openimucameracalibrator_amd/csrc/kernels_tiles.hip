@@ -1,0 +1,456 @@
+// Residual + analytic Jacobian + normal-equation pass of the spline calibration problem, by TIME TILES (gfx950).
+// Design: tiles.h.  What Ceres does per residual block (Evaluate -> J * plus-Jacobian -> block sparse J^T J,
+// reference spline_trajectory_estimator.impl.h:255-276 -> ceres::Solve) is fused into one launch:
+//
+//   workgroup = one tile of consecutive knot windows, 4 waves
+//     P0  knots of the tile -> LDS; per knot pair the segment table (log, axis, Jr^-1: spline_seg.cuh), one lane per pair
+//     P1  every wave pulls units from the tile's queue:  lane = item (corner / IMU sample)
+//           spline evaluation, residual, analytic Jacobian rows (block_items.cuh) -> compact rows in the wave's LDS buffer
+//           per CELL (a view, or the samples sharing one set of knot windows) the augmented Gram matrix [J r]^T [J r]
+//           as 16x16 v_mfma_f64_16x16x4_f64 tiles, operands expanded from the compact rows while they are loaded
+//           tiles -> the tile's band accumulator in LDS (ds_add_f64)
+//     P2  accumulator -> the tile's slab in HBM, plain coalesced stores
+//   slab_merge_kernel: packed normal equations = sum of the overlapping slabs of every band row (fixed order).
+//
+// The cost-only pass (candidate point of an LM step) is the same kernel without rows and accumulators.
+#include <hip/hip_runtime.h>
+#include "oicc_device.h"
+#include "tiles.h"
+#include "block_items.cuh"
+
+namespace oicc {
+namespace {
+
+__device__ __forceinline__ void wave_sync() {   // LDS hand-over between the lanes of ONE wave (the waves of a tile run independently)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct LdsSeg { const double* base; __device__ __forceinline__ const double* operator()(int i) const { return base + i * kSegStride; } };
+struct LdsR3 { const double* base; __device__ __forceinline__ const double* operator()(int j) const { return base + 3 * j; } };
+
+// Sink of block_items.cuh: compact record of one item in the wave's row buffer and, for the parity tests, the dense rows
+// of the ABI layout (oicc_evaluate_blocks).  Record of item m (RowFmt::item_stride doubles, odd: conflict-free lane
+// strides): value (idx, r) at [idx * ROWS + r], factors behind the nbase * ROWS values.  Group pointers are formed once
+// per item, every store then has a compile-time offset.
+template <int KINDSEL, bool JAC>
+struct TileSink {
+  static constexpr int ROWS = KINDSEL == 0 ? 2 : 3;
+  static constexpr int DW = KINDSEL == 0 ? 43 : (KINDSEL == 1 ? 54 : 36);
+  double* p_s; double* p_v; double* p_t; double* p_l; double* p_m; double* p_i; double* p_res; double* p_cf; double* p_cb;
+  double* rec; int nvals, nfac;
+  double* dres; double* djac;
+  __device__ __forceinline__ TileSink(const RowFmt& f, double* record, double* dres_, double* djac_) : rec(record), dres(dres_), djac(djac_) {
+    p_s = record + f.b_s * ROWS; p_v = record + f.b_v * ROWS; p_t = record + f.b_t * ROWS; p_l = record + f.b_l * ROWS;
+    p_m = record + f.b_m * ROWS; p_i = record + f.b_i * ROWS; p_res = record + f.b_res * ROWS;
+    p_cf = record + f.nbase * ROWS + f.f_cf; p_cb = record + f.nbase * ROWS + f.f_cb;
+    nvals = f.b_res * ROWS; nfac = f.nfac;
+  }
+  __device__ __forceinline__ void res(const double* r) const {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) { if (JAC) p_res[i] = r[i]; if (dres) dres[i] = r[i]; }
+  }
+  __device__ __forceinline__ void zero() const {
+    for (int k = 0; k < nvals; ++k) rec[k] = 0.0;
+    for (int k = 0; k < nfac; ++k) p_res[ROWS + k] = 0.0;
+  }
+  __device__ __forceinline__ void so3(int j, const double* a) const {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) { p_s[(3 * j + c) * ROWS + r] = a[r * 3 + c]; if (djac) djac[r * DW + 3 * j + c] = a[r * 3 + c]; }
+  }
+  __device__ __forceinline__ void r3(const double* cf, const double* b) const {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) p_cf[j] = cf[j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) p_v[c * ROWS + r] = b[r * 3 + c];
+    if (djac) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) djac[r * DW + 18 + 3 * j + c] = cf[j] * b[r * 3 + c];
+    }
+  }
+  __device__ __forceinline__ void tic(const double* t) const {
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) { p_t[c * ROWS + r] = t[r * 6 + c]; if (djac) djac[r * DW + 36 + c] = t[r * 6 + c]; }
+  }
+  __device__ __forceinline__ void ld(const double* l) const {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) { p_l[r] = l[r]; if (djac) djac[r * DW + 42] = l[r]; }
+  }
+  __device__ __forceinline__ void grav(const double* b) const {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) { p_v[c * ROWS + r] = b[r * 3 + c]; if (djac) djac[r * DW + 36 + c] = b[r * 3 + c]; }
+  }
+  __device__ __forceinline__ void bias(const double* cb, const double* m) const {
+    constexpr int o = KINDSEL == 1 ? 39 : 18;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p_cb[k] = cb[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) p_m[c * ROWS + r] = m[r * 3 + c];
+    if (djac) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) djac[r * DW + o + 3 * k + c] = cb[k] * m[r * 3 + c];
+    }
+  }
+  __device__ __forceinline__ void intr(int n, const double* d) const {
+    constexpr int o = KINDSEL == 1 ? 48 : 27;
+    for (int r = 0; r < ROWS; ++r)
+      for (int c = 0; c < n; ++c) { p_i[c * ROWS + r] = d[r * n + c]; if (djac) djac[r * DW + o + c] = d[r * n + c]; }
+  }
+};
+
+// Gram column -> (value index, factor index) of the compact record
+__device__ __forceinline__ void col_src(const RowFmt& f, int col, int& bi, int& fi) {
+  bi = -1; fi = -1;
+  if (col >= f.ncols) return;
+  if (col == f.rescol) { bi = f.b_res; return; }
+  if (f.c_s >= 0 && col >= f.c_s && col < f.c_s + 18) { bi = f.b_s + (col - f.c_s); return; }
+  if (f.c_r >= 0 && col >= f.c_r && col < f.c_r + 18) { const int k = col - f.c_r; bi = f.b_v + k % 3; fi = f.f_cf + k / 3; return; }
+  if (f.c_t >= 0 && col >= f.c_t && col < f.c_t + 6) { bi = f.b_t + (col - f.c_t); return; }
+  if (f.c_l >= 0 && col == f.c_l) { bi = f.b_l; return; }
+  if (f.c_g >= 0 && col >= f.c_g && col < f.c_g + 3) { bi = f.b_v + (col - f.c_g); return; }
+  if (f.c_b >= 0 && col >= f.c_b && col < f.c_b + 9) { const int k = col - f.c_b; bi = f.b_m + k % 3; fi = f.f_cb + k / 3; return; }
+  if (f.c_i >= 0 && col >= f.c_i && col < f.c_i + f.n_i) { bi = f.b_i + (col - f.c_i); return; }
+}
+
+// where the Gram entries of a cell go.  i <= j are EXTENDED tangent offsets: band [0, Pb), arrow [Pb, Pb + a), the
+// residual column Pb + a (so (i, Pb + a) is a gradient entry and (Pb + a, Pb + a) twice the cost).
+struct Target {
+  double* acc;          // LDS accumulator of the tile: rows [lo, lo + nrows) x [band W | arrow a | gradient], then the (a + 1)^2 corner
+  int lo, Wl, W, Pb, a, corner0;
+  NormalEq ne;          // DIRECT mode: fp64 atomics on the packed normal equations
+};
+template <bool DIRECT>
+__device__ __forceinline__ void target_add(const Target& T, int i, int j, double v) {
+  if (!DIRECT) {
+    const int t = i < T.Pb ? (i - T.lo) * T.Wl + (j < T.Pb ? j - i : T.W + (j - T.Pb)) : T.corner0 + (i - T.Pb) * (T.a + 1) + (j - T.Pb);
+    unsafeAtomicAdd(T.acc + t, v);                                   // ds_add_f64
+  } else {
+    const int P = T.Pb + T.a;
+    if (j < T.Pb) unsafeAtomicAdd(T.ne.band() + (int64_t)i * T.W + (j - i), v);
+    else if (i < T.Pb) { if (j < P) unsafeAtomicAdd(T.ne.Et() + (int64_t)(j - T.Pb) * T.Pb + i, v); else unsafeAtomicAdd(T.ne.g() + i, v); }
+    else if (j < P) { unsafeAtomicAdd(T.ne.C() + (int64_t)(i - T.Pb) * T.a + (j - T.Pb), v); if (i != j) unsafeAtomicAdd(T.ne.C() + (int64_t)(j - T.Pb) * T.a + (i - T.Pb), v); }
+    else if (i < P) unsafeAtomicAdd(T.ne.g() + i, v);
+    else unsafeAtomicAdd(T.ne.cost(), 0.5 * v);
+  }
+}
+
+// Gram product of the rows [r0, r1) of a unit (one cell) and its scatter.  Operand lane mapping of
+// v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] with i = j = lane & 15, k = lane >> 4 -- the same for both operands, so
+// one operand load per 16-column block and K step feeds all tile pairs; the result lane holds
+// G[16 ti + (lane >> 4) + 4 r][16 tj + (lane & 15)], r = 0..3.  Only the upper block triangle is formed.
+template <int NT, bool DIRECT>
+__device__ __forceinline__ void gram_cell(const RowFmt& f, const double* rb, int r0, int r1, const int* coloff, const Target& T, int lane,
+                                          long long* prof) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  constexpr int NP = NT * (NT + 1) / 2;
+  v4d acc[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int li = lane & 15, lq = lane >> 4;
+  const int rows = f.rows_per_item, S = f.item_stride, fbase = f.nbase * rows;
+  int ba[NT], fa[NT];     // value offset idx * rows inside the record (or -1), factor offset inside the record (or -1)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { int b, q; col_src(f, 16 * t + li, b, q); ba[t] = b < 0 ? -1 : b * rows; fa[t] = q < 0 ? -1 : fbase + q; }
+  const long long t0 = prof ? clock64() : 0;
+  for (int kb = r0; kb < r1; kb += 16) {
+    double a[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + 4 * u + lq;
+      const int kk = k < r1 ? k : r1 - 1;
+      const int item = rows == 2 ? (kk >> 1) : (kk * 0xAAAB) >> 17;               // kk / 3 for kk < 2^15
+      const double* rec = rb + item * S;
+      const int r = kk - item * rows;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double v = rec[(ba[t] < 0 ? 0 : ba[t]) + r];
+        const double q = rec[fa[t] < 0 ? 0 : fa[t]];
+        a[u][t] = (k < r1 && ba[t] >= 0) ? (fa[t] < 0 ? v : v * q) : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int idx = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < NT; ++tj) { acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], a[u][tj], acc[idx], 0, 0, 0); ++idx; }
+    }
+  }
+  const long long t1 = prof ? clock64() : 0;
+  int oj[NT], oi[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int cj = 16 * t + li;
+    oj[t] = cj < f.ncols ? coloff[cj] : -1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int ci = 16 * t + lq + 4 * r; oi[t][r] = ci < f.ncols ? coloff[ci] : -1; }
+  }
+  int idx = 0;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < NT; ++tj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = 16 * ti + lq + 4 * r, cj = 16 * tj + li;
+        int i = oi[ti][r], j = oj[tj];
+        if (ci <= cj && i >= 0 && j >= 0) {
+          if (i > j) { const int t = i; i = j; j = t; }
+          target_add<DIRECT>(T, i, j, acc[idx][r]);
+        }
+      }
+      ++idx;
+    }
+  if (prof && lane == 0) { const long long t2 = clock64(); prof[2] += t1 - t0; prof[3] += t2 - t1; }
+}
+
+// extended tangent offset of Gram column `col` of a cell with knot windows (s_so3, s_r3 relative to the staged knots; s_b); sensor: 0 view, 1 accel, 2 gyro
+__device__ __forceinline__ int cell_col_offset(const RowFmt& f, const TangentLayout& tl, int sensor, int col, const int* l_tl_so3, const int* l_tl_r3,
+                                               int s_so3_rel, int s_r3_rel, int s_b) {
+  if (col >= f.ncols) return -1;
+  if (col == f.rescol) return tl.Pb + tl.a;
+  if (f.c_s >= 0 && col >= f.c_s && col < f.c_s + 18) { const int k = col - f.c_s; const int o = l_tl_so3[s_so3_rel + k / 3]; return o < 0 ? -1 : o + k % 3; }
+  if (f.c_r >= 0 && col >= f.c_r && col < f.c_r + 18) { const int k = col - f.c_r; const int o = l_tl_r3[s_r3_rel + k / 3]; return o < 0 ? -1 : o + k % 3; }
+  if (f.c_t >= 0 && col >= f.c_t && col < f.c_t + 6) return tl.tic + (col - f.c_t);
+  if (f.c_l >= 0 && col == f.c_l) return tl.ld;
+  if (f.c_g >= 0 && col >= f.c_g && col < f.c_g + 3) return tl.g + (col - f.c_g);
+  if (f.c_b >= 0 && col >= f.c_b && col < f.c_b + 9) { const int k = col - f.c_b; const int o = (sensor == 1 ? tl.ab : tl.gb)[s_b + k / 3]; return o < 0 ? -1 : o + k % 3; }
+  if (f.c_i >= 0 && col >= f.c_i && col < f.c_i + f.n_i) return (sensor == 1 ? tl.ai : tl.gi) + (col - f.c_i);
+  return -1;
+}
+
+}  // namespace
+
+template <bool JAC, bool DIRECT>
+__global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewData vd, ImuData ia, ImuData ig, RowFmt fv, RowFmt fa, RowFmt fg,
+                                                            TileParams tp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TileDesc td = tp.tiles[blockIdx.x];
+  double* acc = lds + tp.o_acc;
+  double* l_so3 = lds + tp.o_so3;
+  double* l_r3 = lds + tp.o_r3;
+  double* l_seg = lds + tp.o_seg;
+  int* l_tl_so3 = reinterpret_cast<int*>(lds + tp.o_tl);
+  int* l_tl_r3 = l_tl_so3 + kMaxTileKnots;
+  int* l_queue = reinterpret_cast<int*>(lds + tp.o_misc);
+  int* coloff = reinterpret_cast<int*>(lds + tp.o_wave + (size_t)wave * tp.wave_doubles);
+  double* rb = lds + tp.o_wave + (size_t)wave * tp.wave_doubles + 32;
+
+  // ---- P0: knots, tangent offsets, segment tables, zeroed accumulator ----
+  for (int i = tid; i < td.nks * 4; i += kTileThreads) l_so3[i] = ctx.x[ctx.pl.so3 + (int64_t)td.ks0 * 4 + i];
+  for (int i = tid; i < td.nkr * 3; i += kTileThreads) l_r3[i] = ctx.x[ctx.pl.r3 + (int64_t)td.kr0 * 3 + i];
+  if (JAC) {
+    for (int i = tid; i < td.nks; i += kTileThreads) l_tl_so3[i] = ctx.tl.so3[td.ks0 + i];
+    for (int i = tid; i < td.nkr; i += kTileThreads) l_tl_r3[i] = ctx.tl.r3[td.kr0 + i];
+    if (!DIRECT) {
+      const int nacc = td.nrows * tp.Wl;
+      for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0;
+      for (int i = tid; i < tp.corner; i += kTileThreads) acc[tp.acc_rows * tp.Wl + i] = 0.0;
+    }
+  }
+  if (tid == 0) l_queue[0] = td.unit0;
+  __syncthreads();
+  for (int i = tid; i < td.nks - 1; i += kTileThreads) {
+    const double* a = l_so3 + 4 * i;
+    so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, l_seg + i * kSegStride);
+  }
+  __syncthreads();
+
+  Target T;
+  T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne;
+  const bool prof_on = JAC && ctx.prof != nullptr && blockIdx.x == gridDim.x / 2 && wave == 0;
+  long long* prof = prof_on ? ctx.prof : nullptr;
+
+  // ---- P1: units ----
+  double cost_local = 0.0;
+  while (true) {
+    int u = 0;
+    if (lane == 0) u = atomicAdd(l_queue, 1);
+    u = __shfl(u, 0, 64);
+    if (u >= td.unit1) break;
+    const UnitDesc ud = tp.units[u];
+    if (ctx.only_kind >= 0 && ud.kind != ctx.only_kind) continue;
+    const long long tq0 = prof ? clock64() : 0;
+    const bool valid = lane < ud.count;
+    const int64_t it = (int64_t)ud.first + lane;
+    int s_so3 = 0x3fffffff, s_r3 = 0, s_b = 0;      // knot windows of the lane's item (relative to the staged knots)
+    if (ud.kind == 0) {
+      const int v = ud.view;
+      s_so3 = vd.view_s_so3[v] - td.ks0; s_r3 = vd.view_s_r3[v] - td.kr0;
+      if (valid) {
+        ViewConst vc;
+        view_const_init(vc, ctx.x + ctx.pl.tic);
+        vc.ld = ctx.x[ctx.pl.ld];
+        vc.sh_s = ctx.rs_time_in_seconds ? ctx.inv_so3_dt : 1.0; vc.sh_r = ctx.rs_time_in_seconds ? ctx.inv_r3_dt : 1.0;
+        vc.inv_so3_dt = ctx.inv_so3_dt; vc.inv_r3_dt = ctx.inv_r3_dt; vc.cam_model = ctx.cam_model; vc.intr = ctx.intr; vc.gs_unit_loss = ctx.gs_unit_loss != 0;
+        vc.spline_active = fv.c_s >= 0; vc.tic_active = fv.c_t >= 0; vc.ld_active = fv.c_l >= 0;
+        const double* q0 = l_so3 + 4 * s_so3;
+        const Quat R0{q0[0], q0[1], q0[2], q0[3]};
+        const LdsSeg seg{l_seg + s_so3 * kSegStride};
+        const LdsR3 kr{l_r3 + 3 * s_r3};
+        double* dres = ctx.dbg_res ? ctx.dbg_res + 2 * it : nullptr;
+        double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 2 * it * 43 : nullptr;
+        if (djac) for (int k = 0; k < 2 * 43; ++k) djac[k] = 0.0;
+        const TileSink<0, JAC> sink(fv, rb + lane * fv.item_stride, dres, djac);
+        cost_local += view_item<JAC>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], vd.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
+                                     vd.corner_isx[it], vd.corner_isy[it], ctx.pts + 4 * (int64_t)vd.corner_pt[it], sink);
+      }
+    } else {
+      const bool accel = ud.kind == 1;
+      const ImuData& id = accel ? ia : ig;
+      if (valid) { s_so3 = id.s_so3[it] - td.ks0; s_r3 = accel ? id.s_r3[it] - td.kr0 : 0; s_b = id.s_b[it]; }
+      if (valid) {
+        const double* q0 = l_so3 + 4 * s_so3;
+        const Quat R0{q0[0], q0[1], q0[2], q0[3]};
+        const LdsSeg seg{l_seg + s_so3 * kSegStride};
+        const LdsR3 kr{l_r3 + 3 * s_r3};
+        const double m[3] = {id.mx[it], id.my[it], id.mz[it]};
+        const double* bk = ctx.x + (accel ? ctx.pl.ab : ctx.pl.gb) + 3 * (int64_t)s_b;
+        double* dres = ctx.dbg_res ? ctx.dbg_res + 3 * it : nullptr;
+        ImuConst ic;
+        ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
+        if (accel) {
+          imu_const_init<0>(ic, ctx.x + ctx.pl.ai, ctx.x + ctx.pl.g);
+          ic.spline_active = fa.c_s >= 0; ic.g_active = fa.c_g >= 0; ic.bias_active = fa.c_b >= 0; ic.intr_active = fa.c_i >= 0;
+          double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 54 : nullptr;
+          if (djac) for (int k = 0; k < 3 * 54; ++k) djac[k] = 0.0;
+          const TileSink<1, JAC> sink(fa, rb + lane * fa.item_stride, dres, djac);
+          cost_local += imu_item<0, JAC>(ic, R0, seg, kr, id.u_so3[it], id.u_r3[it], id.u_b[it], bk, m, id.w[it], sink);
+        } else {
+          imu_const_init<1>(ic, ctx.x + ctx.pl.gi, ctx.x + ctx.pl.g);
+          ic.spline_active = fg.c_s >= 0; ic.g_active = false; ic.bias_active = fg.c_b >= 0; ic.intr_active = fg.c_i >= 0;
+          double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 36 : nullptr;
+          if (djac) for (int k = 0; k < 3 * 36; ++k) djac[k] = 0.0;
+          const TileSink<2, JAC> sink(fg, rb + lane * fg.item_stride, dres, djac);
+          cost_local += imu_item<1, JAC>(ic, R0, seg, kr, id.u_so3[it], 0.0, id.u_b[it], bk, m, id.w[it], sink);
+        }
+      }
+    }
+    if (JAC) {
+      // cells: runs of items with identical knot windows share every normal-equation target (a view is one cell).  The
+      // boundaries come from the window indices the lanes already hold (one ballot).
+      const RowFmt& f = ud.kind == 0 ? fv : (ud.kind == 1 ? fa : fg);
+      const int rows = f.rows_per_item;
+      const int p_so3 = __shfl_up(s_so3, 1, 64), p_b = __shfl_up(s_b, 1, 64), p_r3 = __shfl_up(s_r3, 1, 64);
+      const bool starts_cell = valid && (lane == 0 || (ud.kind != 0 && (s_so3 != p_so3 || s_b != p_b || s_r3 != p_r3)));
+      unsigned long long starts = __ballot(starts_cell);
+      const long long tq1 = prof ? clock64() : 0;
+      while (starts != 0ull) {
+        const int l0 = __builtin_ctzll(starts);
+        starts &= starts - 1ull;
+        const int l1 = starts != 0ull ? __builtin_ctzll(starts) : ud.count;
+        const int ks0 = __shfl(s_so3, l0, 64), kb0 = __shfl(s_b, l0, 64), kr0 = __shfl(s_r3, l0, 64);
+        coloff[lane] = cell_col_offset(f, ctx.tl, ud.kind, lane, l_tl_so3, l_tl_r3, ks0, kr0, kb0);
+        wave_sync();
+        if (f.ncols <= 16) gram_cell<1, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
+        else if (f.ncols <= 32) gram_cell<2, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
+        else if (f.ncols <= 48) gram_cell<3, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
+        else gram_cell<4, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
+        wave_sync();
+      }
+      if (prof && lane == 0) { prof[0] += tq1 - tq0; prof[1] += clock64() - tq1; }
+    }
+  }
+
+  if (!JAC) {
+    const double s = wave_sum_d(cost_local);
+    if (lane == 0 && s != 0.0) unsafeAtomicAdd(ctx.ne.cost(), s);
+    return;
+  }
+  // ---- P2: accumulator -> slab ----
+  if (!DIRECT) {
+    __syncthreads();
+    double* slab = tp.slabs + (int64_t)blockIdx.x * tp.slab_stride;
+    const int nacc = td.nrows * tp.Wl;
+    for (int i = tid; i < nacc; i += kTileThreads) slab[i] = acc[i];
+    for (int i = tid; i < tp.corner; i += kTileThreads) slab[tp.acc_rows * tp.Wl + i] = acc[tp.acc_rows * tp.Wl + i];
+  }
+}
+
+// Packed normal equations from the slabs.  Blocks [0, nb_rows): one thread per (band row, accumulator column), the
+// overlapping tiles of the row summed in tile order; blocks [nb_rows, nb_rows + corner): one block per entry of the
+// arrow corner [C | g ; . | 2 cost], reduced over all tiles.
+__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows) {
+  const int b = blockIdx.x;
+  if (b < nb_rows) {
+    const int64_t idx = (int64_t)b * 256 + threadIdx.x;
+    if (idx >= (int64_t)tl.Pb * tp.Wl) return;
+    const int i = int(idx / tp.Wl), e = int(idx - (int64_t)i * tp.Wl);
+    double s = 0.0;
+    for (int t = tp.row_t0[i]; t < tp.row_t1[i]; ++t) {
+      const int r = i - tp.tiles[t].lo;                                // tiles between the first and the last one that cover the row need not cover it
+      if (r >= 0 && r < tp.tiles[t].nrows) s += tp.slabs[(int64_t)t * tp.slab_stride + (int64_t)r * tp.Wl + e];
+    }
+    if (e < tl.W) ne.band()[(int64_t)i * tl.W + e] = s;
+    else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + i] = s;
+    else ne.g()[i] = s;
+    return;
+  }
+  __shared__ double red[256];
+  const int ent = b - nb_rows, a1 = tl.a + 1;
+  const int p = ent / a1, q = ent - p * a1;
+  if (p > q) return;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < tp.n_tiles; t += 256) s += tp.slabs[(int64_t)t * tp.slab_stride + (int64_t)tp.acc_rows * tp.Wl + ent];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const double v = red[0];
+    if (q < tl.a) { ne.C()[(int64_t)p * tl.a + q] = v; ne.C()[(int64_t)q * tl.a + p] = v; }
+    else if (p < tl.a) ne.g()[tl.Pb + p] = v;
+    else ne.cost()[0] = 0.5 * v;
+  }
+}
+
+// ---- launchers ----
+template <bool JAC, bool DIRECT>
+static void launch_tile_kernel(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
+                               const RowFmt& fg, const TileParams& tp, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT>), dim3(tp.n_tiles), dim3(kTileThreads), lds, st, ctx, vd, ia, ig, fv, fa, fg, tp);
+}
+int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
+                     const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st) {
+  if (tp.n_tiles == 0) return 0;
+  if (jac) {
+    if (tp.direct) launch_tile_kernel<true, true>(ctx, vd, ia, ig, fv, fa, fg, tp, tp.lds_bytes, st);
+    else {
+      launch_tile_kernel<true, false>(ctx, vd, ia, ig, fv, fa, fg, tp, tp.lds_bytes, st);
+      const int nb_rows = int(((int64_t)ctx.tl.Pb * tp.Wl + 255) / 256);
+      hipLaunchKernelGGL(slab_merge_kernel, dim3(nb_rows + tp.corner), dim3(256), 0, st, tp, ctx.ne, ctx.tl, nb_rows);
+    }
+  } else {
+    launch_tile_kernel<false, false>(ctx, vd, ia, ig, fv, fa, fg, tp, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace oicc

@@ -76,6 +76,7 @@ struct EvalCtx {
   int32_t rs_time_in_seconds;  // 1: documented fix of quirk Q1
   double* dbg_res;        // optional per-row residual dump (parity tests)
   double* dbg_jac;        // optional per-row Jacobian dump in the fixed ABI layout
+  int32_t only_kind;      // >= 0: evaluate only this residual family (0 views, 1 accelerometer, 2 gyroscope); -1: all
   long long* prof;        // optional: per-phase cycle counters of one block (debug)
   int prof_repeat;        // debug: > 0 runs the profiled block once more, so that the counted pass sees warm caches
 };

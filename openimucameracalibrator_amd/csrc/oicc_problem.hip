@@ -24,6 +24,7 @@
 #include "../../include/oicc_hip.h"
 #include "oicc_device.h"
 #include "lm_launch.h"
+#include "tiles.h"
 
 namespace oicc {
 // kernels_blocks.hip
@@ -35,6 +36,8 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        const double* u_r3, const int32_t* s_gb, const double* u_gb, const int32_t* s_ab, const double* u_ab,
                        double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
                        hipStream_t st);
+int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
+                     const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
 }  // namespace oicc
@@ -124,6 +127,10 @@ struct oicc_problem {
   struct HostPin { LmState st; double cost; double radius; };
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
+  std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1;
+  DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
+  RowFmt fv{}, fa{}, fg{}; TileParams tp{};
   // cached layout
   int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
   Active act{};
@@ -135,6 +142,8 @@ struct oicc_problem {
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0; opt["imu_chunk_cells"] = 0;
+    opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
+    opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
   }
 };
 
@@ -263,6 +272,8 @@ Active active_set(const oicc_problem* p, int flags) {
   return a;
 }
 
+int build_tiles(oicc_problem* p);
+
 // Tangent layout: the ordering contract of include/oicc_hip.h.
 int make_layout(oicc_problem* p, int flags) {
   const Active a = active_set(p, flags);
@@ -328,6 +339,195 @@ int make_layout(oicc_problem* p, int flags) {
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   p->layout_flags = flags;
+  return build_tiles(p);
+}
+
+
+// ---- time tiles of the Jacobian pass (tiles.h) ---------------------------------
+// Row formats: Gram column layout (the reference's parameter-block order of each residual family, active groups only)
+// and the compact row storage the kernels use.
+RowFmt row_fmt_finish(RowFmt f, int rows_per_item) {
+  f.rows_per_item = rows_per_item; f.cap = 0;
+  f.item_stride = (f.nbase * rows_per_item + f.nfac) | 1;   // odd: the lanes' records start in different banks
+  return f;
+}
+RowFmt view_row_fmt(const TangentLayout& tl, bool spline) {
+  RowFmt f{}; int n = 0, b = 0;
+  f.c_g = f.c_b = f.c_i = -1; f.n_i = 0; f.b_m = f.b_i = -1; f.f_cb = -1;
+  f.c_s = spline ? n : -1; if (spline) n += 18;
+  f.c_r = spline ? n : -1; if (spline) n += 18;
+  f.c_t = tl.tic >= 0 ? n : -1; if (tl.tic >= 0) n += 6;
+  f.c_l = tl.ld >= 0 ? n : -1; if (tl.ld >= 0) n += 1;
+  f.rescol = n; f.ncols = n + 1;
+  f.b_s = spline ? b : -1; if (spline) b += 18;
+  f.b_v = spline ? b : -1; if (spline) b += 3;
+  f.b_t = tl.tic >= 0 ? b : -1; if (tl.tic >= 0) b += 6;
+  f.b_l = tl.ld >= 0 ? b : -1; if (tl.ld >= 0) b += 1;
+  f.b_res = b; f.nbase = b + 1;
+  f.f_cf = spline ? 0 : -1; f.nfac = spline ? 6 : 0;
+  return row_fmt_finish(f, 2);
+}
+RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias) {
+  RowFmt f{}; int n = 0, b = 0, k = 0;
+  f.c_t = f.c_l = -1; f.b_t = f.b_l = -1;
+  const bool g = accel && tl.g >= 0, intr = (accel ? tl.ai : tl.gi) >= 0;
+  f.n_i = accel ? 6 : 9;
+  f.c_s = spline ? n : -1; if (spline) n += 18;
+  f.c_r = (spline && accel) ? n : -1; if (spline && accel) n += 18;
+  f.c_g = g ? n : -1; if (g) n += 3;
+  f.c_b = bias ? n : -1; if (bias) n += 9;
+  f.c_i = intr ? n : -1; if (intr) n += f.n_i;
+  f.rescol = n; f.ncols = n + 1;
+  f.b_s = spline ? b : -1; if (spline) b += 18;
+  const bool v = accel && (spline || g);
+  f.b_v = v ? b : -1; if (v) b += 3;
+  f.b_m = bias ? b : -1; if (bias) b += 3;
+  f.b_i = intr ? b : -1; if (intr) b += f.n_i;
+  f.b_res = b; f.nbase = b + 1;
+  f.f_cf = (spline && accel) ? k : -1; if (spline && accel) k += 6;
+  f.f_cb = bias ? k : -1; if (bias) k += 3;
+  f.nfac = k;
+  return row_fmt_finish(f, 3);
+}
+// largest item count whose records fit `rb` doubles
+void row_fmt_capacity(RowFmt& f, int rb, int max_items) { f.cap = std::max(0, std::min({max_items, 64, rb / f.item_stride})); }
+
+struct TileBuild { std::vector<UnitDesc> units; std::vector<int32_t> unit_tile; std::vector<TileDesc> tiles; int max_rows = 0, max_nks = 0, max_nkr = 0; };
+
+// Units (one view / a run of IMU samples, never across a tile boundary) and tiles for `T` fine knot windows per tile.
+void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
+  const HostLayout& L = p->L;
+  const int64_t dt_fine = std::min(p->dt_so3, p->dt_r3);
+  auto tile_of = [&](int32_t s_so3) { return int32_t((int64_t(s_so3) * p->dt_so3) / (int64_t(T) * dt_fine)); };
+  std::vector<UnitDesc>& U = out->units; std::vector<int32_t>& UT = out->unit_tile;
+  U.clear(); UT.clear(); out->tiles.clear();
+  for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) {
+    const int32_t t = tile_of(p->view_s_so3[v]);
+    for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; c += p->fv.cap) {
+      U.push_back(UnitDesc{0, int32_t(c), int32_t(std::min<int64_t>(p->fv.cap, p->view_c0[v + 1] - c)), int32_t(v)}); UT.push_back(t); }
+  }
+  auto imu_units = [&](const ImuHost& h, int kind, int cap) {
+    const int64_t n = int64_t(h.size());
+    const bool accel = kind == 1;
+    auto same_cell = [&](int64_t x, int64_t y) { return h.s_so3[x] == h.s_so3[y] && h.s_b[x] == h.s_b[y] && (!accel || h.s_r3[x] == h.s_r3[y]); };
+    int64_t i = 0;
+    while (i < n) {
+      const int32_t t = tile_of(h.s_so3[i]);
+      int64_t j = i;
+      while (j < n && tile_of(h.s_so3[j]) == t && j - i < cap) {
+        int64_t e = j + 1;                                   // end of the cell that starts at j (whole cells stay together)
+        while (e < n && e - j < cap && tile_of(h.s_so3[e]) == t && same_cell(j, e)) ++e;
+        if (e - i <= cap) j = e; else if (j == i) j = i + cap; else break;
+      }
+      U.push_back(UnitDesc{kind, int32_t(i), int32_t(j - i), -1}); UT.push_back(t);
+      i = j;
+    }
+  };
+  imu_units(p->acc, 1, p->fa.cap);
+  imu_units(p->gyr, 2, p->fg.cap);
+  // order by (tile, kind): views first (longest units), stable
+  std::vector<int32_t> ord(U.size());
+  for (size_t i = 0; i < ord.size(); ++i) ord[i] = int32_t(i);
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return UT[x] != UT[y] ? UT[x] < UT[y] : U[x].kind < U[y].kind; });
+  std::vector<UnitDesc> U2(U.size()); std::vector<int32_t> UT2(U.size());
+  for (size_t i = 0; i < ord.size(); ++i) { U2[i] = U[ord[i]]; UT2[i] = UT[ord[i]]; }
+  U.swap(U2); UT.swap(UT2);
+  out->max_rows = out->max_nks = out->max_nkr = 0;
+  const bool spline = p->act.spline;
+  size_t i = 0;
+  while (i < U.size()) {
+    size_t j = i;
+    int lo = 1 << 30, hi = -1, ks0 = 1 << 30, ks1 = -1, kr0 = 1 << 30, kr1 = -1;
+    auto touch = [&](int32_t s_so3, int32_t s_r3) {
+      ks0 = std::min(ks0, int(s_so3)); ks1 = std::max(ks1, int(s_so3) + kN);
+      if (s_r3 >= 0) { kr0 = std::min(kr0, int(s_r3)); kr1 = std::max(kr1, int(s_r3) + kN); }
+      if (!spline) return;
+      for (int k = 0; k < kN; ++k) {
+        const int o = L.so3[s_so3 + k]; if (o >= 0) { lo = std::min(lo, o); hi = std::max(hi, o + 3); }
+        if (s_r3 >= 0) { const int q = L.r3[s_r3 + k]; if (q >= 0) { lo = std::min(lo, q); hi = std::max(hi, q + 3); } }
+      }
+    };
+    for (; j < U.size() && UT[j] == UT[i]; ++j) {
+      const UnitDesc& u = U[j];
+      if (u.kind == 0) touch(p->view_s_so3[u.view], p->view_s_r3[u.view]);
+      else {
+        const ImuHost& h = u.kind == 1 ? p->acc : p->gyr;
+        int32_t ps = -1, pr = -1;
+        for (int32_t x = u.first; x < u.first + u.count; ++x) {
+          const int32_t sr = u.kind == 1 ? h.s_r3[x] : -1;
+          if (h.s_so3[x] != ps || sr != pr) { touch(h.s_so3[x], sr); ps = h.s_so3[x]; pr = sr; }
+        }
+      }
+    }
+    TileDesc td{};
+    td.unit0 = int32_t(i); td.unit1 = int32_t(j);
+    td.lo = hi >= 0 ? lo : 0; td.nrows = hi >= 0 ? hi - lo : 0;
+    td.ks0 = ks0; td.nks = ks1 - ks0;
+    td.kr0 = kr1 >= 0 ? kr0 : 0; td.nkr = kr1 >= 0 ? kr1 - kr0 : 0;
+    out->tiles.push_back(td);
+    out->max_rows = std::max(out->max_rows, int(td.nrows)); out->max_nks = std::max(out->max_nks, int(td.nks)); out->max_nkr = std::max(out->max_nkr, int(td.nkr));
+    i = j;
+  }
+}
+
+int build_tiles(oicc_problem* p) {
+  const TangentLayout& tl = p->tl; const Active& a = p->act;
+  p->fv = view_row_fmt(tl, a.spline);
+  p->fa = imu_row_fmt(tl, true, a.spline, a.ab);
+  p->fg = imu_row_fmt(tl, false, a.spline, a.gb);
+  TileParams& tp = p->tp; tp = TileParams{};
+  tp.Wl = tl.W + tl.a + 1; tp.corner = (tl.a + 1) * (tl.a + 1);
+  // LDS budget (doubles) and the row buffer of a wave: the largest view in one piece if it fits 26 KB, never less than ~32 IMU samples
+  const int budget = 160 * 1024 / 8 - 64;
+  int max_nc = 1;
+  for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) max_nc = std::max<int>(max_nc, int(std::min<int64_t>(64, p->view_c0[v + 1] - p->view_c0[v])));
+  auto need = [](const RowFmt& f, int items) { return f.item_stride * items; };
+  int rb = std::max(need(p->fv, max_nc), std::max(need(p->fa, 32), need(p->fg, 32)));
+  rb = std::min(rb, 3328);
+  rb = std::max(rb, 512);
+  row_fmt_capacity(p->fv, rb, 64); row_fmt_capacity(p->fa, rb, 64); row_fmt_capacity(p->fg, rb, 64);
+  if (p->fv.cap < 1 || p->fa.cap < 1 || p->fg.cap < 1) { p->err = "row buffer too small for this parameter set"; return OICC_ERR_UNSUPPORTED; }
+  tp.rb_doubles = rb; tp.wave_doubles = 32 + rb;
+  const int64_t dt_fine = std::min(p->dt_so3, p->dt_r3);
+  const int64_t n_windows = (p->end_ns - p->start_ns) / dt_fine + 1;
+  const int mode = int(p->opt["assembly"]);
+  int T = int(p->opt["tile_windows"]);
+  if (T <= 0) T = int(std::max<int64_t>(2, std::min<int64_t>(64, n_windows / 96)));
+  auto carve = [&](int nks, int nkr, int acc_doubles) {   // returns total doubles
+    int o = 0;
+    tp.o_so3 = o; o += nks * 4; tp.o_r3 = o; o += std::max(nkr, 1) * 3; tp.o_seg = o; o += std::max(nks - 1, 1) * 17;
+    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
+    return o;
+  };
+  TileBuild tb;
+  bool fits = false;
+  tp.direct = mode == 2 ? 1 : 0;
+  while (true) {
+    make_tiles(p, T, &tb);
+    if (tb.max_nks <= kMaxTileKnots && tb.max_nkr <= kMaxTileKnots) {
+      const int acc_doubles = tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner;
+      if (carve(tb.max_nks, tb.max_nkr, acc_doubles) <= budget) { fits = true; tp.acc_rows = tp.direct ? 0 : tb.max_rows; break; }
+    }
+    if (T == 1) { if (tp.direct) break; tp.direct = 1; T = int(std::max<int64_t>(2, std::min<int64_t>(16, n_windows / 96))); continue; }   // accumulator does not fit: direct mode
+    T = T > 4 ? T * 3 / 4 : T - 1;
+  }
+  if (!fits) { p->err = "tile geometry does not fit 160 KB LDS"; return OICC_ERR_UNSUPPORTED; }
+  tp.lds_bytes = carve(tb.max_nks, tb.max_nkr, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) * int(sizeof(double));
+  p->h_tiles.swap(tb.tiles); p->h_units.swap(tb.units);
+  tp.n_tiles = int32_t(p->h_tiles.size()); tp.n_units = int32_t(p->h_units.size());
+  tp.slab_stride = int64_t(tp.acc_rows) * tp.Wl + tp.corner;
+  p->h_row_t0.assign(std::max(tl.Pb, 1), 0); p->h_row_t1.assign(std::max(tl.Pb, 1), 0);
+  if (!tp.direct) {
+    std::vector<char> seen(std::max(tl.Pb, 1), 0);
+    for (int32_t t = 0; t < tp.n_tiles; ++t) {
+      const TileDesc& td = p->h_tiles[t];
+      for (int r = td.lo; r < td.lo + td.nrows; ++r) { if (!seen[r]) { seen[r] = 1; p->h_row_t0[r] = t; } p->h_row_t1[r] = t + 1; }
+    }
+  }
+  hipStream_t st = p->stream;
+  if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) ||
+      !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_tiles) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
+  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.row_t0 = p->d_row_t0.p; tp.row_t1 = p->d_row_t1.p; tp.slabs = p->d_slabs.p;
   return OICC_OK;
 }
 
@@ -346,7 +546,7 @@ EvalCtx make_ctx(oicc_problem* p, const double* x) {
   c.inv_so3_dt = p->inv_so3_dt; c.inv_r3_dt = p->inv_r3_dt;
   std::memcpy(c.intr, p->intr, sizeof(c.intr)); c.cam_model = p->cam_model;
   c.gs_unit_loss = p->opt["gs_unit_loss"] != 0.0; c.rs_time_in_seconds = p->opt["rs_time_in_seconds"] != 0.0;
-  c.dbg_res = nullptr; c.dbg_jac = nullptr; c.prof = nullptr; c.prof_repeat = 0;
+  c.dbg_res = nullptr; c.dbg_jac = nullptr; c.prof = nullptr; c.prof_repeat = 0; c.only_kind = -1;
   return c;
 }
 ViewData view_data(oicc_problem* p, bool force_rs = false) {
@@ -369,19 +569,27 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
-              bool cost_already_zero = false, const NormalEq* target = nullptr) {
+              bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr) {
   hipStream_t st = p->stream;
   EvalCtx ctx = make_ctx(p, x);
   const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
   ctx.ne = ne;
-  ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac;
-  if (jac) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
-  else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
+  ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac; ctx.prof = prof;
   const Active& a = p->act;
-  if (only_kind < 0) launch_all_blocks(ctx, view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
-  if (only_kind == 0) launch_view_blocks(ctx, view_data(p), a.spline, jac, st);
-  if (only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
-  if (only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
+  if (int(p->opt["assembly"]) == 1) {   // one wave per view / IMU chunk, fp64 atomics on the packed buffer (kernels_blocks.hip)
+    if (jac) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
+    else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
+    if (only_kind < 0) launch_all_blocks(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
+    if (only_kind == 0) launch_view_blocks(ctx, view_data(p, force_rs), a.spline, jac, st);
+    if (only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
+    if (only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
+  } else {                              // time tiles (kernels_tiles.hip): the slab merge writes every entry of the packed buffer
+    if (jac && (p->tp.direct || p->tp.n_tiles == 0)) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
+    else if (!jac && !cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
+    ctx.only_kind = only_kind;
+    if (launch_tile_pass(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), p->fv, p->fa, p->fg, p->tp, jac, st) != 0) {
+      p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
+  }
   HIPCK(p, hipGetLastError());
   if (p->reduce) {
     int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, ne.cost(), 1, st);
@@ -891,12 +1099,7 @@ int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats, dou
   if (kernel_ms && !rc) {
     for (int k = 0; k < 3 && !rc; ++k) {
       HIPCK(p, hipEventRecord(e0, st));
-      for (int i = 0; i < repeats && !rc; ++i) {
-        EvalCtx ctx = make_ctx(p, p->d_x.p);
-        if (k == 0) launch_view_blocks(ctx, view_data(p), p->act.spline, true, st);
-        if (k == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), p->act.spline, p->act.ab, true, st);
-        if (k == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), p->act.spline, p->act.gb, true, st);
-      }
+      for (int i = 0; i < repeats && !rc; ++i) rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, k);   // this residual family only
       HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
       (void)hipEventElapsedTime(&ms, e0, e1); kernel_ms[k] = double(ms) / std::max(repeats, 1);
     }
@@ -956,25 +1159,15 @@ int oicc_debug_block_profile(oicc_problem* p, int32_t flags, int32_t kind, long 
   int rc = prepare(p, flags); if (rc) return rc;
   DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
   HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
-  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p; ctx.prof_repeat = kind >= 10 ? 1 : 0; kind %= 10;
-  HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), p->stream));
-  if (kind == 0) launch_view_blocks(ctx, view_data(p), p->act.spline, true, p->stream);
-  else launch_imu_blocks(kind - 1, ctx, kind == 1 ? imu_data(p->acc, p->d_acc) : imu_data(p->gyr, p->d_gyr), p->act.spline, kind == 1 ? p->act.ab : p->act.gb, true, p->stream);
+  kind %= 10;
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, kind, false, nullptr, false, d.p);
+  p->reduce = saved; if (rc) return rc;
   HIPCK(p, hipMemcpyAsync(out, d.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
   HIPCK(p, hipStreamSynchronize(p->stream));
   return OICC_OK;
 }
-int oicc_debug_view_profile(oicc_problem* p, int32_t flags, long long out[4]) {
-  int rc = prepare(p, flags); if (rc) return rc;
-  DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
-  HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
-  EvalCtx ctx = make_ctx(p, p->d_x.p); ctx.prof = d.p;
-  HIPCK(p, hipMemsetAsync(p->ne.base, 0, p->ne.total * sizeof(double), p->stream));
-  launch_view_blocks(ctx, view_data(p), p->act.spline, true, p->stream);
-  HIPCK(p, hipMemcpyAsync(out, d.p, 4 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
-  HIPCK(p, hipStreamSynchronize(p->stream));
-  return OICC_OK;
-}
+int oicc_debug_view_profile(oicc_problem* p, int32_t flags, long long out[4]) { return oicc_debug_block_profile(p, flags, 0, out); }
 
 int oicc_get_T_i_c(const oicc_problem* p, double v[7]) { std::memcpy(v, p->x.data() + p->pl.tic, 7 * sizeof(double)); return OICC_OK; }
 int oicc_get_gravity(const oicc_problem* p, double g[3]) { std::memcpy(g, p->x.data() + p->pl.g, 3 * sizeof(double)); return OICC_OK; }
@@ -995,10 +1188,9 @@ int oicc_get_mean_reprojection_error(oicc_problem* p, double* mean_px, int64_t* 
   for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) if (p->view_c0[v + 1] == p->view_c0[v]) { *mean_px = 0.0; if (num) *num = 0; return OICC_OK; }  // quirk Q6
   if (nc == 0) { *mean_px = std::nan(""); if (num) *num = 0; return OICC_OK; }
   if (!p->d_dbg_res.resize(2 * nc)) { p->err = "hipMalloc"; return OICC_ERR_HIP; }
-  EvalCtx ctx = make_ctx(p, p->d_x.p);
-  ctx.dbg_res = p->d_dbg_res.p;
-  HIPCK(p, hipMemsetAsync(p->ne.cost(), 0, sizeof(double), p->stream));
-  launch_view_blocks(ctx, view_data(p, /*force_rs=*/true), p->act.spline, false, p->stream);
+  { auto saved = p->reduce; p->reduce = nullptr;   // residual dump of the RS functor for every view (also in GS mode, impl.h:1021-1056)
+    rc = eval_pass(p, p->d_x.p, false, p->d_dbg_res.p, nullptr, 0, false, nullptr, /*force_rs=*/true);
+    p->reduce = saved; if (rc) return rc; }
   std::vector<double> r(2 * nc);
   HIPCK(p, hipMemcpyAsync(r.data(), p->d_dbg_res.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIPCK(p, hipStreamSynchronize(p->stream));

@@ -1,0 +1,66 @@
+// Time tiles of the Jacobian / normal-equation pass (internal, shared by oicc_problem.hip and kernels_tiles.hip).
+//
+// The measurements are cut into TILES of consecutive knot windows.  One workgroup (4 waves) owns a tile: it stages the
+// tile's knots and per-knot-pair segment tables in LDS, its waves pull UNITS (one camera view, or a run of IMU samples)
+// from a queue, evaluate them lane-per-item into compact rows in LDS, form each cell's Gram product on the matrix pipe
+// and add it into the tile's band accumulator IN LDS (ds_add_f64).  The accumulator -- the tile's rows of the band,
+// their arrow columns and gradient entries, plus the arrow corner -- leaves the CU once, with plain coalesced stores,
+// as the tile's SLAB; slab_merge_kernel sums the (few) overlapping slabs of every band row into the packed normal
+// equations.  No global atomics, no memset of the normal equations, a fixed summation order between tiles.
+// Geometries whose accumulator does not fit in LDS run the same kernel in DIRECT mode (fp64 atomics on the packed buffer).
+#pragma once
+#include <cstdint>
+
+namespace oicc {
+
+constexpr int kTileWaves = 4;
+constexpr int kTileThreads = 64 * kTileWaves;
+constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 / r3)
+
+struct TileDesc {
+  int32_t unit0, unit1;   // units [unit0, unit1)
+  int32_t lo, nrows;      // band rows [lo, lo + nrows) of the tangent layout accumulated by this tile
+  int32_t ks0, nks;       // SO(3) knots staged: [ks0, ks0 + nks)
+  int32_t kr0, nkr;       // R^3 knots staged
+};
+struct UnitDesc {
+  int32_t kind;           // 0 view (items = corners of ONE view), 1 accelerometer samples, 2 gyroscope samples
+  int32_t first, count;   // item range
+  int32_t view;           // kind 0: the view index
+};
+
+// Compact row storage of one residual family and its Gram column layout.
+// Gram columns (cell-local): view [so3 18 | r3 18 | T_i_c 6 | ld 1 | r], accel [so3 18 | r3 18 | g 3 | bias 9 | intr 6 | r],
+// gyro [so3 18 | bias 9 | intr 9 | r]; only active groups exist.  Stored per row ("base", column-major over the rows
+// of the unit): the so3 block, ONE 3-vector shared by the r3 and gravity columns, T_i_c, ld, ONE 3-vector for the bias
+// columns, the intrinsics block, the residual; per item ("fac"): the six spline coefficients, the three bias-spline
+// coefficients.  One record per item (lane), item-major in the wave's row buffer.  Gram column -> value index
+// (x factor index) is resolved when the MFMA operands are loaded.
+struct RowFmt {
+  int32_t ncols, rescol;
+  int32_t c_s, c_r, c_t, c_l, c_g, c_b, c_i;   // first Gram column of the group, or -1
+  int32_t n_i;                                 // intrinsics columns (6 accelerometer / 9 gyroscope)
+  int32_t nbase;
+  int32_t b_s, b_v, b_t, b_l, b_m, b_i, b_res;
+  int32_t nfac, f_cf, f_cb;
+  int32_t rows_per_item;
+  int32_t cap;                                 // items per unit that fit the row buffer
+  int32_t item_stride;                         // doubles per item record (odd): value (idx, r) at idx * rows_per_item + r, factors behind them
+};
+
+struct TileParams {
+  const TileDesc* tiles; const UnitDesc* units;
+  int32_t n_tiles, n_units;
+  int32_t direct;          // 1: no LDS accumulator, fp64 atomics on the packed normal equations
+  int32_t Wl;              // accumulator row length = W + a + 1   [band | arrow columns | gradient]
+  int32_t acc_rows;        // accumulator rows (max over tiles)
+  int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
+  // LDS carve (in doubles from the start of dynamic LDS)
+  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_acc, o_wave, wave_doubles;   // [knots | tables | queue | accumulator | per wave: coloff 64 ints = 32 doubles, row buffer]
+  int32_t rb_doubles;
+  int32_t lds_bytes;
+  double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]
+  const int32_t* row_t0; const int32_t* row_t1;   // per band row: first / one-past-last tile whose accumulator covers it
+};
+
+}  // namespace oicc

@@ -2,8 +2,8 @@
 //
 // "Analytic CPU path" of SURVEY.md 8(d)(ii): residual blocks with the closed-form Jacobians, OpenMP over blocks, feeding
 // the same CPU normal equations / LM loop as the Jet path of oicc_oracle.cpp.  It is NOT an independent checker: the
-// formulas are the device kernels' own (openimucameracalibrator_amd/csrc/spline_math.cuh compiled for the host with
-// OICC_HOST_MATH, and the chain rules of kernels_blocks.hip restated here), so it serves two purposes only:
+// formulas are the device kernels' own (openimucameracalibrator_amd/csrc/block_items.cuh + spline_seg.cuh + spline_math.cuh
+// compiled for the host with OICC_HOST_MATH: the very item functions the kernels call), so it serves two purposes only:
 //   * a second, faster CPU baseline for bench.py (what a CPU implementation WITHOUT autodiff would cost), and
 //   * a CPU-side cross-check of those formulas against forward-mode Jets that runs without a GPU
 //     (tests/test_oracle_problem.py), in addition to the GPU parity tests.
@@ -12,167 +12,70 @@
 // gyro [so3 18 | bias 9 | intr 9].
 #pragma once
 #define OICC_HOST_MATH 1
-#include "../openimucameracalibrator_amd/csrc/spline_math.cuh"
+#include "../openimucameracalibrator_amd/csrc/block_items.cuh"
+
+#include <vector>
 
 namespace cpu_analytic {
 
-struct QuatKnots {   // accessor of so3_spline_eval: knot i of the window
-  const double* base;
-  oicc::Quat operator()(int i) const { const double* q = base + 4 * i; return oicc::Quat{q[0], q[1], q[2], q[3]}; }
-};
-
 struct Common {   // what every block needs from the problem
   const double* so3; const double* r3; const double* ab; const double* gb;   // knot arrays
+  const double* seg;                                                          // segment table of ALL knot pairs (segment_table)
   const double* T_i_c; const double* g; double ld; const double* ai; const double* gi;
   const double* pts; double inv_so3_dt, inv_r3_dt;
   int cam_model; const double* intr; bool gs_unit_loss, rs_time_in_seconds;
 };
 
-// RS / GS reprojection of one view (kernels_blocks.hip view_block, ceres_calib_split_residuals.h:207-282,320-402).
-// r: 2n, J: 2n x 43 (zeroed by the caller), active column groups selected by the flags.
-inline void view_rows(const Common& C, int64_t s_so3, int64_t s_r3, double u_so3, double u_r3, bool rs, int n, const double* uv, const double* cov,
-                      const int32_t* pidx, bool spline_active, bool tic_active, bool ld_active, double* r, double* J) {
-  using namespace oicc;
-  const bool weighted = rs || C.gs_unit_loss;
-  for (int c = 0; c < n; ++c) {
-    const double obs_u = uv[2 * c], obs_v = uv[2 * c + 1];
-    const double tau = rs ? obs_v * C.ld : 0.0;
-    const double sh_s = C.rs_time_in_seconds ? C.inv_so3_dt : 1.0, sh_r = C.rs_time_in_seconds ? C.inv_r3_dt : 1.0;
-    const double u_s = u_so3 + tau * sh_s, u_r = u_r3 + tau * sh_r;
-    So3Fwd so;
-    QuatKnots acc{C.so3 + 4 * s_so3};
-    if (spline_active) { if (ld_active) so3_spline_forward<true, true, true>(acc, u_s, C.inv_so3_dt, so); else so3_spline_forward<true, false, true>(acc, u_s, C.inv_so3_dt, so); }
-    else if (ld_active) so3_spline_forward<true, true, false>(acc, u_s, C.inv_so3_dt, so);
-    else so3_spline_forward<true, false, false>(acc, u_s, C.inv_so3_dt, so);
-    double cf[6]; r3_coeffs<0>(u_r, C.inv_r3_dt, cf);
-    double t_wi[3] = {0, 0, 0};
-    for (int j = 0; j < 6; ++j) { const double* p = C.r3 + 3 * (s_r3 + j); t_wi[0] += cf[j] * p[0]; t_wi[1] += cf[j] * p[1]; t_wi[2] += cf[j] * p[2]; }
-    const Quat q_ic{C.T_i_c[0], C.T_i_c[1], C.T_i_c[2], C.T_i_c[3]};
-    const double t_ic[3] = {C.T_i_c[4], C.T_i_c[5], C.T_i_c[6]};
-    const Quat q_wc = so3_mul(so.R, q_ic);
-    double rt[3]; so3_rotate(so.R, t_ic, rt);
-    const double t_wc[3] = {t_wi[0] + rt[0], t_wi[1] + rt[1], t_wi[2] + rt[2]};
-    const Quat q_cw = so3_inverse(q_wc);
-    const double ntwc[3] = {-t_wc[0], -t_wc[1], -t_wc[2]};
-    double t_cw[3]; so3_rotate(q_cw, ntwc, t_cw);
-    double Rcw[9]; so3_matrix(q_cw, Rcw);
-    const double* X = C.pts + 4 * (int64_t)pidx[c];
-    double p3[3];
-    for (int k = 0; k < 3; ++k) p3[k] = (Rcw[k * 3] * X[0] + Rcw[k * 3 + 1] * X[1] + Rcw[k * 3 + 2] * X[2] + t_cw[k] * X[3]) / X[3];
-    double px[2], Jpi[6];
-    const bool ok = camera_project<true>(C.cam_model, C.intr, p3, px, Jpi);
-    const double isx = 1.0 / std::sqrt(cov[2 * c]), isy = 1.0 / std::sqrt(cov[2 * c + 1]);
-    double r0, r1;
-    if (!ok) { r0 = 1e10; r1 = 1e10; } else { r0 = isx * (px[0] - obs_u); r1 = isy * (px[1] - obs_v); }
-    if (!weighted) { r0 = 0.0; r1 = 0.0; }
-    r[2 * c] = r0; r[2 * c + 1] = r1;
-    if (!J || !ok || !weighted) continue;
-    double* row0 = J + (size_t)(2 * c) * 43; double* row1 = row0 + 43;
-    double Rwi[9], Ric[9];
-    so3_matrix(so.R, Rwi); so3_matrix(q_ic, Ric);
-    const double Xw[3] = {X[0] / X[3] - t_wi[0], X[1] / X[3] - t_wi[1], X[2] / X[3] - t_wi[2]};
-    double qv[3]; mat3_tvec(Rwi, Xw, qv);
-    double M1[6];
-    for (int cc = 0; cc < 3; ++cc) {
-      M1[cc] = isx * (Jpi[0] * Ric[cc * 3] + Jpi[1] * Ric[cc * 3 + 1] + Jpi[2] * Ric[cc * 3 + 2]);
-      M1[3 + cc] = isy * (Jpi[3] * Ric[cc * 3] + Jpi[4] * Ric[cc * 3 + 1] + Jpi[5] * Ric[cc * 3 + 2]);
-    }
-    if (spline_active) {
-      double MQ[6], B[6];
-      for (int rr = 0; rr < 2; ++rr) {
-        const double a = M1[rr * 3], b = M1[rr * 3 + 1], cz = M1[rr * 3 + 2];
-        MQ[rr * 3 + 0] = b * qv[2] - cz * qv[1]; MQ[rr * 3 + 1] = cz * qv[0] - a * qv[2]; MQ[rr * 3 + 2] = a * qv[1] - b * qv[0];
-        for (int cc = 0; cc < 3; ++cc) B[rr * 3 + cc] = M1[rr * 3] * Rwi[cc * 3] + M1[rr * 3 + 1] * Rwi[cc * 3 + 1] + M1[rr * 3 + 2] * Rwi[cc * 3 + 2];
-      }
-      double jr[6][6];
-      so3_spline_backward_rows<2>(so, MQ, jr);
-      for (int j = 0; j < 6; ++j) for (int cc = 0; cc < 3; ++cc) {
-        row0[3 * j + cc] = jr[j][cc];
-        row1[3 * j + cc] = jr[j][3 + cc];
-        row0[18 + 3 * j + cc] = -cf[j] * B[cc]; row1[18 + 3 * j + cc] = -cf[j] * B[3 + cc];
-      }
-    }
-    if (tic_active) {
-      const double J0[3] = {isx * Jpi[0], isx * Jpi[1], isx * Jpi[2]}, J1[3] = {isy * Jpi[3], isy * Jpi[4], isy * Jpi[5]};
-      for (int k = 0; k < 3; ++k) { row0[36 + k] = -J0[k]; row1[36 + k] = -J1[k]; }
-      row0[39] = J0[1] * p3[2] - J0[2] * p3[1]; row0[40] = J0[2] * p3[0] - J0[0] * p3[2]; row0[41] = J0[0] * p3[1] - J0[1] * p3[0];
-      row1[39] = J1[1] * p3[2] - J1[2] * p3[1]; row1[40] = J1[2] * p3[0] - J1[0] * p3[2]; row1[41] = J1[0] * p3[1] - J1[1] * p3[0];
-    }
-    if (ld_active && rs) {
-      double dcf[6]; r3_coeffs<1>(u_r, 1.0, dcf);
-      double tu[3] = {0, 0, 0};
-      for (int j = 0; j < 6; ++j) { const double* p = C.r3 + 3 * (s_r3 + j); tu[0] += dcf[j] * p[0]; tu[1] += dcf[j] * p[1]; tu[2] += dcf[j] * p[2]; }
-      double rtu[3]; mat3_tvec(Rwi, tu, rtu);
-      const double sc_s = sh_s / C.inv_so3_dt;
-      const double wq[3] = {(qv[1] * so.w[2] - qv[2] * so.w[1]) * sc_s - rtu[0] * sh_r, (qv[2] * so.w[0] - qv[0] * so.w[2]) * sc_s - rtu[1] * sh_r,
-                            (qv[0] * so.w[1] - qv[1] * so.w[0]) * sc_s - rtu[2] * sh_r};
-      row0[42] = obs_v * (M1[0] * wq[0] + M1[1] * wq[1] + M1[2] * wq[2]);
-      row1[42] = obs_v * (M1[3] * wq[0] + M1[4] * wq[1] + M1[5] * wq[2]);
-    }
+// per-pair tables for the whole knot vector, once per pass (the kernels do the same per tile)
+inline void segment_table(const double* so3, size_t n_knots, std::vector<double>* out) {
+  out->assign(n_knots > 1 ? (n_knots - 1) * oicc::kSegStride : 0, 0.0);
+  for (size_t i = 0; i + 1 < n_knots; ++i) {
+    const double* a = so3 + 4 * i; const double* b = a + 4;
+    oicc::so3_segment_prepare(oicc::Quat{a[0], a[1], a[2], a[3]}, oicc::Quat{b[0], b[1], b[2], b[3]}, out->data() + i * oicc::kSegStride);
   }
 }
 
-// accelerometer (KIND 0, J 3 x 54) / gyroscope (KIND 1, J 3 x 36) sample: kernels_blocks.hip imu_block,
-// ceres_calib_split_residuals.h:53-93,134-169
+struct SegAcc { const double* base; const double* operator()(int i) const { return base + i * oicc::kSegStride; } };
+struct R3Acc { const double* base; const double* operator()(int j) const { return base + 3 * j; } };
+
+// RS / GS reprojection of one view.  r: 2n, J: 2n x 43 (zeroed by the caller) or null; active column groups by the flags.
+inline void view_rows(const Common& C, int64_t s_so3, int64_t s_r3, double u_so3, double u_r3, bool rs, int n, const double* uv, const double* cov,
+                      const int32_t* pidx, bool spline_active, bool tic_active, bool ld_active, double* r, double* J) {
+  using namespace oicc;
+  ViewConst vc;
+  view_const_init(vc, C.T_i_c);
+  vc.ld = C.ld; vc.sh_s = C.rs_time_in_seconds ? C.inv_so3_dt : 1.0; vc.sh_r = C.rs_time_in_seconds ? C.inv_r3_dt : 1.0;
+  vc.inv_so3_dt = C.inv_so3_dt; vc.inv_r3_dt = C.inv_r3_dt; vc.cam_model = C.cam_model; vc.intr = C.intr; vc.gs_unit_loss = C.gs_unit_loss;
+  vc.spline_active = spline_active; vc.tic_active = tic_active; vc.ld_active = ld_active;
+  const double* q0 = C.so3 + 4 * s_so3;
+  const Quat R0{q0[0], q0[1], q0[2], q0[3]};
+  const SegAcc seg{C.seg + s_so3 * kSegStride};
+  const R3Acc kr{C.r3 + 3 * s_r3};
+  for (int c = 0; c < n; ++c) {
+    DenseSink<0> sink{r + 2 * c, J ? J + (size_t)(2 * c) * 43 : nullptr};
+    const double isx = 1.0 / std::sqrt(cov[2 * c]), isy = 1.0 / std::sqrt(cov[2 * c + 1]);
+    if (J) view_item<true>(vc, R0, seg, kr, u_so3, u_r3, rs, uv[2 * c], uv[2 * c + 1], isx, isy, C.pts + 4 * (int64_t)pidx[c], sink);
+    else view_item<false>(vc, R0, seg, kr, u_so3, u_r3, rs, uv[2 * c], uv[2 * c + 1], isx, isy, C.pts + 4 * (int64_t)pidx[c], sink);
+  }
+}
+
+// accelerometer (KIND 0, J 3 x 54) / gyroscope (KIND 1, J 3 x 36) sample
 template <int KIND>
 inline void imu_rows(const Common& C, int64_t s_so3, int64_t s_r3, int64_t s_b, double u_so3, double u_r3, double u_b, const double m[3], double w,
                      bool spline_active, bool g_active, bool bias_active, bool intr_active, double r[3], double* J) {
   using namespace oicc;
-  constexpr int W = KIND == 0 ? 54 : 36;
-  double cb[3]; bias_coeffs(u_b, cb);
+  ImuConst ic;
+  imu_const_init<KIND>(ic, KIND == 0 ? C.ai : C.gi, C.g);
+  ic.inv_so3_dt = C.inv_so3_dt; ic.inv_r3_dt = C.inv_r3_dt;
+  ic.spline_active = spline_active; ic.g_active = g_active; ic.bias_active = bias_active; ic.intr_active = intr_active;
+  const double* q0 = C.so3 + 4 * s_so3;
+  const Quat R0{q0[0], q0[1], q0[2], q0[3]};
+  const SegAcc seg{C.seg + s_so3 * kSegStride};
+  const R3Acc kr{C.r3 + 3 * s_r3};
   const double* bk = (KIND == 0 ? C.ab : C.gb) + 3 * s_b;
-  double bias[3] = {0, 0, 0};
-  for (int k = 0; k < 3; ++k) { bias[0] += cb[k] * bk[3 * k]; bias[1] += cb[k] * bk[3 * k + 1]; bias[2] += cb[k] * bk[3 * k + 2]; }
-  const double d[3] = {m[0] - bias[0], m[1] - bias[1], m[2] - bias[2]};
-  double MS[9];
-  if (KIND == 0) { const double mis[6] = {C.ai[0], C.ai[1], C.ai[2], 0.0, 0.0, 0.0}; imu_ms_matrix(mis, C.ai + 3, MS); }
-  else imu_ms_matrix(C.gi, C.gi + 6, MS);
-  double un[3]; mat3_vec(MS, d, un);
-  So3Out so; QuatKnots acc{C.so3 + 4 * s_so3};
-  double vr[3] = {0, 0, 0}, cf2[6] = {0, 0, 0, 0, 0, 0};
-  const bool jac = J != nullptr;
-  if (KIND == 0) {
-    if (jac && spline_active) so3_spline_eval<true, false, true, false>(acc, u_so3, C.inv_so3_dt, so);
-    else so3_spline_eval<true, false, false, false>(acc, u_so3, C.inv_so3_dt, so);
-    r3_coeffs<2>(u_r3, C.inv_r3_dt, cf2);
-    double aw[3] = {0, 0, 0};
-    for (int j = 0; j < 6; ++j) { const double* p = C.r3 + 3 * (s_r3 + j); aw[0] += cf2[j] * p[0]; aw[1] += cf2[j] * p[1]; aw[2] += cf2[j] * p[2]; }
-    const double ag[3] = {aw[0] + C.g[0], aw[1] + C.g[1], aw[2] + C.g[2]};
-    so3_rotate(so3_inverse(so.R), ag, vr);
-    for (int k = 0; k < 3; ++k) r[k] = w * (vr[k] - un[k]);
-  } else {
-    if (jac && spline_active) so3_spline_eval<false, true, false, true>(acc, u_so3, C.inv_so3_dt, so);
-    else so3_spline_eval<false, true, false, false>(acc, u_so3, C.inv_so3_dt, so);
-    for (int k = 0; k < 3; ++k) r[k] = w * (so.w[k] - un[k]);
-  }
-  if (!jac) return;
-  if (KIND == 0) {
-    double Rt[9]; so3_matrix(so.R, Rt);
-    if (spline_active) for (int j = 0; j < 6; ++j) for (int cc = 0; cc < 3; ++cc) {
-      const double j0 = so.JR[j][cc], j1 = so.JR[j][3 + cc], j2 = so.JR[j][6 + cc];
-      J[0 * W + 3 * j + cc] = w * (-vr[2] * j1 + vr[1] * j2); J[1 * W + 3 * j + cc] = w * (vr[2] * j0 - vr[0] * j2); J[2 * W + 3 * j + cc] = w * (-vr[1] * j0 + vr[0] * j1);
-      const double wc = w * cf2[j];
-      J[0 * W + 18 + 3 * j + cc] = wc * Rt[cc * 3 + 0]; J[1 * W + 18 + 3 * j + cc] = wc * Rt[cc * 3 + 1]; J[2 * W + 18 + 3 * j + cc] = wc * Rt[cc * 3 + 2];
-    }
-    if (g_active) for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) J[rr * W + 36 + cc] = w * Rt[cc * 3 + rr];
-    if (bias_active) for (int k = 0; k < 3; ++k) for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) J[rr * W + 39 + 3 * k + cc] = w * cb[k] * MS[rr * 3 + cc];
-    if (intr_active) {
-      const double yz = C.ai[0], zy = C.ai[1], zx = C.ai[2], sy = C.ai[4], sz = C.ai[5];
-      const double D[3][6] = {{-sy * d[1], sz * d[2], 0.0, d[0], -yz * d[1], zy * d[2]}, {0.0, 0.0, -sz * d[2], 0.0, d[1], -zx * d[2]}, {0.0, 0.0, 0.0, 0.0, 0.0, d[2]}};
-      for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 6; ++cc) J[rr * W + 48 + cc] = -w * D[rr][cc];
-    }
-  } else {
-    if (spline_active) for (int j = 0; j < 6; ++j) for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) J[rr * W + 3 * j + cc] = w * so.JW[j][rr * 3 + cc];
-    if (bias_active) for (int k = 0; k < 3; ++k) for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) J[rr * W + 18 + 3 * k + cc] = w * cb[k] * MS[rr * 3 + cc];
-    if (intr_active) {
-      const double* in = C.gi;
-      const double yz = in[0], zy = in[1], zx = in[2], xz = in[3], xy = in[4], yx = in[5], sx = in[6], sy = in[7], sz = in[8];
-      const double D[3][9] = {{-sy * d[1], sz * d[2], 0.0, 0.0, 0.0, 0.0, d[0], -yz * d[1], zy * d[2]},
-                              {0.0, 0.0, -sz * d[2], sx * d[0], 0.0, 0.0, xz * d[0], d[1], -zx * d[2]},
-                              {0.0, 0.0, 0.0, 0.0, -sx * d[0], sy * d[1], -xy * d[0], yx * d[1], d[2]}};
-      for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 9; ++cc) J[rr * W + 27 + cc] = -w * D[rr][cc];
-    }
-  }
+  DenseSink<KIND == 0 ? 1 : 2> sink{r, J};
+  if (J) imu_item<KIND, true>(ic, R0, seg, kr, u_so3, u_r3, u_b, bk, m, w, sink);
+  else imu_item<KIND, false>(ic, R0, seg, kr, u_so3, u_r3, u_b, bk, m, w, sink);
 }
 
 }  // namespace cpu_analytic

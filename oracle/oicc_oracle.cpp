@@ -60,6 +60,7 @@ struct Problem {
   std::vector<int> remote_so3, remote_r3;
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
+  mutable std::vector<double> seg_table;   // analytic CPU path: per-knot-pair tables of the current SO(3) knots (cpu_analytic::segment_table)
   Problem() {
     opt["function_tolerance"] = 1e-4; opt["parameter_tolerance"] = 1e-7; opt["gradient_tolerance"] = 1e-10;
     opt["initial_trust_region_radius"] = 1e4; opt["max_trust_region_radius"] = 1e16;
@@ -191,11 +192,15 @@ void so3_cols(const double* Jamb, int nres, const double* q, double* Jt, int ld,
 // ---- analytic CPU path (option analytic_jacobians = 1): see cpu_analytic.hpp ----------------------------------------
 static cpu_analytic::Common analytic_common(const Problem& p) {
   cpu_analytic::Common C{};
-  C.so3 = p.so3.data(); C.r3 = p.r3.data(); C.ab = p.ab.data(); C.gb = p.gb.data();
+  C.so3 = p.so3.data(); C.r3 = p.r3.data(); C.ab = p.ab.data(); C.gb = p.gb.data(); C.seg = p.seg_table.data();
   C.T_i_c = p.T_i_c; C.g = p.g; C.ld = p.ld; C.ai = p.acc_intr; C.gi = p.gyr_intr; C.pts = p.pts.data();
   C.inv_so3_dt = p.inv_so3_dt; C.inv_r3_dt = p.inv_r3_dt; C.cam_model = p.cam_model; C.intr = p.intr;
   C.gs_unit_loss = p.opt.at("gs_unit_loss") != 0.0; C.rs_time_in_seconds = p.opt.at("rs_time_in_seconds") != 0.0;
   return C;
+}
+// once per pass, before the blocks are evaluated in parallel
+static void refresh_segment_table(const Problem& p) {
+  if (p.opt.at("analytic_jacobians") != 0.0) cpu_analytic::segment_table(p.so3.data(), p.so3.size() / 4, &p.seg_table);
 }
 static void eval_view_analytic(const Problem& p, const Layout& L, const Active& a, const ViewBlk& v, BlockEval* out) {
   const int n = int(v.c1 - v.c0);
@@ -386,6 +391,7 @@ void build_normal_equations(const Problem& p, const Layout& L, const Active& a, 
   std::vector<NormalEq> part(nt);
   for (auto& q : part) q.init(L);
   const int64_t nv = p.views.size(), na = p.acc.size(), ng = p.gyr.size();
+  refresh_segment_table(p);
 #pragma omp parallel num_threads(nt)
   {
 #ifdef _OPENMP
@@ -719,6 +725,7 @@ int oicc_oracle_evaluate_cost(oicc_problem* prob, int32_t flags, double* cost) {
 
 int oicc_oracle_evaluate_blocks(oicc_problem* prob, int32_t flags, int32_t kind, double* residuals, double* jac) {
   const Layout L = make_layout(P_, flags); const Active a = active_set(P_, flags);
+  refresh_segment_table(P_);
   BlockEval be;
   if (kind == 0) {
     for (const auto& v : P_.views) { eval_view(P_, L, a, v, jac != nullptr, &be);

@@ -406,3 +406,43 @@ def test_ragged_views_empty_view_and_views_above_64_corners():
     sg = gpu.trajectory_.Optimize(10, FLAGS1); sc = cpu.trajectory_.Optimize(10, FLAGS1)
     assert sg["num_iterations"] == sc["num_iterations"] and abs(sg["final_cost"] - sc["final_cost"]) <= 1e-8 * sc["final_cost"]
     assert gpu.trajectory_.GetMeanReprojectionError() == 0.0 == cpu.trajectory_.GetMeanReprojectionError()
+
+
+# ---- time-tile assembly (kernels_tiles.hip): LDS accumulators + slab merge vs direct atomics vs the one-wave-per-chunk kernels ----
+@pytest.mark.parametrize("mode,tile_windows", [(0, 0), (0, 1), (0, 3), (0, 7), (0, 64), (2, 0), (2, 5), (1, 0)])
+def test_assembly_modes_match_the_oracle(tiny, mode, tile_windows):
+    """Every way the normal equations can be assembled gives the oracle's J^T J / J^T r / cost: tiles of 1 ... all windows
+    (halo rows summed by the merge kernel), tiles in direct mode (fp64 atomics), the one-wave-per-view kernels."""
+    ds, _, cpu = tiny
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    gpu.trajectory_.SetOption("assembly", mode); gpu.trajectory_.SetOption("tile_windows", tile_windows)
+    for flags in (FLAGS1, FLAGS1 | E.CAM_LINE_DELAY | E.IMU_BIASES | E.IMU_INTRINSICS, E.CAM_LINE_DELAY):
+        cg, Hg, gg = gpu.trajectory_.Evaluate(flags); cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
+        assert abs(cg - cc) <= 1e-11 * cc, (flags, cg, cc)
+        assert rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9, (flags, rel_err(Hg, Hc), rel_err(gg, gc))
+        assert np.abs(Hg - Hg.T).max() == 0.0 or mode != 0     # the merge writes both halves of the arrow corner from one value
+        assert abs(gpu.trajectory_.EvaluateCost(flags) - cc) <= 1e-11 * cc
+
+
+def test_tiles_are_run_to_run_reproducible_up_to_lds_order():
+    """Two passes over the same problem: the slab merge sums tiles in a fixed order, so the only freedom left is the order of
+    the LDS additions inside a tile (a few ulp)."""
+    ds = synthetic.make_config("C2")
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    c0, H0, g0 = gpu.trajectory_.Evaluate(FLAGS1)
+    c1, H1, g1 = gpu.trajectory_.Evaluate(FLAGS1)
+    assert abs(c0 - c1) <= 1e-14 * c0 and rel_err(H1, H0) < 1e-14 and rel_err(g1, g0) < 1e-13
+
+
+@pytest.mark.parametrize("cfg,tile_windows", [("C2", 0), ("C2", 2), ("C3", 0)])
+def test_tiles_on_baseline_configs_match_direct_atomics(cfg, tile_windows):
+    """Full-size BASELINE configurations: tiled assembly against the direct-atomics mode of the same kernel (independent
+    accumulation paths: LDS + slabs + merge vs global fp64 atomics)."""
+    ds = synthetic.make_config(cfg)
+    a = E.ImuCameraCalibrator().BatchInitSpline(ds); b = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    a.trajectory_.SetOption("tile_windows", tile_windows)
+    b.trajectory_.SetOption("assembly", 2)
+    ca, _, ga = a.trajectory_.Evaluate(FLAGS1, want_H=False); cb, _, gb = b.trajectory_.Evaluate(FLAGS1, want_H=False)
+    assert abs(ca - cb) <= 1e-12 * cb and rel_err(ga, gb) < 1e-11
+    sa = a.trajectory_.Optimize(8, FLAGS1); sb = b.trajectory_.Optimize(8, FLAGS1)
+    assert sa["num_iterations"] == sb["num_iterations"] and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
