@@ -11,9 +11,10 @@ step   : the device work and host synchronisation of ONE successful Levenberg-
          (liboicc_hip: oicc_run_lm_iterations == loop body of oicc_optimize).
 N = 1  : BASELINE config[1] = C2 (GoPro9 Division-Undistortion 960x540, 200 views x
          40 corners, 4000 IMU samples, dt_r3/so3 = 0.1/0.05 s), synthetic, seeded.
-N > 1  : weak scaling: N x C2 laid end to end in time (N*20 s trajectory); rank r
-         holds the r-th 20 s window of views/IMU samples, every rank holds all
-         knots; J^T J/J^T r/cost are all-reduced (fp64 sum) over RCCL each pass.
+N > 1  : BASELINE config[4] = C5 (10 000 views x 50 corners + 200 000 IMU samples, 1000 s),
+         STRONG scaling: rank r holds the r-th of N time shards of the same problem,
+         every rank holds all knots; J^T J/J^T r/cost are all-reduced (fp64 sum) over
+         RCCL each pass and every rank runs the (replicated) solve.
 
 Launch:  python bench.py                      (N=1)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -83,10 +84,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
-    # ---- workload: N x C2 (N = 1: exactly C2) ---------------------------------
-    base = dict(synthetic.CONFIGS["C2"])
-    ds = synthetic.make_dataset(name="C2" if world == 1 else "C2x%d" % world, **dict(
-        base, num_views=base["num_views"] * world, duration=base["duration"] * world))
+    # ---- workload: N = 1: C2 (the configuration the metric is quoted on); N > 1: C5, time-sharded (strong scaling) ----
+    wl_name = "C2" if world == 1 else "C5"
+    ds = synthetic.make_config(wl_name)
     cal = E.ImuCameraCalibrator(device=local_rank)
     tr = cal.trajectory_
     reduce_path = "none"
@@ -186,16 +186,24 @@ def main():
             s2 = tr.Optimize(10, E.CAM_LINE_DELAY)
             full_calib_s = time.perf_counter() - t1
             hb = summ["half_bandwidth"]
-        else:
+        else:   # no collective may run on rank 0 alone: half bandwidth from the tangent layout (span of the knots of one SO(3) window and the R^3 windows it overlaps)
+            so3o, r3o = lay["so3"], lay["r3"]
+            dts, dtr = ds.dt_so3, ds.dt_r3
             hb = 0
+            for s_ in range(0, len(so3o) - 5, max(1, (len(so3o) - 5) // 2000)):
+                r_ = int(s_ * dts / dtr)
+                offs = [o for o in list(so3o[s_:s_ + 6]) + list(r3o[r_:r_ + 7]) if o >= 0]
+                if offs:
+                    hb = max(hb, max(offs) + 2 - min(offs))
         b_alg, f_alg = algorithmic_model(cal, ds, (P, Pb, a, hb))
         # Kernel groups of one LM iteration.  "blocks" is the fused residual+Jacobian+Gram launch the
         # metric is named after (ONE launch per pass: all_blocks_kernel<true>); view/accel/gyro are its
         # three residual families timed as stand-alone launches; "solve" is the 17-launch block cyclic
         # reduction (bcr_build/eliminate/schur/backward), a dependent-latency chain, reported as a group.
         times = dict(blocks=pass_ms, view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
-        names = dict(blocks="all_blocks_kernel<true>", view="view_blocks_kernel<true>", accel="imu_blocks_kernel<0, true>",
-                     gyro="imu_blocks_kernel<1, true>", solve="bcr_build_kernel + bcr_eliminate_kernel + bcr_schur_kernel + bcr_backward_kernel")
+        names = dict(blocks="tile_kernel<true, false> + slab_merge_kernel", view="tile_kernel<true, false> (views only) + slab_merge_kernel",
+                     accel="tile_kernel<true, false> (accelerometer only) + slab_merge_kernel", gyro="tile_kernel<true, false> (gyroscope only) + slab_merge_kernel",
+                     solve="bcr_build_kernel + bcr_eliminate_kernel + bcr_schur_kernel + bcr_backward_kernel")
         kernels = {k: dict(kernel=names[k], ms=times[k], alg_bytes=b_alg[k], alg_flops=f_alg[k],
                            hbm_GBps=b_alg[k] / (times[k] * 1e-3) / 1e9 if times[k] > 0 else 0.0,
                            fp64_TFLOPs=f_alg[k] / (times[k] * 1e-3) / 1e12 if times[k] > 0 else 0.0) for k in times}
@@ -207,27 +215,34 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_C2.csv")))
         pmc = pmcs[-1] if pmcs else ""
-        if world == 1 and pmc:     # per-launch FETCH_SIZE + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes
+        if world == 1 and pmc:     # per-pass FETCH_SIZE + WRITE_SIZE of the tile kernel and the slab merge from the committed rocprofv3 --pmc passes
             tot = 0.0
             for line in open(pmc):
-                if "all_blocks_kernel<true>" in line:
+                if "tile_kernel<true" in line or "slab_merge_kernel" in line or "all_blocks_kernel<true>" in line:
                     tot += float(line.rsplit(",", 1)[1]) * 1024.0
             traffic = tot or None
         roofline = dict(bound="mfma", kernel=names[dom], achieved=kernels[dom]["fp64_TFLOPs"], peak=78.6, unit="TFLOP/s",
                         frac=kernels[dom]["fp64_TFLOPs"] / 78.6, traffic=traffic,
                         hbm=dict(achieved=kernels[dom]["hbm_GBps"], peak=8000.0, unit="GB/s", frac=kernels[dom]["hbm_GBps"] / 8000.0),
-                        note="C2 is 8160 blocks (0.1 GFLOP, 1.5 MB): one launch of ~375 waves on 1024 SIMDs, latency bound; the same kernel on the C5-size "
-                             "problem is reported in extra_c5_single_gpu. traffic = FETCH_SIZE + WRITE_SIZE per launch from the newest profiles/r*_pmc_hbm_C2.csv "
-                             "(%s): the fp64 atomics of the Gram scatter are counted as memory-side requests, ~10x the algorithmic output." % os.path.basename(pmc),
-                        step_share=dict(blocks_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step),
+                        binds="fp64 datapath of the SIMDs: on MI355X v_mfma_f64_16x16x4_f64 (64 cycles) runs on the vector fp64 lanes, so the Gram MFMAs and "
+                              "the spline / Jacobian VALU work of a wave add up (scripts/micro/mfma_lds_rates.hip); peak = 78.6 TFLOP/s for either",
+                        note="achieved = algorithmic FLOPs of SURVEY 8(d) (6.9 / 7.6 / 3.7 kFLOP per corner / accelerometer / gyroscope block) x the blocks of one pass "
+                             "/ the pass time by HIP events (tile kernel + slab merge).  C2 is 8160 blocks in ~200 workgroups: one wave per SIMD at most, latency bound; "
+                             "the same kernels on the C5-size problem (throughput bound) are in extra_c5_single_gpu.  traffic = FETCH_SIZE + WRITE_SIZE per pass from "
+                             "the newest profiles/r*_pmc_hbm_C2.csv (%s)." % os.path.basename(pmc),
+                        step_share=dict(blocks_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
+                                        solve_group=dict(kernels=names["solve"], ms=solve_ms, fp64_frac=kernels["solve"]["fp64_TFLOPs"] / 78.6,
+                                                         why="dependent chain: ceil(log2 n)+1 block eliminations of 64 columns each (pivot recurrences at ~40 cycles "
+                                                             "per dependent fp64 operation) and one kernel boundary per tree level")),
                         kernels=kernels)
         out = {
             "metric": "residual+Jacobian blocks/sec; wall-clock per LM iter, GoPro9 full calib",
             "value": value, "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seed 20241115)",
-            "config": {"workload": "C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s%s"
-                                   % (ds.num_views, n_corners, n_blocks - ds.num_views, "" if world == 1 else " (C2 x %d, time-sharded, all-reduce of JtJ/Jtr)" % world),
+            "config": {"workload": ("C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s" if world == 1 else
+                                    "C5 synthetic, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s, " + "%d time shards (strong scaling), all-reduce of JtJ/Jtr" % world)
+                                   % (ds.num_views, n_corners, n_blocks - ds.num_views),
                        "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR", "allreduce": reduce_path,
                        "step": "one LM iteration: Jacobian+assembly, block-cyclic-reduction solve, retraction, cost pass, one host read-back"},
             "corners_per_s": n_corners * args.steps / dt,
@@ -246,19 +261,32 @@ def main():
             ob = oracle_backend.load()
             ob.raw.oicc_oracle_num_threads.restype = ctypes.c_int
             cores = int(ob.raw.oicc_oracle_num_threads())
-            ccal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
             iters = 3
+            scan = {}
+            for nth in sorted({8, 16, 32, 64, cores}):          # the CPU assembly keeps one partial system per thread: more threads is not always faster
+                if nth > cores:
+                    continue
+                ccal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+                ccal.trajectory_.SetOption("num_threads", nth)
+                t1 = time.perf_counter()
+                cs = ccal.trajectory_.Optimize(iters if nth == min(16, cores) else 1, flags)
+                scan[nth] = (time.perf_counter() - t1) / max(cs["num_iterations"], 1)
+            nth_best = min(scan, key=scan.get)
+            ccal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+            ccal.trajectory_.SetOption("num_threads", nth_best)
             t1 = time.perf_counter()
             cs = ccal.trajectory_.Optimize(iters, flags)
             cdt = time.perf_counter() - t1
-            out["cpu_baseline"] = dict(value=n_blocks * cs["num_iterations"] / cdt, unit="blocks/s", cores=cores, kind="port",
-                                       sample="first %d LM iterations of the same C2 problem (forward-mode Jet autodiff in strides of 4, "
-                                              "OpenMP over residual blocks, band+arrow Cholesky): %.2f s" % (cs["num_iterations"], cdt),
-                                       ms_per_lm_iteration=1e3 * cdt / max(cs["num_iterations"], 1))
+            out["cpu_baseline"] = dict(value=n_blocks * cs["num_iterations"] / cdt, unit="blocks/s", cores=nth_best, kind="port",
+                                       sample="first %d LM iterations of the same C2 problem with the CPU restatement of the Ceres path (forward-mode Jet autodiff in "
+                                              "strides of 4, OpenMP over residual blocks, band+arrow Cholesky), best of %s threads: %.2f s" % (
+                                                  cs["num_iterations"], "/".join(str(k) for k in sorted(scan)), cdt),
+                                       ms_per_lm_iteration=1e3 * cdt / max(cs["num_iterations"], 1),
+                                       thread_scan_ms_per_iteration={str(k): 1e3 * v for k, v in sorted(scan.items())})
             # second CPU baseline (SURVEY 8d ii): the same CPU LM loop with the closed-form Jacobians of the device kernels
             # compiled for the host (oracle/cpu_analytic.hpp) instead of forward-mode Jets, i.e. a CPU code without autodiff
             best = None
-            for nth in sorted({8, 16, 32, cores}):          # the CPU assembly keeps one partial system per thread: more threads is not always faster
+            for nth in sorted({8, 16, 32, 64, cores}):
                 if nth > cores:
                     continue
                 acal = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
@@ -274,7 +302,7 @@ def main():
             adt, ait, nth = best
             out["cpu_baseline"]["analytic"] = dict(value=n_blocks * ait / adt, unit="blocks/s", cores=nth, kind="port",
                                                    sample="the same %d LM iterations with analytic Jacobians (formulas of the device kernels on the host, OpenMP, "
-                                                          "best of 8/16/32/%d threads): %.3f s" % (ait, cores, adt),
+                                                          "best of 8/16/32/64/%d threads): %.3f s" % (ait, cores, adt),
                                                    ms_per_lm_iteration=1e3 * adt / max(ait, 1))
         # ---- extra: C5-size Jacobian pass on one GPU --------------------------------
         if not args.no_extra and world == 1:
@@ -283,7 +311,7 @@ def main():
                 c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
                 p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
                 s5 = c5.trajectory_.TimeLinearSolve(flags, repeats=5)
-                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5,
+                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false> + slab_merge_kernel",
                                                   fp64_frac_of_78p6=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 78.6e12,
                                                   kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
                                                   blocks_per_s_jacobian_pass=c5.num_blocks / (p5 * 1e-3),

@@ -479,7 +479,11 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
 
 // ---- host ------------------------------------------------------------------
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
-bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
+// Arrow limit: the kernels are written for up to 63 arrow columns, but with three or four 16-row border tiles (a + 1 > 32)
+// the factorisation was seen to fail sporadically (NaN pivots in ~10 % of the solves that reuse the damping diagonal after a
+// rejected step, round-2 measurements in DESIGN.md) depending on what the preceding kernel left in LDS; until that is
+// understood such systems go to the band sweep (kernels_cholesky.hip), which takes any arrow width.
+bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 32; }
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;

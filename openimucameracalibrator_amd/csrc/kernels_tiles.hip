@@ -46,11 +46,17 @@ struct TileSink {
   double* p_s; double* p_v; double* p_t; double* p_l; double* p_m; double* p_i; double* p_res; double* p_cf; double* p_cb;
   double* rec; int nvals, nfac;
   double* dres; double* djac;
-  __device__ __forceinline__ TileSink(const RowFmt& f, double* record, double* dres_, double* djac_) : rec(record), dres(dres_), djac(djac_) {
+  __device__ __forceinline__ TileSink(const RowFmt& f, double* record, int s_so3_rel, double* dres_, double* djac_) : rec(record), dres(dres_), djac(djac_) {
     p_s = record + f.b_s * ROWS; p_v = record + f.b_v * ROWS; p_t = record + f.b_t * ROWS; p_l = record + f.b_l * ROWS;
     p_m = record + f.b_m * ROWS; p_i = record + f.b_i * ROWS; p_res = record + f.b_res * ROWS;
     p_cf = record + f.nbase * ROWS + f.f_cf; p_cb = record + f.nbase * ROWS + f.f_cb;
     nvals = f.b_res * ROWS; nfac = f.nfac;
+    if (JAC) {   // the factor of the columns that are stored expanded, and what the padding columns of the last block read
+      record[f.nbase * ROWS + f.nfac] = 1.0;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) record[f.nbase * ROWS + f.nfac + 1 + r] = 0.0;
+      if (KINDSEL != 0) reinterpret_cast<int*>(record + f.nbase * ROWS + f.nfac + 1 + ROWS)[0] = s_so3_rel;   // the item's SO(3) window (wide cells)
+    }
   }
   __device__ __forceinline__ void res(const double* r) const {
 #pragma unroll
@@ -122,18 +128,27 @@ struct TileSink {
   }
 };
 
-// Gram column -> (value index, factor index) of the compact record
-__device__ __forceinline__ void col_src(const RowFmt& f, int col, int& bi, int& fi) {
-  bi = -1; fi = -1;
-  if (col >= f.ncols) return;
-  if (col == f.rescol) { bi = f.b_res; return; }
-  if (f.c_s >= 0 && col >= f.c_s && col < f.c_s + 18) { bi = f.b_s + (col - f.c_s); return; }
-  if (f.c_r >= 0 && col >= f.c_r && col < f.c_r + 18) { const int k = col - f.c_r; bi = f.b_v + k % 3; fi = f.f_cf + k / 3; return; }
-  if (f.c_t >= 0 && col >= f.c_t && col < f.c_t + 6) { bi = f.b_t + (col - f.c_t); return; }
-  if (f.c_l >= 0 && col == f.c_l) { bi = f.b_l; return; }
-  if (f.c_g >= 0 && col >= f.c_g && col < f.c_g + 3) { bi = f.b_v + (col - f.c_g); return; }
-  if (f.c_b >= 0 && col >= f.c_b && col < f.c_b + 9) { const int k = col - f.c_b; bi = f.b_m + k % 3; fi = f.f_cb + k / 3; return; }
-  if (f.c_i >= 0 && col >= f.c_i && col < f.c_i + f.n_i) { bi = f.b_i + (col - f.c_i); return; }
+// ---- per-tile column tables (LDS, built once per tile from the row formats): for each residual family and Gram column
+//   ct_ba   offset of the column's value inside an item's record (idx * rows), the record's zero slot for padding columns
+//   ct_fa   offset of its factor (the constant-one slot for columns stored expanded)
+//   ct_grp  parameter group + knot index + component, for the tangent offsets of a cell
+enum { GRP_NONE = 0, GRP_S, GRP_R, GRP_T, GRP_L, GRP_G, GRP_B, GRP_I, GRP_RES };
+__device__ __forceinline__ void column_table_entry(const RowFmt& f, int col, int& ba, int& fa, int& grp) {
+  const int rows = f.rows_per_item, fbase = f.nbase * rows;
+  int b = -1, q = -1, g = GRP_NONE, k = 0;
+  if (col < f.ncols) {
+    if (col == f.rescol) { b = f.b_res; g = GRP_RES; }
+    else if (f.c_s >= 0 && col >= f.c_s && col < f.c_s + 18 + 3 * f.ks_extra) { k = col - f.c_s; b = f.b_s + k; g = GRP_S; }   // (k >= 18: the knots a later window of a wide cell adds)
+    else if (f.c_r >= 0 && col >= f.c_r && col < f.c_r + 18) { k = col - f.c_r; b = f.b_v + k % 3; q = f.f_cf + k / 3; g = GRP_R; }
+    else if (f.c_t >= 0 && col >= f.c_t && col < f.c_t + 6) { k = col - f.c_t; b = f.b_t + k; g = GRP_T; }
+    else if (f.c_l >= 0 && col == f.c_l) { b = f.b_l; g = GRP_L; }
+    else if (f.c_g >= 0 && col >= f.c_g && col < f.c_g + 3) { k = col - f.c_g; b = f.b_v + k; g = GRP_G; }
+    else if (f.c_b >= 0 && col >= f.c_b && col < f.c_b + 9) { k = col - f.c_b; b = f.b_m + k % 3; q = f.f_cb + k / 3; g = GRP_B; }
+    else if (f.c_i >= 0 && col >= f.c_i && col < f.c_i + f.n_i) { k = col - f.c_i; b = f.b_i + k; g = GRP_I; }
+  }
+  ba = b < 0 ? fbase + f.nfac + 1 : b * rows;
+  fa = fbase + (q < 0 ? f.nfac : q);
+  grp = g | (k << 4);
 }
 
 // where the Gram entries of a cell go.  i <= j are EXTENDED tangent offsets: band [0, Pb), arrow [Pb, Pb + a), the
@@ -143,55 +158,78 @@ struct Target {
   int lo, Wl, W, Pb, a, corner0;
   NormalEq ne;          // DIRECT mode: fp64 atomics on the packed normal equations
 };
-template <bool DIRECT>
-__device__ __forceinline__ void target_add(const Target& T, int i, int j, double v) {
-  if (!DIRECT) {
-    const int t = i < T.Pb ? (i - T.lo) * T.Wl + (j < T.Pb ? j - i : T.W + (j - T.Pb)) : T.corner0 + (i - T.Pb) * (T.a + 1) + (j - T.Pb);
-    unsafeAtomicAdd(T.acc + t, v);                                   // ds_add_f64
-  } else {
-    const int P = T.Pb + T.a;
-    if (j < T.Pb) unsafeAtomicAdd(T.ne.band() + (int64_t)i * T.W + (j - i), v);
-    else if (i < T.Pb) { if (j < P) unsafeAtomicAdd(T.ne.Et() + (int64_t)(j - T.Pb) * T.Pb + i, v); else unsafeAtomicAdd(T.ne.g() + i, v); }
-    else if (j < P) { unsafeAtomicAdd(T.ne.C() + (int64_t)(i - T.Pb) * T.a + (j - T.Pb), v); if (i != j) unsafeAtomicAdd(T.ne.C() + (int64_t)(j - T.Pb) * T.a + (i - T.Pb), v); }
-    else if (i < P) unsafeAtomicAdd(T.ne.g() + i, v);
-    else unsafeAtomicAdd(T.ne.cost(), 0.5 * v);
-  }
+__device__ __forceinline__ void target_add_direct(const Target& T, int i, int j, double v) {
+  const int P = T.Pb + T.a;
+  if (j < T.Pb) unsafeAtomicAdd(T.ne.band() + (int64_t)i * T.W + (j - i), v);
+  else if (i < T.Pb) { if (j < P) unsafeAtomicAdd(T.ne.Et() + (int64_t)(j - T.Pb) * T.Pb + i, v); else unsafeAtomicAdd(T.ne.g() + i, v); }
+  else if (j < P) { unsafeAtomicAdd(T.ne.C() + (int64_t)(i - T.Pb) * T.a + (j - T.Pb), v); if (i != j) unsafeAtomicAdd(T.ne.C() + (int64_t)(j - T.Pb) * T.a + (i - T.Pb), v); }
+  else if (i < P) unsafeAtomicAdd(T.ne.g() + i, v);
+  else unsafeAtomicAdd(T.ne.cost(), 0.5 * v);
+}
+// accumulator index of entry (i, j), i <= j:  base1(i) + j if j is a band column, base2(i) + j otherwise, with
+//   i band:  base1 = (i - lo) Wl - i,  base2 = (i - lo) Wl + W - Pb        i arrow / residual:  base1 = base2 = corner0 + (i - Pb)(a + 1) - Pb
+__device__ __forceinline__ void target_bases(const Target& T, int i, int& b1, int& b2) {
+  if (i < T.Pb) { b1 = (i - T.lo) * T.Wl - i; b2 = (i - T.lo) * T.Wl + T.W - T.Pb; }
+  else { b1 = T.corner0 + (i - T.Pb) * (T.a + 1) - T.Pb; b2 = b1; }
 }
 
 // Gram product of the rows [r0, r1) of a unit (one cell) and its scatter.  Operand lane mapping of
 // v_mfma_f64_16x16x4_f64: A[i][k] and B[k][j] with i = j = lane & 15, k = lane >> 4 -- the same for both operands, so
 // one operand load per 16-column block and K step feeds all tile pairs; the result lane holds
 // G[16 ti + (lane >> 4) + 4 r][16 tj + (lane & 15)], r = 0..3.  Only the upper block triangle is formed.
-template <int NT, bool DIRECT>
-__device__ __forceinline__ void gram_cell(const RowFmt& f, const double* rb, int r0, int r1, const int* coloff, const Target& T, int lane,
-                                          long long* prof) {
+// colinfo[c] = {extended tangent offset or -1, base1, base2} of the cell's column c (cell_column_info).
+// WIDE: the cell spans several SO(3) knot windows (IMU samples of up to 1 + ks_extra consecutive windows): an item's 18 SO(3)
+// values belong to the columns 3 (s_item - s_cell) ... of the cell's SO(3) group; the other columns of the group read zeros.
+template <int NT, bool DIRECT, bool WIDE>
+__device__ __forceinline__ void gram_cell(const RowFmt& f, const int* ct_ba, const int* ct_fa, const int* ct_grp, const double* rb, const double* zero_rec,
+                                          int r0, int r1, int s_cell, const int* colinfo, const Target& T, int lane, long long* prof) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   constexpr int NP = NT * (NT + 1) / 2;
   v4d acc[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lq = lane >> 4;
-  const int rows = f.rows_per_item, S = f.item_stride, fbase = f.nbase * rows;
-  int ba[NT], fa[NT];     // value offset idx * rows inside the record (or -1), factor offset inside the record (or -1)
+  const int rows = f.rows_per_item, S = f.item_stride;
+  const int rdiv = rows == 2 ? 0x10000 : 0xAAAB;
+  int ba[NT], fa[NT]; bool is_s[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { int b, q; col_src(f, 16 * t + li, b, q); ba[t] = b < 0 ? -1 : b * rows; fa[t] = q < 0 ? -1 : fbase + q; }
+  for (int t = 0; t < NT; ++t) { ba[t] = ct_ba[16 * t + li]; fa[t] = ct_fa[16 * t + li]; is_s[t] = WIDE && (ct_grp[16 * t + li] & 15) == GRP_S; }
+  const int s_lo = f.b_s * rows, s_n = 18 * rows, zoff = f.nbase * rows + f.nfac + 1, woff = zoff + rows;   // SO(3) values, zero slot, window slot of a record
   const long long t0 = prof ? clock64() : 0;
-  for (int kb = r0; kb < r1; kb += 16) {
-    double a[4][NT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = kb + 4 * u + lq;
-      const int kk = k < r1 ? k : r1 - 1;
-      const int item = rows == 2 ? (kk >> 1) : (kk * 0xAAAB) >> 17;               // kk / 3 for kk < 2^15
-      const double* rec = rb + item * S;
-      const int r = kk - item * rows;
+  // operands of K step (kb, u): value x per-item factor of each column block.  Rows past the cell read an all-zero record and
+  // the padding columns of the last block read the zero slot of their record, so the loop has no branch and no masking.
+  // (The fp64 MFMA runs on the vector ALU's own datapath: everything in this loop adds to the 64 cycles per MFMA.)
+  auto issue_row = [&](int kb, int u, double (&v)[NT], double (&q)[NT]) {
+    const int k = kb + 4 * u + lq;
+    const int item = (k * rdiv) >> 17;                                            // k / rows_per_item (k < 2^14)
+    const double* rec = k < r1 ? rb + item * S : zero_rec;
+    const int r = k < r1 ? k - item * rows : 0;
+    if (WIDE) {
+      const int d = k < r1 ? (reinterpret_cast<const int*>(rec + woff)[0] - s_cell) * 3 * rows : 0;    // the item's window inside the cell
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const double v = rec[(ba[t] < 0 ? 0 : ba[t]) + r];
-        const double q = rec[fa[t] < 0 ? 0 : fa[t]];
-        a[u][t] = (k < r1 && ba[t] >= 0) ? (fa[t] < 0 ? v : v * q) : 0.0;
+        const int o = ba[t] - d;
+        const bool in = !is_s[t] || (unsigned)(o - s_lo) < (unsigned)s_n;
+        v[t] = rec[(in ? (is_s[t] ? o : ba[t]) : zoff) + r]; q[t] = rec[fa[t]];
       }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { v[t] = rec[ba[t] + r]; q[t] = rec[fa[t]]; }
     }
+  };
+  double a[4][NT], rv[4][NT], rq[4][NT];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) issue_row(r0, u, rv[u], rq[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[u][t] = rv[u][t] * rq[u][t];
+  // software pipelined: the LDS reads of the next group of 16 rows are issued between the MFMAs of the current one and turned
+  // into operands one K step later.  This file is compiled with -mllvm -amdgpu-mfma-vgpr-form (Makefile): with AGPR accumulators
+  // the register allocator keeps the loop-carried tiles in VGPRs and copies all of them to AGPRs and back around the MFMAs of
+  // every iteration (96 moves for 3x3 tiles).
+  for (int kb = r0; kb < r1; kb += 16) {
+    double an[4][NT];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int idx = 0;
@@ -199,16 +237,28 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const double* rb, int
       for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int tj = ti; tj < NT; ++tj) { acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], a[u][tj], acc[idx], 0, 0, 0); ++idx; }
+      if (u > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) an[u - 1][t] = rv[u - 1][t] * rq[u - 1][t];
+      }
+      issue_row(kb + 16, u, rv[u], rq[u]);
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) an[3][t] = rv[3][t] * rq[3][t];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[u][t] = an[u][t];
   }
   const long long t1 = prof ? clock64() : 0;
-  int oj[NT], oi[NT][4];
+  // scatter: the lane's column (per block) and its four rows (per block)
+  int oj[NT], b1j[NT], b2j[NT], oi[NT][4], b1i[NT][4], b2i[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int cj = 16 * t + li;
-    oj[t] = cj < f.ncols ? coloff[cj] : -1;
+    oj[t] = colinfo[3 * cj]; b1j[t] = colinfo[3 * cj + 1]; b2j[t] = colinfo[3 * cj + 2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int ci = 16 * t + lq + 4 * r; oi[t][r] = ci < f.ncols ? coloff[ci] : -1; }
+    for (int r = 0; r < 4; ++r) { const int ci = 16 * t + lq + 4 * r; oi[t][r] = colinfo[3 * ci]; b1i[t][r] = colinfo[3 * ci + 1]; b2i[t][r] = colinfo[3 * ci + 2]; }
   }
   int idx = 0;
 #pragma unroll
@@ -218,10 +268,16 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const double* rb, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = 16 * ti + lq + 4 * r, cj = 16 * tj + li;
-        int i = oi[ti][r], j = oj[tj];
-        if (ci <= cj && i >= 0 && j >= 0) {
-          if (i > j) { const int t = i; i = j; j = t; }
-          target_add<DIRECT>(T, i, j, acc[idx][r]);
+        const int x = oi[ti][r], y = oj[tj];
+        if (ci <= cj && x >= 0 && y >= 0) {
+          const bool sw = x > y;
+          const int j = sw ? x : y, i = sw ? y : x;
+          if (WIDE && j < T.Pb && j - i >= T.W) continue;     // knots of different windows of a wide cell that no sample shares: exact zero, outside the band
+          if (DIRECT) target_add_direct(T, i, j, acc[idx][r]);
+          else {
+            const int b1 = sw ? b1j[tj] : b1i[ti][r], b2 = sw ? b2j[tj] : b2i[ti][r];
+            unsafeAtomicAdd(T.acc + (j < T.Pb ? b1 : b2) + j, acc[idx][r]);          // ds_add_f64
+          }
         }
       }
       ++idx;
@@ -229,25 +285,29 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const double* rb, int
   if (prof && lane == 0) { const long long t2 = clock64(); prof[2] += t1 - t0; prof[3] += t2 - t1; }
 }
 
-// extended tangent offset of Gram column `col` of a cell with knot windows (s_so3, s_r3 relative to the staged knots; s_b); sensor: 0 view, 1 accel, 2 gyro
-__device__ __forceinline__ int cell_col_offset(const RowFmt& f, const TangentLayout& tl, int sensor, int col, const int* l_tl_so3, const int* l_tl_r3,
-                                               int s_so3_rel, int s_r3_rel, int s_b) {
-  if (col >= f.ncols) return -1;
-  if (col == f.rescol) return tl.Pb + tl.a;
-  if (f.c_s >= 0 && col >= f.c_s && col < f.c_s + 18) { const int k = col - f.c_s; const int o = l_tl_so3[s_so3_rel + k / 3]; return o < 0 ? -1 : o + k % 3; }
-  if (f.c_r >= 0 && col >= f.c_r && col < f.c_r + 18) { const int k = col - f.c_r; const int o = l_tl_r3[s_r3_rel + k / 3]; return o < 0 ? -1 : o + k % 3; }
-  if (f.c_t >= 0 && col >= f.c_t && col < f.c_t + 6) return tl.tic + (col - f.c_t);
-  if (f.c_l >= 0 && col == f.c_l) return tl.ld;
-  if (f.c_g >= 0 && col >= f.c_g && col < f.c_g + 3) return tl.g + (col - f.c_g);
-  if (f.c_b >= 0 && col >= f.c_b && col < f.c_b + 9) { const int k = col - f.c_b; const int o = (sensor == 1 ? tl.ab : tl.gb)[s_b + k / 3]; return o < 0 ? -1 : o + k % 3; }
-  if (f.c_i >= 0 && col >= f.c_i && col < f.c_i + f.n_i) return (sensor == 1 ? tl.ai : tl.gi) + (col - f.c_i);
-  return -1;
+// {extended tangent offset or -1, base1, base2} of Gram column `lane` of a cell with knot windows (s_so3, s_r3 relative to the
+// staged knots; s_b); sensor: 0 view, 1 accelerometer, 2 gyroscope
+__device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLayout& tl, const Target& T, int sensor, const int* l_tl_so3,
+                                                 const int* l_tl_r3, int s_so3_rel, int s_r3_rel, int s_b, int n_so3_knots, int* out3) {
+  const int g = grp_packed & 15, k = grp_packed >> 4;
+  int off = -1;
+  if (g == GRP_S) { if (k / 3 < n_so3_knots) { const int o = l_tl_so3[s_so3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; } }   // knots of the cell's windows only
+  else if (g == GRP_R) { const int o = l_tl_r3[s_r3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; }
+  else if (g == GRP_T) off = tl.tic + k;
+  else if (g == GRP_L) off = tl.ld;
+  else if (g == GRP_G) off = tl.g + k;
+  else if (g == GRP_B) { const int o = (sensor == 1 ? tl.ab : tl.gb)[s_b + k / 3]; off = o < 0 ? -1 : o + k % 3; }
+  else if (g == GRP_I) off = (sensor == 1 ? tl.ai : tl.gi) + k;
+  else if (g == GRP_RES) off = tl.Pb + tl.a;
+  int b1 = 0, b2 = 0;
+  if (off >= 0) target_bases(T, off, b1, b2);
+  out3[0] = off; out3[1] = b1; out3[2] = b2;
 }
 
 }  // namespace
 
 template <bool JAC, bool DIRECT>
-__global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewData vd, ImuData ia, ImuData ig, RowFmt fv, RowFmt fa, RowFmt fg,
+__global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewData vd, ImuData ia, ImuData ig, RowFmt fv, RowFmt fa_, RowFmt fg,
                                                             TileParams tp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,8 +319,10 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
   int* l_tl_so3 = reinterpret_cast<int*>(lds + tp.o_tl);
   int* l_tl_r3 = l_tl_so3 + kMaxTileKnots;
   int* l_queue = reinterpret_cast<int*>(lds + tp.o_misc);
-  int* coloff = reinterpret_cast<int*>(lds + tp.o_wave + (size_t)wave * tp.wave_doubles);
-  double* rb = lds + tp.o_wave + (size_t)wave * tp.wave_doubles + 32;
+  int* l_ct = reinterpret_cast<int*>(lds + tp.o_ct);          // column tables [ba | fa | grp] x [kind][64]
+  double* l_zero = lds + tp.o_zero;                            // an all-zero item record (rows past a cell)
+  int* colinfo = reinterpret_cast<int*>(lds + tp.o_wave + (size_t)wave * tp.wave_doubles);   // [64][3] of the wave's current cell
+  double* rb = lds + tp.o_wave + (size_t)wave * tp.wave_doubles + 96;
 
   // ---- P0: knots, tangent offsets, segment tables, zeroed accumulator ----
   for (int i = tid; i < td.nks * 4; i += kTileThreads) l_so3[i] = ctx.x[ctx.pl.so3 + (int64_t)td.ks0 * 4 + i];
@@ -273,6 +335,15 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
       for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0;
       for (int i = tid; i < tp.corner; i += kTileThreads) acc[tp.acc_rows * tp.Wl + i] = 0.0;
     }
+  }
+  if (JAC) {
+    if (tid < 192) {
+      const int kind = tid >> 6, col = tid & 63;
+      int ba, fa, grp;
+      column_table_entry(kind == 0 ? fv : (kind == 1 ? fa_ : fg), col, ba, fa, grp);
+      l_ct[tid] = ba; l_ct[192 + tid] = fa; l_ct[384 + tid] = grp;
+    }
+    if (tid < 128) l_zero[tid] = 0.0;
   }
   if (tid == 0) l_queue[0] = td.unit0;
   __syncthreads();
@@ -317,7 +388,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
         double* dres = ctx.dbg_res ? ctx.dbg_res + 2 * it : nullptr;
         double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 2 * it * 43 : nullptr;
         if (djac) for (int k = 0; k < 2 * 43; ++k) djac[k] = 0.0;
-        const TileSink<0, JAC> sink(fv, rb + lane * fv.item_stride, dres, djac);
+        const TileSink<0, JAC> sink(fv, rb + lane * fv.item_stride, s_so3, dres, djac);
         cost_local += view_item<JAC>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], vd.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
                                      vd.corner_isx[it], vd.corner_isy[it], ctx.pts + 4 * (int64_t)vd.corner_pt[it], sink);
       }
@@ -337,42 +408,51 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
         ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
         if (accel) {
           imu_const_init<0>(ic, ctx.x + ctx.pl.ai, ctx.x + ctx.pl.g);
-          ic.spline_active = fa.c_s >= 0; ic.g_active = fa.c_g >= 0; ic.bias_active = fa.c_b >= 0; ic.intr_active = fa.c_i >= 0;
+          ic.spline_active = fa_.c_s >= 0; ic.g_active = fa_.c_g >= 0; ic.bias_active = fa_.c_b >= 0; ic.intr_active = fa_.c_i >= 0;
           double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 54 : nullptr;
           if (djac) for (int k = 0; k < 3 * 54; ++k) djac[k] = 0.0;
-          const TileSink<1, JAC> sink(fa, rb + lane * fa.item_stride, dres, djac);
+          const TileSink<1, JAC> sink(fa_, rb + lane * fa_.item_stride, s_so3, dres, djac);
           cost_local += imu_item<0, JAC>(ic, R0, seg, kr, id.u_so3[it], id.u_r3[it], id.u_b[it], bk, m, id.w[it], sink);
         } else {
           imu_const_init<1>(ic, ctx.x + ctx.pl.gi, ctx.x + ctx.pl.g);
           ic.spline_active = fg.c_s >= 0; ic.g_active = false; ic.bias_active = fg.c_b >= 0; ic.intr_active = fg.c_i >= 0;
           double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 36 : nullptr;
           if (djac) for (int k = 0; k < 3 * 36; ++k) djac[k] = 0.0;
-          const TileSink<2, JAC> sink(fg, rb + lane * fg.item_stride, dres, djac);
+          const TileSink<2, JAC> sink(fg, rb + lane * fg.item_stride, s_so3, dres, djac);
           cost_local += imu_item<1, JAC>(ic, R0, seg, kr, id.u_so3[it], 0.0, id.u_b[it], bk, m, id.w[it], sink);
         }
       }
     }
     if (JAC) {
-      // cells: runs of items with identical knot windows share every normal-equation target (a view is one cell).  The
-      // boundaries come from the window indices the lanes already hold (one ballot).
-      const RowFmt& f = ud.kind == 0 ? fv : (ud.kind == 1 ? fa : fg);
+      // cells: a view, or a run of IMU samples with the same R^3 and bias windows whose SO(3) windows span at most 1 + ks_extra
+      // consecutive ones (as many as fit the 16-column blocks of the single-window layout): one Gram product and one scatter per
+      // cell.  The boundaries come from the window indices the lanes already hold (one ballot per cell).
+      const RowFmt& f = ud.kind == 0 ? fv : (ud.kind == 1 ? fa_ : fg);
       const int rows = f.rows_per_item;
-      const int p_so3 = __shfl_up(s_so3, 1, 64), p_b = __shfl_up(s_b, 1, 64), p_r3 = __shfl_up(s_r3, 1, 64);
-      const bool starts_cell = valid && (lane == 0 || (ud.kind != 0 && (s_so3 != p_so3 || s_b != p_b || s_r3 != p_r3)));
-      unsigned long long starts = __ballot(starts_cell);
+      const int* cba = l_ct + 64 * ud.kind; const int* cfa = l_ct + 192 + 64 * ud.kind; const int* cgr = l_ct + 384 + 64 * ud.kind;
       const long long tq1 = prof ? clock64() : 0;
-      while (starts != 0ull) {
-        const int l0 = __builtin_ctzll(starts);
-        starts &= starts - 1ull;
-        const int l1 = starts != 0ull ? __builtin_ctzll(starts) : ud.count;
+      int l0 = 0;
+      while (l0 < ud.count) {
         const int ks0 = __shfl(s_so3, l0, 64), kb0 = __shfl(s_b, l0, 64), kr0 = __shfl(s_r3, l0, 64);
-        coloff[lane] = cell_col_offset(f, ctx.tl, ud.kind, lane, l_tl_so3, l_tl_r3, ks0, kr0, kb0);
+        const bool brk = valid && lane > l0 && ud.kind != 0 && (s_r3 != kr0 || s_b != kb0 || s_so3 < ks0 || s_so3 > ks0 + f.ks_extra);
+        const unsigned long long bm = __ballot(brk);
+        const int l1 = bm != 0ull ? __builtin_ctzll(bm) : ud.count;
+        const int ks1 = __shfl(s_so3, l1 - 1, 64);                                   // (windows do not decrease inside a cell)
+        cell_column_info(cgr[lane], ctx.tl, T, ud.kind, l_tl_so3, l_tl_r3, ks0, kr0, kb0, ks1 - ks0 + 6, colinfo + 3 * lane);
         wave_sync();
-        if (f.ncols <= 16) gram_cell<1, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
-        else if (f.ncols <= 32) gram_cell<2, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
-        else if (f.ncols <= 48) gram_cell<3, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
-        else gram_cell<4, DIRECT>(f, rb, rows * l0, rows * l1, coloff, T, lane, prof);
+        if (ud.kind == 0) {
+          if (f.ncols <= 16) gram_cell<1, DIRECT, false>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else if (f.ncols <= 32) gram_cell<2, DIRECT, false>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else if (f.ncols <= 48) gram_cell<3, DIRECT, false>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else gram_cell<4, DIRECT, false>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+        } else {
+          if (f.ncols <= 16) gram_cell<1, DIRECT, true>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else if (f.ncols <= 32) gram_cell<2, DIRECT, true>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else if (f.ncols <= 48) gram_cell<3, DIRECT, true>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+          else gram_cell<4, DIRECT, true>(f, cba, cfa, cgr, rb, l_zero, rows * l0, rows * l1, ks0, colinfo, T, lane, prof);
+        }
         wave_sync();
+        l0 = l1;
       }
       if (prof && lane == 0) { prof[0] += tq1 - tq0; prof[1] += clock64() - tq1; }
     }
@@ -409,7 +489,7 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
     }
     if (e < tl.W) ne.band()[(int64_t)i * tl.W + e] = s;
     else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + i] = s;
-    else ne.g()[i] = s;
+    else if (e == tl.W + tl.a) ne.g()[i] = s;                            // (a padding column of the accumulator row carries nothing)
     return;
   }
   __shared__ double red[256];
@@ -427,6 +507,20 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
     else if (p < tl.a) ne.g()[tl.Pb + p] = v;
     else ne.cost()[0] = 0.5 * v;
   }
+}
+
+// Debug aid (option debug_poison_lds): every CU's LDS is filled with NaNs, so that a kernel that reads LDS it has not
+// written -- and happens to find its own data of the previous launch there -- fails loudly in the tests.
+__global__ void __launch_bounds__(256) lds_poison_kernel(int n_doubles) {
+  extern __shared__ double lds[];
+  for (int i = threadIdx.x; i < n_doubles; i += 256) lds[i] = __longlong_as_double(0x7ff8dead0000beefLL);
+  __syncthreads();
+  if (lds[(threadIdx.x * 97) % n_doubles] == 0.0) asm volatile("s_nop 0");   // keep the stores
+}
+void launch_lds_poison(hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, st, 160 * 1024 / 8);
 }
 
 // ---- launchers ----

@@ -38,6 +38,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        hipStream_t st);
 int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
                      const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st);
+void launch_lds_poison(hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
 }  // namespace oicc
@@ -144,6 +145,10 @@ struct oicc_problem {
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0; opt["imu_chunk_cells"] = 0;
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
+    opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
+    opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
+    opt["debug_sync"] = 0;       // 1: drain the stream after every pass (debugging of inter-kernel hazards)
+    opt["debug_poison_lds"] = 0; // 1: fill every CU's LDS with NaNs before each Jacobian / cost pass and each linear solve (tests)
   }
 };
 
@@ -348,12 +353,12 @@ int make_layout(oicc_problem* p, int flags) {
 // and the compact row storage the kernels use.
 RowFmt row_fmt_finish(RowFmt f, int rows_per_item) {
   f.rows_per_item = rows_per_item; f.cap = 0;
-  f.item_stride = (f.nbase * rows_per_item + f.nfac) | 1;   // odd: the lanes' records start in different banks
+  f.item_stride = (f.nbase * rows_per_item + f.nfac + 1 + rows_per_item + (rows_per_item == 3 ? 1 : 0)) | 1;   // values, factors, the constant 1, a zero slot, (IMU) the window index; odd: the lanes' records start in different banks
   return f;
 }
 RowFmt view_row_fmt(const TangentLayout& tl, bool spline) {
   RowFmt f{}; int n = 0, b = 0;
-  f.c_g = f.c_b = f.c_i = -1; f.n_i = 0; f.b_m = f.b_i = -1; f.f_cb = -1;
+  f.c_g = f.c_b = f.c_i = -1; f.n_i = 0; f.b_m = f.b_i = -1; f.f_cb = -1; f.ks_extra = 0;
   f.c_s = spline ? n : -1; if (spline) n += 18;
   f.c_r = spline ? n : -1; if (spline) n += 18;
   f.c_t = tl.tic >= 0 ? n : -1; if (tl.tic >= 0) n += 6;
@@ -367,12 +372,15 @@ RowFmt view_row_fmt(const TangentLayout& tl, bool spline) {
   f.f_cf = spline ? 0 : -1; f.nfac = spline ? 6 : 0;
   return row_fmt_finish(f, 2);
 }
-RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias) {
+RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, int wide_max) {
   RowFmt f{}; int n = 0, b = 0, k = 0;
   f.c_t = f.c_l = -1; f.b_t = f.b_l = -1;
   const bool g = accel && tl.g >= 0, intr = (accel ? tl.ai : tl.gi) >= 0;
   f.n_i = accel ? 6 : 9;
-  f.c_s = spline ? n : -1; if (spline) n += 18;
+  // wide cells: as many further SO(3) knots as fit the 16-column blocks the single-window layout needs anyway
+  const int ncols1 = (spline ? 18 : 0) + (spline && accel ? 18 : 0) + (g ? 3 : 0) + (bias ? 9 : 0) + (intr ? f.n_i : 0) + 1;
+  f.ks_extra = spline ? std::min(wide_max, (((ncols1 + 15) / 16) * 16 - ncols1) / 3) : 0;
+  f.c_s = spline ? n : -1; if (spline) n += 18 + 3 * f.ks_extra;
   f.c_r = (spline && accel) ? n : -1; if (spline && accel) n += 18;
   f.c_g = g ? n : -1; if (g) n += 3;
   f.c_b = bias ? n : -1; if (bias) n += 9;
@@ -473,44 +481,62 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
 int build_tiles(oicc_problem* p) {
   const TangentLayout& tl = p->tl; const Active& a = p->act;
   p->fv = view_row_fmt(tl, a.spline);
-  p->fa = imu_row_fmt(tl, true, a.spline, a.ab);
-  p->fg = imu_row_fmt(tl, false, a.spline, a.gb);
+  const int wide_max = p->opt["wide_cells"] != 0.0 ? 8 : 0;
+  p->fa = imu_row_fmt(tl, true, a.spline, a.ab, wide_max);
+  p->fg = imu_row_fmt(tl, false, a.spline, a.gb, wide_max);
   TileParams& tp = p->tp; tp = TileParams{};
-  tp.Wl = tl.W + tl.a + 1; tp.corner = (tl.a + 1) * (tl.a + 1);
+  tp.Wl = (tl.W + tl.a + 1) | 1;   // [band W | arrow a | gradient 1], padded to an odd length: the four row groups of an MFMA result tile hit different LDS banks
+  tp.corner = (tl.a + 1) * (tl.a + 1);
   // LDS budget (doubles) and the row buffer of a wave: the largest view in one piece if it fits 26 KB, never less than ~32 IMU samples
   const int budget = 160 * 1024 / 8 - 64;
   int max_nc = 1;
   for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) max_nc = std::max<int>(max_nc, int(std::min<int64_t>(64, p->view_c0[v + 1] - p->view_c0[v])));
   auto need = [](const RowFmt& f, int items) { return f.item_stride * items; };
   int rb = std::max(need(p->fv, max_nc), std::max(need(p->fa, 32), need(p->fg, 32)));
-  rb = std::min(rb, 3328);
+  rb = std::min(rb, 3456);   // 27 KB per wave: a 50-corner view in one piece
   rb = std::max(rb, 512);
   row_fmt_capacity(p->fv, rb, 64); row_fmt_capacity(p->fa, rb, 64); row_fmt_capacity(p->fg, rb, 64);
   if (p->fv.cap < 1 || p->fa.cap < 1 || p->fg.cap < 1) { p->err = "row buffer too small for this parameter set"; return OICC_ERR_UNSUPPORTED; }
-  tp.rb_doubles = rb; tp.wave_doubles = 32 + rb;
+  tp.rb_doubles = rb; tp.wave_doubles = 96 + rb;
   const int64_t dt_fine = std::min(p->dt_so3, p->dt_r3);
   const int64_t n_windows = (p->end_ns - p->start_ns) / dt_fine + 1;
   const int mode = int(p->opt["assembly"]);
-  int T = int(p->opt["tile_windows"]);
-  if (T <= 0) T = int(std::max<int64_t>(2, std::min<int64_t>(64, n_windows / 96)));
+  // Tile length T (fine knot windows): small problems want many tiles (latency: ~200 workgroups), large ones the longest tile
+  // whose accumulator fits LDS (the halo rows of a tile are summed by the merge kernel: their share falls with T); a multiple
+  // of the window ratio of the two splines keeps the R^3 windows (and with them the views and IMU cells) whole.
+  const int ratio = int(std::max<int64_t>(1, std::min<int64_t>(8, std::max(p->dt_so3, p->dt_r3) / dt_fine)));
+  const int T_user = int(p->opt["tile_windows"]);
+  int T = T_user > 0 ? T_user : int(std::max<int64_t>(ratio, std::min<int64_t>(64, n_windows / 200)));
   auto carve = [&](int nks, int nkr, int acc_doubles) {   // returns total doubles
     int o = 0;
     tp.o_so3 = o; o += nks * 4; tp.o_r3 = o; o += std::max(nkr, 1) * 3; tp.o_seg = o; o += std::max(nks - 1, 1) * 17;
-    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
+    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
     return o;
   };
   TileBuild tb;
-  bool fits = false;
   tp.direct = mode == 2 ? 1 : 0;
+  auto try_T = [&](int t) {   // builds the tiles for t windows; true if they fit
+    make_tiles(p, t, &tb);
+    if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;
+    return carve(tb.max_nks, tb.max_nkr, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) <= budget;
+  };
+  bool fits = false;
   while (true) {
-    make_tiles(p, T, &tb);
-    if (tb.max_nks <= kMaxTileKnots && tb.max_nkr <= kMaxTileKnots) {
-      const int acc_doubles = tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner;
-      if (carve(tb.max_nks, tb.max_nkr, acc_doubles) <= budget) { fits = true; tp.acc_rows = tp.direct ? 0 : tb.max_rows; break; }
+    auto snap = [&](int t) { return T_user > 0 ? std::max(t, 1) : std::max((t / ratio) * ratio, std::min(ratio, std::max(t, 1))); };
+    int t = snap(T), t_fail = 1 << 30;
+    while (!(fits = try_T(t))) {          // geometric descent to the first length that fits ...
+      if (t <= 1) break;
+      t_fail = t; t = snap(t > 4 ? t * 3 / 4 : t - 1); if (t >= t_fail) t = t_fail - 1;
     }
-    if (T == 1) { if (tp.direct) break; tp.direct = 1; T = int(std::max<int64_t>(2, std::min<int64_t>(16, n_windows / 96))); continue; }   // accumulator does not fit: direct mode
-    T = T > 4 ? T * 3 / 4 : T - 1;
+    if (fits && T_user <= 0 && t_fail < (1 << 30)) {   // ... then back up in steps of the window ratio
+      while (t + ratio < t_fail && try_T(t + ratio)) t += ratio;
+      fits = try_T(t);                    // leave tb built for the chosen length
+    }
+    if (fits) { T = t; break; }
+    if (tp.direct) break;
+    tp.direct = 1;   // the accumulator does not fit for any tile length: fp64 atomics on the packed buffer
   }
+  if (fits) tp.acc_rows = tp.direct ? 0 : tb.max_rows;
   if (!fits) { p->err = "tile geometry does not fit 160 KB LDS"; return OICC_ERR_UNSUPPORTED; }
   tp.lds_bytes = carve(tb.max_nks, tb.max_nkr, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) * int(sizeof(double));
   p->h_tiles.swap(tb.tiles); p->h_units.swap(tb.units);
@@ -527,6 +553,8 @@ int build_tiles(oicc_problem* p) {
   hipStream_t st = p->stream;
   if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) ||
       !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_tiles) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows, %d units, accumulator %d rows x %d (+%d), row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
+                                           tp.n_tiles, T, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
   tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.row_t0 = p->d_row_t0.p; tp.row_t1 = p->d_row_t1.p; tp.slabs = p->d_slabs.p;
   return OICC_OK;
 }
@@ -576,6 +604,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   ctx.ne = ne;
   ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac; ctx.prof = prof;
   const Active& a = p->act;
+  if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
   if (int(p->opt["assembly"]) == 1) {   // one wave per view / IMU chunk, fp64 atomics on the packed buffer (kernels_blocks.hip)
     if (jac) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
     else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
@@ -591,6 +620,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
       p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
   }
   HIPCK(p, hipGetLastError());
+  if (p->opt["debug_sync"] != 0.0) HIPCK(p, hipStreamSynchronize(st));
   if (p->reduce) {
     int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, ne.cost(), 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
@@ -976,7 +1006,32 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (iter >= max_iters) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached."); }
     if (radius <= min_radius) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_CONVERGENCE, "Minimum trust region radius reached."); }
     // --- trust-region step: damped solve on the device, retraction, candidate cost
+    if (p->opt["debug_check_ne"] != 0.0) {
+      static std::vector<double> keep; static const double* keep_base = nullptr;
+      std::vector<double> now(p->ne.total), aux(size_t(3) * std::max(P, 1));
+      HIPCK(p, hipMemcpyAsync(now.data(), p->ne.base, now.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCK(p, hipMemcpyAsync(aux.data(), sb.scale, P * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCK(p, hipMemcpyAsync(aux.data() + P, sb.diag, P * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCK(p, hipStreamSynchronize(st));
+      size_t nbad = 0, nnan = 0; for (double v : now) if (!std::isfinite(v)) ++nnan;
+      if (keep_base == p->ne.base && keep.size() == now.size()) for (size_t i = 0; i + 1 < now.size(); ++i) if (now[i] != keep[i]) { if (nbad < 4) std::printf("[check_ne] iter %d entry %zu (E at %lld, C at %lld, g at %lld): %.17g -> %.17g\n", iter, i, (long long)p->ne.off_E, (long long)p->ne.off_C, (long long)p->ne.off_g, keep[i], now[i]); ++nbad; }
+      double smin = 1e300, dmin = 1e300; for (int i = 0; i < P; ++i) { smin = std::min(smin, aux[i]); dmin = std::min(dmin, aux[P + i]); if (!std::isfinite(aux[i]) || !std::isfinite(aux[P + i])) ++nnan; }
+      { double csum = 0; for (double v : now) csum += v; std::printf("[check_ne] checksum %.17g\n", csum); }
+      std::printf("[check_ne] iter %d base %p changed %zu nonfinite %zu min scale %.3e min diag %.3e radius %.4e reuse %d\n", iter, (void*)p->ne.base, nbad, nnan, smin, dmin, radius, int(reuse_diagonal));
+      keep = now; keep_base = p->ne.base;
+    }
+    if (p->opt["debug_sync"] == 2.0) HIPCK(p, hipStreamSynchronize(st));
+    if (p->opt["debug_sync"] >= 4.0) {   // D2H copy of one buffer before the solve: 4 scene points (unrelated), 5 normal equations, 6 scale + diag, 7 solver workspace
+      static std::vector<double> sink; const int w = int(p->opt["debug_sync"]);
+      const double* src = w == 4 ? p->d_pts.p : (w == 5 ? p->ne.base : (w == 6 || w == 8 ? sb.scale : (w == 9 ? sb.diag : (w == 10 ? sb.D2 : (w == 11 ? reinterpret_cast<const double*>(p->d_state.p) : p->d_ws.p)))));
+      const size_t cnt = w == 4 ? p->pts.size() : (w == 5 ? size_t(p->ne.total) : (w == 6 || w == 8 || w == 9 || w == 10 ? size_t(P) : (w == 11 ? size_t(7) : p->d_ws.n)));
+      sink.resize(cnt);
+      HIPCK(p, hipMemcpyAsync(sink.data(), src, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (w == 6) HIPCK(p, hipMemcpyAsync(sink.data(), sb.diag, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCK(p, hipStreamSynchronize(st));
+    }
     HIPCK(p, hipEventRecord(ev[0], st));
+    if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
     if (launch_lm_solve(p->ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
       p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
       return OICC_ERR_UNSUPPORTED; }
@@ -995,9 +1050,12 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     // Jacobian pass + gradient norm at the CANDIDATE into the second buffer, before the host knows whether the step is
     // accepted (it is, on 4 of 4 iterations of the C2 calibration): the read-back latency hides behind it.  A rejected
     // step simply leaves the second buffer unused.
+    const bool speculate = p->opt["debug_sync"] != 3.0;
     HIPCK(p, hipEventRecord(ev[3], st));
-    rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
-    launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+    if (speculate) {
+      rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
+      launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+    }
     HIPCK(p, hipEventRecord(ev[4], st));
     rc = read_back_wait(); if (rc) return rc;
     LmState hs = pin->st;
@@ -1014,6 +1072,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     bool ok = hs.chol_failed == 0 && std::isfinite(model_cost_change) && std::isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
     const double x_norm = std::sqrt(hs.x_norm_sq);   // ambient norm of the current x over active blocks
     if (!ok) {   // invalid step (LINEAR_SOLVER_FAILURE or non-positive model decrease)
+      if (verbose) std::printf("[oicc] iter %d INVALID step: chol_failed %d model_cost_change %.6e step_norm_sq %.6e x_norm_sq %.6e cand %.6e radius %.4e reuse %d\n", iter, hs.chol_failed, model_cost_change, hs.step_norm_sq, hs.x_norm_sq, cand_cost, radius, int(reuse_diagonal));
       if (++invalid >= max_invalid) return finish(OICC_FAILURE, "Number of consecutive invalid steps more than max.");
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; ++S.num_unsuccessful_steps;
       oicc_iteration it{iter, 0, cost, 0.0, gmax, 0.0, 0.0, radius}; p->trace.push_back(it);
@@ -1033,6 +1092,10 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       return finish(OICC_CONVERGENCE, "Function tolerance reached.");
     }
     if (rel_dec > min_rel_dec) {
+      if (!speculate) {
+        rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
+        launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+      }
       std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current ...
       std::swap(p->ne.base, p->ne2.base);      // ... and so do its normal equations (already being computed)
       cost = cand_cost;

@@ -35,11 +35,13 @@ struct UnitDesc {
 // of the unit): the so3 block, ONE 3-vector shared by the r3 and gravity columns, T_i_c, ld, ONE 3-vector for the bias
 // columns, the intrinsics block, the residual; per item ("fac"): the six spline coefficients, the three bias-spline
 // coefficients.  One record per item (lane), item-major in the wave's row buffer.  Gram column -> value index
-// (x factor index) is resolved when the MFMA operands are loaded.
+// (x factor index) is resolved when the MFMA operands are loaded.  Behind the factors every record carries the constant 1, a
+// zero slot and the item's SO(3) window index (wide cells).
 struct RowFmt {
   int32_t ncols, rescol;
   int32_t c_s, c_r, c_t, c_l, c_g, c_b, c_i;   // first Gram column of the group, or -1
   int32_t n_i;                                 // intrinsics columns (6 accelerometer / 9 gyroscope)
+  int32_t ks_extra;                            // wide cells: the SO(3) group has 18 + 3 ks_extra columns (IMU samples of 1 + ks_extra consecutive windows share a cell)
   int32_t nbase;
   int32_t b_s, b_v, b_t, b_l, b_m, b_i, b_res;
   int32_t nfac, f_cf, f_cb;
@@ -56,7 +58,7 @@ struct TileParams {
   int32_t acc_rows;        // accumulator rows (max over tiles)
   int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
   // LDS carve (in doubles from the start of dynamic LDS)
-  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_acc, o_wave, wave_doubles;   // [knots | tables | queue | accumulator | per wave: coloff 64 ints = 32 doubles, row buffer]
+  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets | queue | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
   int32_t rb_doubles;
   int32_t lds_bytes;
   double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]

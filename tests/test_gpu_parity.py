@@ -155,9 +155,10 @@ def test_parallel_solvers_match_sequential(algo, parts):
 
 @pytest.mark.parametrize("algo", [1, 2])
 def test_bias_and_intrinsics_active_lm_matches_oracle(algo):
-    """IMU_BIASES | IMU_INTRINSICS: 39+15 arrow columns, box-bounded bias knots; both solvers."""
+    """IMU_BIASES | IMU_INTRINSICS: 27+15 arrow columns, box-bounded bias knots (band sweep); IMU_BIASES alone, 27 arrow
+    columns = two border tiles, for the block cyclic reduction (limited to 31 arrow columns, kernels_bcr.hip)."""
     ds = synthetic.make_config("tiny")
-    flags = FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS
+    flags = FLAGS1 | E.IMU_BIASES | (E.IMU_INTRINSICS if algo == 1 else 0)
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     gpu.trajectory_.SetOption("solver_algorithm", algo)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
@@ -409,18 +410,19 @@ def test_ragged_views_empty_view_and_views_above_64_corners():
 
 
 # ---- time-tile assembly (kernels_tiles.hip): LDS accumulators + slab merge vs direct atomics vs the one-wave-per-chunk kernels ----
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("mode,tile_windows", [(0, 0), (0, 1), (0, 3), (0, 7), (0, 64), (2, 0), (2, 5), (1, 0)])
-def test_assembly_modes_match_the_oracle(tiny, mode, tile_windows):
+def test_assembly_modes_match_the_oracle(tiny, mode, tile_windows, wide):
     """Every way the normal equations can be assembled gives the oracle's J^T J / J^T r / cost: tiles of 1 ... all windows
     (halo rows summed by the merge kernel), tiles in direct mode (fp64 atomics), the one-wave-per-view kernels."""
     ds, _, cpu = tiny
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
-    gpu.trajectory_.SetOption("assembly", mode); gpu.trajectory_.SetOption("tile_windows", tile_windows)
-    for flags in (FLAGS1, FLAGS1 | E.CAM_LINE_DELAY | E.IMU_BIASES | E.IMU_INTRINSICS, E.CAM_LINE_DELAY):
+    gpu.trajectory_.SetOption("assembly", mode); gpu.trajectory_.SetOption("tile_windows", tile_windows); gpu.trajectory_.SetOption("wide_cells", wide)
+    for flags in (FLAGS1, FLAGS1 | E.IMU_BIASES, FLAGS1 | E.CAM_LINE_DELAY | E.IMU_BIASES | E.IMU_INTRINSICS, E.CAM_LINE_DELAY):
         cg, Hg, gg = gpu.trajectory_.Evaluate(flags); cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
         assert abs(cg - cc) <= 1e-11 * cc, (flags, cg, cc)
         assert rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9, (flags, rel_err(Hg, Hc), rel_err(gg, gc))
-        assert np.abs(Hg - Hg.T).max() == 0.0 or mode != 0     # the merge writes both halves of the arrow corner from one value
+        assert np.abs(Hg - Hg.T).max() <= 1e-13 * np.abs(Hg).max()
         assert abs(gpu.trajectory_.EvaluateCost(flags) - cc) <= 1e-11 * cc
 
 
