@@ -68,6 +68,9 @@ struct Problem {
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["analytic_jacobians"] = 0;
+    opt["inner_iterations"] = 0;            // 1: Ceres' use_inner_iterations = true (impl.h:266), ceres_inner.hpp
+    opt["inner_iteration_tolerance"] = 1e-3; // Solver::Options default
+    opt["bounds_line_search"] = 0;          // 1: Ceres' Armijo search along the projected path when bias knots are box bounded
   }
 };
 
@@ -558,6 +561,8 @@ double ambient_sq(const Problem& p, const Layout& L, const ParamSnapshot* other)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+#include "ceres_inner.hpp"
+
 }  // namespace
 
 // =============================== C API =======================================
@@ -779,6 +784,12 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   double x_norm = std::sqrt(ambient_sq(p, L, nullptr));
   std::vector<double> diag(P), D2(P), step_s(P), step(P);
   int iter = 0, invalid = 0;
+  // inner iterations (ceres_inner.hpp): set up when the reduced program has at least two parameter blocks
+  inner::Ordering ord; bool inner_enabled = false; int64_t inner_lm_iterations = 0; int inner_sweeps = 0;
+  if (p.opt["inner_iterations"] != 0) { inner::build_ordering(p, L, a, &ord); inner_enabled = ord.blocks.size() >= 2; }
+  const double inner_tol = p.opt["inner_iteration_tolerance"];
+  const bool line_search = p.opt["bounds_line_search"] != 0 && (a.ab || a.gb);   // is_constrained
+  int line_search_steps = 0;
   while (true) {
     if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.", cost);
     if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.", cost);
@@ -806,8 +817,45 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
     invalid = 0;
     for (int i = 0; i < P; ++i) step[i] = step_s[i] * scale[i];
     ParamSnapshot snap; snapshot(p, &snap);
+    if (line_search) {   // TrustRegionMinimizer::DoLineSearch: Armijo along x(alpha) = clamp(x (+) alpha delta), alpha_0 = 1
+      double g0 = 0, dmax = 0; for (int i = 0; i < P; ++i) { g0 += ne.g[i] * step[i]; dmax = std::max(dmax, std::fabs(step[i])); }
+      auto at = [&](double alpha, bool want_grad, inner::Sample* out) {
+        std::vector<double> sa(P); for (int i = 0; i < P; ++i) sa[i] = alpha * step[i];
+        restore(&p, snap); apply_step(&p, L, sa);
+        out->x = alpha; out->has_gradient = want_grad;
+        if (want_grad) { NormalEq nt; build_normal_equations(p, L, a, &nt); out->value = nt.cost; out->gradient = 0; for (int i = 0; i < P; ++i) out->gradient += nt.g[i] * step[i]; }
+        else out->value = total_cost(p, L, a);
+        restore(&p, snap); };
+      inner::Sample init{0.0, cost, g0, true}, prev{0, 0, 0, false}, cur; bool have_prev = false, success = true;
+      at(1.0, false, &cur);
+      int its = 0;
+      while (!std::isfinite(cur.value) || cur.value > cost + 1e-4 * g0 * cur.x) {
+        if (++its >= 20) { success = false; break; }
+        if (!cur.has_gradient && std::isfinite(cur.value)) at(cur.x, true, &cur);     // cubic interpolation uses the slope at the trial point
+        std::vector<inner::Sample> ss{init}; if (have_prev && std::isfinite(prev.value)) ss.push_back(prev); if (std::isfinite(cur.value)) ss.push_back(cur);
+        std::vector<double> poly; double next = 0.6 * cur.x;
+        if (inner::fit_polynomial(ss, &poly)) next = inner::minimize_polynomial(poly, 1e-3 * cur.x, 0.6 * cur.x);
+        if (next * dmax < 1e-9) { success = false; break; }
+        prev = cur; have_prev = true;
+        at(next, false, &cur);
+      }
+      line_search_steps += its;
+      if (success && cur.x != 1.0) for (int i = 0; i < P; ++i) step[i] *= cur.x;
+    }
     apply_step(&p, L, step);
-    t0 = now_s(); const double cand_cost = total_cost(p, L, a); S.seconds_residual += now_s() - t0;
+    t0 = now_s(); double cand_cost = total_cost(p, L, a); S.seconds_residual += now_s() - t0;
+    bool inner_useful = false;
+    if (inner_enabled && std::isfinite(cand_cost)) {   // TrustRegionMinimizer::DoInnerIterationsIfNeeded
+      t0 = now_s();
+      inner::sweep(p, L, a, ord, num_threads(p), &inner_lm_iterations); ++inner_sweeps;
+      const double inner_cost = total_cost(p, L, a);
+      S.seconds_residual += now_s() - t0;
+      model_cost_change += cand_cost - inner_cost;
+      inner_useful = inner_cost < cost;
+      inner_enabled = 1.0 - inner_cost / cand_cost > inner_tol;
+      if (verbose) std::printf("[oracle] iter %d inner iterations: %.12e -> %.12e (%s)\n", iter, cand_cost, inner_cost, inner_enabled ? "stay on" : "switched off");
+      cand_cost = inner_cost;
+    }
     const double step_norm = std::sqrt(ambient_sq(p, L, &snap));
     const double cost_change = cost - cand_cost;
     const double rel_dec = cost_change / model_cost_change;
@@ -822,7 +870,7 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
       oicc_iteration it{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius}; p.trace.push_back(it);
       return finish(OICC_CONVERGENCE, "Function tolerance reached.", cost);
     }
-    if (rel_dec > min_rel_dec) {  // HandleSuccessfulStep
+    if (rel_dec > min_rel_dec || inner_useful) {  // IsStepSuccessful, HandleSuccessfulStep
       cost = cand_cost; x_norm = std::sqrt(ambient_sq(p, L, nullptr));
       t0 = now_s(); build_normal_equations(p, L, a, &ne); S.seconds_jacobian += now_s() - t0;
       gmax = grad_max();
