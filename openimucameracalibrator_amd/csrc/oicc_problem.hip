@@ -25,6 +25,7 @@
 #include "oicc_device.h"
 #include "lm_launch.h"
 #include "tiles.h"
+#include "inner_plan.h"
 
 namespace oicc {
 // kernels_blocks.hip
@@ -39,6 +40,11 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
 int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
                      const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st);
 void launch_lds_poison(hipStream_t st);
+void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
+void launch_inner_eval(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const double* seg, const InnerBlock* blocks, InnerState* states,
+                       const int32_t* map_view, const int32_t* map_acc, const int32_t* map_gyr, bool jac, hipStream_t st);
+void launch_inner_step(double* xv, const InnerBlock* blocks, InnerState* states, int b0, int b1, int phase, double max_ab, double max_gb, int32_t* not_done, hipStream_t st);
+void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
 }  // namespace oicc
@@ -132,6 +138,12 @@ struct oicc_problem {
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
+  // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
+  struct InnerPlan {
+    std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<char> group_has_so3; std::vector<int32_t> maps;
+    DevBuf<InnerBlock> d_blocks; DevBuf<InnerState> d_states; DevBuf<int32_t> d_maps, d_not_done; DevBuf<double> d_seg;
+    int flags = -2; size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
+  } inner;
   // cached layout
   int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
   Active act{};
@@ -143,6 +155,9 @@ struct oicc_problem {
     opt["min_lm_diagonal"] = 1e-6; opt["max_lm_diagonal"] = 1e32; opt["jacobi_scaling"] = 1;
     opt["max_num_consecutive_invalid_steps"] = 5; opt["gs_unit_loss"] = 0; opt["rs_time_in_seconds"] = 0;
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["solver_partitions"] = 0; opt["solver_algorithm"] = 0; opt["imu_chunk_cells"] = 0;
+    opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
+                                   //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
+    opt["inner_iteration_tolerance"] = 1e-3;
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
@@ -559,6 +574,7 @@ int build_tiles(oicc_problem* p) {
   return OICC_OK;
 }
 
+
 int prepare(oicc_problem* p, int flags) {
   ARG(p, p->pl.n_so3 > 0, "oicc_set_times has not been called");
   ARG(p, !(flags & OICC_POINTS), "OICC_POINTS (board point refinement) is not supported on this path");
@@ -593,6 +609,135 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
   i.u_b = d.u_b.p; i.mx = d.mx.p; i.my = d.my.p; i.mz = d.mz.p; i.w = d.w.p;
   i.chunk_i0 = d.chunk_i0.p; i.chunk_n = d.chunk_n.p; i.n_chunks = d.n_chunks;
   return i;
+}
+
+// ---- inner iterations: plan (host) and sweep (device), see inner_iterations.hip / oracle/ceres_inner.hpp ----------------
+// Parameter blocks of the reduced program in the order the reference's AddResidualBlock calls create them, the Hessian
+// graph, and Ceres' recursive independent-set ordering (reversed).
+int build_inner_plan(oicc_problem* p, int flags) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  if (ip.flags == flags && !ip.blocks.empty()) return OICC_OK;
+  const HostLayout& L = p->L; const ParamLayout& pl = p->pl;
+  struct HB { InnerBlock b; int order; std::vector<int32_t> views, accs, gyrs; };
+  std::vector<HB> B;
+  std::vector<int> id_so3(pl.n_so3, -1), id_r3(pl.n_r3, -1), id_ab(pl.n_ab, -1), id_gb(pl.n_gb, -1); int id_o[5] = {-1, -1, -1, -1, -1};
+  auto get = [&](int kind, int idx, int dim, int amb, int off, int64_t xoff, int* slot) -> int {
+    if (off < 0) return -1;
+    if (*slot < 0) { HB h; h.b = InnerBlock{kind, idx, dim, amb, xoff}; h.order = int(B.size()); *slot = int(B.size()); B.push_back(h); }
+    return *slot; };
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  const size_t nv = p->view_rs.size();
+  for (size_t v = 0; v < nv; ++v) {
+    if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
+    std::vector<int> ids;
+    const int ss = p->view_s_so3[v], sr = p->view_s_r3[v];
+    for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+    for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
+    ids.push_back(get(IK_TIC, 0, 6, 7, L.other[0], pl.tic, &id_o[0]));
+    if (p->view_rs[v]) ids.push_back(get(IK_LD, 0, 1, 1, L.other[2], pl.ld, &id_o[2]));
+    for (int id : ids) if (id >= 0) B[id].views.push_back(int32_t(v));
+  }
+  const size_t na = p->acc.size(), ng = p->gyr.size();
+  for (size_t i = 0; i < std::max(na, ng); ++i) {
+    if (i < na) {
+      std::vector<int> ids; const int ss = p->acc.s_so3[i], sr = p->acc.s_r3[i], sb = p->acc.s_b[i];
+      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
+      for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_AB, sb + k, 3, 3, L.ab[sb + k], pl.ab + 3 * int64_t(sb + k), &id_ab[sb + k]));
+      ids.push_back(get(IK_G, 0, 3, 3, L.other[1], pl.g, &id_o[1]));
+      ids.push_back(get(IK_AI, 0, 6, 6, L.other[3], pl.ai, &id_o[3]));
+      for (int id : ids) if (id >= 0) B[id].accs.push_back(int32_t(i));
+    }
+    if (i < ng) {
+      std::vector<int> ids; const int ss = p->gyr.s_so3[i], sb = p->gyr.s_b[i];
+      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+      for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_GB, sb + k, 3, 3, L.gb[sb + k], pl.gb + 3 * int64_t(sb + k), &id_gb[sb + k]));
+      ids.push_back(get(IK_GI, 0, 9, 9, L.other[4], pl.gi, &id_o[4]));
+      for (int id : ids) if (id >= 0) B[id].gyrs.push_back(int32_t(i));
+    }
+  }
+  const int n = int(B.size());
+  std::vector<std::vector<int>> adj(n);
+  {
+    std::vector<std::vector<int>> ofv(nv), ofa(na), ofg(ng);
+    for (int b = 0; b < n; ++b) { for (int v : B[b].views) ofv[v].push_back(b); for (int v : B[b].accs) ofa[v].push_back(b); for (int v : B[b].gyrs) ofg[v].push_back(b); }
+    auto clique = [&](const std::vector<int>& ids) { for (int x : ids) for (int y : ids) if (x != y) adj[x].push_back(y); };
+    for (auto& ids : ofv) clique(ids);
+    for (auto& ids : ofa) clique(ids);
+    for (auto& ids : ofg) clique(ids);
+    for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  }
+  std::vector<char> removed(n, 0);
+  std::vector<std::vector<int>> rounds;
+  for (int covered = 0; covered < n;) {
+    std::vector<int> deg(n, 0), queue;
+    for (int v = 0; v < n; ++v) if (!removed[v]) { queue.push_back(v); for (int w : adj[v]) if (!removed[w]) ++deg[v]; }
+    std::sort(queue.begin(), queue.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : B[x].order < B[y].order; });
+    std::vector<char> color(n, 0);
+    std::vector<int> set;
+    for (int v : queue) { if (color[v]) continue; set.push_back(v); color[v] = 2; for (int w : adj[v]) if (!removed[w]) color[w] = 1; }
+    for (int v : set) removed[v] = 1;
+    covered += int(set.size());
+    rounds.push_back(set);
+  }
+  // processing order: last set first; blocks of a set contiguous
+  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.group_has_so3.clear();
+  ip.n_items = nv + na + ng;
+  const size_t ngroups = rounds.size();
+  ip.maps.assign(ngroups * ip.n_items, -1);
+  size_t g = 0;
+  for (auto it = rounds.rbegin(); it != rounds.rend(); ++it, ++g) {
+    char has = 0;
+    for (int v : *it) {
+      const int nb = int(ip.blocks.size());
+      ip.blocks.push_back(B[v].b); has |= B[v].b.kind == IK_SO3;
+      int32_t* m = ip.maps.data() + g * ip.n_items;
+      for (int x : B[v].views) m[x] = nb;
+      for (int x : B[v].accs) m[nv + x] = nb;
+      for (int x : B[v].gyrs) m[nv + na + x] = nb;
+    }
+    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_has_so3.push_back(has);
+  }
+  hipStream_t st = p->stream;
+  if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_maps.upload(ip.maps, st) || !ip.d_states.resize(std::max<size_t>(ip.blocks.size(), 1)) || !ip.d_not_done.resize(1) ||
+      !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * 17)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
+  ip.flags = flags;
+  return OICC_OK;
+}
+
+// One sweep of coordinate descent on the parameter vector `xv` (device, modified in place).
+int inner_sweep(oicc_problem* p, double* xv) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  hipStream_t st = p->stream;
+  EvalCtx ctx = make_ctx(p, xv);
+  const ViewData vd = view_data(p); const ImuData ia = imu_data(p->acc, p->d_acc), ig = imu_data(p->gyr, p->d_gyr);
+  const size_t nv = p->view_rs.size(), na = p->acc.size();
+  const int n_pairs = std::max(p->pl.n_so3 - 1, 0);
+  ++ip.sweeps;
+  for (size_t g = 0; g + 1 < ip.group_first.size(); ++g) {
+    const int b0 = ip.group_first[g], b1 = ip.group_first[g + 1];
+    const int32_t* m = ip.d_maps.p + g * ip.n_items;
+    launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 0, p->max_ab, p->max_gb, ip.d_not_done.p, st);
+    launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
+    for (int rounds = 0; rounds < 56;) {
+      for (int r = 0; r < 4; ++r, ++rounds) {
+        if (ip.group_has_so3[g] && rounds > 0) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
+        launch_inner_eval(ctx, vd, ia, ig, ip.d_seg.p, ip.d_blocks.p, ip.d_states.p, m, m + nv, m + nv + na, true, st);
+        launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 1, p->max_ab, p->max_gb, ip.d_not_done.p, st);
+        if (ip.group_has_so3[g]) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
+        launch_inner_eval(ctx, vd, ia, ig, ip.d_seg.p, ip.d_blocks.p, ip.d_states.p, m, m + nv, m + nv + na, false, st);
+        if (r == 3) HIPCK(p, hipMemsetAsync(ip.d_not_done.p, 0, sizeof(int32_t), st));
+        launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 2, p->max_ab, p->max_gb, ip.d_not_done.p, st);
+      }
+      int32_t nd = 0;
+      HIPCK(p, hipMemcpyAsync(&nd, ip.d_not_done.p, sizeof(nd), hipMemcpyDeviceToHost, st));
+      HIPCK(p, hipStreamSynchronize(st));
+      if (nd == 0) break;
+    }
+    if (ip.group_has_so3[g]) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);   // rejected candidates were undone after the last evaluation
+  }
+  HIPCK(p, hipGetLastError());
+  return OICC_OK;
 }
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
@@ -807,7 +952,7 @@ static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, 
     for (int i = 0; i < kN; ++i) { p->so3_in[s_so3 + i] = 1; p->r3_in[s_r3 + i] = 1; }
     p->has_tic_block = true; if (rs) p->has_ld_block = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1;
+  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 int oicc_add_rs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* t, const int64_t* co, const double* uv, const double* cov,
@@ -832,7 +977,7 @@ int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_
     for (int k = 0; k < kNb; ++k) p->ab_in[s_b + k] = 1;
     p->has_acc = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1;
+  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
@@ -851,7 +996,7 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t
     for (int k = 0; k < kNb; ++k) p->gb_in[s_b + k] = 1;
     p->has_gyr = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1;
+  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 
@@ -995,6 +1140,12 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));   // inactive entries of the candidate
   int iter = 0, invalid = 0;
+  bool inner_enabled = false;
+  if (p->opt["inner_iterations"] != 0.0) {
+    if (p->reduce) { p->err = "inner iterations are not available with an all-reduce hook (time-sharded problems)"; return OICC_ERR_UNSUPPORTED; }
+    rc = build_inner_plan(p, flags); if (rc) return rc;
+    inner_enabled = p->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
+  }
   bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
   auto settle_gmax = [&]() -> int {   // used on the exits that do not go through the per-iteration read-back
     if (!gmax_pending) return OICC_OK;
@@ -1039,6 +1190,20 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     HIPCK(p, hipGetLastError());
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
+    // Inner iterations (TrustRegionMinimizer::DoInnerIterationsIfNeeded): one coordinate descent sweep from the candidate; its
+    // cost decrease is credited to the model, the candidate becomes the swept point.
+    double cand_before_inner = 0.0; bool inner_ran = false;
+    if (inner_enabled) {
+      rc = read_back(); if (rc) return rc;
+      cand_before_inner = pin->cost;
+      if (std::isfinite(cand_before_inner)) {
+        rc = inner_sweep(p, p->d_xc.p); if (rc) return rc;
+        rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+        HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, sizeof(double), st));
+        launch_inner_diff_norm(p->d_x.p, p->d_xc.p, p->inner.d_blocks.p, int(p->inner.blocks.size()), &p->d_state.p->step_norm_sq, st);
+        inner_ran = true;
+      }
+    }
     HIPCK(p, hipEventRecord(ev[2], st));
     // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave
     // last-bit differences in the model cost change and the step norms.  Summing the three scalars over the ranks and
@@ -1061,6 +1226,13 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     LmState hs = pin->st;
     if (rank_consistent) { const double inv = 1.0 / double(p->rccl_nranks); hs.model_cost_change *= inv; hs.step_norm_sq *= inv; hs.x_norm_sq *= inv; }
     const double cand_cost = pin->cost;
+    bool inner_useful = false;
+    if (inner_ran) {
+      hs.model_cost_change += cand_before_inner - cand_cost;
+      inner_useful = cand_cost < cost;
+      inner_enabled = 1.0 - cand_cost / cand_before_inner > p->opt["inner_iteration_tolerance"];
+      if (verbose) std::printf("[oicc] iter %d inner iterations: %.12e -> %.12e (%s)\n", iter + 1, cand_before_inner, cand_cost, inner_enabled ? "stay on" : "switched off");
+    }
     S.seconds_linear_solver += elapsed_s(ev[0], ev[1]); S.seconds_residual += elapsed_s(ev[1], ev[2]);
     if (gmax_pending) {   // gradient of the point accepted in the previous iteration
       gmax = hs.gradient_max_norm; p->trace.back().gradient_max_norm = gmax; gmax_pending = false;
@@ -1091,7 +1263,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       oicc_iteration it{iter, 0, cost, cost_change, gmax, step_norm, rel_dec, radius}; p->trace.push_back(it);
       return finish(OICC_CONVERGENCE, "Function tolerance reached.");
     }
-    if (rel_dec > min_rel_dec) {
+    if (rel_dec > min_rel_dec || inner_useful) {   // IsStepSuccessful
       if (!speculate) {
         rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
         launch_lm_gradmax(p->ne2, P, p->d_state.p, st);

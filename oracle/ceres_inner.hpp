@@ -251,10 +251,13 @@ inline int solve_block(Problem& p, const Layout& L, const Active& a, const PBloc
 // CoordinateDescentMinimizer::Minimize: the independent sets in order, the blocks of a set in parallel
 inline void sweep(Problem& p, const Layout& L, const Active& a, const Ordering& ord, int nthreads, int64_t* lm_iterations) {
   int64_t total = 0;
+  refresh_segment_table(p);   // analytic CPU path: the sweep starts from the candidate, whose knots differ from the last Jacobian pass
+
   for (const std::vector<int>& set : ord.groups) {
     const int64_t n = int64_t(set.size());
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total)
     for (int64_t i = 0; i < n; ++i) total += solve_block(p, L, a, ord.blocks[set[i]]);
+    if (std::getenv("OICC_ORACLE_TRACE_SWEEP")) std::printf("[oracle] sweep: set of %lld blocks (first kind %d) -> cost %.9e\n", (long long)n, ord.blocks[set[0]].kind, total_cost(p, L, a));
   }
   if (lm_iterations) *lm_iterations += total;
 }

@@ -448,3 +448,28 @@ def test_tiles_on_baseline_configs_match_direct_atomics(cfg, tile_windows):
     assert abs(ca - cb) <= 1e-12 * cb and rel_err(ga, gb) < 1e-11
     sa = a.trajectory_.Optimize(8, FLAGS1); sb = b.trajectory_.Optimize(8, FLAGS1)
     assert sa["num_iterations"] == sb["num_iterations"] and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
+
+
+# ---- Ceres' inner iterations (reference impl.h:266), device sweep (inner_iterations.hip) against oracle/ceres_inner.hpp ----
+@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES), ("tiny", FLAGS1 | E.CAM_LINE_DELAY), ("C2", FLAGS1)])
+def test_inner_iterations_match_the_oracle(cfg, flags):
+    """use_inner_iterations = true: after every candidate one block coordinate descent sweep over the independent sets of the
+    parameter blocks.  Same outer iterate sequence (costs to 1e-7: hundreds of small LM loops whose accept / reject decisions
+    see fp64-atomic summation order) and final extrinsics as the CPU restatement."""
+    ds = synthetic.make_config(cfg)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("inner_iterations", 1)
+    cpu.trajectory_.SetOption("analytic_jacobians", 1 if cfg != "tiny" else 0)
+    sg = gpu.trajectory_.Optimize(50, flags); sc = cpu.trajectory_.Optimize(50, flags)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert sg["num_iterations"] == sc["num_iterations"], ([i["cost"] for i in ig], [i["cost"] for i in ic])
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-5
+    # and the sweep changes the trajectory of the solve (it is not a no-op)
+    plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    sp = plain.trajectory_.Optimize(50, flags)
+    assert abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
