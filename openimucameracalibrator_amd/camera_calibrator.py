@@ -268,6 +268,7 @@ class CameraCalibrator:
         from . import io_files, planar_init
         ids = sorted(int(k) for k in scene_json["scene_pts"])
         index = {k: i for i, k in enumerate(ids)}
+        self.point_ids_ = ids
         points = np.array([[*scene_json["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64)
         w, h = int(scene_json["image_width"]), int(scene_json["image_height"])
         px, py = w / 2.0, h / 2.0                                          # initial principal point, camera_calibrator.cc:228-230
@@ -276,6 +277,7 @@ class CameraCalibrator:
             ip = scene_json["views"][key]["image_points"]
             if len(ip) < 4:
                 continue
+            ip = {k: v for k, v in ip.items() if int(k) in index}              # ids without a board point are skipped, as in the C++ loader
             pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
             uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
             ok, R, C, f = planar_init.initialize_view(points, pid, uv - [px, py])
@@ -307,7 +309,7 @@ class CameraCalibrator:
         total = self.TotalReprojectionError()
         print("Final camera calibration reprojection error: %s from %d view." % (total, self.NumViews()))
         if output_path:
-            io_files.write_pose_dataset(output_path + ".calibdata.json", self.views.t_s, self.views.pose, self.points)
+            io_files.write_pose_dataset(output_path + ".calibdata.json", self.views.t_s, self.views.pose, self.points, getattr(self, "point_ids_", None))
             io_files.write_camera_calibration(output_path + ".json", self.model, self.GetIntrinsics(), w, h, scene_json.get("camera_fps", 0.0),
                                               self.NumViews(), total)
             io_files.write_ply_cameras(output_path + "_final_poses.ply", self.views.pose, self.points)
@@ -483,6 +485,7 @@ class PoseEstimator:
         from . import planar_init
         ids = sorted(int(k) for k in scene_json["scene_pts"])
         index = {k: i for i, k in enumerate(ids)}
+        self.point_ids_ = ids
         self.SetScenePoints(np.array([[*scene_json["scene_pts"][str(k)][:3], 1.0] for k in ids], dtype=np.float64))
         self.calib_ = (int(model), np.asarray(intrinsics, dtype=np.float64))
         self.max_reproj_error_ = 0.004 * image_height                        # pose_estimator.cc:97
@@ -491,6 +494,7 @@ class PoseEstimator:
             ip = scene_json["views"][key]["image_points"]
             if len(ip) < min_num_points:                                     # pose_estimator.cc:131-135
                 continue
+            ip = {k: v for k, v in ip.items() if int(k) in index}
             pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
             uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
             xy = planar_init.pixel_to_normalized(model, intrinsics, uv)      # camera.PixelToNormalizedCoordinates, :119-121

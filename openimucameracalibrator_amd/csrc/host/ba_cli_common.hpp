@@ -16,6 +16,7 @@ namespace oicc_cli {
 struct SceneView { std::string key; double t_s; std::vector<int> pid; std::vector<std::array<double, 2>> uv; };
 struct Scene {
   std::vector<std::array<double, 4>> points;   // io::scene_points_to_calib_dataset: homogeneous board points, w = 1
+  std::vector<int> point_ids;                  // the corner file's id of every point (TrackId = stoi(key), read_scene.cc:47-49)
   std::vector<SceneView> views;                // in nlohmann::json (std::map<std::string>) key order
   int width = 0, height = 0; double fps = 0.0;
 };
@@ -24,7 +25,7 @@ inline bool load_scene(const std::string& path, Scene* sc) {
   std::map<int, int> index;
   std::map<int, std::array<double, 4>> pts;
   for (const auto& kv : j.at("scene_pts").obj) pts[std::stoi(kv.first)] = {kv.second.at(0).as_double(), kv.second.at(1).as_double(), kv.second.at(2).as_double(), 1.0};
-  for (const auto& kv : pts) { index[kv.first] = int(sc->points.size()); sc->points.push_back(kv.second); }
+  for (const auto& kv : pts) { index[kv.first] = int(sc->points.size()); sc->points.push_back(kv.second); sc->point_ids.push_back(kv.first); }
   sc->width = int(j.at("image_width").as_double()); sc->height = int(j.at("image_height").as_double());
   sc->fps = j.contains("camera_fps") ? j.at("camera_fps").as_double() : 0.0;
   for (const auto& kv : j.at("views").obj) {
@@ -64,17 +65,28 @@ inline bool write_camera_calibration(const std::string& path, int model, const s
   return true;
 }
 
-// JSON twin of theia::WriteReconstruction for a pose data set (read back by read_pose_dataset of cli_common.hpp)
-inline bool write_pose_dataset(const std::string& path, const OpenICC::core::BaViews& views, const std::vector<std::array<double, 4>>& points) {
+// View name of a pose data set: the reference names a view std::to_string((uint64_t)(timestamp_s * 1e6)) (pose_estimator.cc:144)
+// and looks it up as std::to_string((uint64_t)stod(corner key)) (continuous_time_imu_to_camera_calibration.cc:133): TRUNCATED
+// microseconds.  timestamp_s is the key times 1e-6, so the product can land a few ulp below an integer key; those are snapped up.
+inline std::string pose_view_name(double t_s) {
+  const double us = t_s * 1e6;
+  unsigned long long k = (unsigned long long)us;
+  if (us - double(k) > 1.0 - 1e-5) ++k;
+  return std::to_string(k);
+}
+// JSON twin of theia::WriteReconstruction for a pose data set (read back by read_pose_dataset of cli_common.hpp); tracks carry the
+// corner file's point ids (`point_ids`, empty: 0 .. n-1)
+inline bool write_pose_dataset(const std::string& path, const OpenICC::core::BaViews& views, const std::vector<std::array<double, 4>>& points,
+                               const std::vector<int>& point_ids = {}) {
   std::ofstream f(path); if (!f.is_open()) return false;
   Value o, V, T;
   for (size_t v = 0; v < views.pose.size(); ++v) {
     Value e, aa, pos;
     for (int k = 0; k < 3; ++k) { pos.push_back(Value(views.pose[v][size_t(k)])); aa.push_back(Value(views.pose[v][size_t(3 + k)])); }
     e["orientation_angle_axis"] = aa; e["position"] = pos;
-    V[std::to_string((long long)std::llround(views.t_s[v] * 1e6))] = e;
+    V[pose_view_name(views.t_s[v])] = e;
   }
-  for (size_t i = 0; i < points.size(); ++i) { Value p; for (double c : points[i]) p.push_back(Value(c)); T[std::to_string(i)] = p; }
+  for (size_t i = 0; i < points.size(); ++i) { Value p; for (double c : points[i]) p.push_back(Value(c)); T[std::to_string(i < point_ids.size() ? point_ids[i] : int(i))] = p; }
   o["views"] = V; o["tracks"] = T;
   oicc_json::dump(o, f, 0); f << std::endl;
   return true;

@@ -73,7 +73,7 @@ int main(int argc, char* argv[]) {
   const double total = cal.TotalReprojectionError();
   std::cout << "Final camera calibration reprojection error: " << total << " from " << cal.NumViews() << " view." << std::endl;
   if (!out.empty()) {
-    CHECK_MSG(write_pose_dataset(out + ".calibdata.json", cal.Views(), cal.Points()), "Could not write " << out << ".calibdata.json");
+    CHECK_MSG(write_pose_dataset(out + ".calibdata.json", cal.Views(), cal.Points(), sc.point_ids), "Could not write " << out << ".calibdata.json");
     CHECK_MSG(write_camera_calibration(out + ".json", model, model_name, cal.Intrinsics(), sc.width, sc.height, sc.fps, cal.NumViews(), total),
               "Could not write calibration file.");
     write_ply_cameras(out + "_final_poses.ply", cal.Views().pose, cal.Points());

@@ -76,7 +76,8 @@ int main(int argc, char* argv[]) {
            {"gyro_to_cam_initial_calibration", ""}, {"imu_intrinsics", ""}, {"imu_bias_file", ""}, {"global_shutter", "false"},
            {"spline_error_weighting_json", ""}, {"output_path", ""}, {"calibrate_cam_line_delay", "false"}, {"result_output_json", ""},
            {"max_t", "1000."}, {"reestimate_biases", "false"}, {"gravity_const", "9.81"}, {"known_grav_dir_axis", "Z"},
-           {"debug_video_path", ""}, {"dry_run", "false"}, {"device", "0"}, {"solver_partitions", "0"}, {"solver_algorithm", "0"}});
+           {"debug_video_path", ""}, {"dry_run", "false"}, {"device", "0"}, {"solver_partitions", "0"}, {"solver_algorithm", "0"},
+           {"use_inner_iterations", "true"}});   // the reference's Optimize sets options.use_inner_iterations = true (impl.h:266)
   if (!F.parse(argc, argv)) return 2;
 
   // pose dataset, corners, camera (cc:93-105)
@@ -153,6 +154,7 @@ int main(int argc, char* argv[]) {
   ImuCameraCalibrator imu_cam_calibrator(int(F.d("device")));
   imu_cam_calibrator.trajectory_.SetOption("solver_partitions", F.d("solver_partitions"));
   imu_cam_calibrator.trajectory_.SetOption("solver_algorithm", F.d("solver_algorithm"));
+  imu_cam_calibrator.trajectory_.SetOption("inner_iterations", F.b("use_inner_iterations") ? 1.0 : 0.0);
   imu_cam_calibrator.BatchInitSpline(recon_calib_dataset, T_i_c_init, weight_data, time_offset_imu_to_cam, telemetry_data, init_line_delay_us, acc_intr, gyr_intr);
   const std::string axis = F.str("known_grav_dir_axis");   // GravDirStringToInt, utils.cc:150-161
   const int grav_dir_axis = axis == "X" ? 0 : (axis == "Y" ? 1 : (axis == "Z" ? 2 : -1));

@@ -83,7 +83,7 @@ int main(int argc, char* argv[]) {
     V.remove(bad);
   }
   std::cout << "Estimated " << V.pose.size() << " camera poses, mean reprojection error " << (err_n ? err_sum / err_n : 0.0) << " px\n";
-  CHECK_MSG(write_pose_dataset(F.str("output_pose_dataset"), V, pe.Points()), "Could not write " << F.str("output_pose_dataset"));
+  CHECK_MSG(write_pose_dataset(F.str("output_pose_dataset"), V, pe.Points(), sc.point_ids), "Could not write " << F.str("output_pose_dataset"));
   write_ply_cameras(F.str("output_pose_dataset") + ".ply", V.pose, pe.Points());
   return 0;
 }

@@ -44,7 +44,7 @@ def main(argv=None):
     t_s, pose, points, err = estimate_poses_from_json(scene, model, intr, h,
                                                       optimize_board_points=str(a.optimize_board_points).lower() in ("1", "true", "yes", ""))
     print("Estimated %d camera poses, mean reprojection error %.4f px" % (len(t_s), float(np.mean(err)) if len(err) else float("nan")))
-    io_files.write_pose_dataset(a.output_pose_dataset, t_s, pose, points)
+    io_files.write_pose_dataset(a.output_pose_dataset, t_s, pose, points, sorted(int(k) for k in scene["scene_pts"]))
     io_files.write_ply_cameras(a.output_pose_dataset + ".ply", pose, points)
     return 0
 

@@ -179,12 +179,22 @@ def read_camera_calibration(path):
     return model, intr, int(obj["image_width"]), int(obj["image_height"]), float(obj.get("fps", 0.0))
 
 
-def write_pose_dataset(path, t_s, pose6, points):
+def pose_view_name(t_s):
+    """View name of a pose data set: the reference names a view std::to_string((uint64_t)(timestamp_s * 1e6)) (pose_estimator.cc:144)
+    and looks it up as std::to_string((uint64_t)stod(corner key)) (continuous_time_imu_to_camera_calibration.cc:133): TRUNCATED
+    microseconds.  timestamp_s is the key times 1e-6, so the product can land a few ulp below an integer key; those are snapped up."""
+    us = t_s * 1e6
+    k = int(us)
+    return str(k + 1 if us - k > 1.0 - 1e-5 else k)
+
+
+def write_pose_dataset(path, t_s, pose6, points, point_ids=None):
     """JSON twin of theia::WriteReconstruction for a pose data set (the file continuous_time_imu_to_camera_calibration
-    reads with --input_pose_dataset): view key = timestamp in microseconds (camera_calibrator.cc:96)."""
-    views = {str(int(round(t * 1e6))): dict(orientation_angle_axis=[float(x) for x in p[3:]], position=[float(x) for x in p[:3]])
+    reads with --input_pose_dataset); tracks carry the corner file's point ids (TrackId = stoi(key), read_scene.cc:47-49)."""
+    views = {pose_view_name(t): dict(orientation_angle_axis=[float(x) for x in p[3:]], position=[float(x) for x in p[:3]])
              for t, p in zip(t_s, pose6)}
-    json.dump(dict(views=views, tracks={str(i): [float(x) for x in points[i]] for i in range(len(points))}), open(path, "w"))
+    ids = list(range(len(points))) if point_ids is None else [int(i) for i in point_ids]
+    json.dump(dict(views=views, tracks={str(ids[i]): [float(x) for x in points[i]] for i in range(len(points))}), open(path, "w"))
 
 
 def write_ply_cameras(path, pose6, points, color=(255, 0, 0)):

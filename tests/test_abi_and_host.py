@@ -216,3 +216,20 @@ def test_calibrator_pose_estimator_and_rotation_mirrors_carry_the_reference_name
     assert public_methods("pose_estimator.h", "PoseEstimator") <= names
     ri = set(re.findall(r"def ([A-Z][A-Za-z0-9_]+)\(", open(os.path.join(pkg, "rotation_init.py")).read()))
     assert public_methods("imu_to_camera_rotation_estimator.h", "ImuToCameraRotationEstimator") - {"SolveClosedForm"} <= ri   # one probe: inside the device call
+
+
+def test_pose_dataset_names_views_by_truncated_microseconds_and_keeps_point_ids(tmp_path):
+    """The reference names the views of a pose data set by TRUNCATED microseconds (pose_estimator.cc:144) and looks them up the
+    same way from the corner-file key (continuous_time_imu_to_camera_calibration.cc:133); corner keys are '%f' microseconds with
+    a fraction.  Board points keep the corner file's ids (TrackId = stoi(key), read_scene.cc:47-49)."""
+    import json
+    from openimucameracalibrator_amd import io_files
+    keys = ["33366.700033", "66733.400066", "100000", "133466.999900", "2000000.500000", "999999", "7", "1000000000.25"]
+    t_s = [float(k) * 1e-6 for k in keys]
+    assert [io_files.pose_view_name(t) for t in t_s] == [str(int(float(k))) for k in keys]
+    path = str(tmp_path / "poses.json")
+    pts = np.array([[0.0, 0, 0, 1], [0.1, 0, 0, 1], [0, 0.1, 0, 1]])
+    io_files.write_pose_dataset(path, t_s, np.zeros((len(t_s), 6)), pts, point_ids=[1, 5, 9])
+    obj = json.load(open(path))
+    assert sorted(obj["tracks"]) == ["1", "5", "9"] and obj["tracks"]["5"][0] == 0.1
+    assert set(obj["views"]) == {str(int(float(k))) for k in keys}

@@ -60,6 +60,7 @@ def test_cli_full_calibration_matches_python_mirror(tmp_path):
         assert k in out
     # same problem through the Python mirror (file round trip quantises timestamps to ns/us)
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cal.trajectory_.SetOption("inner_iterations", 1)   # the application's default, as the reference's Optimize (impl.h:266)
     cal.Optimize(50, E.SPLINE | E.T_I_C | E.GRAVITY_DIR)
     T = cal.trajectory_.GetT_i_c()
     q = np.array([out["q_i_c"][c] for c in "xyzw"]); t = np.array([out["t_i_c"][c] for c in "xyz"])
@@ -237,7 +238,7 @@ def test_every_gflag_of_the_reference_applications_is_accepted():
     reference's main is a flag of the C++ application here (extra flags: device selection, --dry_run, solver options)."""
     import re
     host = os.path.join(os.path.dirname(CLI), "host")
-    extras = {"device", "dry_run", "solver_algorithm", "solver_partitions"}
+    extras = {"device", "dry_run", "solver_algorithm", "solver_partitions", "use_inner_iterations"}
     for app in ("continuous_time_imu_to_camera_calibration", "estimate_imu_to_camera_rotation", "calibrate_camera",
                 "estimate_camera_poses_from_checkerboard"):
         ref = set(re.findall(r"DEFINE_\w+\(\s*(\w+)", open("/root/reference/applications/%s.cc" % app).read()))
