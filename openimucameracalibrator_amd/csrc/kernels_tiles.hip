@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
     if (tid < 128) l_zero[tid] = 0.0;
   }
   if (tid == 0) l_queue[0] = td.unit0;
+  if (JAC && tp.gmax != nullptr && blockIdx.x == 0 && tid == 0) *tp.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   __syncthreads();
   for (int i = tid; i < td.nks - 1; i += kTileThreads) {
     const double* a = l_so3 + 4 * i;
@@ -489,7 +490,10 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
     }
     if (e < tl.W) ne.band()[(int64_t)i * tl.W + e] = s;
     else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + i] = s;
-    else if (e == tl.W + tl.a) ne.g()[i] = s;                            // (a padding column of the accumulator row carries nothing)
+    else if (e == tl.W + tl.a) {                                         // (a padding column of the accumulator row carries nothing)
+      ne.g()[i] = s;
+      if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(s)));   // non-negative doubles order like their bit patterns
+    }
     return;
   }
   __shared__ double red[256];
@@ -504,7 +508,7 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
   if (threadIdx.x == 0) {
     const double v = red[0];
     if (q < tl.a) { ne.C()[(int64_t)p * tl.a + q] = v; ne.C()[(int64_t)q * tl.a + p] = v; }
-    else if (p < tl.a) ne.g()[tl.Pb + p] = v;
+    else if (p < tl.a) { ne.g()[tl.Pb + p] = v; if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(v))); }
     else ne.cost()[0] = 0.5 * v;
   }
 }

@@ -138,6 +138,7 @@ struct oicc_problem {
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
+  bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
   // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
   struct InnerPlan {
     std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<char> group_has_so3; std::vector<int32_t> maps;
@@ -742,7 +743,8 @@ int inner_sweep(oicc_problem* p, double* xv) {
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
-              bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr) {
+              bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false) {
+  p->gmax_folded = false;
   hipStream_t st = p->stream;
   EvalCtx ctx = make_ctx(p, x);
   const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
@@ -761,7 +763,10 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
     if (jac && (p->tp.direct || p->tp.n_tiles == 0)) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
     else if (!jac && !cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
     ctx.only_kind = only_kind;
-    if (launch_tile_pass(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), p->fv, p->fa, p->fg, p->tp, jac, st) != 0) {
+    TileParams tp = p->tp;
+    p->gmax_folded = jac && want_gmax && !tp.direct && tp.n_tiles > 0 && !p->reduce;   // (with an all-reduce the gradient is only final afterwards)
+    tp.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
+    if (launch_tile_pass(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), p->fv, p->fa, p->fg, tp, jac, st) != 0) {
       p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
   }
   HIPCK(p, hipGetLastError());
@@ -788,6 +793,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   bool ok = false;
 };
 RcclApi& rccl_api() {
@@ -803,7 +809,8 @@ RcclApi& rccl_api() {
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
+    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.Broadcast;
   }
   return api;
 }
@@ -811,6 +818,10 @@ int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stre
   oicc_problem* p = static_cast<oicc_problem*>(user);
   return rccl_api().AllReduce(device_ptr, device_ptr, size_t(count), ncclDouble, ncclSum, static_cast<ncclComm_t>(p->rccl_comm),
                               static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : -1;
+}
+// rank 0's copy to every rank, in place (candidate parameters and the step's scalars: all ranks continue from identical bits)
+int rccl_broadcast_from_root(oicc_problem* p, void* device_ptr, int64_t count_doubles, hipStream_t stream) {
+  return rccl_api().Broadcast(device_ptr, device_ptr, size_t(count_doubles), ncclDouble, 0, static_cast<ncclComm_t>(p->rccl_comm), stream) == ncclSuccess ? 0 : -1;
 }
 }  // namespace
 // ================================= C API =======================================
@@ -1126,10 +1137,10 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   auto elapsed_s = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? double(ms) * 1e-3 : 0.0; };
 
   double t0 = now_s();
-  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   HIPCK(p, hipMemsetAsync(p->d_state.p, 0, sizeof(LmState), st));
-  if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); launch_lm_gradmax(p->ne, P, p->d_state.p, st); }
+  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); if (!p->gmax_folded) launch_lm_gradmax(p->ne, P, p->d_state.p, st); }
   rc = read_back(); if (rc) return rc;
   cost = pin->cost; gmax = pin->st.gradient_max_norm;
   S.seconds_jacobian += now_s() - t0;
@@ -1188,6 +1199,13 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
     HIPCK(p, hipGetLastError());
+    // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave last-bit
+    // differences in the step.  Rank 0's candidate parameters (<= 0.9 MB at C5) and its step scalars (model cost change, step
+    // norms, Cholesky flag) are broadcast, so that all ranks evaluate, decide and continue from bit-identical state.
+    if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
+      if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 || rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) {
+        p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+    }
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     // Inner iterations (TrustRegionMinimizer::DoInnerIterationsIfNeeded): one coordinate descent sweep from the candidate; its
@@ -1205,12 +1223,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       }
     }
     HIPCK(p, hipEventRecord(ev[2], st));
-    // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave
-    // last-bit differences in the model cost change and the step norms.  Summing the three scalars over the ranks and
-    // dividing by their number gives every rank bit-identical inputs to the accept / reject / terminate decisions, so
-    // the ranks can never take different branches (and then wait in different collectives).
+    // (several ranks: see the broadcast behind the retraction above)
     const bool rank_consistent = p->rccl_comm != nullptr && p->rccl_nranks > 1;
-    if (rank_consistent && rccl_reduce_in_place(p, &p->d_state.p->model_cost_change, 3, st) != 0) { p->err = "all-reduce of the step state failed"; return OICC_ERR_STATE; }
     rc = read_back_begin(); if (rc) return rc;
     // Jacobian pass + gradient norm at the CANDIDATE into the second buffer, before the host knows whether the step is
     // accepted (it is, on 4 of 4 iterations of the C2 calibration): the read-back latency hides behind it.  A rejected
@@ -1218,13 +1232,13 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     const bool speculate = p->opt["debug_sync"] != 3.0;
     HIPCK(p, hipEventRecord(ev[3], st));
     if (speculate) {
-      rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
-      launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+      rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
+      if (!p->gmax_folded) launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
     }
     HIPCK(p, hipEventRecord(ev[4], st));
     rc = read_back_wait(); if (rc) return rc;
     LmState hs = pin->st;
-    if (rank_consistent) { const double inv = 1.0 / double(p->rccl_nranks); hs.model_cost_change *= inv; hs.step_norm_sq *= inv; hs.x_norm_sq *= inv; }
+    (void)rank_consistent;
     const double cand_cost = pin->cost;
     bool inner_useful = false;
     if (inner_ran) {
@@ -1265,8 +1279,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     }
     if (rel_dec > min_rel_dec || inner_useful) {   // IsStepSuccessful
       if (!speculate) {
-        rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
-        launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+        rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
+        if (!p->gmax_folded) launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
       }
       std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current ...
       std::swap(p->ne.base, p->ne2.base);      // ... and so do its normal equations (already being computed)
@@ -1302,18 +1316,20 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));
   // Same pipeline as oicc_optimize with every step accepted: the Jacobian pass of the NEXT iteration (here: at x again)
   // is enqueued into the second buffer right behind the read-back copies, the host waits for the copies only.
-  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
-  launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
+  if (!p->gmax_folded) launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
   for (int it = 0; it < steps; ++it) {
     if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
+    if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
+        rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipEventRecord(p->ev[5], st));
-    rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, &p->ne2); if (rc) return rc;
-    launch_lm_gradmax(p->ne2, tl.P, p->d_state.p, st);
+    rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
+    if (!p->gmax_folded) launch_lm_gradmax(p->ne2, tl.P, p->d_state.p, st);
     HIPCK(p, hipEventSynchronize(p->ev[5]));
     if (pin->st.chol_failed) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
     std::swap(p->ne.base, p->ne2.base);

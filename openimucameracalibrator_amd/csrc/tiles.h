@@ -62,6 +62,7 @@ struct TileParams {
   int32_t rb_doubles;
   int32_t lds_bytes;
   double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]
+  double* gmax;            // not null: the merge kernel also leaves max |g| there (LmState::gradient_max_norm), reset by the tile kernel
   const int32_t* row_t0; const int32_t* row_t1;   // per band row: first / one-past-last tile whose accumulator covers it
 };
 
