@@ -204,8 +204,15 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * device-side choices (no effect on the result beyond rounding):
  *   solver_algorithm 0 (0 auto, 1 LDS-window band sweep, 2 block cyclic reduction; any geometry neither takes
  *   goes to a global-memory band Cholesky), solver_partitions 0 (time partitions of algorithm 1; 0 = heuristic),
- *   imu_chunk_cells 0 (knot-window cells per IMU work-list chunk; 0 = 1 on small problems, as many as fit on large ones).
- * Inner iterations (impl.h:266) are NOT reproduced (DESIGN.md deviation D1). */
+ *   imu_chunk_cells 0 (knot-window cells per IMU work-list chunk of assembly 1; 0 = 1 on small problems, as many as fit on large ones),
+ *   assembly 0 (0: time tiles - LDS accumulators + slab merge, 1: one wave per view / IMU chunk with global fp64 atomics,
+ *   2: time tiles adding straight into the packed matrix), tile_windows 0 (knot windows per tile; 0 = automatic),
+ *   wide_cells 1 (IMU samples of neighbouring knot windows share one Gram product).
+ * Ceres' inner iterations, which the reference switches on (impl.h:266), change the iterates and are therefore an
+ * option of the RESULT, not of the device: inner_iterations 0|1 (1 = Solver::Options::use_inner_iterations with the
+ * automatic ordering of Ceres 2.1.0, coordinate_descent_minimizer.cc / trust_region_minimizer.cc:352-412),
+ * inner_iteration_tolerance 1e-3.  The applications set inner_iterations = 1 as the reference does; the library default
+ * is 0 so that plain LM steps stay available to callers and tests. */
 int oicc_set_option(oicc_problem* p, const char* name, double value);
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,
                   oicc_summary* summary);
