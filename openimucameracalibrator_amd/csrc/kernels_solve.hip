@@ -123,8 +123,10 @@ __device__ __forceinline__ void se3_exp_dev(const double a6[6], Quat* q, double 
   mat3_vec(V, a6, t);
 }
 
+// alpha scales the step (1 for the trust-region candidate; the bounds line search of oicc_optimize re-retracts with its
+// step sizes, and then the model cost change of the FULL step is kept: with_model = 0).
 __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, TangentLayout tl, SolveBuffers sb,
-                                  NormalEq ne, double max_ab, double max_gb) {
+                                  NormalEq ne, double max_ab, double max_gb, double alpha, int with_model) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   double step_sq = 0.0, x_sq = 0.0, model = 0.0;
@@ -132,7 +134,7 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
   // all active blocks are rewritten here.  The cost slot is cleared for the candidate cost pass.
   if (tid == 0) *ne.cost() = 0.0;
   // model cost change = 0.5 * d.(D2 d - g_s)  (from (H_s + D2) d = -g_s)
-  for (int64_t i = tid; i < tl.P; i += nthreads) {
+  if (with_model) for (int64_t i = tid; i < tl.P; i += nthreads) {
     const double d = sb.step_s[i];
     model += 0.5 * d * (sb.D2[i] * d - ne.g()[i] * sb.scale[i]);
   }
@@ -141,7 +143,7 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
     const double* q0 = x + pl.so3 + 4 * k;
     double* q1 = xc + pl.so3 + 4 * k;
     if (o >= 0) {
-      const double om[3] = {sb.step_s[o] * sb.scale[o], sb.step_s[o + 1] * sb.scale[o + 1], sb.step_s[o + 2] * sb.scale[o + 2]};
+      const double om[3] = {alpha * (sb.step_s[o] * sb.scale[o]), alpha * (sb.step_s[o + 1] * sb.scale[o + 1]), alpha * (sb.step_s[o + 2] * sb.scale[o + 2])};
       const Quat r = so3_mul(Quat{q0[0], q0[1], q0[2], q0[3]}, so3_exp(om));
       q1[0] = r.x; q1[1] = r.y; q1[2] = r.z; q1[3] = r.w;
       for (int c = 0; c < 4; ++c) { const double dd = q1[c] - q0[c]; step_sq += dd * dd; x_sq += q0[c] * q0[c]; }
@@ -150,27 +152,27 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
   for (int64_t k = tid; k < pl.n_r3; k += nthreads) {
     const int o = tl.r3[k];
     if (o >= 0) for (int c = 0; c < 3; ++c) {
-      const double v0 = x[pl.r3 + 3 * k + c]; const double dd = sb.step_s[o + c] * sb.scale[o + c];
+      const double v0 = x[pl.r3 + 3 * k + c]; const double dd = alpha * (sb.step_s[o + c] * sb.scale[o + c]);
       const double v1 = v0 + dd; xc[pl.r3 + 3 * k + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
   }
   for (int64_t k = tid; k < pl.n_ab; k += nthreads) {
     const int o = tl.ab[k];
     if (o >= 0) for (int c = 0; c < 3; ++c) {
       const double v0 = x[pl.ab + 3 * k + c];
-      const double v1 = fmin(fmax(v0 + sb.step_s[o + c] * sb.scale[o + c], -max_ab), max_ab);
+      const double v1 = fmin(fmax(v0 + alpha * (sb.step_s[o + c] * sb.scale[o + c]), -max_ab), max_ab);
       xc[pl.ab + 3 * k + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
   }
   for (int64_t k = tid; k < pl.n_gb; k += nthreads) {
     const int o = tl.gb[k];
     if (o >= 0) for (int c = 0; c < 3; ++c) {
       const double v0 = x[pl.gb + 3 * k + c];
-      const double v1 = fmin(fmax(v0 + sb.step_s[o + c] * sb.scale[o + c], -max_gb), max_gb);
+      const double v1 = fmin(fmax(v0 + alpha * (sb.step_s[o + c] * sb.scale[o + c]), -max_gb), max_gb);
       xc[pl.gb + 3 * k + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
   }
   if (tid == 0) {
     if (tl.tic >= 0) {
       double a6[6];
-      for (int c = 0; c < 6; ++c) a6[c] = sb.step_s[tl.tic + c] * sb.scale[tl.tic + c];
+      for (int c = 0; c < 6; ++c) a6[c] = alpha * (sb.step_s[tl.tic + c] * sb.scale[tl.tic + c]);
       Quat dq; double dt[3];
       se3_exp_dev(a6, &dq, dt);
       const double* T0 = x + pl.tic; double* T1 = xc + pl.tic;
@@ -183,7 +185,7 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
     }
     auto eucl = [&](int off, int64_t po, int n) {
       if (off < 0) return;
-      for (int c = 0; c < n; ++c) { const double v0 = x[po + c]; const double v1 = v0 + sb.step_s[off + c] * sb.scale[off + c];
+      for (int c = 0; c < n; ++c) { const double v0 = x[po + c]; const double v1 = v0 + alpha * (sb.step_s[off + c] * sb.scale[off + c]);
         xc[po + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
     };
     eucl(tl.g, pl.g, 3); eucl(tl.ld, pl.ld, 1); eucl(tl.ai, pl.ai, 6); eucl(tl.gi, pl.gi, 9);
@@ -199,11 +201,28 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
   if (threadIdx.x == 0) {
     unsafeAtomicAdd(&sb.st->step_norm_sq, red[0][0]);
     unsafeAtomicAdd(&sb.st->x_norm_sq, red[1][0]);
-    unsafeAtomicAdd(&sb.st->model_cost_change, red[2][0]);
+    if (with_model) unsafeAtomicAdd(&sb.st->model_cost_change, red[2][0]);
   }
 }
 
+// out[0] = g . step, out[1] = max |step| (unscaled step = step_s * scale): the slope and the direction norm of the bounds line search
+__global__ void lm_step_slope_kernel(const double* g, const double* step_s, const double* scale, int P, double* out) {
+  __shared__ double red[2][1024];
+  double dot = 0.0, mx = 0.0;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) { const double d = step_s[i] * scale[i]; dot += g[i] * d; mx = fmax(mx, fabs(d)); }
+  red[0][threadIdx.x] = dot; red[1][threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + s]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+
 // ---- launchers ----------------------------------------------------------------
+void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(lm_step_slope_kernel, dim3(1), dim3(1024), 0, st, g, sb.step_s, sb.scale, P, out);
+}
 void launch_lm_scale(const NormalEq& ne, const TangentLayout& tl, double* scale, int jacobi, hipStream_t st) {
   if (tl.P == 0) return;
   hipLaunchKernelGGL(lm_scale_kernel, dim3((tl.P + 255) / 256), dim3(256), 0, st, ne, tl, scale, jacobi);
@@ -218,10 +237,10 @@ void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   hipLaunchKernelGGL(lm_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag);
 }
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
-                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st) {
+                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha, int with_model) {
   int64_t work = pl.total;
   int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb);
+  hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model);
 }
 
 }  // namespace oicc

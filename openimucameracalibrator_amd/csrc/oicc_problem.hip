@@ -26,6 +26,7 @@
 #include "lm_launch.h"
 #include "tiles.h"
 #include "inner_plan.h"
+#include "line_search.h"
 
 namespace oicc {
 // kernels_blocks.hip
@@ -46,7 +47,8 @@ void launch_inner_eval(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia
 void launch_inner_step(double* xv, const InnerBlock* blocks, InnerState* states, int b0, int b1, int phase, double max_ab, double max_gb, int32_t* not_done, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
-                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st);
+                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1);
+void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st);
 }  // namespace oicc
 
 using namespace oicc;
@@ -130,8 +132,8 @@ struct oicc_problem {
   DevBuf<double> d_ne2;   // second normal-equation buffer: the Jacobian pass at the candidate runs while the host decides
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
-  DevBuf<LmState> d_state;
-  struct HostPin { LmState st; double cost; double radius; };
+  DevBuf<LmState> d_state; DevBuf<double> d_ls; int64_t line_search_steps = 0;   // d_ls: slope and max norm of the step (bounds line search)
+  struct HostPin { LmState st; double cost; double radius; double ls[2]; };
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
@@ -159,6 +161,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
@@ -354,7 +357,7 @@ int make_layout(oicc_problem* p, int flags) {
   const int ar = tl.a + 1;
   if (!p->d_ne.resize(ne.total) || !p->d_ne2.resize(ne.total) || !p->d_Mb.resize(std::max<int64_t>(nband, 1)) || !p->d_Mt.resize(std::max<int64_t>(int64_t(ar) * tl.Pb, 1)) ||
       !p->d_Mc.resize(int64_t(ar) * ar) || !p->d_scale.resize(std::max(tl.P, 1)) || !p->d_diag.resize(std::max(tl.P, 1)) ||
-      !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1) ||
+      !p->d_D2.resize(std::max(tl.P, 1)) || !p->d_step.resize(std::max(tl.P, 1)) || !p->d_state.resize(1) || !p->d_ls.resize(2) ||
       !p->d_ws.resize(size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))))) {
     p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   ne.base = p->d_ne.p;
@@ -1101,7 +1104,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   S.num_parameters_tangent = P; S.band_dim = tl.Pb; S.arrow_dim = tl.a; S.half_bandwidth = tl.hb;
   S.num_residual_blocks = int64_t(p->view_rs.size() + p->acc.size() + p->gyr.size());
   S.num_residuals = int64_t(2 * p->corner_view.size() + 3 * p->acc.size() + 3 * p->gyr.size());
-  p->trace.clear();
+  p->trace.clear(); p->line_search_steps = 0;
   const double ftol = p->opt["function_tolerance"], ptol = p->opt["parameter_tolerance"], gtol = p->opt["gradient_tolerance"];
   double radius = p->opt["initial_trust_region_radius"]; const double max_radius = p->opt["max_trust_region_radius"];
   const double min_radius = p->opt["min_trust_region_radius"], min_rel_dec = p->opt["min_relative_decrease"];
@@ -1157,6 +1160,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     rc = build_inner_plan(p, flags); if (rc) return rc;
     inner_enabled = p->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
   }
+  const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
   bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
   auto settle_gmax = [&]() -> int {   // used on the exits that do not go through the per-iteration read-back
     if (!gmax_pending) return OICC_OK;
@@ -1208,6 +1212,53 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     }
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
+    // Bounds line search (TrustRegionMinimizer::DoLineSearch): with box-bounded bias knots among the variables Ceres shortens
+    // the step by an Armijo search along x(alpha) = project(x (+) alpha delta), alpha_0 = 1, cubic interpolation, before the
+    // candidate is judged.  Host-driven: every trial is one retraction + cost pass, a failed trial adds one Jacobian pass for
+    // its slope.  The model cost change stays the one of the full trust-region step (Ceres scales delta only).
+    if (line_search) {
+      launch_lm_step_slope(p->ne.g(), sb, P, p->d_ls.p, st);
+      HIPCK(p, hipMemcpyAsync(pin->ls, p->d_ls.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      rc = read_back(); if (rc) return rc;
+      if (gmax_pending) {   // the gradient of the point accepted in the previous iteration arrived with this read-back
+        gmax = pin->st.gradient_max_norm; p->trace.back().gradient_max_norm = gmax; gmax_pending = false;
+        S.seconds_jacobian += elapsed_s(ev[3], ev[4]);
+        if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
+      }
+      const bool step_ok = pin->st.chol_failed == 0 && std::isfinite(pin->st.model_cost_change) && pin->st.model_cost_change > 0.0;
+      const double g0 = pin->ls[0], dmax = pin->ls[1];
+      if (step_ok && std::isfinite(g0)) {
+        auto trial = [&](double alpha, double* value) -> int {
+          HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, 2 * sizeof(double), st));   // step_norm_sq, x_norm_sq
+          launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, alpha, 0);
+          if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
+              rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+          int r = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (r) return r;
+          r = read_back(); if (r) return r;
+          *value = pin->cost; return OICC_OK; };
+        LsSample init, prev, cur; bool have_prev = false, success = true; int its = 0;
+        init.x = 0.0; init.value = cost; init.gradient = g0; init.has_gradient = true;
+        cur.x = 1.0; cur.value = pin->cost;
+        while (!std::isfinite(cur.value) || cur.value > cost + 1e-4 * g0 * cur.x) {
+          if (++its >= 20) { success = false; break; }
+          if (!cur.has_gradient && std::isfinite(cur.value)) {   // slope at the trial point: gradient there (in its own tangent space) . delta
+            rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, false); if (rc) return rc;
+            launch_lm_step_slope(p->ne2.g(), sb, P, p->d_ls.p, st);
+            HIPCK(p, hipMemcpyAsync(pin->ls, p->d_ls.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCK(p, hipStreamSynchronize(st));
+            cur.gradient = pin->ls[0]; cur.has_gradient = true;
+          }
+          const double next = ls_next_step_size(init, have_prev ? &prev : nullptr, cur);
+          if (next * dmax < 1e-9) { success = false; break; }
+          prev = cur; have_prev = true;
+          cur = LsSample(); cur.x = next;
+          rc = trial(next, &cur.value); if (rc) return rc;
+        }
+        p->line_search_steps += its;
+        if (verbose && its > 0) std::printf("[oicc] iter %d line search: %d steps, step size %.6e (%s)\n", iter + 1, its, cur.x, success ? "ok" : "failed, full step kept");
+        if (!success && cur.x != 1.0) { double v; rc = trial(1.0, &v); if (rc) return rc; }
+      }
+    }
     // Inner iterations (TrustRegionMinimizer::DoInnerIterationsIfNeeded): one coordinate descent sweep from the candidate; its
     // cost decrease is credited to the model, the candidate becomes the swept point.
     double cand_before_inner = 0.0; bool inner_ran = false;
@@ -1386,6 +1437,14 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
 
 // Debug: shader-cycle counters of the solver kernel's phases for the current system
 // [init, prefetch, stepA, barrier1, stepB, barrier2, corner+t, backward].
+// Test hook (host only, no device): next trial step size of the bounds line search from [x, value, slope] triples; prev may be NULL.
+double oicc_debug_ls_next_step_size(const double init[3], const double* prev, int32_t prev_has_slope, const double cur[3], int32_t cur_has_slope) {
+  LsSample i, q, c;
+  i.x = init[0]; i.value = init[1]; i.gradient = init[2]; i.has_gradient = true;
+  c.x = cur[0]; c.value = cur[1]; c.gradient = cur[2]; c.has_gradient = cur_has_slope != 0;
+  if (prev) { q.x = prev[0]; q.value = prev[1]; q.gradient = prev[2]; q.has_gradient = prev_has_slope != 0; }
+  return ls_next_step_size(i, prev ? &q : nullptr, c);
+}
 int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12]) {
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;

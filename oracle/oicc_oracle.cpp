@@ -834,7 +834,8 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
         if (!cur.has_gradient && std::isfinite(cur.value)) at(cur.x, true, &cur);     // cubic interpolation uses the slope at the trial point
         std::vector<inner::Sample> ss{init}; if (have_prev && std::isfinite(prev.value)) ss.push_back(prev); if (std::isfinite(cur.value)) ss.push_back(cur);
         std::vector<double> poly; double next = 0.6 * cur.x;
-        if (inner::fit_polynomial(ss, &poly)) next = inner::minimize_polynomial(poly, 1e-3 * cur.x, 0.6 * cur.x);
+        if (!std::isfinite(cur.value)) next = 0.5 * cur.x;   // InterpolatingPolynomialMinimizingStepSize: an invalid sample is bisected
+        else if (inner::fit_polynomial(ss, &poly)) next = inner::minimize_polynomial(poly, 1e-3 * cur.x, 0.6 * cur.x);
         if (next * dmax < 1e-9) { success = false; break; }
         prev = cur; have_prev = true;
         at(next, false, &cur);
@@ -887,6 +888,16 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
     }
     S.final_gradient_max_norm = gmax;
   }
+}
+// Test hook: the step-size interpolation of the line search above on explicit samples ([x, value, slope]; prev may be NULL).
+double oicc_oracle_ls_next_step_size(const double init[3], const double* prev, int32_t prev_has_slope, const double cur[3], int32_t cur_has_slope) {
+  std::vector<inner::Sample> ss{inner::Sample{init[0], init[1], init[2], true}};
+  if (!std::isfinite(cur[1])) return 0.5 * cur[0];
+  if (prev && std::isfinite(prev[1])) ss.push_back(inner::Sample{prev[0], prev[1], prev[2], prev_has_slope != 0});
+  ss.push_back(inner::Sample{cur[0], cur[1], cur[2], cur_has_slope != 0});
+  std::vector<double> poly; double next = 0.6 * cur[0];
+  if (inner::fit_polynomial(ss, &poly)) next = inner::minimize_polynomial(poly, 1e-3 * cur[0], 0.6 * cur[0]);
+  return next;
 }
 int oicc_oracle_get_iterations(const oicc_problem* prob, oicc_iteration* out, int32_t cap) {
   const int n = std::min<int>(cap, int(prob->p.trace.size())); std::copy(prob->p.trace.begin(), prob->p.trace.begin() + n, out); return n; }

@@ -233,3 +233,35 @@ def test_pose_dataset_names_views_by_truncated_microseconds_and_keeps_point_ids(
     obj = json.load(open(path))
     assert sorted(obj["tracks"]) == ["1", "5", "9"] and obj["tracks"]["5"][0] == 0.1
     assert set(obj["views"]) == {str(int(float(k))) for k in keys}
+
+
+def test_line_search_step_size_interpolation_matches_the_oracle():
+    """Host side of the bounds line search: the Newton-form (Hermite divided differences) minimiser of csrc/line_search.h
+    against the oracle's Vandermonde fit of the same Ceres rule, on random value / slope samples, with and without a
+    previous trial, with and without a slope at the current one; a trial without a finite cost is halved."""
+    oracle_backend.build()
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    a = ctypes.CDLL(_lib.LIB_PATH).oicc_debug_ls_next_step_size
+    b = ctypes.CDLL(oracle_backend.ORACLE_LIB).oicc_oracle_ls_next_step_size
+    D3 = ctypes.c_double * 3
+    for f in (a, b):
+        f.restype = ctypes.c_double
+        f.argtypes = [D3, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, D3, ctypes.c_int32]
+    rng = np.random.default_rng(7)
+    for k in range(600):
+        f0 = rng.uniform(1, 100); g0 = -rng.uniform(0.1, 50)
+        x1 = rng.uniform(0.01, 1.0); f1 = f0 + rng.uniform(-0.2, 3.0) * abs(g0) * x1; g1 = rng.normal() * 30
+        init = D3(0.0, f0, g0); cur = D3(x1, f1, g1)
+        pp = None
+        if k % 2:
+            x2 = x1 / rng.uniform(0.2, 0.6)
+            prev = D3(x2, f0 + rng.uniform(0, 5.0) * abs(g0) * x2, rng.normal() * 30)
+            pp = ctypes.cast(prev, ctypes.POINTER(ctypes.c_double))
+        cg = int(k % 3 != 0)
+        ra, rb = a(init, pp, 1, cur, cg), b(init, pp, 1, cur, cg)
+        assert 1e-3 * x1 * (1 - 1e-12) <= ra <= 0.6 * x1 * (1 + 1e-12)
+        assert abs(ra - rb) <= 1e-10 * x1, (k, ra, rb)
+    nan = D3(0.8, float("nan"), 0.0)
+    assert a(D3(0, 1, -1), None, 0, nan, 0) == 0.4 and b(D3(0, 1, -1), None, 0, nan, 0) == 0.4

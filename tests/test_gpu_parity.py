@@ -473,3 +473,27 @@ def test_inner_iterations_match_the_oracle(cfg, flags):
     plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
     sp = plain.trajectory_.Optimize(50, flags)
     assert abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
+
+
+# ---- Ceres' bounds line search (box-bounded bias knots, impl.h:206-240): host-driven Armijo search of oicc_optimize ----
+@pytest.mark.parametrize("cfg,flags,inner", [("C1", FLAGS1 | E.ACC_BIAS, 0), ("C1", FLAGS1 | E.ACC_BIAS, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1)])
+def test_bounds_line_search_matches_the_oracle(cfg, flags, inner):
+    """With bias knots among the variables Ceres runs an Armijo search along the projected path (cubic interpolation on value
+    and slope samples) before it judges the candidate; a step that plain LM would reject is shortened instead.  Same iterate
+    sequence as oracle/oicc_oracle.cpp with the option on, and a different one than without it."""
+    ds = synthetic.make_config(cfg)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("inner_iterations", inner); c.trajectory_.SetOption("bounds_line_search", 1)
+    cpu.trajectory_.SetOption("analytic_jacobians", 1 if cfg != "tiny" else 0)
+    sg = gpu.trajectory_.Optimize(50, flags); sc = cpu.trajectory_.Optimize(50, flags)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert sg["num_iterations"] == sc["num_iterations"], ([i["cost"] for i in ig], [i["cost"] for i in ic])
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+    plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    plain.trajectory_.SetOption("inner_iterations", inner)
+    sp = plain.trajectory_.Optimize(50, flags)
+    assert sp["num_iterations"] != sg["num_iterations"] or abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
