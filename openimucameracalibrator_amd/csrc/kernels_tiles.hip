@@ -307,11 +307,13 @@ __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLa
 }  // namespace
 
 template <bool JAC, bool DIRECT>
-__global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewData vd, ImuData ia, ImuData ig, RowFmt fv, RowFmt fa_, RowFmt fg,
-                                                            TileParams tp) {
+__global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __restrict__ S, TileDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const EvalCtx& ctx = S->ctx; const ViewData& vd = S->vd; const ImuData& ia = S->ia; const ImuData& ig = S->ig;
+  const RowFmt& fv = S->fmt[0]; const RowFmt& fa_ = S->fmt[1]; const RowFmt& fg = S->fmt[2]; const TileParams& tp = S->tp;
+  const double* __restrict__ xg = dyn.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileDesc td = tp.tiles[blockIdx.x];
+  const TileDesc td = tp.tiles[blockIdx.x];   // (issued here, first needed after the staging below)
   double* acc = lds + tp.o_acc;
   double* l_so3 = lds + tp.o_so3;
   double* l_r3 = lds + tp.o_r3;
@@ -319,24 +321,22 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
   int* l_tl_so3 = reinterpret_cast<int*>(lds + tp.o_tl);
   int* l_tl_r3 = l_tl_so3 + kMaxTileKnots;
   int* l_queue = reinterpret_cast<int*>(lds + tp.o_misc);
+  int* l_units = reinterpret_cast<int*>(lds + tp.o_units);
   int* l_ct = reinterpret_cast<int*>(lds + tp.o_ct);          // column tables [ba | fa | grp] x [kind][64]
   double* l_zero = lds + tp.o_zero;                            // an all-zero item record (rows past a cell)
   int* colinfo = reinterpret_cast<int*>(lds + tp.o_wave + (size_t)wave * tp.wave_doubles);   // [64][3] of the wave's current cell
   double* rb = lds + tp.o_wave + (size_t)wave * tp.wave_doubles + 96;
 
+  const bool prof_on = JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && wave == 0;
+  long long* prof = prof_on ? dyn.prof : nullptr;
+  const long long tp0 = prof ? clock64() : 0;
   // ---- P0: knots, tangent offsets, segment tables, zeroed accumulator ----
-  for (int i = tid; i < td.nks * 4; i += kTileThreads) l_so3[i] = ctx.x[ctx.pl.so3 + (int64_t)td.ks0 * 4 + i];
-  for (int i = tid; i < td.nkr * 3; i += kTileThreads) l_r3[i] = ctx.x[ctx.pl.r3 + (int64_t)td.kr0 * 3 + i];
+  // (what does not depend on the tile descriptor comes first: it overlaps the descriptor's load)
   if (JAC) {
-    for (int i = tid; i < td.nks; i += kTileThreads) l_tl_so3[i] = ctx.tl.so3[td.ks0 + i];
-    for (int i = tid; i < td.nkr; i += kTileThreads) l_tl_r3[i] = ctx.tl.r3[td.kr0 + i];
     if (!DIRECT) {
-      const int nacc = td.nrows * tp.Wl;
+      const int nacc = tp.acc_rows * tp.Wl + tp.corner;
       for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0;
-      for (int i = tid; i < tp.corner; i += kTileThreads) acc[tp.acc_rows * tp.Wl + i] = 0.0;
     }
-  }
-  if (JAC) {
     if (tid < 192) {
       const int kind = tid >> 6, col = tid & 63;
       int ba, fa, grp;
@@ -345,9 +345,32 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
     }
     if (tid < 128) l_zero[tid] = 0.0;
   }
-  if (tid == 0) l_queue[0] = td.unit0;
-  if (JAC && tp.gmax != nullptr && blockIdx.x == 0 && tid == 0) *tp.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
+  // Knots and their tangent offsets: loaded for the knot ranges the affine model of TileParams predicts (clamped to the knot
+  // vectors) without waiting for the descriptor, and once more for the few tiles whose descriptor says otherwise.
+  auto stage_knots = [&](int ks0, int nks, int kr0, int nkr) {
+    for (int i = tid; i < nks * 4; i += kTileThreads) l_so3[i] = xg[ctx.pl.so3 + (int64_t)ks0 * 4 + i];
+    for (int i = tid; i < nkr * 3; i += kTileThreads) l_r3[i] = xg[ctx.pl.r3 + (int64_t)kr0 * 3 + i];
+    if (JAC) {
+      for (int i = tid; i < nks; i += kTileThreads) l_tl_so3[i] = ctx.tl.so3[ks0 + i];
+      for (int i = tid; i < nkr; i += kTileThreads) l_tl_r3[i] = ctx.tl.r3[kr0 + i];
+    }
+  };
+  int g_ks0 = -1, g_nks = 0, g_kr0 = -1, g_nkr = 0;
+  if (tp.affine) {
+    const int b = blockIdx.x;
+    g_ks0 = tp.td0.ks0 + b * tp.tds.ks0; g_nks = tp.td0.nks + b * tp.tds.nks; g_kr0 = tp.td0.kr0 + b * tp.tds.kr0; g_nkr = tp.td0.nkr + b * tp.tds.nkr;
+    const bool sane = g_ks0 >= 0 && g_nks >= 0 && g_nks <= kMaxTileKnots && g_ks0 + g_nks <= (int)ctx.pl.n_so3 && g_kr0 >= 0 && g_nkr >= 0 && g_nkr <= kMaxTileKnots && g_kr0 + g_nkr <= (int)ctx.pl.n_r3;
+    if (sane) stage_knots(g_ks0, g_nks, g_kr0, g_nkr); else g_ks0 = -1;
+  }
+  if (td.ks0 != g_ks0 || td.nks != g_nks || td.kr0 != g_kr0 || td.nkr != g_nkr) stage_knots(td.ks0, td.nks, td.kr0, td.nkr);
+  {   // the tile's unit descriptors (4 ints each): the waves read them from LDS instead of a dependent global load per unit
+    const int* src = reinterpret_cast<const int*>(tp.units + td.unit0);
+    for (int i = tid; i < 4 * (td.unit1 - td.unit0); i += kTileThreads) l_units[i] = src[i];
+  }
+  if (tid == 0) l_queue[0] = 0;
+  if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   __syncthreads();
+  const long long tp1 = prof ? clock64() : 0;
   for (int i = tid; i < td.nks - 1; i += kTileThreads) {
     const double* a = l_so3 + 4 * i;
     so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, l_seg + i * kSegStride);
@@ -355,9 +378,8 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
   __syncthreads();
 
   Target T;
-  T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne;
-  const bool prof_on = JAC && ctx.prof != nullptr && blockIdx.x == gridDim.x / 2 && wave == 0;
-  long long* prof = prof_on ? ctx.prof : nullptr;
+  T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
+  const long long tp2 = prof ? clock64() : 0;
 
   // ---- P1: units ----
   double cost_local = 0.0;
@@ -365,9 +387,9 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
     int u = 0;
     if (lane == 0) u = atomicAdd(l_queue, 1);
     u = __shfl(u, 0, 64);
-    if (u >= td.unit1) break;
-    const UnitDesc ud = tp.units[u];
-    if (ctx.only_kind >= 0 && ud.kind != ctx.only_kind) continue;
+    if (u >= td.unit1 - td.unit0) break;
+    const UnitDesc ud{l_units[4 * u], l_units[4 * u + 1], l_units[4 * u + 2], l_units[4 * u + 3]};
+    if (dyn.only_kind >= 0 && ud.kind != dyn.only_kind) continue;
     const long long tq0 = prof ? clock64() : 0;
     const bool valid = lane < ud.count;
     const int64_t it = (int64_t)ud.first + lane;
@@ -377,8 +399,8 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
       s_so3 = vd.view_s_so3[v] - td.ks0; s_r3 = vd.view_s_r3[v] - td.kr0;
       if (valid) {
         ViewConst vc;
-        view_const_init(vc, ctx.x + ctx.pl.tic);
-        vc.ld = ctx.x[ctx.pl.ld];
+        view_const_init(vc, xg + ctx.pl.tic);
+        vc.ld = xg[ctx.pl.ld];
         vc.sh_s = ctx.rs_time_in_seconds ? ctx.inv_so3_dt : 1.0; vc.sh_r = ctx.rs_time_in_seconds ? ctx.inv_r3_dt : 1.0;
         vc.inv_so3_dt = ctx.inv_so3_dt; vc.inv_r3_dt = ctx.inv_r3_dt; vc.cam_model = ctx.cam_model; vc.intr = ctx.intr; vc.gs_unit_loss = ctx.gs_unit_loss != 0;
         vc.spline_active = fv.c_s >= 0; vc.tic_active = fv.c_t >= 0; vc.ld_active = fv.c_l >= 0;
@@ -386,11 +408,11 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
         const Quat R0{q0[0], q0[1], q0[2], q0[3]};
         const LdsSeg seg{l_seg + s_so3 * kSegStride};
         const LdsR3 kr{l_r3 + 3 * s_r3};
-        double* dres = ctx.dbg_res ? ctx.dbg_res + 2 * it : nullptr;
-        double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 2 * it * 43 : nullptr;
+        double* dres = dyn.dbg_res ? dyn.dbg_res + 2 * it : nullptr;
+        double* djac = (JAC && dyn.dbg_jac) ? dyn.dbg_jac + 2 * it * 43 : nullptr;
         if (djac) for (int k = 0; k < 2 * 43; ++k) djac[k] = 0.0;
         const TileSink<0, JAC> sink(fv, rb + lane * fv.item_stride, s_so3, dres, djac);
-        cost_local += view_item<JAC>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], vd.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
+        cost_local += view_item<JAC>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], dyn.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
                                      vd.corner_isx[it], vd.corner_isy[it], ctx.pts + 4 * (int64_t)vd.corner_pt[it], sink);
       }
     } else {
@@ -403,21 +425,21 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
         const LdsSeg seg{l_seg + s_so3 * kSegStride};
         const LdsR3 kr{l_r3 + 3 * s_r3};
         const double m[3] = {id.mx[it], id.my[it], id.mz[it]};
-        const double* bk = ctx.x + (accel ? ctx.pl.ab : ctx.pl.gb) + 3 * (int64_t)s_b;
-        double* dres = ctx.dbg_res ? ctx.dbg_res + 3 * it : nullptr;
+        const double* bk = xg + (accel ? ctx.pl.ab : ctx.pl.gb) + 3 * (int64_t)s_b;
+        double* dres = dyn.dbg_res ? dyn.dbg_res + 3 * it : nullptr;
         ImuConst ic;
         ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
         if (accel) {
-          imu_const_init<0>(ic, ctx.x + ctx.pl.ai, ctx.x + ctx.pl.g);
+          imu_const_init<0>(ic, xg + ctx.pl.ai, xg + ctx.pl.g);
           ic.spline_active = fa_.c_s >= 0; ic.g_active = fa_.c_g >= 0; ic.bias_active = fa_.c_b >= 0; ic.intr_active = fa_.c_i >= 0;
-          double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 54 : nullptr;
+          double* djac = (JAC && dyn.dbg_jac) ? dyn.dbg_jac + 3 * it * 54 : nullptr;
           if (djac) for (int k = 0; k < 3 * 54; ++k) djac[k] = 0.0;
           const TileSink<1, JAC> sink(fa_, rb + lane * fa_.item_stride, s_so3, dres, djac);
           cost_local += imu_item<0, JAC>(ic, R0, seg, kr, id.u_so3[it], id.u_r3[it], id.u_b[it], bk, m, id.w[it], sink);
         } else {
-          imu_const_init<1>(ic, ctx.x + ctx.pl.gi, ctx.x + ctx.pl.g);
+          imu_const_init<1>(ic, xg + ctx.pl.gi, xg + ctx.pl.g);
           ic.spline_active = fg.c_s >= 0; ic.g_active = false; ic.bias_active = fg.c_b >= 0; ic.intr_active = fg.c_i >= 0;
-          double* djac = (JAC && ctx.dbg_jac) ? ctx.dbg_jac + 3 * it * 36 : nullptr;
+          double* djac = (JAC && dyn.dbg_jac) ? dyn.dbg_jac + 3 * it * 36 : nullptr;
           if (djac) for (int k = 0; k < 3 * 36; ++k) djac[k] = 0.0;
           const TileSink<2, JAC> sink(fg, rb + lane * fg.item_stride, s_so3, dres, djac);
           cost_local += imu_item<1, JAC>(ic, R0, seg, kr, id.u_so3[it], 0.0, id.u_b[it], bk, m, id.w[it], sink);
@@ -428,7 +450,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
       // cells: a view, or a run of IMU samples with the same R^3 and bias windows whose SO(3) windows span at most 1 + ks_extra
       // consecutive ones (as many as fit the 16-column blocks of the single-window layout): one Gram product and one scatter per
       // cell.  The boundaries come from the window indices the lanes already hold (one ballot per cell).
-      const RowFmt& f = ud.kind == 0 ? fv : (ud.kind == 1 ? fa_ : fg);
+      const RowFmt& f = S->fmt[__builtin_amdgcn_readfirstlane(ud.kind)];
       const int rows = f.rows_per_item;
       const int* cba = l_ct + 64 * ud.kind; const int* cfa = l_ct + 192 + 64 * ud.kind; const int* cgr = l_ct + 384 + 64 * ud.kind;
       const long long tq1 = prof ? clock64() : 0;
@@ -461,16 +483,22 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(EvalCtx ctx, ViewDat
 
   if (!JAC) {
     const double s = wave_sum_d(cost_local);
-    if (lane == 0 && s != 0.0) unsafeAtomicAdd(ctx.ne.cost(), s);
+    if (lane == 0 && s != 0.0) unsafeAtomicAdd(dyn.ne_base + ctx.ne.off_cost, s);
     return;
   }
   // ---- P2: accumulator -> slab ----
+  const long long tp3 = prof ? clock64() : 0;
   if (!DIRECT) {
     __syncthreads();
     double* slab = tp.slabs + (int64_t)blockIdx.x * tp.slab_stride;
     const int nacc = td.nrows * tp.Wl;
     for (int i = tid; i < nacc; i += kTileThreads) slab[i] = acc[i];
     for (int i = tid; i < tp.corner; i += kTileThreads) slab[tp.acc_rows * tp.Wl + i] = acc[tp.acc_rows * tp.Wl + i];
+  }
+  if (prof && lane == 0) {   // [4] staging, [5] segment tables, [6] the wave's units, [7] wait for the other waves + slab stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp4 = clock64();
+    prof[4] += tp1 - tp0; prof[5] += tp2 - tp1; prof[6] += tp3 - tp2; prof[7] += tp4 - tp3;
   }
 }
 
@@ -529,24 +557,26 @@ void launch_lds_poison(hipStream_t st) {
 
 // ---- launchers ----
 template <bool JAC, bool DIRECT>
-static void launch_tile_kernel(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
-                               const RowFmt& fg, const TileParams& tp, size_t lds, hipStream_t st) {
+static void launch_tile_kernel(const TileStatic* dS, const TileDyn& dyn, int n_tiles, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT>), dim3(tp.n_tiles), dim3(kTileThreads), lds, st, ctx, vd, ia, ig, fv, fa, fg, tp);
+  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT>), dim3(n_tiles), dim3(kTileThreads), lds, st, dS, dyn);
 }
-int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
-                     const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st) {
+// hS: the host copy of *dS (already uploaded on this stream)
+int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st) {
+  const TileParams& tp = hS.tp;
   if (tp.n_tiles == 0) return 0;
   if (jac) {
-    if (tp.direct) launch_tile_kernel<true, true>(ctx, vd, ia, ig, fv, fa, fg, tp, tp.lds_bytes, st);
+    if (tp.direct) launch_tile_kernel<true, true>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
     else {
-      launch_tile_kernel<true, false>(ctx, vd, ia, ig, fv, fa, fg, tp, tp.lds_bytes, st);
-      const int nb_rows = int(((int64_t)ctx.tl.Pb * tp.Wl + 255) / 256);
-      hipLaunchKernelGGL(slab_merge_kernel, dim3(nb_rows + tp.corner), dim3(256), 0, st, tp, ctx.ne, ctx.tl, nb_rows);
+      launch_tile_kernel<true, false>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
+      const int nb_rows = int(((int64_t)hS.ctx.tl.Pb * tp.Wl + 255) / 256);
+      TileParams tpm = tp; tpm.gmax = dyn.gmax;
+      NormalEq ne = hS.ctx.ne; ne.base = dyn.ne_base;
+      hipLaunchKernelGGL(slab_merge_kernel, dim3(nb_rows + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows);
     }
   } else {
-    launch_tile_kernel<false, false>(ctx, vd, ia, ig, fv, fa, fg, tp, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only
+    launch_tile_kernel<false, false>(dS, dyn, tp.n_tiles, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -38,8 +40,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        const double* u_r3, const int32_t* s_gb, const double* u_gb, const int32_t* s_ab, const double* u_ab,
                        double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
                        hipStream_t st);
-int launch_tile_pass(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const RowFmt& fv, const RowFmt& fa,
-                     const RowFmt& fg, const TileParams& tp, bool jac, hipStream_t st);
+int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st);
 void launch_lds_poison(hipStream_t st);
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
 void launch_inner_eval(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const double* seg, const InnerBlock* blocks, InnerState* states,
@@ -140,6 +141,7 @@ struct oicc_problem {
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
+  std::unique_ptr<TileStatic> h_tstatic; DevBuf<TileStatic> d_tstatic; bool tstatic_valid = false;   // problem-constant kernel arguments in device memory
   bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
   // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
   struct InnerPlan {
@@ -419,7 +421,7 @@ RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, 
 // largest item count whose records fit `rb` doubles
 void row_fmt_capacity(RowFmt& f, int rb, int max_items) { f.cap = std::max(0, std::min({max_items, 64, rb / f.item_stride})); }
 
-struct TileBuild { std::vector<UnitDesc> units; std::vector<int32_t> unit_tile; std::vector<TileDesc> tiles; int max_rows = 0, max_nks = 0, max_nkr = 0; };
+struct TileBuild { std::vector<UnitDesc> units; std::vector<int32_t> unit_tile; std::vector<TileDesc> tiles; int max_rows = 0, max_nks = 0, max_nkr = 0, max_units = 0; };
 
 // Units (one view / a run of IMU samples, never across a tile boundary) and tiles for `T` fine knot windows per tile.
 void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
@@ -459,7 +461,7 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
   std::vector<UnitDesc> U2(U.size()); std::vector<int32_t> UT2(U.size());
   for (size_t i = 0; i < ord.size(); ++i) { U2[i] = U[ord[i]]; UT2[i] = UT[ord[i]]; }
   U.swap(U2); UT.swap(UT2);
-  out->max_rows = out->max_nks = out->max_nkr = 0;
+  out->max_rows = out->max_nks = out->max_nkr = out->max_units = 0;
   const bool spline = p->act.spline;
   size_t i = 0;
   while (i < U.size()) {
@@ -492,6 +494,7 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
     td.ks0 = ks0; td.nks = ks1 - ks0;
     td.kr0 = kr1 >= 0 ? kr0 : 0; td.nkr = kr1 >= 0 ? kr1 - kr0 : 0;
     out->tiles.push_back(td);
+    out->max_units = std::max(out->max_units, int(j - i));
     out->max_rows = std::max(out->max_rows, int(td.nrows)); out->max_nks = std::max(out->max_nks, int(td.nks)); out->max_nkr = std::max(out->max_nkr, int(td.nkr));
     i = j;
   }
@@ -526,10 +529,10 @@ int build_tiles(oicc_problem* p) {
   const int ratio = int(std::max<int64_t>(1, std::min<int64_t>(8, std::max(p->dt_so3, p->dt_r3) / dt_fine)));
   const int T_user = int(p->opt["tile_windows"]);
   int T = T_user > 0 ? T_user : int(std::max<int64_t>(ratio, std::min<int64_t>(64, n_windows / 200)));
-  auto carve = [&](int nks, int nkr, int acc_doubles) {   // returns total doubles
+  auto carve = [&](int nks, int nkr, int nunits, int acc_doubles) {   // returns total doubles
     int o = 0;
     tp.o_so3 = o; o += nks * 4; tp.o_r3 = o; o += std::max(nkr, 1) * 3; tp.o_seg = o; o += std::max(nks - 1, 1) * 17;
-    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
+    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_units = o; o += 2 * std::max(nunits, 1); tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
     return o;
   };
   TileBuild tb;
@@ -537,7 +540,7 @@ int build_tiles(oicc_problem* p) {
   auto try_T = [&](int t) {   // builds the tiles for t windows; true if they fit
     make_tiles(p, t, &tb);
     if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;
-    return carve(tb.max_nks, tb.max_nkr, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) <= budget;
+    return carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) <= budget;
   };
   bool fits = false;
   while (true) {
@@ -557,7 +560,7 @@ int build_tiles(oicc_problem* p) {
   }
   if (fits) tp.acc_rows = tp.direct ? 0 : tb.max_rows;
   if (!fits) { p->err = "tile geometry does not fit 160 KB LDS"; return OICC_ERR_UNSUPPORTED; }
-  tp.lds_bytes = carve(tb.max_nks, tb.max_nkr, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) * int(sizeof(double));
+  tp.lds_bytes = carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) * int(sizeof(double));
   p->h_tiles.swap(tb.tiles); p->h_units.swap(tb.units);
   tp.n_tiles = int32_t(p->h_tiles.size()); tp.n_units = int32_t(p->h_units.size());
   tp.slab_stride = int64_t(tp.acc_rows) * tp.Wl + tp.corner;
@@ -568,6 +571,19 @@ int build_tiles(oicc_problem* p) {
       const TileDesc& td = p->h_tiles[t];
       for (int r = td.lo; r < td.lo + td.nrows; ++r) { if (!seen[r]) { seen[r] = 1; p->h_row_t0[r] = t; } p->h_row_t1[r] = t + 1; }
     }
+  }
+  // affine guess of the knot ranges (see TileParams): fitted on two interior tiles, used if at least half of the tiles follow it
+  tp.affine = 0;
+  if (tp.n_tiles >= 4) {
+    const TileDesc& A = p->h_tiles[1]; const TileDesc& B = p->h_tiles[2];
+    TileDesc d{}; d.lo = B.lo - A.lo; d.nrows = B.nrows - A.nrows; d.ks0 = B.ks0 - A.ks0; d.nks = B.nks - A.nks; d.kr0 = B.kr0 - A.kr0; d.nkr = B.nkr - A.nkr;
+    TileDesc b{}; b.lo = A.lo - d.lo; b.nrows = A.nrows - d.nrows; b.ks0 = A.ks0 - d.ks0; b.nks = A.nks - d.nks; b.kr0 = A.kr0 - d.kr0; b.nkr = A.nkr - d.nkr;
+    int good = 0;
+    for (int32_t t = 0; t < tp.n_tiles; ++t) {
+      const TileDesc& x = p->h_tiles[t];
+      if (x.ks0 == b.ks0 + t * d.ks0 && x.nks == b.nks + t * d.nks && x.kr0 == b.kr0 + t * d.kr0 && x.nkr == b.nkr + t * d.nkr) ++good;
+    }
+    if (2 * good >= tp.n_tiles) { tp.affine = 1; tp.td0 = b; tp.tds = d; }
   }
   hipStream_t st = p->stream;
   if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) ||
@@ -765,11 +781,30 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   } else {                              // time tiles (kernels_tiles.hip): the slab merge writes every entry of the packed buffer
     if (jac && (p->tp.direct || p->tp.n_tiles == 0)) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
     else if (!jac && !cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
-    ctx.only_kind = only_kind;
-    TileParams tp = p->tp;
+    const TileParams& tp = p->tp;
     p->gmax_folded = jac && want_gmax && !tp.direct && tp.n_tiles > 0 && !p->reduce;   // (with an all-reduce the gradient is only final afterwards)
-    tp.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
-    if (launch_tile_pass(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), p->fv, p->fa, p->fg, tp, jac, st) != 0) {
+    // the problem-constant arguments live in device memory (tiles.h: TileStatic); uploaded when they differ from the last upload
+    if (!p->h_tstatic) { p->h_tstatic.reset(new TileStatic); std::memset(p->h_tstatic.get(), 0, sizeof(TileStatic)); p->tstatic_valid = false; }
+    {
+      static_assert(std::is_trivially_copyable<TileStatic>::value, "TileStatic is copied bytewise");
+      TileStatic S; std::memset(&S, 0, sizeof(S));
+      S.ctx = make_ctx(p, nullptr); S.ctx.ne = p->ne; S.ctx.ne.base = nullptr;
+      S.vd = view_data(p, false); S.vd.view_rs = nullptr;
+      S.ia = imu_data(p->acc, p->d_acc); S.ig = imu_data(p->gyr, p->d_gyr);
+      S.fmt[0] = p->fv; S.fmt[1] = p->fa; S.fmt[2] = p->fg; S.tp = tp; S.tp.gmax = nullptr;
+      if (!p->tstatic_valid || std::memcmp(&S, p->h_tstatic.get(), sizeof(S)) != 0) {
+        if (!p->d_tstatic.resize(1)) { p->err = "hipMalloc tile arguments"; return OICC_ERR_HIP; }
+        *p->h_tstatic = S;
+        HIPCK(p, hipMemcpyAsync(p->d_tstatic.p, p->h_tstatic.get(), sizeof(TileStatic), hipMemcpyHostToDevice, st));
+        HIPCK(p, hipStreamSynchronize(st));   // (rare: layout or measurement changes) the host copy may be rewritten right away
+        p->tstatic_valid = true;
+      }
+    }
+    TileDyn dyn{};
+    dyn.x = x; dyn.ne_base = ne.base; dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
+    dyn.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
+    dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
+    if (launch_tile_pass(*p->h_tstatic, p->d_tstatic.p, dyn, jac, st) != 0) {
       p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
   }
   HIPCK(p, hipGetLastError());
@@ -1435,8 +1470,6 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   return OICC_OK;
 }
 
-// Debug: shader-cycle counters of the solver kernel's phases for the current system
-// [init, prefetch, stepA, barrier1, stepB, barrier2, corner+t, backward].
 // Test hook (host only, no device): next trial step size of the bounds line search from [x, value, slope] triples; prev may be NULL.
 double oicc_debug_ls_next_step_size(const double init[3], const double* prev, int32_t prev_has_slope, const double cur[3], int32_t cur_has_slope) {
   LsSample i, q, c;
@@ -1445,6 +1478,8 @@ double oicc_debug_ls_next_step_size(const double init[3], const double* prev, in
   if (prev) { q.x = prev[0]; q.value = prev[1]; q.gradient = prev[2]; q.has_gradient = prev_has_slope != 0; }
   return ls_next_step_size(i, prev ? &q : nullptr, c);
 }
+// Debug: shader-cycle counters of the solver kernel's phases for the current system
+// [init, prefetch, stepA, barrier1, stepB, barrier2, corner+t, backward].
 int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12]) {
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;
@@ -1465,10 +1500,21 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
 
 // Debug: cycle counters of one mid-grid view block: [phase 1 (spline+residual+Jacobian rows), phase 2+3 (Gram + atomic flush)]
 // kind 0: views, 1: accelerometer, 2: gyroscope -- [evaluation phase, Gram+scatter, MFMA part, scatter part] of the middle chunk
+int oicc_debug_tile_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[8]) {   // kind -1: all units of the tile
+  int rc = prepare(p, flags); if (rc) return rc;
+  DevBuf<long long> d; if (!d.resize(8)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 8 * sizeof(long long), p->stream));
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, kind, false, nullptr, false, d.p);
+  p->reduce = saved; if (rc) return rc;
+  HIPCK(p, hipMemcpyAsync(out, d.p, 8 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  return OICC_OK;
+}
 int oicc_debug_block_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[4]) {
   int rc = prepare(p, flags); if (rc) return rc;
-  DevBuf<long long> d; if (!d.resize(4)) return OICC_ERR_HIP;
-  HIPCK(p, hipMemsetAsync(d.p, 0, 4 * sizeof(long long), p->stream));
+  DevBuf<long long> d; if (!d.resize(8)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 8 * sizeof(long long), p->stream));
   kind %= 10;
   auto saved = p->reduce; p->reduce = nullptr;
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, kind, false, nullptr, false, d.p);

@@ -10,6 +10,7 @@
 // Geometries whose accumulator does not fit in LDS run the same kernel in DIRECT mode (fp64 atomics on the packed buffer).
 #pragma once
 #include <cstdint>
+#include "oicc_device.h"
 
 namespace oicc {
 
@@ -58,12 +59,31 @@ struct TileParams {
   int32_t acc_rows;        // accumulator rows (max over tiles)
   int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
   // LDS carve (in doubles from the start of dynamic LDS)
-  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets | queue | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
+  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_units, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets | queue | the tile's unit descriptors | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
   int32_t rb_doubles;
   int32_t lds_bytes;
   double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]
   double* gmax;            // not null: the merge kernel also leaves max |g| there (LmState::gradient_max_norm), reset by the tile kernel
+  // Regular problems: lo / nrows / ks0 / nks / kr0 / nkr of tile t are td0 + t * tds for (almost) every tile.  The kernel starts its
+  // knot loads from this guess while the descriptor itself is still on its way and repeats them only for the tiles that differ.
+  TileDesc td0, tds; int32_t affine;
   const int32_t* row_t0; const int32_t* row_t1;   // per band row: first / one-past-last tile whose accumulator covers it
+};
+
+// Arguments of tile_kernel.  Everything that only changes with the problem (layouts, measurement arrays, row formats, tile
+// tables: ~1.5 KB) lives in DEVICE memory and is read where it is needed; by value it would be loaded and spilled lane by
+// lane in the kernel's prologue (86 dependent scalar loads, ~9k cycles per workgroup, round-2 measurement).  What changes from
+// launch to launch travels by value.
+struct TileStatic {
+  EvalCtx ctx;            // x / ne.base / dbg_* / prof / only_kind are taken from TileDyn
+  ViewData vd;            // view_rs is taken from TileDyn
+  ImuData ia, ig;
+  RowFmt fmt[3];          // view, accelerometer, gyroscope
+  TileParams tp;          // gmax is taken from TileDyn
+};
+struct TileDyn {
+  const double* x; double* ne_base; double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
+  int32_t only_kind, pad;
 };
 
 }  // namespace oicc
