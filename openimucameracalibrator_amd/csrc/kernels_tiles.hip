@@ -338,22 +338,28 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
       for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0;
     }
     if (tid < 192) {
-      const int kind = tid >> 6, col = tid & 63;
+      const int kind = __builtin_amdgcn_readfirstlane(tid >> 6), col = tid & 63;   // (wave-uniform: the format's fields are scalar loads)
       int ba, fa, grp;
-      column_table_entry(kind == 0 ? fv : (kind == 1 ? fa_ : fg), col, ba, fa, grp);
+      const RowFmt fk = S->fmt[kind];   // (by value: a few wide scalar loads instead of one per field)
+      column_table_entry(fk, col, ba, fa, grp);
       l_ct[tid] = ba; l_ct[192 + tid] = fa; l_ct[384 + tid] = grp;
     }
     if (tid < 128) l_zero[tid] = 0.0;
   }
   // Knots and their tangent offsets: loaded for the knot ranges the affine model of TileParams predicts (clamped to the knot
   // vectors) without waiting for the descriptor, and once more for the few tiles whose descriptor says otherwise.
+  // (at most kMaxTileKnots knots of a kind: one element per thread and array, all four loads in flight before the first LDS store)
+  static_assert(4 * kMaxTileKnots <= kTileThreads, "one staged element per thread");
   auto stage_knots = [&](int ks0, int nks, int kr0, int nkr) {
-    for (int i = tid; i < nks * 4; i += kTileThreads) l_so3[i] = xg[ctx.pl.so3 + (int64_t)ks0 * 4 + i];
-    for (int i = tid; i < nkr * 3; i += kTileThreads) l_r3[i] = xg[ctx.pl.r3 + (int64_t)kr0 * 3 + i];
-    if (JAC) {
-      for (int i = tid; i < nks; i += kTileThreads) l_tl_so3[i] = ctx.tl.so3[ks0 + i];
-      for (int i = tid; i < nkr; i += kTileThreads) l_tl_r3[i] = ctx.tl.r3[kr0 + i];
-    }
+    const bool ha = tid < nks * 4, hb = tid < nkr * 3, hc = JAC && tid < nks, hd = JAC && tid < nkr;
+    const double va = ha ? xg[ctx.pl.so3 + (int64_t)ks0 * 4 + tid] : 0.0;
+    const double vb = hb ? xg[ctx.pl.r3 + (int64_t)kr0 * 3 + tid] : 0.0;
+    const int vc = hc ? ctx.tl.so3[ks0 + tid] : 0;
+    const int vd_ = hd ? ctx.tl.r3[kr0 + tid] : 0;
+    if (ha) l_so3[tid] = va;
+    if (hb) l_r3[tid] = vb;
+    if (hc) l_tl_so3[tid] = vc;
+    if (hd) l_tl_r3[tid] = vd_;
   };
   int g_ks0 = -1, g_nks = 0, g_kr0 = -1, g_nkr = 0;
   if (tp.affine) {
