@@ -189,8 +189,8 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const int* ct_ba, con
 #pragma unroll
   for (int t = 0; t < NP; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   const int li = lane & 15, lq = lane >> 4;
-  const int rows = f.rows_per_item, S = f.item_stride;
-  const int rdiv = rows == 2 ? 0x10000 : 0xAAAB;
+  constexpr int rows = WIDE ? 3 : 2;      // rows per item: 2 for a corner (views never form wide cells), 3 for an IMU sample
+  const int S = f.item_stride;
   int ba[NT], fa[NT]; bool is_s[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) { ba[t] = ct_ba[16 * t + li]; fa[t] = ct_fa[16 * t + li]; is_s[t] = WIDE && (ct_grp[16 * t + li] & 15) == GRP_S; }
@@ -201,9 +201,9 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const int* ct_ba, con
   // (The fp64 MFMA runs on the vector ALU's own datapath: everything in this loop adds to the 64 cycles per MFMA.)
   auto issue_row = [&](int kb, int u, double (&v)[NT], double (&q)[NT]) {
     const int k = kb + 4 * u + lq;
-    const int item = (k * rdiv) >> 17;                                            // k / rows_per_item (k < 2^14)
-    const double* rec = k < r1 ? rb + item * S : zero_rec;
-    const int r = k < r1 ? k - item * rows : 0;
+    const int item = rows == 2 ? k >> 1 : int(__umul24(k, 0xAAAB) >> 17);        // k / rows (k < 2^14); 24-bit multiplies are full rate, v_mul_lo_u32 is not
+    const double* rec = k < r1 ? rb + __umul24(item, S) : zero_rec;
+    const int r = k < r1 ? k - rows * item : 0;
     if (WIDE) {
       const int d = k < r1 ? (reinterpret_cast<const int*>(rec + woff)[0] - s_cell) * 3 * rows : 0;    // the item's window inside the cell
 #pragma unroll
