@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"
 #include "spline_math.cuh"
+#include "spline_seg.cuh"
 
 namespace oicc {
 
@@ -126,7 +127,7 @@ __device__ __forceinline__ void se3_exp_dev(const double a6[6], Quat* q, double 
 // alpha scales the step (1 for the trust-region candidate; the bounds line search of oicc_optimize re-retracts with its
 // step sizes, and then the model cost change of the FULL step is kept: with_model = 0).
 __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, TangentLayout tl, SolveBuffers sb,
-                                  NormalEq ne, double max_ab, double max_gb, double alpha, int with_model) {
+                                  NormalEq ne, double max_ab, double max_gb, double alpha, int with_model, double* seg_out) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   double step_sq = 0.0, x_sq = 0.0, model = 0.0;
@@ -142,12 +143,22 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
     const int o = tl.so3[k];
     const double* q0 = x + pl.so3 + 4 * k;
     double* q1 = xc + pl.so3 + 4 * k;
+    auto moved = [&](int64_t kk) {   // knot kk of the candidate
+      const int ok = tl.so3[kk];
+      const double* q = x + pl.so3 + 4 * kk;
+      const Quat qk{q[0], q[1], q[2], q[3]};
+      if (ok < 0) return qk;
+      const double om[3] = {alpha * (sb.step_s[ok] * sb.scale[ok]), alpha * (sb.step_s[ok + 1] * sb.scale[ok + 1]), alpha * (sb.step_s[ok + 2] * sb.scale[ok + 2])};
+      return so3_mul(qk, so3_exp(om));
+    };
+    const Quat r = moved(k);
     if (o >= 0) {
-      const double om[3] = {alpha * (sb.step_s[o] * sb.scale[o]), alpha * (sb.step_s[o + 1] * sb.scale[o + 1]), alpha * (sb.step_s[o + 2] * sb.scale[o + 2])};
-      const Quat r = so3_mul(Quat{q0[0], q0[1], q0[2], q0[3]}, so3_exp(om));
       q1[0] = r.x; q1[1] = r.y; q1[2] = r.z; q1[3] = r.w;
       for (int c = 0; c < 4; ++c) { const double dd = q1[c] - q0[c]; step_sq += dd * dd; x_sq += q0[c] * q0[c]; }
     }
+    // segment table of the candidate's knot pair (k, k+1) for the residual passes at xc (tiles.h: TileDyn::seg); the neighbour's
+    // retraction is repeated here with the same operations, hence the same bits as its own thread stores
+    if (seg_out != nullptr && k + 1 < pl.n_so3) so3_segment_prepare(r, moved(k + 1), seg_out + k * kSegStride);
   }
   for (int64_t k = tid; k < pl.n_r3; k += nthreads) {
     const int o = tl.r3[k];
@@ -237,10 +248,10 @@ void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   hipLaunchKernelGGL(lm_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag);
 }
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
-                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha, int with_model) {
+                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha, int with_model, double* seg_out) {
   int64_t work = pl.total;
   int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model);
+  hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model, seg_out);
 }
 
 }  // namespace oicc

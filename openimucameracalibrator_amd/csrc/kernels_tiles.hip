@@ -17,6 +17,7 @@
 #include "oicc_device.h"
 #include "tiles.h"
 #include "block_items.cuh"
+static_assert(oicc::kSegDoubles == oicc::kSegStride, "segment table stride");
 
 namespace oicc {
 namespace {
@@ -356,10 +357,19 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     const double vb = hb ? xg[ctx.pl.r3 + (int64_t)kr0 * 3 + tid] : 0.0;
     const int vc = hc ? ctx.tl.so3[ks0 + tid] : 0;
     const int vd_ = hd ? ctx.tl.r3[kr0 + tid] : 0;
+    // segment tables of the staged knot pairs: kSegStride doubles per pair, precomputed for this parameter vector
+    constexpr int kSegPerThread = (kMaxTileKnots * kSegStride + kTileThreads - 1) / kTileThreads;
+    const int nseg = (nks - 1) * kSegStride;
+    const double* sg = dyn.seg + (int64_t)ks0 * kSegStride;
+    double vs[kSegPerThread];
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) { const int i = tid + j * kTileThreads; vs[j] = i < nseg ? sg[i] : 0.0; }
     if (ha) l_so3[tid] = va;
     if (hb) l_r3[tid] = vb;
     if (hc) l_tl_so3[tid] = vc;
     if (hd) l_tl_r3[tid] = vd_;
+#pragma unroll
+    for (int j = 0; j < kSegPerThread; ++j) { const int i = tid + j * kTileThreads; if (i < nseg) l_seg[i] = vs[j]; }
   };
   int g_ks0 = -1, g_nks = 0, g_kr0 = -1, g_nkr = 0;
   if (tp.affine) {
@@ -377,11 +387,6 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   __syncthreads();
   const long long tp1 = prof ? clock64() : 0;
-  for (int i = tid; i < td.nks - 1; i += kTileThreads) {
-    const double* a = l_so3 + 4 * i;
-    so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, l_seg + i * kSegStride);
-  }
-  __syncthreads();
 
   Target T;
   T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;

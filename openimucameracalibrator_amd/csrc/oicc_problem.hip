@@ -48,7 +48,7 @@ void launch_inner_eval(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia
 void launch_inner_step(double* xv, const InnerBlock* blocks, InnerState* states, int b0, int b1, int phase, double max_ab, double max_gb, int32_t* not_done, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
-                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1);
+                       const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st);
 }  // namespace oicc
 
@@ -122,6 +122,11 @@ struct oicc_problem {
   int rccl_nranks = 1;
   // device
   DevBuf<double> d_x, d_xc, d_pts;
+  // segment tables (spline_seg.cuh) of the SO(3) knot pairs of the two parameter buffers, keyed by the buffer's address (d_x.p and
+  // d_xc.p trade places when a step is accepted); valid = computed for the buffer's current contents
+  struct SegTable { DevBuf<double> buf; const double* of = nullptr; bool valid = false; } seg_tab[2];
+  SegTable* seg_of(const double* xbuf) { for (auto& t : seg_tab) if (t.of == xbuf) return &t; return nullptr; }
+  void seg_invalidate(const double* xbuf) { if (SegTable* t = seg_of(xbuf)) t->valid = false; }
   DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
   DevBuf<double> d_cu, d_cv, d_cisx, d_cisy, d_view_u_so3, d_view_u_r3;
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
@@ -216,6 +221,9 @@ int sync_params_to_device(oicc_problem* p) {
   if (!p->x_host_dirty) return OICC_OK;
   if (!p->d_x.resize(p->x.size()) || !p->d_xc.resize(p->x.size())) { p->err = "hipMalloc params"; return OICC_ERR_HIP; }
   HIPCK(p, hipMemcpyAsync(p->d_x.p, p->x.data(), p->x.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  const size_t nseg = size_t(std::max<int64_t>(p->pl.n_so3 - 1, 1)) * kSegDoubles;
+  if (!p->seg_tab[0].buf.resize(nseg) || !p->seg_tab[1].buf.resize(nseg)) { p->err = "hipMalloc segment tables"; return OICC_ERR_HIP; }
+  p->seg_tab[0].of = p->d_x.p; p->seg_tab[1].of = p->d_xc.p; p->seg_tab[0].valid = p->seg_tab[1].valid = false;
   p->x_host_dirty = false;
   return OICC_OK;
 }
@@ -804,7 +812,11 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
         p->tstatic_valid = true;
       }
     }
+    oicc_problem::SegTable* sgt = p->seg_of(x);
+    if (sgt == nullptr) { p->err = "residual pass on an unknown parameter buffer"; return OICC_ERR_STATE; }
+    if (!sgt->valid) { launch_inner_seg(x + p->pl.so3, int(p->pl.n_so3 - 1), sgt->buf.p, st); sgt->valid = true; }
     TileDyn dyn{};
+    dyn.seg = sgt->buf.p;
     dyn.x = x; dyn.ne_base = ne.base; dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
     dyn.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
     dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
@@ -1192,6 +1204,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   if (verbose) std::printf("[oicc] iter 0 cost %.12e gmax %.3e radius %.3e P=%d (band %d hb %d arrow %d)\n", cost, gmax, radius, P, tl.Pb, tl.hb, tl.a);
   if (gmax <= gtol) return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));   // inactive entries of the candidate
+  p->seg_invalidate(p->d_xc.p);
   int iter = 0, invalid = 0;
   bool inner_enabled = false;
   if (p->opt["inner_iterations"] != 0.0) {
@@ -1240,7 +1253,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (launch_lm_solve(p->ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
       p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
       return OICC_ERR_UNSUPPORTED; }
-    launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
+    {   // the retraction also leaves the candidate's segment tables (one kernel fewer per cost pass)
+      oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
+      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, sgt ? sgt->buf.p : nullptr);
+      if (sgt) sgt->valid = true;
+    }
     HIPCK(p, hipGetLastError());
     // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave last-bit
     // differences in the step.  Rank 0's candidate parameters (<= 0.9 MB at C5) and its step scalars (model cost change, step
@@ -1248,6 +1265,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
       if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 || rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) {
         p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+      p->seg_invalidate(p->d_xc.p);   // rank 0's knots replaced this rank's
     }
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
@@ -1270,6 +1288,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
         auto trial = [&](double alpha, double* value) -> int {
           HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, 2 * sizeof(double), st));   // step_norm_sq, x_norm_sq
           launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, alpha, 0);
+          p->seg_invalidate(p->d_xc.p);
           if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
               rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
           int r = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (r) return r;
@@ -1306,6 +1325,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       cand_before_inner = pin->cost;
       if (std::isfinite(cand_before_inner)) {
         rc = inner_sweep(p, p->d_xc.p); if (rc) return rc;
+        p->seg_invalidate(p->d_xc.p);
         rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
         HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, sizeof(double), st));
         launch_inner_diff_norm(p->d_x.p, p->d_xc.p, p->inner.d_blocks.p, int(p->inner.blocks.size()), &p->d_state.p->step_norm_sq, st);
@@ -1404,6 +1424,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   oicc_problem::HostPin* pin = p->pin;
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));
+  p->seg_invalidate(p->d_xc.p);
   // Same pipeline as oicc_optimize with every step accepted: the Jacobian pass of the NEXT iteration (here: at x again)
   // is enqueued into the second buffer right behind the read-back copies, the host waits for the copies only.
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
@@ -1411,9 +1432,16 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   if (!p->gmax_folded) launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
   for (int it = 0; it < steps; ++it) {
     if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
-    launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st);
-    if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
-        rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+    {
+      oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
+      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, sgt ? sgt->buf.p : nullptr);
+      if (sgt) sgt->valid = true;
+    }
+    if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
+      if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
+          rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+      p->seg_invalidate(p->d_xc.p);
+    }
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));

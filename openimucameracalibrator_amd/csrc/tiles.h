@@ -16,6 +16,7 @@ namespace oicc {
 
 constexpr int kTileWaves = 4;
 constexpr int kTileThreads = 64 * kTileWaves;
+constexpr int kSegDoubles = 17;       // = kSegStride of spline_seg.cuh (checked in kernels_tiles.hip): doubles of one knot pair's segment table
 constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 / r3)
 
 struct TileDesc {
@@ -82,7 +83,8 @@ struct TileStatic {
   TileParams tp;          // gmax is taken from TileDyn
 };
 struct TileDyn {
-  const double* x; double* ne_base; double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
+  const double* x; const double* seg;   // seg: kSegStride doubles per SO(3) knot pair of x (spline_seg.cuh), computed once per parameter vector
+  double* ne_base; double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
   int32_t only_kind, pad;
 };
 
