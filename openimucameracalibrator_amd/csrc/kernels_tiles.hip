@@ -501,9 +501,25 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   const long long tp3 = prof ? clock64() : 0;
   if (!DIRECT) {
     __syncthreads();
+    // Rows no other tile touches ([x0, x1): the tile's interior) are final: their band rows are one contiguous piece of the
+    // packed band, their arrow columns and gradient entries contiguous pieces of Et / g -- flat, coalesced stores.  The halo
+    // rows and the arrow corner go to the slab for the merge.
     double* slab = tp.slabs + (int64_t)blockIdx.x * tp.slab_stride;
-    const int nacc = td.nrows * tp.Wl;
-    for (int i = tid; i < nacc; i += kTileThreads) slab[i] = acc[i];
+    const int Wl = tp.Wl, W = T.W, a = T.a, Pb = T.Pb, x0 = td.x0, x1 = td.x1, nown = x1 - x0;
+    for (int i = tid; i < x0 * Wl; i += kTileThreads) slab[i] = acc[i];
+    for (int i = x1 * Wl + tid; i < td.nrows * Wl; i += kTileThreads) slab[i] = acc[i];
+    if (nown > 0) {
+      const unsigned magic = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);     // idx / W for idx < 2^16
+      double* band = T.ne.band() + (int64_t)(td.lo + x0) * W;
+      for (int idx = tid; idx < nown * W; idx += kTileThreads) {
+        const int r = int(__umulhi((unsigned)idx, magic)), e = idx - r * W;
+        band[idx] = acc[(x0 + r) * Wl + e];
+      }
+      for (int c = wave; c <= a; c += kTileWaves) {
+        double* dst = (c < a ? T.ne.Et() + (int64_t)c * Pb : T.ne.g()) + td.lo + x0;
+        for (int r = lane; r < nown; r += 64) dst[r] = acc[(x0 + r) * Wl + W + c];
+      }
+    }
     for (int i = tid; i < tp.corner; i += kTileThreads) slab[tp.acc_rows * tp.Wl + i] = acc[tp.acc_rows * tp.Wl + i];
   }
   if (prof && lane == 0) {   // [4] staging, [5] segment tables, [6] the wave's units, [7] wait for the other waves + slab stores
@@ -516,27 +532,53 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
 // Packed normal equations from the slabs.  Blocks [0, nb_rows): one thread per (band row, accumulator column), the
 // overlapping tiles of the row summed in tile order; blocks [nb_rows, nb_rows + corner): one block per entry of the
 // arrow corner [C | g ; . | 2 cost], reduced over all tiles.
-__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows) {
+template <int kMergeU>
+__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows, int nb_g) {
   const int b = blockIdx.x;
   if (b < nb_rows) {
-    const int64_t idx = (int64_t)b * 256 + threadIdx.x;
-    if (idx >= (int64_t)tl.Pb * tp.Wl) return;
-    const int i = int(idx / tp.Wl), e = int(idx - (int64_t)i * tp.Wl);
-    double s = 0.0;
-    for (int t = tp.row_t0[i]; t < tp.row_t1[i]; ++t) {
-      const int r = i - tp.tiles[t].lo;                                // tiles between the first and the last one that cover the row need not cover it
-      if (r >= 0 && r < tp.tiles[t].nrows) s += tp.slabs[(int64_t)t * tp.slab_stride + (int64_t)r * tp.Wl + e];
+    // kMergeU entries per thread, a quarter of the index space apart: the three dependent loads of an entry (row tables ->
+    // slab offsets -> slab values) are issued for all of them before the first is needed (the kernel is latency bound otherwise)
+    const int64_t total = (int64_t)tp.n_merge_rows * tp.Wl, stride = (int64_t)nb_rows * 256;
+    int i[kMergeU], e[kMergeU], k0[kMergeU], k1[kMergeU]; bool ok[kMergeU];
+#pragma unroll
+    for (int u = 0; u < kMergeU; ++u) {
+      const int64_t idx = (int64_t)b * 256 + threadIdx.x + u * stride;
+      ok[u] = idx < total;
+      const int h = ok[u] ? int(idx / tp.Wl) : 0;
+      e[u] = ok[u] ? int(idx - (int64_t)h * tp.Wl) : 0;
+      i[u] = tp.merge_rows[h]; k0[u] = tp.merge_ptr[h]; k1[u] = ok[u] ? tp.merge_ptr[h + 1] : k0[u];
     }
-    if (e < tl.W) ne.band()[(int64_t)i * tl.W + e] = s;
-    else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + i] = s;
-    else if (e == tl.W + tl.a) {                                         // (a padding column of the accumulator row carries nothing)
-      ne.g()[i] = s;
-      if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(s)));   // non-negative doubles order like their bit patterns
+    int64_t s0[kMergeU], s1[kMergeU];
+#pragma unroll
+    for (int u = 0; u < kMergeU; ++u) { s0[u] = k1[u] > k0[u] ? tp.merge_src[k0[u]] : -1; s1[u] = k1[u] > k0[u] + 1 ? tp.merge_src[k0[u] + 1] : -1; }
+    double v0[kMergeU], v1[kMergeU];
+#pragma unroll
+    for (int u = 0; u < kMergeU; ++u) { v0[u] = s0[u] >= 0 ? tp.slabs[s0[u] + e[u]] : 0.0; v1[u] = s1[u] >= 0 ? tp.slabs[s1[u] + e[u]] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < kMergeU; ++u) {
+      if (!ok[u]) continue;
+      double s = v0[u] + v1[u];                                          // (tile order: a fixed summation order)
+      for (int k = k0[u] + 2; k < k1[u]; ++k) s += tp.slabs[tp.merge_src[k] + e[u]];
+      const int ii = i[u], ee = e[u];
+      if (ee < tl.W) ne.band()[(int64_t)ii * tl.W + ee] = s;
+      else if (ee < tl.W + tl.a) ne.Et()[(int64_t)(ee - tl.W) * tl.Pb + ii] = s;
+      else if (ee == tl.W + tl.a) {                                      // (a padding column of the accumulator row carries nothing)
+        ne.g()[ii] = s;
+        if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(s)));   // non-negative doubles order like their bit patterns
+      }
     }
     return;
   }
   __shared__ double red[256];
-  const int ent = b - nb_rows, a1 = tl.a + 1;
+  if (b < nb_rows + nb_g) {   // max |g| over the rows the tiles stored themselves
+    const int i = (b - nb_rows) * 256 + threadIdx.x;
+    red[threadIdx.x] = (i < tl.Pb && tp.row_direct[i]) ? fabs(ne.g()[i]) : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(red[0]));
+    return;
+  }
+  const int ent = b - nb_rows - nb_g, a1 = tl.a + 1;
   const int p = ent / a1, q = ent - p * a1;
   if (p > q) return;
   double s = 0.0;
@@ -581,10 +623,14 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
     if (tp.direct) launch_tile_kernel<true, true>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
     else {
       launch_tile_kernel<true, false>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
-      const int nb_rows = int(((int64_t)hS.ctx.tl.Pb * tp.Wl + 255) / 256);
+      const int64_t entries = (int64_t)tp.n_merge_rows * tp.Wl;
+      const int U = entries > (int64_t)256 * 2048 * 4 ? 4 : 1;           // several entries per thread only when there are enough workgroups to fill the chip anyway
+      const int nb_rows = int((entries + 256 * U - 1) / (256 * U));
+      const int nb_g = (dyn.gmax != nullptr && tp.n_merge_rows < hS.ctx.tl.Pb) ? (hS.ctx.tl.Pb + 255) / 256 : 0;
       TileParams tpm = tp; tpm.gmax = dyn.gmax;
       NormalEq ne = hS.ctx.ne; ne.base = dyn.ne_base;
-      hipLaunchKernelGGL(slab_merge_kernel, dim3(nb_rows + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows);
+      if (U == 4) hipLaunchKernelGGL(slab_merge_kernel<4>, dim3(nb_rows + nb_g + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_g);
+      else hipLaunchKernelGGL(slab_merge_kernel<1>, dim3(nb_rows + nb_g + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_g);
     }
   } else {
     launch_tile_kernel<false, false>(dS, dyn, tp.n_tiles, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only

@@ -143,7 +143,8 @@ struct oicc_problem {
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
-  std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1;
+  std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1, h_merge_rows; std::vector<uint8_t> h_row_direct;
+  DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
   std::unique_ptr<TileStatic> h_tstatic; DevBuf<TileStatic> d_tstatic; bool tstatic_valid = false;   // problem-constant kernel arguments in device memory
@@ -173,6 +174,7 @@ struct oicc_problem {
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
+    opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
     opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
     opt["debug_sync"] = 0;       // 1: drain the stream after every pass (debugging of inter-kernel hazards)
     opt["debug_poison_lds"] = 0; // 1: fill every CU's LDS with NaNs before each Jacobian / cost pass and each linear solve (tests)
@@ -583,7 +585,36 @@ int build_tiles(oicc_problem* p) {
       const TileDesc& td = p->h_tiles[t];
       for (int r = td.lo; r < td.lo + td.nrows; ++r) { if (!seen[r]) { seen[r] = 1; p->h_row_t0[r] = t; } p->h_row_t1[r] = t + 1; }
     }
+    // rows of exactly one tile (its interior): the longest run of them is stored by the tile itself (TileDesc::x0, x1)
+    for (int32_t t = 0; t < tp.n_tiles; ++t) {
+      TileDesc& td = p->h_tiles[t];
+      td.x0 = td.x1 = 0;
+      if (p->opt["debug_no_direct_rows"] != 0.0) continue;
+      int best0 = 0, best1 = 0, run0 = -1;
+      for (int r = 0; r <= td.nrows; ++r) {
+        const bool own = r < td.nrows && p->h_row_t1[td.lo + r] - p->h_row_t0[td.lo + r] == 1;
+        if (own && run0 < 0) run0 = r;
+        if (!own && run0 >= 0) { if (r - run0 > best1 - best0) { best0 = run0; best1 = r; } run0 = -1; }
+      }
+      td.x0 = best0; td.x1 = best1;
+    }
   }
+  p->h_row_direct.assign(std::max(tl.Pb, 1), 0);
+  if (!tp.direct) for (const TileDesc& td : p->h_tiles) for (int r = td.x0; r < td.x1; ++r) p->h_row_direct[td.lo + r] = 1;
+  p->h_merge_rows.clear();
+  for (int i = 0; i < tl.Pb; ++i) if (!p->h_row_direct[i]) p->h_merge_rows.push_back(i);
+  tp.n_merge_rows = int32_t(p->h_merge_rows.size());
+  if (p->h_merge_rows.empty()) p->h_merge_rows.push_back(0);
+  p->h_merge_ptr.assign(1, 0); p->h_merge_src.clear();
+  if (!tp.direct) for (int32_t h = 0; h < tp.n_merge_rows; ++h) {
+    const int i = p->h_merge_rows[h];
+    for (int32_t t = p->h_row_t0[i]; t < p->h_row_t1[i]; ++t) {       // tiles between the first and the last one that cover the row need not cover it
+      const int r = i - p->h_tiles[t].lo;
+      if (r >= 0 && r < p->h_tiles[t].nrows) p->h_merge_src.push_back(int64_t(t) * tp.slab_stride + int64_t(r) * tp.Wl);
+    }
+    p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size()));
+  }
+  if (p->h_merge_src.empty()) p->h_merge_src.push_back(0);
   // affine guess of the knot ranges (see TileParams): fitted on two interior tiles, used if at least half of the tiles follow it
   tp.affine = 0;
   if (tp.n_tiles >= 4) {
@@ -598,11 +629,11 @@ int build_tiles(oicc_problem* p) {
     if (2 * good >= tp.n_tiles) { tp.affine = 1; tp.td0 = b; tp.tds = d; }
   }
   hipStream_t st = p->stream;
-  if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) ||
+  if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) || !p->d_merge_rows.upload(p->h_merge_rows, st) || !p->d_merge_ptr.upload(p->h_merge_ptr, st) || !p->d_merge_src.upload(p->h_merge_src, st) || !p->d_row_direct.upload(p->h_row_direct, st) ||
       !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_tiles) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows, %d units, accumulator %d rows x %d (+%d), row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
                                            tp.n_tiles, T, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
-  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.row_t0 = p->d_row_t0.p; tp.row_t1 = p->d_row_t1.p; tp.slabs = p->d_slabs.p;
+  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.row_t0 = p->d_row_t0.p; tp.row_t1 = p->d_row_t1.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.row_direct = p->d_row_direct.p;
   return OICC_OK;
 }
 

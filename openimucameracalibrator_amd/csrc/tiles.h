@@ -24,6 +24,7 @@ struct TileDesc {
   int32_t lo, nrows;      // band rows [lo, lo + nrows) of the tangent layout accumulated by this tile
   int32_t ks0, nks;       // SO(3) knots staged: [ks0, ks0 + nks)
   int32_t kr0, nkr;       // R^3 knots staged
+  int32_t x0, x1;         // accumulator rows [x0, x1) belong to no other tile: they go straight into the packed normal equations, the rest into the slab
 };
 struct UnitDesc {
   int32_t kind;           // 0 view (items = corners of ONE view), 1 accelerometer samples, 2 gyroscope samples
@@ -69,6 +70,9 @@ struct TileParams {
   // knot loads from this guess while the descriptor itself is still on its way and repeats them only for the tiles that differ.
   TileDesc td0, tds; int32_t affine;
   const int32_t* row_t0; const int32_t* row_t1;   // per band row: first / one-past-last tile whose accumulator covers it
+  const int32_t* merge_rows; int32_t n_merge_rows;   // the band rows the merge kernel sums from slabs (every row that is not some tile's interior row)
+  const int32_t* merge_ptr; const int64_t* merge_src; // CSR over merge_rows: offsets (in doubles) of the slab rows to add, in tile order
+  const uint8_t* row_direct;                          // per band row: 1 = stored by its tile
 };
 
 // Arguments of tile_kernel.  Everything that only changes with the problem (layouts, measurement arrays, row formats, tile
