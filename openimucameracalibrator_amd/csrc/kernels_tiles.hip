@@ -499,6 +499,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   }
   // ---- P2: accumulator -> slab ----
   const long long tp3 = prof ? clock64() : 0;
+  if (JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0) { dyn.prof[8 + wave] = clock64(); if (wave == 0) dyn.prof[12] = tp0; }   // when each wave ran out of units
   if (!DIRECT) {
     __syncthreads();
     // Rows no other tile touches ([x0, x1): the tile's interior) are final: their band rows are one contiguous piece of the

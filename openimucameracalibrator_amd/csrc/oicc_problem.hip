@@ -556,17 +556,28 @@ int build_tiles(oicc_problem* p) {
     if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;
     return carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) <= budget;
   };
+  // Automatic tile length: a workgroup costs a fixed ~3.75 windows' worth of time (launch, staging, first-unit latency, flush:
+  // fitted on C2 ... C5, scripts/time_tile_windows.py) plus its windows, and the tiles run in ceil(tiles / CUs) rounds:
+  //   cost(T) ~ ceil(ceil(n_windows / T) / CUs) * (3.75 + T);
+  // the candidates (multiples of the window ratio) are tried in order of that cost until one fits LDS.
+  int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); if (n_cu < 1) n_cu = 256;
   bool fits = false;
   while (true) {
-    auto snap = [&](int t) { return T_user > 0 ? std::max(t, 1) : std::max((t / ratio) * ratio, std::min(ratio, std::max(t, 1))); };
-    int t = snap(T), t_fail = 1 << 30;
-    while (!(fits = try_T(t))) {          // geometric descent to the first length that fits ...
-      if (t <= 1) break;
-      t_fail = t; t = snap(t > 4 ? t * 3 / 4 : t - 1); if (t >= t_fail) t = t_fail - 1;
-    }
-    if (fits && T_user <= 0 && t_fail < (1 << 30)) {   // ... then back up in steps of the window ratio
-      while (t + ratio < t_fail && try_T(t + ratio)) t += ratio;
-      fits = try_T(t);                    // leave tb built for the chosen length
+    int t = std::max(T, 1);
+    if (T_user > 0) fits = try_T(t);
+    else {
+      std::vector<std::pair<double, int>> cand;
+      for (int c = ratio; c <= 64; c += ratio) {
+        const int64_t tiles = (n_windows + c - 1) / c;
+        cand.push_back({double((tiles + n_cu - 1) / n_cu) * (3.75 + c) - 1e-6 * c, c});   // (ties: the longer tile, less halo traffic)
+      }
+      std::sort(cand.begin(), cand.end());
+      int smallest_fail = 1 << 30;
+      for (const auto& c : cand) {
+        if (c.second >= smallest_fail) continue;            // a shorter tile already failed to fit
+        if ((fits = try_T(c.second))) { t = c.second; break; }
+        smallest_fail = std::min(smallest_fail, c.second);
+      }
     }
     if (fits) { T = t; break; }
     if (tp.direct) break;
@@ -1563,21 +1574,21 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
 
 // Debug: cycle counters of one mid-grid view block: [phase 1 (spline+residual+Jacobian rows), phase 2+3 (Gram + atomic flush)]
 // kind 0: views, 1: accelerometer, 2: gyroscope -- [evaluation phase, Gram+scatter, MFMA part, scatter part] of the middle chunk
-int oicc_debug_tile_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[8]) {   // kind -1: all units of the tile
+int oicc_debug_tile_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[16]) {   // kind -1: all units of the tile
   int rc = prepare(p, flags); if (rc) return rc;
-  DevBuf<long long> d; if (!d.resize(8)) return OICC_ERR_HIP;
-  HIPCK(p, hipMemsetAsync(d.p, 0, 8 * sizeof(long long), p->stream));
+  DevBuf<long long> d; if (!d.resize(16)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 16 * sizeof(long long), p->stream));
   auto saved = p->reduce; p->reduce = nullptr;
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, kind, false, nullptr, false, d.p);
   p->reduce = saved; if (rc) return rc;
-  HIPCK(p, hipMemcpyAsync(out, d.p, 8 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipMemcpyAsync(out, d.p, 16 * sizeof(long long), hipMemcpyDeviceToHost, p->stream));
   HIPCK(p, hipStreamSynchronize(p->stream));
   return OICC_OK;
 }
 int oicc_debug_block_profile(oicc_problem* p, int32_t flags, int32_t kind, long long out[4]) {
   int rc = prepare(p, flags); if (rc) return rc;
-  DevBuf<long long> d; if (!d.resize(8)) return OICC_ERR_HIP;
-  HIPCK(p, hipMemsetAsync(d.p, 0, 8 * sizeof(long long), p->stream));
+  DevBuf<long long> d; if (!d.resize(16)) return OICC_ERR_HIP;
+  HIPCK(p, hipMemsetAsync(d.p, 0, 16 * sizeof(long long), p->stream));
   kind %= 10;
   auto saved = p->reduce; p->reduce = nullptr;
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, kind, false, nullptr, false, d.p);

@@ -8,10 +8,11 @@ cal = E.ImuCameraCalibrator().BatchInitSpline(synthetic.make_config(cfg))
 tr = cal.trajectory_
 f = tr._b.lib.oicc_debug_tile_profile
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_longlong)]
-out = (C.c_longlong * 8)()
+out = (C.c_longlong * 16)()
 for kind in kinds:
     for k in range(3):
         rc = f(tr._h, E.SPLINE | E.T_I_C | E.GRAVITY_DIR, kind, out)
         if k == 0: continue
         print(cfg, "kind", kind, rc, "eval %d gram %d (mfma %d scatter %d) | staging %d segments %d units %d wait+flush %d | total %d" % (
-            out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[4] + out[5] + out[6] + out[7]))
+            out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[4] + out[5] + out[6] + out[7]),
+            "| waves out of units at", [out[8 + w] - out[12] for w in range(4)])
