@@ -492,9 +492,12 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     }
   }
 
-  if (!JAC) {
+  if (!JAC) {   // cost pass: one atomic per tile (the cost slot is a single address: thousands of atomics on it serialise)
     const double s = wave_sum_d(cost_local);
-    if (lane == 0 && s != 0.0) unsafeAtomicAdd(dyn.ne_base + ctx.ne.off_cost, s);
+    double* part = lds + tp.o_misc + 2;
+    if (lane == 0) part[wave] = s;
+    __syncthreads();
+    if (tid == 0) { const double t = (part[0] + part[1]) + (part[2] + part[3]); if (t != 0.0) unsafeAtomicAdd(dyn.ne_base + ctx.ne.off_cost, t); }
     return;
   }
   // ---- P2: accumulator -> slab ----
@@ -533,20 +536,25 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
 // Packed normal equations from the slabs.  Blocks [0, nb_rows): one thread per (band row, accumulator column), the
 // overlapping tiles of the row summed in tile order; blocks [nb_rows, nb_rows + corner): one block per entry of the
 // arrow corner [C | g ; . | 2 cost], reduced over all tiles.
+// Block ranges: [0, nb_rows) band + arrow entries of the merge rows; [nb_rows, nb_rows + nb_gm) their gradient entries;
+// then nb_gd blocks that take max |g| over the rows the tiles stored themselves; then one block per entry of the arrow corner.
+// max |g| (LmState::gradient_max_norm, tp.gmax) is reduced per block first: one atomic per block, and only few blocks carry
+// gradient entries -- thousands of atomicMax on one address cost more than the whole merge (15 us at C2, round-2 profile).
 template <int kMergeU>
-__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows, int nb_g) {
+__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows, int nb_gm, int nb_gd) {
   const int b = blockIdx.x;
   if (b < nb_rows) {
     // kMergeU entries per thread, a quarter of the index space apart: the three dependent loads of an entry (row tables ->
     // slab offsets -> slab values) are issued for all of them before the first is needed (the kernel is latency bound otherwise)
-    const int64_t total = (int64_t)tp.n_merge_rows * tp.Wl, stride = (int64_t)nb_rows * 256;
+    const int WA = tl.W + tl.a;
+    const int64_t total = (int64_t)tp.n_merge_rows * WA, stride = (int64_t)nb_rows * 256;
     int i[kMergeU], e[kMergeU], k0[kMergeU], k1[kMergeU]; bool ok[kMergeU];
 #pragma unroll
     for (int u = 0; u < kMergeU; ++u) {
       const int64_t idx = (int64_t)b * 256 + threadIdx.x + u * stride;
       ok[u] = idx < total;
-      const int h = ok[u] ? int(idx / tp.Wl) : 0;
-      e[u] = ok[u] ? int(idx - (int64_t)h * tp.Wl) : 0;
+      const int h = ok[u] ? int(idx / WA) : 0;
+      e[u] = ok[u] ? int(idx - (int64_t)h * WA) : 0;
       i[u] = tp.merge_rows[h]; k0[u] = tp.merge_ptr[h]; k1[u] = ok[u] ? tp.merge_ptr[h + 1] : k0[u];
     }
     int64_t s0[kMergeU], s1[kMergeU];
@@ -562,24 +570,38 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
       for (int k = k0[u] + 2; k < k1[u]; ++k) s += tp.slabs[tp.merge_src[k] + e[u]];
       const int ii = i[u], ee = e[u];
       if (ee < tl.W) ne.band()[(int64_t)ii * tl.W + ee] = s;
-      else if (ee < tl.W + tl.a) ne.Et()[(int64_t)(ee - tl.W) * tl.Pb + ii] = s;
-      else if (ee == tl.W + tl.a) {                                      // (a padding column of the accumulator row carries nothing)
-        ne.g()[ii] = s;
-        if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(s)));   // non-negative doubles order like their bit patterns
-      }
+      else ne.Et()[(int64_t)(ee - tl.W) * tl.Pb + ii] = s;
     }
     return;
   }
   __shared__ double red[256];
-  if (b < nb_rows + nb_g) {   // max |g| over the rows the tiles stored themselves
-    const int i = (b - nb_rows) * 256 + threadIdx.x;
-    red[threadIdx.x] = (i < tl.Pb && tp.row_direct[i]) ? fabs(ne.g()[i]) : 0.0;
+  if (b < nb_rows + nb_gm + nb_gd) {
+    double m = 0.0;
+    if (b < nb_rows + nb_gm) {   // gradient entries of the merge rows: kMergeU rows per thread
+      const int ge = tl.W + tl.a;
+#pragma unroll
+      for (int u = 0; u < kMergeU; ++u) {
+        const int h = ((b - nb_rows) * kMergeU + u) * 256 + threadIdx.x;
+        if (h < tp.n_merge_rows) {
+          double s = 0.0;
+          for (int k = tp.merge_ptr[h]; k < tp.merge_ptr[h + 1]; ++k) s += tp.slabs[tp.merge_src[k] + ge];
+          ne.g()[tp.merge_rows[h]] = s;
+          m = fmax(m, fabs(s));
+        }
+      }
+    } else {                     // rows stored by their tiles: 16 per thread
+      const int i0 = (b - nb_rows - nb_gm) * 4096 + threadIdx.x;
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) { const int i = i0 + 256 * k; if (i < tl.Pb && tp.row_direct[i]) m = fmax(m, fabs(ne.g()[i])); }
+    }
+    if (tp.gmax == nullptr) return;
+    red[threadIdx.x] = m;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-    if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(red[0]));
+    if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(red[0]));   // non-negative doubles order like their bit patterns
     return;
   }
-  const int ent = b - nb_rows - nb_g, a1 = tl.a + 1;
+  const int ent = b - nb_rows - nb_gm - nb_gd, a1 = tl.a + 1;
   const int p = ent / a1, q = ent - p * a1;
   if (p > q) return;
   double s = 0.0;
@@ -624,14 +646,16 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
     if (tp.direct) launch_tile_kernel<true, true>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
     else {
       launch_tile_kernel<true, false>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
-      const int64_t entries = (int64_t)tp.n_merge_rows * tp.Wl;
+      const int64_t entries = (int64_t)tp.n_merge_rows * (hS.ctx.tl.W + hS.ctx.tl.a);
       const int U = entries > (int64_t)256 * 2048 * 4 ? 4 : 1;           // several entries per thread only when there are enough workgroups to fill the chip anyway
       const int nb_rows = int((entries + 256 * U - 1) / (256 * U));
-      const int nb_g = (dyn.gmax != nullptr && tp.n_merge_rows < hS.ctx.tl.Pb) ? (hS.ctx.tl.Pb + 255) / 256 : 0;
+      const int nb_gm = (tp.n_merge_rows + 256 * U - 1) / (256 * U);
+      const int nb_gd = (dyn.gmax != nullptr && tp.n_merge_rows < hS.ctx.tl.Pb) ? (hS.ctx.tl.Pb + 4095) / 4096 : 0;
       TileParams tpm = tp; tpm.gmax = dyn.gmax;
       NormalEq ne = hS.ctx.ne; ne.base = dyn.ne_base;
-      if (U == 4) hipLaunchKernelGGL(slab_merge_kernel<4>, dim3(nb_rows + nb_g + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_g);
-      else hipLaunchKernelGGL(slab_merge_kernel<1>, dim3(nb_rows + nb_g + tp.corner), dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_g);
+      const dim3 grid(nb_rows + nb_gm + nb_gd + tp.corner);
+      if (U == 4) hipLaunchKernelGGL(slab_merge_kernel<4>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
+      else hipLaunchKernelGGL(slab_merge_kernel<1>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
     }
   } else {
     launch_tile_kernel<false, false>(dS, dyn, tp.n_tiles, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only
