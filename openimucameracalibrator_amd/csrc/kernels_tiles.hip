@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     double* part = lds + tp.o_misc + 2;
     if (lane == 0) part[wave] = s;
     __syncthreads();
-    if (tid == 0) { const double t = (part[0] + part[1]) + (part[2] + part[3]); if (t != 0.0) unsafeAtomicAdd(dyn.ne_base + ctx.ne.off_cost, t); }
+    if (tid == 0) { const double t = (part[0] + part[1]) + (part[2] + part[3]); if (t != 0.0) unsafeAtomicAdd(dyn.cost_out, t); }
     return;
   }
   // ---- P2: accumulator -> slab ----

@@ -816,7 +816,8 @@ int inner_sweep(oicc_problem* p, double* xv) {
 
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
-              bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false) {
+              bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false,
+              double* cost_out = nullptr) {   // cost_out (tile assembly, cost passes): device address the cost is added to instead of the cost slot
   p->gmax_folded = false;
   hipStream_t st = p->stream;
   EvalCtx ctx = make_ctx(p, x);
@@ -859,7 +860,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
     if (!sgt->valid) { launch_inner_seg(x + p->pl.so3, int(p->pl.n_so3 - 1), sgt->buf.p, st); sgt->valid = true; }
     TileDyn dyn{};
     dyn.seg = sgt->buf.p;
-    dyn.x = x; dyn.ne_base = ne.base; dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
+    dyn.x = x; dyn.ne_base = ne.base; dyn.cost_out = (!jac && cost_out) ? cost_out : ne.cost(); dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
     dyn.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
     dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
     if (launch_tile_pass(*p->h_tstatic, p->d_tstatic.p, dyn, jac, st) != 0) {
@@ -868,7 +869,8 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   HIPCK(p, hipGetLastError());
   if (p->opt["debug_sync"] != 0.0) HIPCK(p, hipStreamSynchronize(st));
   if (p->reduce) {
-    int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, ne.cost(), 1, st);
+    double* cdst = (!jac && cost_out && int(p->opt["assembly"]) != 1) ? cost_out : ne.cost();
+    int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, cdst, 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   }
   return OICC_OK;
@@ -1219,15 +1221,20 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   // before the next step is taken, so the iterate sequence is the reference's).
   oicc_problem::HostPin* pin = p->pin;
   hipEvent_t* ev = p->ev;
-  auto read_back = [&]() -> int {
+  // The candidate's cost is accumulated in LmState::cand_cost (tile assembly), so that ONE small copy brings back everything the
+  // host decides on; the cost slot of the normal equations is only read where a Jacobian pass left the cost there.
+  const bool cost_in_state = int(p->opt["assembly"]) != 1;
+  double* const cand_dst = cost_in_state ? &p->d_state.p->cand_cost : nullptr;
+  auto cand_cost_of = [&]() { return cost_in_state ? pin->st.cand_cost : pin->cost; };
+  auto read_back = [&](bool with_ne_cost = false) -> int {
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
-    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
+    if (with_ne_cost || !cost_in_state) HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipStreamSynchronize(st)); return OICC_OK; };
   // read-back without draining the stream: the host waits for an event recorded right after the two copies, so that
   // work enqueued behind it (the Jacobian pass at the candidate) runs while the host takes the accept/reject decision
   auto read_back_begin = [&]() -> int {
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
-    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!cost_in_state) HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipEventRecord(ev[5], st)); return OICC_OK; };
   auto read_back_wait = [&]() -> int { HIPCK(p, hipEventSynchronize(ev[5])); return OICC_OK; };
   auto elapsed_s = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? double(ms) * 1e-3 : 0.0; };
@@ -1237,7 +1244,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
   if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); if (!p->gmax_folded) launch_lm_gradmax(p->ne, P, p->d_state.p, st); }
-  rc = read_back(); if (rc) return rc;
+  rc = read_back(true); if (rc) return rc;
   cost = pin->cost; gmax = pin->st.gradient_max_norm;
   S.seconds_jacobian += now_s() - t0;
   S.initial_cost = cost;
@@ -1310,7 +1317,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       p->seg_invalidate(p->d_xc.p);   // rank 0's knots replaced this rank's
     }
     HIPCK(p, hipEventRecord(ev[1], st));
-    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
+    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cand_dst); if (rc) return rc;   // (cost slot cleared by lm_retract_kernel, cand_cost by the solver's build kernel)
     // Bounds line search (TrustRegionMinimizer::DoLineSearch): with box-bounded bias knots among the variables Ceres shortens
     // the step by an Armijo search along x(alpha) = project(x (+) alpha delta), alpha_0 = 1, cubic interpolation, before the
     // candidate is judged.  Host-driven: every trial is one retraction + cost pass, a failed trial adds one Jacobian pass for
@@ -1328,17 +1335,17 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       const double g0 = pin->ls[0], dmax = pin->ls[1];
       if (step_ok && std::isfinite(g0)) {
         auto trial = [&](double alpha, double* value) -> int {
-          HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, 2 * sizeof(double), st));   // step_norm_sq, x_norm_sq
+          HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, 3 * sizeof(double), st));   // step_norm_sq, x_norm_sq, cand_cost
           launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, alpha, 0);
           p->seg_invalidate(p->d_xc.p);
           if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
               rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
-          int r = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (r) return r;
+          int r = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cand_dst); if (r) return r;
           r = read_back(); if (r) return r;
-          *value = pin->cost; return OICC_OK; };
+          *value = cand_cost_of(); return OICC_OK; };
         LsSample init, prev, cur; bool have_prev = false, success = true; int its = 0;
         init.x = 0.0; init.value = cost; init.gradient = g0; init.has_gradient = true;
-        cur.x = 1.0; cur.value = pin->cost;
+        cur.x = 1.0; cur.value = cand_cost_of();
         while (!std::isfinite(cur.value) || cur.value > cost + 1e-4 * g0 * cur.x) {
           if (++its >= 20) { success = false; break; }
           if (!cur.has_gradient && std::isfinite(cur.value)) {   // slope at the trial point: gradient there (in its own tangent space) . delta
@@ -1364,11 +1371,12 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     double cand_before_inner = 0.0; bool inner_ran = false;
     if (inner_enabled) {
       rc = read_back(); if (rc) return rc;
-      cand_before_inner = pin->cost;
+      cand_before_inner = cand_cost_of();
       if (std::isfinite(cand_before_inner)) {
         rc = inner_sweep(p, p->d_xc.p); if (rc) return rc;
         p->seg_invalidate(p->d_xc.p);
-        rc = eval_pass(p, p->d_xc.p, false); if (rc) return rc;
+        if (cost_in_state) HIPCK(p, hipMemsetAsync(&p->d_state.p->cand_cost, 0, sizeof(double), st));
+        rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, cost_in_state, nullptr, false, nullptr, false, cand_dst); if (rc) return rc;
         HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, sizeof(double), st));
         launch_inner_diff_norm(p->d_x.p, p->d_xc.p, p->inner.d_blocks.p, int(p->inner.blocks.size()), &p->d_state.p->step_norm_sq, st);
         inner_ran = true;
@@ -1391,7 +1399,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     rc = read_back_wait(); if (rc) return rc;
     LmState hs = pin->st;
     (void)rank_consistent;
-    const double cand_cost = pin->cost;
+    const double cand_cost = cand_cost_of();
     bool inner_useful = false;
     if (inner_ran) {
       hs.model_cost_change += cand_before_inner - cand_cost;
@@ -1484,9 +1492,10 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
           rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
       p->seg_invalidate(p->d_xc.p);
     }
-    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true); if (rc) return rc;   // lm_retract_kernel cleared the cost slot
+    const bool cost_in_state = int(p->opt["assembly"]) != 1;   // as in oicc_optimize: the candidate cost comes back inside LmState
+    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cost_in_state ? &p->d_state.p->cand_cost : nullptr); if (rc) return rc;
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
-    HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!cost_in_state) HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipEventRecord(p->ev[5], st));
     rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
     if (!p->gmax_folded) launch_lm_gradmax(p->ne2, tl.P, p->d_state.p, st);
