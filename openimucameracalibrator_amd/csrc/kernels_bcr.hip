@@ -360,20 +360,21 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(BcrArgs A) {
 // lane = column.  Every global load is issued before the first use; wave 0 keeps its column of
 // L_ii in registers so that the 64 dependent steps of the triangular solve are
 // mul -> v_readlane -> fma with nothing else on the chain.
-__global__ __launch_bounds__(256) void bcr_backward_kernel(BcrArgs A) {
+constexpr int kBackWaves = 8;    // (wave 0 keeps a 64-double column of L_ii in registers: at most 2 waves per SIMD) the kernel is a 100 KB load (the pivot's factor rows) followed by a 64-step dependent chain: more waves, more loads in flight
+__global__ __launch_bounds__(64 * kBackWaves) void bcr_backward_kernel(BcrArgs A) {
   __shared__ double xs[192];
-  __shared__ double part[4][64];
+  __shared__ double part[kBackWaves][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = A.a, a1 = a + 1, Ru = 192 + a1, s = A.s;
   const int i = s * (2 * (int)blockIdx.x + 1), il = i - s, ir = i + s;
   const bool hasR = ir < A.n;
   const double* Lg = A.Lf + (int64_t)i * Ru * 64;
-  constexpr int RW = 48;                       // border rows per wave: 4 * 48 = 192 >= 128 + a
+  constexpr int RW = 192 / kBackWaves;         // border rows per wave: 192 >= 128 + a
   double lv[RW];
 #pragma unroll
   for (int k = 0; k < RW; ++k) {
-    const int r = wave + 4 * k;
+    const int r = wave + kBackWaves * k;
     const int row = r < 128 ? 64 + r : 192 + (r - 128);
     lv[k] = r < 128 + a ? Lg[row * 64 + lane] : 0.0;
   }
@@ -392,11 +393,14 @@ __global__ __launch_bounds__(256) void bcr_backward_kernel(BcrArgs A) {
   __syncthreads();
   double sum = 0.0;
 #pragma unroll
-  for (int k = 0; k < RW; ++k) { const int r = wave + 4 * k; sum = fma(lv[k], r < 128 + a ? xs[r] : 0.0, sum); }
+  for (int k = 0; k < RW; ++k) { const int r = wave + kBackWaves * k; sum = fma(lv[k], r < 128 + a ? xs[r] : 0.0, sum); }
   part[wave][lane] = sum;
   __syncthreads();
   if (wave == 0) {
-    double z = yv - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBackWaves; ++w) acc += part[w][lane];
+    double z = yv - acc;
     double xv = 0.0;
 #pragma unroll
     for (int j = 63; j >= 0; --j) {
@@ -542,7 +546,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
   for (int l = nlev - 1; l >= 0; --l) {
     A.s = strides[l];
-    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
   }
   return 0;
 }
