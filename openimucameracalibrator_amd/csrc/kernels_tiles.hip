@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     const int vd_ = hd ? ctx.tl.r3[kr0 + tid] : 0;
     // segment tables of the staged knot pairs: kSegStride doubles per pair, precomputed for this parameter vector
     constexpr int kSegPerThread = (kMaxTileKnots * kSegStride + kTileThreads - 1) / kTileThreads;
-    const int nseg = (nks - 1) * kSegStride;
+    const int nseg = dyn.seg != nullptr ? (nks - 1) * kSegStride : 0;
     const double* sg = dyn.seg + (int64_t)ks0 * kSegStride;
     double vs[kSegPerThread];
 #pragma unroll
@@ -387,6 +387,13 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   __syncthreads();
   const long long tp1 = prof ? clock64() : 0;
+  if (dyn.seg == nullptr) {   // small problems (one round of tiles): the tables are computed here, 1.2 us, rather than by a ~13 us chain in the retraction
+    for (int i = tid; i < td.nks - 1; i += kTileThreads) {
+      const double* a = l_so3 + 4 * i;
+      so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, l_seg + i * kSegStride);
+    }
+    __syncthreads();
+  }
 
   Target T;
   T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;

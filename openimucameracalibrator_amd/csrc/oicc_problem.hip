@@ -127,6 +127,10 @@ struct oicc_problem {
   struct SegTable { DevBuf<double> buf; const double* of = nullptr; bool valid = false; } seg_tab[2];
   SegTable* seg_of(const double* xbuf) { for (auto& t : seg_tab) if (t.of == xbuf) return &t; return nullptr; }
   void seg_invalidate(const double* xbuf) { if (SegTable* t = seg_of(xbuf)) t->valid = false; }
+  // Tables once per parameter vector pay when the tiles run in several rounds (every tile would recompute its halo pairs and wait
+  // 1.2 us for them); on a one-round problem the dependent chain they add to the retraction kernel (+9 us at C2) costs more.
+  int n_cu = 256;
+  bool seg_precomputed() const { const auto it = opt.find("debug_seg_precompute"); const int force = it == opt.end() ? 0 : int(it->second); return force == 1 || (force == 0 && tp.n_tiles > n_cu); }
   DevBuf<int32_t> d_corner_view, d_corner_pt, d_view_s_so3, d_view_s_r3;
   DevBuf<double> d_cu, d_cv, d_cisx, d_cisy, d_view_u_so3, d_view_u_r3;
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all;
@@ -175,6 +179,7 @@ struct oicc_problem {
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
     opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
+    opt["debug_seg_precompute"] = 0;   // 1 / 2: segment tables always / never precomputed per parameter vector (default: by problem size)
     opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
     opt["debug_sync"] = 0;       // 1: drain the stream after every pass (debugging of inter-kernel hazards)
     opt["debug_poison_lds"] = 0; // 1: fill every CU's LDS with NaNs before each Jacobian / cost pass and each linear solve (tests)
@@ -561,6 +566,7 @@ int build_tiles(oicc_problem* p) {
   //   cost(T) ~ ceil(ceil(n_windows / T) / CUs) * (3.75 + T);
   // the candidates (multiples of the window ratio) are tried in order of that cost until one fits LDS.
   int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); if (n_cu < 1) n_cu = 256;
+  p->n_cu = n_cu;
   bool fits = false;
   while (true) {
     int t = std::max(T, 1);
@@ -855,11 +861,13 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
         p->tstatic_valid = true;
       }
     }
-    oicc_problem::SegTable* sgt = p->seg_of(x);
-    if (sgt == nullptr) { p->err = "residual pass on an unknown parameter buffer"; return OICC_ERR_STATE; }
-    if (!sgt->valid) { launch_inner_seg(x + p->pl.so3, int(p->pl.n_so3 - 1), sgt->buf.p, st); sgt->valid = true; }
     TileDyn dyn{};
-    dyn.seg = sgt->buf.p;
+    if (p->seg_precomputed()) {
+      oicc_problem::SegTable* sgt = p->seg_of(x);
+      if (sgt == nullptr) { p->err = "residual pass on an unknown parameter buffer"; return OICC_ERR_STATE; }
+      if (!sgt->valid) { launch_inner_seg(x + p->pl.so3, int(p->pl.n_so3 - 1), sgt->buf.p, st); sgt->valid = true; }
+      dyn.seg = sgt->buf.p;
+    }
     dyn.x = x; dyn.ne_base = ne.base; dyn.cost_out = (!jac && cost_out) ? cost_out : ne.cost(); dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
     dyn.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
     dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
@@ -1304,8 +1312,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       return OICC_ERR_UNSUPPORTED; }
     {   // the retraction also leaves the candidate's segment tables (one kernel fewer per cost pass)
       oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
-      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, sgt ? sgt->buf.p : nullptr);
-      if (sgt) sgt->valid = true;
+      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, (sgt && p->seg_precomputed()) ? sgt->buf.p : nullptr);
+      if (sgt) sgt->valid = p->seg_precomputed();
     }
     HIPCK(p, hipGetLastError());
     // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave last-bit
@@ -1484,8 +1492,8 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
     if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     {
       oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
-      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, sgt ? sgt->buf.p : nullptr);
-      if (sgt) sgt->valid = true;
+      launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, (sgt && p->seg_precomputed()) ? sgt->buf.p : nullptr);
+      if (sgt) sgt->valid = p->seg_precomputed();
     }
     if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
       if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||

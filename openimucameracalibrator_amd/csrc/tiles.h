@@ -87,7 +87,7 @@ struct TileStatic {
   TileParams tp;          // gmax is taken from TileDyn
 };
 struct TileDyn {
-  const double* x; const double* seg;   // seg: kSegStride doubles per SO(3) knot pair of x (spline_seg.cuh), computed once per parameter vector
+  const double* x; const double* seg;   // seg: kSegStride doubles per SO(3) knot pair of x (spline_seg.cuh), computed once per parameter vector; nullptr: every tile computes its own
   double* ne_base; double* cost_out;   // cost_out: where a cost pass adds its cost (the normal equations' cost slot, or LmState::cand_cost)
   double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
   int32_t only_kind, pad;

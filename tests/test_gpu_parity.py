@@ -471,6 +471,33 @@ def test_interior_rows_stored_by_the_tile_equal_the_slab_route(cfg, tile_windows
     assert sa["num_iterations"] == sb["num_iterations"] and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
 
 
+@pytest.mark.parametrize("cfg,flags,inner", [("C2", FLAGS1, 0), ("tiny", FLAGS1 | E.IMU_BIASES, 1), ("C1", FLAGS1 | E.ACC_BIAS, 0)])   # (C1 with the line delay free is chaotic from run to run within ONE mode: scripts/dbg_segdiff.py)
+def test_segment_tables_per_parameter_vector_equal_per_tile(cfg, flags, inner):
+    """The per-knot-pair segment tables (log of the relative rotation, J_r^-1) are either computed by every tile for its own
+    knots (small problems) or once per parameter vector -- by the retraction kernel for the candidate, by a small kernel
+    otherwise -- and kept valid across accepted steps, inner sweeps and line-search trials.  Both routes run the same code
+    on the same knots: identical solves."""
+    ds = synthetic.make_config(cfg)
+    a = E.ImuCameraCalibrator().BatchInitSpline(ds); b = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    a.trajectory_.SetOption("debug_seg_precompute", 1); b.trajectory_.SetOption("debug_seg_precompute", 2)
+    for c in (a, b):
+        c.trajectory_.SetOption("inner_iterations", inner); c.trajectory_.SetOption("bounds_line_search", 1)
+    ca, Ha, ga = a.trajectory_.Evaluate(flags); cb, Hb, gb = b.trajectory_.Evaluate(flags)
+    assert abs(ca - cb) <= 1e-14 * cb and rel_err(Ha, Hb) < 1e-13 and rel_err(ga, gb) < 1e-12
+    # (ten iterations: the candidate's tables come from a second inlined copy of the retraction arithmetic, whose FMA contraction
+    # may differ in the last bit; the inner-iteration solves amplify that over dozens of iterations)
+    sa = a.trajectory_.Optimize(10, flags); sb = b.trajectory_.Optimize(10, flags)
+    ia, ib = a.trajectory_.GetIterations(), b.trajectory_.GetIterations()
+    assert sa["num_iterations"] == sb["num_iterations"], ([i["cost"] for i in ia], [i["cost"] for i in ib])
+    for x, y in zip(ia, ib):
+        assert x["step_is_successful"] == y["step_is_successful"] and abs(x["cost"] - y["cost"]) <= 1e-8 * y["cost"], (x, y)
+    assert np.abs(a.trajectory_.GetT_i_c() - b.trajectory_.GetT_i_c()).max() < 1e-7
+    # a second solve from the accepted point (tables of the swapped buffers still valid) and a host-side parameter change
+    for c in (a, b):
+        c.trajectory_.SetGravity(np.array([0.05, -0.03, 9.79]))
+    assert abs(a.trajectory_.EvaluateCost(flags) - b.trajectory_.EvaluateCost(flags)) <= 1e-12 * b.trajectory_.EvaluateCost(flags)
+
+
 # ---- Ceres' inner iterations (reference impl.h:266), device sweep (inner_iterations.hip) against oracle/ceres_inner.hpp ----
 @pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES), ("tiny", FLAGS1 | E.CAM_LINE_DELAY), ("C2", FLAGS1)])
 def test_inner_iterations_match_the_oracle(cfg, flags):
