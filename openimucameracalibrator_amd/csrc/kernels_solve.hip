@@ -180,7 +180,11 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
       const double v1 = fmin(fmax(v0 + alpha * (sb.step_s[o + c] * sb.scale[o + c]), -max_gb), max_gb);
       xc[pl.gb + 3 * k + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
   }
-  if (tid == 0) {
+  // the extrinsics (coupled SE(3) exponential) and the small Euclidean blocks are each one thread's work: threads that have no
+  // knot of their own, in different waves, so that their chains run beside the SO(3) retractions instead of behind thread 0's
+  const int64_t busy = pl.n_so3 > pl.n_r3 ? pl.n_so3 : pl.n_r3;
+  const int64_t t_tic = busy < nthreads ? busy : nthreads - 1, t_eu = busy + 64 < nthreads ? busy + 64 : nthreads - 1;
+  if (tid == t_tic) {
     if (tl.tic >= 0) {
       double a6[6];
       for (int c = 0; c < 6; ++c) a6[c] = alpha * (sb.step_s[tl.tic + c] * sb.scale[tl.tic + c]);
@@ -194,6 +198,8 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
       for (int c = 0; c < 3; ++c) T1[4 + c] = T0[4 + c] + rt[c];
       for (int c = 0; c < 7; ++c) { const double dd = T1[c] - T0[c]; step_sq += dd * dd; x_sq += T0[c] * T0[c]; }
     }
+  }
+  if (tid == t_eu) {
     auto eucl = [&](int off, int64_t po, int n) {
       if (off < 0) return;
       for (int c = 0; c < n; ++c) { const double v0 = x[po + c]; const double v1 = v0 + alpha * (sb.step_s[off + c] * sb.scale[off + c]);
