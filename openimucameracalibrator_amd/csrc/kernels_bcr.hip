@@ -39,6 +39,7 @@ struct BcrArgs {
   int32_t* fail;
   long long* prof;   // optional cycle counters of block 0 / wave 0 (debug)
   int n, a, Pb, rtf, LD;
+  int no_diag_copy;            // debug: panel waves read the diagonal block in place (the hazard described in the panel factorisation)
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
 };
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
   double* const dinvs = W + 64 * LD;     // [64]
   double* const da = dinvs + 64;         // [64] arrow solution (LAST)
   int* const failp = reinterpret_cast<int*>(da + 64);
+  double* const dg = da + 64 + 8;        // [8][8] copy of the current panel's diagonal block (column major), see the panel factorisation
 
   const int s = A.s;
   const int i = LAST ? 0 : s * (2 * (int)blockIdx.x + 1);
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
       const int e = tid + k * kBcrThreads;
       const int c = e >> 6, r = e & 63;
       W[c * LD + r] = r >= c ? gd[k] : 0.0;
+      if (c < 8 && r < 8) dg[c * 8 + r] = r >= c ? gd[k] : 0.0;
       W[c * LD + 64 + r] = gl[k];
       W[c * LD + 128 + r] = gr[k];
       const int cf = e / fr, q = e - cf * fr;
@@ -132,10 +135,15 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
       const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru);
       // eight reads off one base address (LD is a compile-time constant: immediate offsets); inactive lanes
       // read row 0 and are masked afterwards
-      const double* colp = W + j0 * LD + (act ? rho : 0);
+      // The 8x8 diagonal block is read by lanes 0..7 of EVERY panel wave and rewritten in place by wave 0 at the end of its
+      // panel: a wave that starts late (two panel waves share a SIMD once the border has three 16-row tiles, a + 1 > 32) could
+      // read factored entries.  The waves therefore read the block from a copy the previous trailing update left in `dg`.
+      const bool from_copy = lane < 8 && !A.no_diag_copy;
+      const double* colp = from_copy ? dg + lane : W + j0 * LD + (act ? rho : 0);
+      const int cstride = from_copy ? 8 : LD;
       double av[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { const double v = colp[c * LD]; av[c] = (act && (lane >= 8 || lane >= c)) ? v : 0.0; }
+      for (int c = 0; c < 8; ++c) { const double v = colp[c * cstride]; av[c] = (act && (lane >= 8 || lane >= c)) ? v : 0.0; }
       if (PROF && prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
       BCR_MARK(6);
       double rsd = 1.0;
@@ -191,6 +199,12 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
             double* dst = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
             if (jn & 8) { dst[8 * LD] = acc[k][2]; dst[12 * LD] = acc[k][3]; }
             else { dst[0] = acc[k][0]; dst[4 * LD] = acc[k][1]; }
+            // the next panel's diagonal block once more, for the panel waves (rows jn..jn+7 of the diagonal tile)
+            const int rr = li - (jn & 8);
+            if (t_rt[k] == t_ct[k] && rr >= 0 && rr < 8) {
+              if (jn & 8) { dg[lq * 8 + rr] = acc[k][2]; dg[(lq + 4) * 8 + rr] = acc[k][3]; }
+              else { dg[lq * 8 + rr] = acc[k][0]; dg[(lq + 4) * 8 + rr] = acc[k][1]; }
+            }
           }
         }
       }
@@ -483,11 +497,13 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
 
 // ---- host ------------------------------------------------------------------
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
-// Arrow limit: the kernels are written for up to 63 arrow columns, but with three or four 16-row border tiles (a + 1 > 32)
+// Arrow limit (DESIGN.md section 6): the kernels are written for up to 63 arrow columns, but with three or four 16-row border tiles (a + 1 > 32)
 // the factorisation was seen to fail sporadically (NaN pivots in ~10 % of the solves that reuse the damping diagonal after a
 // rejected step, round-2 measurements in DESIGN.md) depending on what the preceding kernel left in LDS; until that is
 // understood such systems go to the band sweep (kernels_cholesky.hip), which takes any arrow width.
-bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 32; }
+int g_bcr_no_diag_copy = 0;   // debug option debug_bcr_no_diag_copy: reproduces the round-2 failure of wide borders
+int g_bcr_max_border = 32;   // rows of arrow + rhs the solver takes (debug option bcr_max_border of oicc_problem; see the note above)
+bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= g_bcr_max_border; }
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
@@ -506,11 +522,11 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.S = w; w += (int64_t)2 * n * 4096;
   A.Lf = w;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
-  A.n = n; A.a = tl.a; A.Pb = tl.Pb;
+  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = g_bcr_no_diag_copy;
   A.rtf = (a1 + 15) / 16;
   const int Rp = 192 + 16 * A.rtf;
   A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;
-  const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8) * sizeof(double);
+  const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8 + 64) * sizeof(double);
   if (lds > 160 * 1024 - 64) return -1;
   {
     int64_t work = (int64_t)n * 4096;

@@ -180,6 +180,8 @@ struct oicc_problem {
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
     opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
     opt["debug_seg_precompute"] = 0;   // 1 / 2: segment tables always / never precomputed per parameter vector (default: by problem size)
+    opt["debug_bcr_no_diag_copy"] = 0;
+    opt["bcr_max_border"] = 32;        // arrow + rhs rows the block cyclic reduction accepts (kernels_bcr.hip: up to 64 by construction)
     opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
     opt["debug_sync"] = 0;       // 1: drain the stream after every pass (debugging of inter-kernel hazards)
     opt["debug_poison_lds"] = 0; // 1: fill every CU's LDS with NaNs before each Jacobian / cost pass and each linear solve (tests)
@@ -318,6 +320,7 @@ int build_tiles(oicc_problem* p);
 
 // Tangent layout: the ordering contract of include/oicc_hip.h.
 int make_layout(oicc_problem* p, int flags) {
+  g_bcr_max_border = int(p->opt["bcr_max_border"]); g_bcr_no_diag_copy = int(p->opt["debug_bcr_no_diag_copy"]);
   const Active a = active_set(p, flags);
   // the layout also depends on whether line delay is currently zero (active_set) -> recompute when it might differ
   HostLayout& L = p->L;
@@ -559,7 +562,9 @@ int build_tiles(oicc_problem* p) {
   auto try_T = [&](int t) {   // builds the tiles for t windows; true if they fit
     make_tiles(p, t, &tb);
     if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;
-    return carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) <= budget;
+    const int need_d = carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner);
+    if (p->opt["verbose"] >= 3.0) std::printf("[oicc] tile length %d: %zu tiles, rows %d, knots %d / %d, units %d, LDS %d of %d doubles (direct %d)\n", t, tb.tiles.size(), tb.max_rows, tb.max_nks, tb.max_nkr, tb.max_units, need_d, budget, tp.direct);
+    return need_d <= budget;
   };
   // Automatic tile length: a workgroup costs a fixed ~3.75 windows' worth of time (launch, staging, first-unit latency, flush:
   // fitted on C2 ... C5, scripts/time_tile_windows.py) plus its windows, and the tiles run in ceil(tiles / CUs) rounds:
@@ -573,9 +578,10 @@ int build_tiles(oicc_problem* p) {
     if (T_user > 0) fits = try_T(t);
     else {
       std::vector<std::pair<double, int>> cand;
-      for (int c = ratio; c <= 64; c += ratio) {
+      for (int c = 1; c <= 64; ++c) {
         const int64_t tiles = (n_windows + c - 1) / c;
-        cand.push_back({double((tiles + n_cu - 1) / n_cu) * (3.75 + c) - 1e-6 * c, c});   // (ties: the longer tile, less halo traffic)
+        const double split = c % ratio ? 0.5 : 0.0;            // lengths that cut R^3 windows make more, smaller units: only when nothing else fits
+        cand.push_back({double((tiles + n_cu - 1) / n_cu) * (3.75 + c + split) - 1e-6 * c, c});   // (ties: the longer tile, less halo traffic)
       }
       std::sort(cand.begin(), cand.end());
       int smallest_fail = 1 << 30;
