@@ -156,7 +156,7 @@ __device__ __forceinline__ void column_table_entry(const RowFmt& f, int col, int
 // residual column Pb + a (so (i, Pb + a) is a gradient entry and (Pb + a, Pb + a) twice the cost).
 struct Target {
   double* acc;          // LDS accumulator of the tile: rows [lo, lo + nrows) x [band W | arrow a | gradient], then the (a + 1)^2 corner
-  int lo, Wl, W, Pb, a, corner0;
+  int Wl, W, Pb, a, corner0;
   NormalEq ne;          // DIRECT mode: fp64 atomics on the packed normal equations
 };
 __device__ __forceinline__ void target_add_direct(const Target& T, int i, int j, double v) {
@@ -168,9 +168,9 @@ __device__ __forceinline__ void target_add_direct(const Target& T, int i, int j,
   else unsafeAtomicAdd(T.ne.cost(), 0.5 * v);
 }
 // accumulator index of entry (i, j), i <= j:  base1(i) + j if j is a band column, base2(i) + j otherwise, with
-//   i band:  base1 = (i - lo) Wl - i,  base2 = (i - lo) Wl + W - Pb        i arrow / residual:  base1 = base2 = corner0 + (i - Pb)(a + 1) - Pb
-__device__ __forceinline__ void target_bases(const Target& T, int i, int& b1, int& b2) {
-  if (i < T.Pb) { b1 = (i - T.lo) * T.Wl - i; b2 = (i - T.lo) * T.Wl + T.W - T.Pb; }
+//   i band (accumulator row r):  base1 = r Wl - i,  base2 = r Wl + W - Pb        i arrow / residual:  base1 = base2 = corner0 + (i - Pb)(a + 1) - Pb
+__device__ __forceinline__ void target_bases(const Target& T, int i, int acc_row, int& b1, int& b2) {   // acc_row: accumulator row of band row i
+  if (i < T.Pb) { b1 = acc_row * T.Wl - i; b2 = acc_row * T.Wl + T.W - T.Pb; }
   else { b1 = T.corner0 + (i - T.Pb) * (T.a + 1) - T.Pb; b2 = b1; }
 }
 
@@ -291,9 +291,9 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const int* ct_ba, con
 __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLayout& tl, const Target& T, int sensor, const int* l_tl_so3,
                                                  const int* l_tl_r3, int s_so3_rel, int s_r3_rel, int s_b, int n_so3_knots, int* out3) {
   const int g = grp_packed & 15, k = grp_packed >> 4;
-  int off = -1;
-  if (g == GRP_S) { if (k / 3 < n_so3_knots) { const int o = l_tl_so3[s_so3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; } }   // knots of the cell's windows only
-  else if (g == GRP_R) { const int o = l_tl_r3[s_r3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; }
+  int off = -1, arow = 0;   // (the accumulator rows of the knots follow their tangent offsets in the same LDS tables, kMaxTileKnots * 2 further on)
+  if (g == GRP_S) { if (k / 3 < n_so3_knots) { const int o = l_tl_so3[s_so3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; arow = l_tl_so3[2 * kMaxTileKnots + s_so3_rel + k / 3] + k % 3; } }   // knots of the cell's windows only
+  else if (g == GRP_R) { const int o = l_tl_r3[s_r3_rel + k / 3]; off = o < 0 ? -1 : o + k % 3; arow = l_tl_r3[2 * kMaxTileKnots + s_r3_rel + k / 3] + k % 3; }
   else if (g == GRP_T) off = tl.tic + k;
   else if (g == GRP_L) off = tl.ld;
   else if (g == GRP_G) off = tl.g + k;
@@ -301,7 +301,7 @@ __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLa
   else if (g == GRP_I) off = (sensor == 1 ? tl.ai : tl.gi) + k;
   else if (g == GRP_RES) off = tl.Pb + tl.a;
   int b1 = 0, b2 = 0;
-  if (off >= 0) target_bases(T, off, b1, b2);
+  if (off >= 0) target_bases(T, off, arow, b1, b2);
   out3[0] = off; out3[1] = b1; out3[2] = b2;
 }
 
@@ -382,6 +382,11 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   {   // the tile's unit descriptors (4 ints each): the waves read them from LDS instead of a dependent global load per unit
     const int* src = reinterpret_cast<const int*>(tp.units + td.unit0);
     for (int i = tid; i < 4 * (td.unit1 - td.unit0); i += kTileThreads) l_units[i] = src[i];
+    if (JAC && !DIRECT) {   // accumulator row of every staged knot
+      const int* ar = tp.tile_rows + td.rows_off;
+      if (tid < td.nks) l_tl_so3[2 * kMaxTileKnots + tid] = ar[tid];
+      else if (tid >= 64 && tid - 64 < td.nkr) l_tl_r3[2 * kMaxTileKnots + tid - 64] = ar[td.nks + tid - 64];
+    }
   }
   if (tid == 0) l_queue[0] = 0;
   if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
@@ -396,7 +401,7 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   }
 
   Target T;
-  T.acc = acc; T.lo = td.lo; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
+  T.acc = acc; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
   const long long tp2 = prof ? clock64() : 0;
 
   // ---- P1: units ----
@@ -521,13 +526,13 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     for (int i = x1 * Wl + tid; i < td.nrows * Wl; i += kTileThreads) slab[i] = acc[i];
     if (nown > 0) {
       const unsigned magic = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);     // idx / W for idx < 2^16
-      double* band = T.ne.band() + (int64_t)(td.lo + x0) * W;
+      double* band = T.ne.band() + (int64_t)td.g0 * W;
       for (int idx = tid; idx < nown * W; idx += kTileThreads) {
         const int r = int(__umulhi((unsigned)idx, magic)), e = idx - r * W;
         band[idx] = acc[(x0 + r) * Wl + e];
       }
       for (int c = wave; c <= a; c += kTileWaves) {
-        double* dst = (c < a ? T.ne.Et() + (int64_t)c * Pb : T.ne.g()) + td.lo + x0;
+        double* dst = (c < a ? T.ne.Et() + (int64_t)c * Pb : T.ne.g()) + td.g0;
         for (int r = lane; r < nown; r += 64) dst[r] = acc[(x0 + r) * Wl + W + c];
       }
     }

@@ -147,9 +147,9 @@ struct oicc_problem {
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
-  std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_row_t0, h_row_t1, h_merge_rows; std::vector<uint8_t> h_row_direct;
+  std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_tile_rows, h_merge_rows; std::vector<uint8_t> h_row_direct;
   DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src;
-  DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_row_t0, d_row_t1; DevBuf<double> d_slabs;
+  DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_tile_rows; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
   std::unique_ptr<TileStatic> h_tstatic; DevBuf<TileStatic> d_tstatic; bool tstatic_valid = false;   // problem-constant kernel arguments in device memory
   bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
@@ -440,7 +440,8 @@ RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, 
 // largest item count whose records fit `rb` doubles
 void row_fmt_capacity(RowFmt& f, int rb, int max_items) { f.cap = std::max(0, std::min({max_items, 64, rb / f.item_stride})); }
 
-struct TileBuild { std::vector<UnitDesc> units; std::vector<int32_t> unit_tile; std::vector<TileDesc> tiles; int max_rows = 0, max_nks = 0, max_nkr = 0, max_units = 0; };
+struct TileBuild { std::vector<UnitDesc> units; std::vector<int32_t> unit_tile; std::vector<TileDesc> tiles; std::vector<int32_t> knot_rows, row_of;   // knot_rows: TileDesc::rows_off; row_of: per tile, the tangent row of every accumulator row (tiles[t].rows_g0 ...)
+                   std::vector<int64_t> row_of_off; int max_rows = 0, max_nks = 0, max_nkr = 0, max_units = 0; };
 
 // Units (one view / a run of IMU samples, never across a tile boundary) and tiles for `T` fine knot windows per tile.
 void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
@@ -448,7 +449,7 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
   const int64_t dt_fine = std::min(p->dt_so3, p->dt_r3);
   auto tile_of = [&](int32_t s_so3) { return int32_t((int64_t(s_so3) * p->dt_so3) / (int64_t(T) * dt_fine)); };
   std::vector<UnitDesc>& U = out->units; std::vector<int32_t>& UT = out->unit_tile;
-  U.clear(); UT.clear(); out->tiles.clear();
+  U.clear(); UT.clear(); out->tiles.clear(); out->knot_rows.clear(); out->row_of.clear(); out->row_of_off.assign(1, 0);
   for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) {
     const int32_t t = tile_of(p->view_s_so3[v]);
     for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; c += p->fv.cap) {
@@ -512,9 +513,30 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
     }
     TileDesc td{};
     td.unit0 = int32_t(i); td.unit1 = int32_t(j);
-    td.lo = hi >= 0 ? lo : 0; td.nrows = hi >= 0 ? hi - lo : 0;
     td.ks0 = ks0; td.nks = ks1 - ks0;
     td.kr0 = kr1 >= 0 ? kr0 : 0; td.nkr = kr1 >= 0 ? kr1 - kr0 : 0;
+    // accumulator rows: the tangent rows of the active staged knots in ascending order (both knot sequences ascend: a merge)
+    td.rows_off = int32_t(out->knot_rows.size());
+    out->knot_rows.resize(out->knot_rows.size() + size_t(td.nks + td.nkr), -1);
+    int32_t* kr = out->knot_rows.data() + td.rows_off;
+    {
+      int a = 0, b = 0, r = 0;
+      auto off_s = [&](int k) { return spline ? L.so3[td.ks0 + k] : -1; };
+      auto off_r = [&](int k) { return spline ? L.r3[td.kr0 + k] : -1; };
+      while (a < td.nks || b < td.nkr) {
+        while (a < td.nks && off_s(a) < 0) ++a;
+        while (b < td.nkr && off_r(b) < 0) ++b;
+        if (a >= td.nks && b >= td.nkr) break;
+        const bool take_s = b >= td.nkr || (a < td.nks && off_s(a) < off_r(b));
+        const int o = take_s ? off_s(a) : off_r(b);
+        (take_s ? kr[a] : kr[td.nks + b]) = r;
+        for (int c = 0; c < 3; ++c) out->row_of.push_back(o + c);
+        r += 3; if (take_s) ++a; else ++b;
+      }
+      td.nrows = r; td.lo = r > 0 ? out->row_of[size_t(out->row_of_off.back())] : 0;
+    }
+    out->row_of_off.push_back(int64_t(out->row_of.size()));
+    (void)lo; (void)hi;
     out->tiles.push_back(td);
     out->max_units = std::max(out->max_units, int(j - i));
     out->max_rows = std::max(out->max_rows, int(td.nrows)); out->max_nks = std::max(out->max_nks, int(td.nks)); out->max_nkr = std::max(out->max_nkr, int(td.nkr));
@@ -554,7 +576,7 @@ int build_tiles(oicc_problem* p) {
   auto carve = [&](int nks, int nkr, int nunits, int acc_doubles) {   // returns total doubles
     int o = 0;
     tp.o_so3 = o; o += nks * 4; tp.o_r3 = o; o += std::max(nkr, 1) * 3; tp.o_seg = o; o += std::max(nks - 1, 1) * 17;
-    tp.o_tl = o; o += kMaxTileKnots; tp.o_misc = o; o += 8; tp.o_units = o; o += 2 * std::max(nunits, 1); tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
+    tp.o_tl = o; o += 2 * kMaxTileKnots; /* int tables: tangent offsets [so3 | r3], accumulator rows [so3 | r3] */ tp.o_misc = o; o += 8; tp.o_units = o; o += 2 * std::max(nunits, 1); tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
     return o;
   };
   TileBuild tb;
@@ -566,12 +588,15 @@ int build_tiles(oicc_problem* p) {
     if (p->opt["verbose"] >= 3.0) std::printf("[oicc] tile length %d: %zu tiles, rows %d, knots %d / %d, units %d, LDS %d of %d doubles (direct %d)\n", t, tb.tiles.size(), tb.max_rows, tb.max_nks, tb.max_nkr, tb.max_units, need_d, budget, tp.direct);
     return need_d <= budget;
   };
-  // Automatic tile length: a workgroup costs a fixed ~3.75 windows' worth of time (launch, staging, first-unit latency, flush:
-  // fitted on C2 ... C5, scripts/time_tile_windows.py) plus its windows, and the tiles run in ceil(tiles / CUs) rounds:
-  //   cost(T) ~ ceil(ceil(n_windows / T) / CUs) * (3.75 + T);
-  // the candidates (multiples of the window ratio) are tried in order of that cost until one fits LDS.
+  // Automatic tile length.  Measured (scripts/time_tile_windows.py, prof_tile.py; C2 ... C5): pass time ~ 8 us (launch) +
+  // rounds * (3 us staging and flush + w * T), rounds = ceil(tiles / CUs), w = time of one window's units on the four waves
+  // (a corner ~800 cycles, an accelerometer sample ~1300, a gyroscope sample ~800, +15 % imbalance): the candidates are tried in
+  // order of rounds * (3 / w + T) until one fits LDS.  One-round problems thus get the shortest tile that still is one round,
+  // multi-round problems the best trade of round count against round length (C5: T = 10, 8 rounds, over T = 14, 6 rounds).
   int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); if (n_cu < 1) n_cu = 256;
   p->n_cu = n_cu;
+  const double work_cycles = 800.0 * double(p->corner_view.size()) + 1300.0 * double(p->acc.size()) + 800.0 * double(p->gyr.size());
+  const double w_us = std::min(50.0, std::max(1.0, 1.15 * work_cycles / double(std::max<int64_t>(n_windows, 1)) / kTileWaves / 2400.0));
   bool fits = false;
   while (true) {
     int t = std::max(T, 1);
@@ -581,7 +606,7 @@ int build_tiles(oicc_problem* p) {
       for (int c = 1; c <= 64; ++c) {
         const int64_t tiles = (n_windows + c - 1) / c;
         const double split = c % ratio ? 0.5 : 0.0;            // lengths that cut R^3 windows make more, smaller units: only when nothing else fits
-        cand.push_back({double((tiles + n_cu - 1) / n_cu) * (3.75 + c + split) - 1e-6 * c, c});   // (ties: the longer tile, less halo traffic)
+        cand.push_back({double((tiles + n_cu - 1) / n_cu) * (3.0 / w_us + c + split) - 1e-6 * c, c});   // (ties: the longer tile, less halo traffic)
       }
       std::sort(cand.begin(), cand.end());
       int smallest_fail = 1 << 30;
@@ -601,43 +626,39 @@ int build_tiles(oicc_problem* p) {
   p->h_tiles.swap(tb.tiles); p->h_units.swap(tb.units);
   tp.n_tiles = int32_t(p->h_tiles.size()); tp.n_units = int32_t(p->h_units.size());
   tp.slab_stride = int64_t(tp.acc_rows) * tp.Wl + tp.corner;
-  p->h_row_t0.assign(std::max(tl.Pb, 1), 0); p->h_row_t1.assign(std::max(tl.Pb, 1), 0);
-  if (!tp.direct) {
-    std::vector<char> seen(std::max(tl.Pb, 1), 0);
-    for (int32_t t = 0; t < tp.n_tiles; ++t) {
-      const TileDesc& td = p->h_tiles[t];
-      for (int r = td.lo; r < td.lo + td.nrows; ++r) { if (!seen[r]) { seen[r] = 1; p->h_row_t0[r] = t; } p->h_row_t1[r] = t + 1; }
-    }
-    // rows of exactly one tile (its interior): the longest run of them is stored by the tile itself (TileDesc::x0, x1)
-    for (int32_t t = 0; t < tp.n_tiles; ++t) {
-      TileDesc& td = p->h_tiles[t];
-      td.x0 = td.x1 = 0;
-      if (p->opt["debug_no_direct_rows"] != 0.0) continue;
-      int best0 = 0, best1 = 0, run0 = -1;
-      for (int r = 0; r <= td.nrows; ++r) {
-        const bool own = r < td.nrows && p->h_row_t1[td.lo + r] - p->h_row_t0[td.lo + r] == 1;
-        if (own && run0 < 0) run0 = r;
-        if (!own && run0 >= 0) { if (r - run0 > best1 - best0) { best0 = run0; best1 = r; } run0 = -1; }
-      }
-      td.x0 = best0; td.x1 = best1;
-    }
-  }
+  // Which tiles hold which band row: (tile, accumulator row) lists in tile order.  Rows of exactly one tile that are consecutive
+  // in the layout form the tile's interior (TileDesc::x0, x1, g0): stored by the tile itself; every other row is merged from slabs.
+  p->h_tile_rows.swap(tb.knot_rows);
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> holders(std::max(tl.Pb, 1));
+  if (!tp.direct) for (int32_t t = 0; t < tp.n_tiles; ++t)
+    for (int r = 0; r < p->h_tiles[t].nrows; ++r) holders[tb.row_of[size_t(tb.row_of_off[t]) + r]].push_back({t, r});
   p->h_row_direct.assign(std::max(tl.Pb, 1), 0);
-  if (!tp.direct) for (const TileDesc& td : p->h_tiles) for (int r = td.x0; r < td.x1; ++r) p->h_row_direct[td.lo + r] = 1;
+  for (int32_t t = 0; t < tp.n_tiles; ++t) {
+    TileDesc& td = p->h_tiles[t];
+    td.x0 = td.x1 = 0; td.g0 = 0;
+    if (tp.direct || p->opt["debug_no_direct_rows"] != 0.0) continue;
+    const int32_t* g = tb.row_of.data() + tb.row_of_off[t];
+    int best0 = 0, best1 = 0, run0 = -1;
+    for (int r = 0; r <= td.nrows; ++r) {
+      const bool own = r < td.nrows && holders[g[r]].size() == 1;
+      const bool cont = own && run0 >= 0 && g[r] == g[r - 1] + 1;
+      if (run0 >= 0 && !cont) { if (r - run0 > best1 - best0) { best0 = run0; best1 = r; } run0 = -1; }
+      if (own && run0 < 0) run0 = r;
+    }
+    td.x0 = best0; td.x1 = best1; td.g0 = best1 > best0 ? g[best0] : 0;
+    for (int r = td.x0; r < td.x1; ++r) p->h_row_direct[g[r]] = 1;
+  }
   p->h_merge_rows.clear();
   for (int i = 0; i < tl.Pb; ++i) if (!p->h_row_direct[i]) p->h_merge_rows.push_back(i);
   tp.n_merge_rows = int32_t(p->h_merge_rows.size());
   if (p->h_merge_rows.empty()) p->h_merge_rows.push_back(0);
   p->h_merge_ptr.assign(1, 0); p->h_merge_src.clear();
   if (!tp.direct) for (int32_t h = 0; h < tp.n_merge_rows; ++h) {
-    const int i = p->h_merge_rows[h];
-    for (int32_t t = p->h_row_t0[i]; t < p->h_row_t1[i]; ++t) {       // tiles between the first and the last one that cover the row need not cover it
-      const int r = i - p->h_tiles[t].lo;
-      if (r >= 0 && r < p->h_tiles[t].nrows) p->h_merge_src.push_back(int64_t(t) * tp.slab_stride + int64_t(r) * tp.Wl);
-    }
+    for (const auto& tr : holders[p->h_merge_rows[h]]) p->h_merge_src.push_back(int64_t(tr.first) * tp.slab_stride + int64_t(tr.second) * tp.Wl);
     p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size()));
   }
   if (p->h_merge_src.empty()) p->h_merge_src.push_back(0);
+  if (p->h_tile_rows.empty()) p->h_tile_rows.push_back(0);
   // affine guess of the knot ranges (see TileParams): fitted on two interior tiles, used if at least half of the tiles follow it
   tp.affine = 0;
   if (tp.n_tiles >= 4) {
@@ -652,11 +673,11 @@ int build_tiles(oicc_problem* p) {
     if (2 * good >= tp.n_tiles) { tp.affine = 1; tp.td0 = b; tp.tds = d; }
   }
   hipStream_t st = p->stream;
-  if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_row_t0.upload(p->h_row_t0, st) || !p->d_row_t1.upload(p->h_row_t1, st) || !p->d_merge_rows.upload(p->h_merge_rows, st) || !p->d_merge_ptr.upload(p->h_merge_ptr, st) || !p->d_merge_src.upload(p->h_merge_src, st) || !p->d_row_direct.upload(p->h_row_direct, st) ||
+  if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_tile_rows.upload(p->h_tile_rows, st) || !p->d_merge_rows.upload(p->h_merge_rows, st) || !p->d_merge_ptr.upload(p->h_merge_ptr, st) || !p->d_merge_src.upload(p->h_merge_src, st) || !p->d_row_direct.upload(p->h_row_direct, st) ||
       !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_tiles) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows, %d units, accumulator %d rows x %d (+%d), row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
                                            tp.n_tiles, T, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
-  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.row_t0 = p->d_row_t0.p; tp.row_t1 = p->d_row_t1.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.row_direct = p->d_row_direct.p;
+  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.tile_rows = p->d_tile_rows.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.row_direct = p->d_row_direct.p;
   return OICC_OK;
 }
 

@@ -21,10 +21,14 @@ constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 
 
 struct TileDesc {
   int32_t unit0, unit1;   // units [unit0, unit1)
-  int32_t lo, nrows;      // band rows [lo, lo + nrows) of the tangent layout accumulated by this tile
+  int32_t lo, nrows;      // the accumulator has nrows rows: the tangent rows of the tile's ACTIVE staged knots in ascending order (lo = the first one);
+                          // rows of other knots that lie between them in the layout (the R^3 windows reach further in time) are not stored
   int32_t ks0, nks;       // SO(3) knots staged: [ks0, ks0 + nks)
   int32_t kr0, nkr;       // R^3 knots staged
-  int32_t x0, x1;         // accumulator rows [x0, x1) belong to no other tile: they go straight into the packed normal equations, the rest into the slab
+  int32_t x0, x1;         // accumulator rows [x0, x1) belong to no other tile AND are consecutive rows g0, g0 + 1, ... of the layout:
+                          // they go straight into the packed normal equations, the rest into the slab
+  int32_t g0;             // tangent row of accumulator row x0
+  int32_t rows_off;       // TileParams::tile_rows + rows_off: accumulator row of each staged knot's first component ([nks] SO(3), [nkr] R^3; -1 inactive)
 };
 struct UnitDesc {
   int32_t kind;           // 0 view (items = corners of ONE view), 1 accelerometer samples, 2 gyroscope samples
@@ -61,7 +65,7 @@ struct TileParams {
   int32_t acc_rows;        // accumulator rows (max over tiles)
   int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
   // LDS carve (in doubles from the start of dynamic LDS)
-  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_units, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets | queue | the tile's unit descriptors | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
+  int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_units, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets and accumulator rows of the knots | queue | the tile's unit descriptors | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
   int32_t rb_doubles;
   int32_t lds_bytes;
   double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]
@@ -69,7 +73,7 @@ struct TileParams {
   // Regular problems: lo / nrows / ks0 / nks / kr0 / nkr of tile t are td0 + t * tds for (almost) every tile.  The kernel starts its
   // knot loads from this guess while the descriptor itself is still on its way and repeats them only for the tiles that differ.
   TileDesc td0, tds; int32_t affine;
-  const int32_t* row_t0; const int32_t* row_t1;   // per band row: first / one-past-last tile whose accumulator covers it
+  const int32_t* tile_rows;                           // see TileDesc::rows_off
   const int32_t* merge_rows; int32_t n_merge_rows;   // the band rows the merge kernel sums from slabs (every row that is not some tile's interior row)
   const int32_t* merge_ptr; const int64_t* merge_src; // CSR over merge_rows: offsets (in doubles) of the slab rows to add, in tile order
   const uint8_t* row_direct;                          // per band row: 1 = stored by its tile
