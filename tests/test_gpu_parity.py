@@ -348,6 +348,12 @@ def test_c5_time_shards_sum_to_the_whole():
     assert abs(c_sum - c_all) <= 1e-11 * c_all and rel_err(g_sum, g_all) < 1e-10
     s = whole.trajectory_.Optimize(1, FLAGS1)
     assert s["num_successful_steps"] == 1 and s["final_cost"] < 0.5 * s["initial_cost"] and s["band_dim"] > 85000
+    # at this size the segment tables come once per parameter vector (written by the retraction kernel for the candidate);
+    # the same iteration with every tile computing its own gives the same candidate cost
+    alt = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    alt.trajectory_.SetOption("debug_seg_precompute", 2)
+    s2 = alt.trajectory_.Optimize(1, FLAGS1)
+    assert abs(s2["final_cost"] - s["final_cost"]) <= 1e-10 * s["final_cost"]
 
 
 def test_wide_band_falls_back_to_the_global_memory_solver():
