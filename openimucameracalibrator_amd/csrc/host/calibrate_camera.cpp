@@ -7,6 +7,8 @@
 // length per view from closed forms for a planar board (planar_init.hpp) instead of Theia's RANSAC solvers [EXT], the
 // start focal length is the median over the views, `<out>.calibdata` is written as the JSON twin `<out>.calibdata.json`.
 // C++ twin of openimucameracalibrator_amd/calibrate_camera.py.
+#include <exception>
+#include <iostream>
 #include <algorithm>
 #include <cmath>
 
@@ -15,7 +17,7 @@
 using namespace oicc_cli;
 using namespace OpenICC::core;
 
-int main(int argc, char* argv[]) {
+static int run_main(int argc, char* argv[]) {
   Flags F({{"input_corners", ""}, {"camera_model_to_calibrate", "DOUBLE_SPHERE"}, {"save_path_calib_dataset", ""}, {"grid_size", "0.04"},
            {"optimize_board_points", "false"}, {"verbose", "false"}, {"dry_run", "false"}});   // dry_run: print the start values, no device
   if (!F.parse(argc, argv)) return 2;
@@ -80,4 +82,10 @@ int main(int argc, char* argv[]) {
   }
   cal.PrintResult();
   return 0;
+}
+
+// A malformed input file (missing key, bad number, truncated UBJSON) ends with a message and exit code 1, not in std::terminate.
+int main(int argc, char* argv[]) {
+  try { return run_main(argc, argv); }
+  catch (const std::exception& e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }

@@ -12,6 +12,8 @@
 //    input data set) -- theia::WritePlyFile [EXT] is not available; the OpenCV debug overlay (:366-454) is not produced;
 //  * --dry_run parses and cross-checks every input without touching the GPU;
 //  * --device selects the HIP device.
+#include <exception>
+#include <iostream>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -71,7 +73,7 @@ Value xyz(const double* v) { return xyz(Vec3{{v[0], v[1], v[2]}}); }
 
 }  // namespace
 
-int main(int argc, char* argv[]) {
+static int run_main(int argc, char* argv[]) {
   Flags F({{"telemetry_json", ""}, {"input_pose_dataset", ""}, {"input_corners", ""}, {"camera_calibration_json", ""},
            {"gyro_to_cam_initial_calibration", ""}, {"imu_intrinsics", ""}, {"imu_bias_file", ""}, {"global_shutter", "false"},
            {"spline_error_weighting_json", ""}, {"output_path", ""}, {"calibrate_cam_line_delay", "false"}, {"result_output_json", ""},
@@ -247,4 +249,10 @@ int main(int argc, char* argv[]) {
   const oicc_summary& s = imu_cam_calibrator.last_summary_;
   std::cout << "done: P=" << s.num_parameters_tangent << " blocks=" << s.num_residual_blocks << "\n";
   return 0;
+}
+
+// A malformed input file (missing key, bad number, truncated UBJSON) ends with a message and exit code 1, not in std::terminate.
+int main(int argc, char* argv[]) {
+  try { return run_main(argc, argv); }
+  catch (const std::exception& e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }

@@ -7,6 +7,8 @@
 // BundleAdjustView (Huber 1.345) of ALL frames is one kernel launch (oicc_ba_optimize_views).  The start pose per frame
 // comes from planar_init.hpp instead of Theia's RANSAC PnP [EXT]; the output is the JSON twin of the Theia archive plus
 // `<out>.ply`.  C++ twin of openimucameracalibrator_amd/estimate_camera_poses_from_checkerboard.py.
+#include <exception>
+#include <iostream>
 #include <algorithm>
 #include <cmath>
 
@@ -15,7 +17,7 @@
 using namespace oicc_cli;
 using namespace OpenICC::core;
 
-int main(int argc, char* argv[]) {
+static int run_main(int argc, char* argv[]) {
   Flags F({{"input_corners", ""}, {"camera_calibration_json", ""}, {"output_pose_dataset", ""}, {"optimize_board_points", "false"}, {"dry_run", "false"}});   // dry_run: print the start poses, no device
   if (!F.parse(argc, argv)) return 2;
   Scene sc;
@@ -86,4 +88,10 @@ int main(int argc, char* argv[]) {
   CHECK_MSG(write_pose_dataset(F.str("output_pose_dataset"), V, pe.Points(), sc.point_ids), "Could not write " << F.str("output_pose_dataset"));
   write_ply_cameras(F.str("output_pose_dataset") + ".ply", V.pose, pe.Points());
   return 0;
+}
+
+// A malformed input file (missing key, bad number, truncated UBJSON) ends with a message and exit code 1, not in std::terminate.
+int main(int argc, char* argv[]) {
+  try { return run_main(argc, argv); }
+  catch (const std::exception& e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }

@@ -7,6 +7,8 @@
 // golden-section probes run on the MI355X -- and the output JSON of :199-211.
 // --input_pose_calibration_dataset takes the JSON twin of the TheiaSfM archive (see the other application);
 // view time = "timestamp_s" of the twin if present, else the view name in microseconds (the corner-file convention).
+#include <exception>
+#include <iostream>
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -15,7 +17,7 @@
 
 using namespace oicc_cli;
 
-int main(int argc, char* argv[]) {
+static int run_main(int argc, char* argv[]) {
   Flags F({{"input_pose_calibration_dataset", ""}, {"telemetry_json", ""}, {"imu_bias_estimate", ""},
            {"imu_rotation_init_output", "gyro_to_cam_calibration.json"}, {"delta_t_imu_to_cam", "0.0"}, {"device", "0"}});
   if (!F.parse(argc, argv)) return 2;
@@ -81,4 +83,10 @@ int main(int argc, char* argv[]) {
   CHECK_MSG(f.is_open(), "cannot write " << F.str("imu_rotation_init_output"));
   oicc_json::dump(out, f, 4); f << std::endl;
   return 0;
+}
+
+// A malformed input file (missing key, bad number, truncated UBJSON) ends with a message and exit code 1, not in std::terminate.
+int main(int argc, char* argv[]) {
+  try { return run_main(argc, argv); }
+  catch (const std::exception& e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }
