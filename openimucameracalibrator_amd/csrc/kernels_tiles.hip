@@ -3,14 +3,18 @@
 // reference spline_trajectory_estimator.impl.h:255-276 -> ceres::Solve) is fused into one launch:
 //
 //   workgroup = one tile of consecutive knot windows, 4 waves
-//     P0  knots of the tile -> LDS; per knot pair the segment table (log, axis, Jr^-1: spline_seg.cuh), one lane per pair
+//     P0  knots, tangent offsets, accumulator rows of the knots and the tile's unit descriptors -> LDS (one round trip: the knot
+//         range is predicted from the tile index while the descriptor is in flight); per knot pair the segment table (log, axis,
+//         Jr^-1: spline_seg.cuh), loaded from the table of this parameter vector or, on one-round problems, computed here
 //     P1  every wave pulls units from the tile's queue:  lane = item (corner / IMU sample)
 //           spline evaluation, residual, analytic Jacobian rows (block_items.cuh) -> compact rows in the wave's LDS buffer
 //           per CELL (a view, or the samples sharing one set of knot windows) the augmented Gram matrix [J r]^T [J r]
 //           as 16x16 v_mfma_f64_16x16x4_f64 tiles, operands expanded from the compact rows while they are loaded
 //           tiles -> the tile's band accumulator in LDS (ds_add_f64)
-//     P2  accumulator -> the tile's slab in HBM, plain coalesced stores
-//   slab_merge_kernel: packed normal equations = sum of the overlapping slabs of every band row (fixed order).
+//     P2  interior rows (no other tile has them) -> the packed normal equations; halo rows + arrow corner -> the tile's slab in
+//         HBM; plain coalesced stores either way
+//   slab_merge_kernel: halo rows of the packed normal equations = sum of the slab rows that hold them (fixed order), max |g|.
+//   Problem-constant arguments live in device memory (TileStatic): by value they cost a 9k-cycle spill prologue per workgroup.
 //
 // The cost-only pass (candidate point of an LM step) is the same kernel without rows and accumulators.
 #include <hip/hip_runtime.h>

@@ -4,9 +4,10 @@
 // tile's knots and per-knot-pair segment tables in LDS, its waves pull UNITS (one camera view, or a run of IMU samples)
 // from a queue, evaluate them lane-per-item into compact rows in LDS, form each cell's Gram product on the matrix pipe
 // and add it into the tile's band accumulator IN LDS (ds_add_f64).  The accumulator -- the tile's rows of the band,
-// their arrow columns and gradient entries, plus the arrow corner -- leaves the CU once, with plain coalesced stores,
-// as the tile's SLAB; slab_merge_kernel sums the (few) overlapping slabs of every band row into the packed normal
-// equations.  No global atomics, no memset of the normal equations, a fixed summation order between tiles.
+// their arrow columns and gradient entries, plus the arrow corner -- leaves the CU once, with plain coalesced stores:
+// the rows no other tile has go straight into the packed normal equations, the halo rows and the corner into the tile's
+// SLAB; slab_merge_kernel sums the (few) slab rows of every halo row.  No global atomics, no memset of the normal
+// equations, a fixed summation order between tiles.
 // Geometries whose accumulator does not fit in LDS run the same kernel in DIRECT mode (fp64 atomics on the packed buffer).
 #pragma once
 #include <cstdint>
