@@ -252,7 +252,7 @@ def main():
         if world > 1:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
             out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
                                    allreduce_and_rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms),
-                                   allreduce_bytes=8 * int(lay["P"]) * 0 + int(8 * (Pb * (hb + 1) + a * Pb + a * a + P + 1)))
+                                   allreduce_bytes=int(8 * (Pb * (hb + 1) + a * Pb + a * a + P + 1)))
         if summ is not None:
             out["full_calibration"] = dict(seconds=full_calib_s, stage1_iterations=summ["num_iterations"], stage1_seconds=summ["seconds_total"],
                                            stage2_iterations=s2["num_iterations"], final_reproj_error_px=reproj,
