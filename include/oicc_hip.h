@@ -325,7 +325,9 @@ int oicc_get_trajectory(oicc_problem* p, int64_t n, const int64_t* t_ns,
  *   variance signal_energy((1 - H) Xhat) / n at that dt (sew.py:192-195)
  * min_dt <= 0 / max_dt <= 0 select the reference defaults 1/rate and (n/4)/rate (sew.py:153-157).
  * FFT and the spectral reductions run on the device (hipFFT D2Z + one reduction launch per trial dt).
- * Returns OICC_ERR_INVALID_ARG for n < 8 or a non-increasing time base. */
+ * Returns OICC_ERR_INVALID_ARG for n < 8 or a non-increasing time base.
+ * Thread safety: calls are serialised inside the library (the device buffers and the hipFFT plan of the last
+ * (device, dims, n) are cached for the next call and live until the process ends). */
 int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_t dims, int64_t n, const double* signal,
                                        const double* times, double quality, double min_dt, double max_dt,
                                        double* dt, double* variance, int32_t* num_evaluations);

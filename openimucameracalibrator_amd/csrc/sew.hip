@@ -10,6 +10,7 @@
 #include <hipfft/hipfft.h>
 #include <cmath>
 #include <cstdint>
+#include <mutex>
 #include <vector>
 #include "../../include/oicc_hip.h"
 
@@ -82,7 +83,9 @@ extern "C" int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_
   // get_sew_for_dataset.py calls this twice per data set (accelerometer, gyroscope) and plan creation costs milliseconds
   struct Cache { int device = -1, dims = 0; int64_t n = 0; double* d_sig = nullptr; hipfftDoubleComplex* d_spec = nullptr;
                  double* pw = nullptr; double* acc = nullptr; hipStream_t st = nullptr; hipfftHandle plan = 0; bool have_plan = false; };
-  static Cache C;   // not thread safe (the reference's pre-stage is a single-threaded script)
+  static Cache C;
+  static std::mutex cache_mutex;   // one call at a time: concurrent callers (other devices, other sizes) would rebuild each other's plan mid-use
+  std::lock_guard<std::mutex> cache_lock(cache_mutex);
   auto release = [&]() {
     if (C.have_plan) (void)hipfftDestroy(C.plan);
     if (C.d_sig) (void)hipFree(C.d_sig); if (C.d_spec) (void)hipFree(C.d_spec); if (C.pw) (void)hipFree(C.pw); if (C.acc) (void)hipFree(C.acc);
@@ -102,7 +105,6 @@ extern "C" int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_
   }
   SewDevice D; D.n = n; D.nh = nh; D.bin_hz = sample_rate / double(n); D.pw = C.pw; D.acc = C.acc; D.st = C.st;
   int rc = OICC_OK;
-  auto cleanup = [&]() {};
   if (hipMemcpyAsync(C.d_sig, signal, sizeof(double) * dims * n, hipMemcpyHostToDevice, D.st) != hipSuccess) { release(); return OICC_ERR_HIP; }
   if (hipfftExecD2Z(C.plan, C.d_sig, C.d_spec) != HIPFFT_SUCCESS) { release(); return OICC_ERR_HIP; }
   hipLaunchKernelGGL(sew_power_kernel, dim3(int((nh + 255) / 256)), dim3(256), 0, D.st, C.d_spec, dims, n, nh, D.pw);
@@ -169,6 +171,5 @@ extern "C" int oicc_sew_knot_spacing_and_variance(int32_t device_ordinal, int32_
   } else if (ok) { rc = OICC_ERR_STATE; }
   if (num_evaluations) *num_evaluations = D.evals;
   if (!ok) rc = OICC_ERR_HIP;
-  cleanup();
   return rc;
 }
