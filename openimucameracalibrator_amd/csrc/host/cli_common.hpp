@@ -19,7 +19,10 @@ using oicc_json::Value;
 // gflags-style command line: --name=value, --name value, --bool / --nobool; the table gives names and defaults
 struct Flags {
   std::map<std::string, std::string> s;
-  explicit Flags(std::map<std::string, std::string> table) : s(std::move(table)) {}
+  std::map<std::string, bool> is_bool_flag;   // from the DEFAULTS ("true" / "false"), not from what a previous occurrence set
+  explicit Flags(std::map<std::string, std::string> table) : s(std::move(table)) {
+    for (const auto& kv : s) is_bool_flag[kv.first] = kv.second == "true" || kv.second == "false";
+  }
   bool parse(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -43,7 +46,7 @@ struct Flags {
         if (ignored) continue;
         std::cerr << "unknown flag --" << k << "\n"; return false;
       }
-      const bool is_bool = s[k] == "true" || s[k] == "false";
+      const bool is_bool = is_bool_flag[k];
       if (!has) { if (is_bool) v = neg ? "false" : "true"; else if (i + 1 < argc) v = argv[++i]; else { std::cerr << "flag --" << k << " needs a value\n"; return false; } }
       s[k] = v;
     }
