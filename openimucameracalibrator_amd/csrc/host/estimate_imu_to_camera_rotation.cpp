@@ -33,6 +33,15 @@ static int run_main(int argc, char* argv[]) {
   CameraTelemetryData telemetry;
   CHECK_MSG(ReadTelemetryJSON(F.str("telemetry_json"), &telemetry), "Could not read: " << F.str("telemetry_json"));
   const double delta_t0_cam = telemetry.img_timestamps_s.empty() ? 0.0 : telemetry.img_timestamps_s[0];   // cc:93-100
+  // The reference keys the angular velocities by their timestamp in a std::map (cc:111-115): time order, the last sample
+  // of a repeated timestamp wins.  Same here (the ABI wants strictly increasing times).
+  {
+    std::vector<ImuReading>& g = telemetry.gyroscope;
+    std::stable_sort(g.begin(), g.end(), [](const ImuReading& a, const ImuReading& b) { return a.t_s < b.t_s; });
+    size_t w = 0;
+    for (size_t i = 0; i < g.size(); ++i) { if (w > 0 && g[w - 1].t_s == g[i].t_s) g[w - 1] = g[i]; else g[w++] = g[i]; }
+    g.resize(w);
+  }
   const size_t n_imu = telemetry.gyroscope.size();
   CHECK_MSG(n_imu >= 16, "telemetry too short");
   std::vector<double> t_imu(n_imu), gyro(3 * n_imu);
