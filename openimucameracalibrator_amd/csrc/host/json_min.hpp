@@ -108,8 +108,11 @@ class Parser {
     ++p;
     return s;
   }
+  int depth = 0;
+  struct Nest { int& d; explicit Nest(int& x) : d(x) { ++d; } ~Nest() { --d; } };
   Value parse_value() {
     ws(); if (p >= e) fail("unexpected end");
+    const Nest nest(depth); if (depth > 256) fail("nesting too deep");
     Value v;
     if (*p == '{') {
       ++p; v.type = Value::Object; ws();
@@ -201,7 +204,12 @@ class UbjsonReader {
     switch (t) { case 'i': return be<int8_t>(); case 'U': return be<uint8_t>(); case 'I': return be<int16_t>(); case 'l': return be<int32_t>(); case 'L': return be<int64_t>(); default: fail("expected integer type"); }
   }
   std::string read_str_body() { const int64_t n = read_int(get()); if (n < 0 || e - p < n) fail("bad string length"); std::string s(reinterpret_cast<const char*>(p), size_t(n)); p += n; return s; }
+  int depth = 0;
+  struct Nest { int& d; explicit Nest(int& x) : d(x) { ++d; } ~Nest() { --d; } };
+  // a counted container cannot hold more elements than bytes are left, unless its elements carry no payload (Z, T, F): those are capped
+  void check_count(int64_t n, uint8_t ct) { if (n < 0) fail("negative count"); const bool empty_type = ct == 'Z' || ct == 'T' || ct == 'F'; if (empty_type ? n > (int64_t(1) << 20) : n > int64_t(e - p)) fail("container count exceeds the file"); }
   Value read_value(uint8_t t) {
+    const Nest nest(depth); if (depth > 256) fail("nesting too deep");
     Value v;
     switch (t) {
       case 'Z': return v; case 'T': return Value(true); case 'F': return Value(false);
@@ -214,14 +222,14 @@ class UbjsonReader {
       case '[': {
         v.type = Value::Array; uint8_t ct = 0; int64_t n = -1;
         if (p < e && *p == '$') { ++p; ct = get(); }
-        if (p < e && *p == '#') { ++p; n = read_int(get()); }
+        if (p < e && *p == '#') { ++p; n = read_int(get()); check_count(n, ct); }
         if (n >= 0) { for (int64_t i = 0; i < n; ++i) v.arr.push_back(read_value(ct ? ct : get())); }
         else { while (true) { uint8_t c = get(); if (c == ']') break; v.arr.push_back(read_value(c)); } }
         return v; }
       case '{': {
         v.type = Value::Object; uint8_t ct = 0; int64_t n = -1;
         if (p < e && *p == '$') { ++p; ct = get(); }
-        if (p < e && *p == '#') { ++p; n = read_int(get()); }
+        if (p < e && *p == '#') { ++p; n = read_int(get()); check_count(n, ct); }
         if (n >= 0) { for (int64_t i = 0; i < n; ++i) { std::string k = read_str_body(); v.obj[k] = read_value(ct ? ct : get()); } }
         else { while (true) { if (p < e && *p == '}') { ++p; break; } std::string k = read_str_body(); v.obj[k] = read_value(get()); } }
         return v; }
