@@ -1,0 +1,46 @@
+"""Worker of test_two_processes_on_one_gpu_reduce_through_the_hook: rank r of WORLD_SIZE processes, ALL on GPU 0, holds the
+r-th time shard of a problem and runs oicc_optimize with an all-reduce hook that stages through host memory and gloo
+(RCCL refuses two ranks on one device; the hook is the product path under test, the transport is not).
+usage: python mp_shard_worker.py <cfg> <flags> <iterations> <bounds_line_search> <out.json>   (RANK / WORLD_SIZE / MASTER_* from the env)"""
+import ctypes, json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openimucameracalibrator_amd import synthetic, estimator as E
+
+
+def main():
+    cfg, flags, iters, ls, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    calls = {"n": 0, "doubles": 0}
+
+    def allreduce(ptr, count, strm):
+        assert hip.hipStreamSynchronize(strm) == 0
+        buf = torch.empty(count, dtype=torch.float64)
+        assert hip.hipMemcpy(buf.data_ptr(), ptr, count * 8, 2) == 0      # device -> host
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        assert hip.hipMemcpy(ptr, buf.data_ptr(), count * 8, 1) == 0      # host -> device
+        calls["n"] += 1; calls["doubles"] += count
+
+    ds = synthetic.make_config(cfg)
+    cal = E.ImuCameraCalibrator().BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
+    tr = cal.trajectory_
+    tr.SetOption("bounds_line_search", ls)
+    if world > 1:
+        tr.SetAllReduce(allreduce)
+    s = tr.Optimize(iters, flags)
+    it = tr.GetIterations()
+    res = dict(rank=rank, blocks=cal.num_blocks, iterations=[dict(cost=i["cost"], ok=i["step_is_successful"], gmax=i["gradient_max_norm"]) for i in it],
+               final_cost=s["final_cost"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"])
+    json.dump(res, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -551,3 +551,38 @@ def test_bounds_line_search_matches_the_oracle(cfg, flags, inner):
     plain.trajectory_.SetOption("inner_iterations", inner)
     sp = plain.trajectory_.Optimize(50, flags)
     assert sp["num_iterations"] != sg["num_iterations"] or abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
+
+
+# ---- two processes, one GPU: the product's all-reduce hook inside oicc_optimize ---------------------------------------------
+@pytest.mark.parametrize("cfg,flags,ls", [("C1", FLAGS1, 0), ("tiny", FLAGS1 | E.ACC_BIAS, 1)])
+def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, tmp_path):
+    """Rank r of two PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
+    all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
+    LmState) after every cost pass, slopes of the bounds line search.  RCCL refuses two ranks on one device, so the hook stages
+    through host memory and gloo -- the product side of the hook is what is tested.  Both ranks must take the same steps as ONE
+    process holding the whole problem."""
+    import os, subprocess, sys as _sys, json as _json, socket
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_shard_worker.py")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+
+    def run(world):
+        procs, outs = [], []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), LOCAL_RANK="0")
+            out = str(tmp_path / ("w%d_r%d.json" % (world, r))); outs.append(out)
+            procs.append(subprocess.Popen([_sys.executable, worker, cfg, str(int(flags)), "6", str(ls), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        for p_ in procs:
+            o, _ = p_.communicate(timeout=240)
+            assert p_.returncode == 0, o.decode()[-2000:]
+        return [_json.load(open(o)) for o in outs]
+
+    whole = run(1)[0]
+    parts = run(2)
+    assert sum(p_["blocks"] for p_ in parts) == whole["blocks"] and all(p_["hook_calls"] >= 2 * (len(whole["iterations"]) - 1) for p_ in parts)
+    for p_ in parts:
+        assert len(p_["iterations"]) == len(whole["iterations"])
+        for a, b in zip(p_["iterations"], whole["iterations"]):
+            assert a["ok"] == b["ok"] and abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"], (a, b)
+        assert np.abs(np.array(p_["T_i_c"]) - np.array(whole["T_i_c"])).max() < 1e-7
+    assert np.abs(np.array(parts[0]["T_i_c"]) - np.array(parts[1]["T_i_c"])).max() < 1e-9
+
