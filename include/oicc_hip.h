@@ -213,7 +213,8 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * automatic ordering of Ceres 2.1.0, coordinate_descent_minimizer.cc / trust_region_minimizer.cc:352-412),
  * inner_iteration_tolerance 1e-3; bounds_line_search 0|1 (1 = the Armijo search along the projected path that Ceres runs
  * before every candidate evaluation once bias knots with box bounds, impl.h:206-240, are variable).
- * The applications set both to 1 as the reference's Ceres behaves; the library default
+ * projected_gradient_norm 0|1 (1 = gradient_max_norm of such a bounds-constrained program as Ceres computes it).
+ * The applications set all three to 1 as the reference's Ceres behaves; the library default
  * is 0 so that plain LM steps stay available to callers and tests. */
 int oicc_set_option(oicc_problem* p, const char* name, double value);
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,

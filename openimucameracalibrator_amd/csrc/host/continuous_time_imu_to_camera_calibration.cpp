@@ -157,6 +157,7 @@ static int run_main(int argc, char* argv[]) {
   imu_cam_calibrator.trajectory_.SetOption("solver_partitions", F.d("solver_partitions"));
   imu_cam_calibrator.trajectory_.SetOption("solver_algorithm", F.d("solver_algorithm"));
   imu_cam_calibrator.trajectory_.SetOption("inner_iterations", F.b("use_inner_iterations") ? 1.0 : 0.0);
+  imu_cam_calibrator.trajectory_.SetOption("projected_gradient_norm", 1.0);   // likewise: Ceres' gradient norm of a bounds-constrained program
   imu_cam_calibrator.trajectory_.SetOption("bounds_line_search", 1.0);   // what Ceres does by itself once the bias knots carry bounds (--reestimate_biases, impl.h:206-240)
   imu_cam_calibrator.BatchInitSpline(recon_calib_dataset, T_i_c_init, weight_data, time_offset_imu_to_cam, telemetry_data, init_line_delay_us, acc_intr, gyr_intr);
   const std::string axis = F.str("known_grav_dir_axis");   // GravDirStringToInt, utils.cc:150-161

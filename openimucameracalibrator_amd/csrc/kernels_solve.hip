@@ -222,6 +222,58 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
   }
 }
 
+// Ceres' gradient norm of a bounds-constrained program (TrustRegionMinimizer::EvaluateGradientAndJacobian): max norm of
+// Plus(x, -g) - x in the AMBIENT space over the active blocks, Plus = the retraction above including the projection of the bias
+// knots onto their box.  (A quaternion block can contribute at most 2, an unbounded Euclidean entry |g_i|.)  atomicMax on the bit
+// pattern of the non-negative result; the caller zeroes LmState::gradient_max_norm first.
+__global__ void lm_projected_gradient_kernel(const double* x, ParamLayout pl, TangentLayout tl, const double* g, double max_ab, double max_gb, LmState* st) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  double m = 0.0;
+  for (int64_t k = tid; k < pl.n_so3; k += nthreads) {
+    const int o = tl.so3[k];
+    if (o >= 0) {
+      const double* q0 = x + pl.so3 + 4 * k;
+      const double om[3] = {-g[o], -g[o + 1], -g[o + 2]};
+      const Quat r = so3_mul(Quat{q0[0], q0[1], q0[2], q0[3]}, so3_exp(om));
+      m = fmax(m, fmax(fmax(fabs(r.x - q0[0]), fabs(r.y - q0[1])), fmax(fabs(r.z - q0[2]), fabs(r.w - q0[3]))));
+    }
+  }
+  for (int64_t k = tid; k < pl.n_r3; k += nthreads) {
+    const int o = tl.r3[k];
+    if (o >= 0) for (int c = 0; c < 3; ++c) { const double v0 = x[pl.r3 + 3 * k + c]; m = fmax(m, fabs((v0 - g[o + c]) - v0)); }
+  }
+  for (int64_t k = tid; k < pl.n_ab; k += nthreads) {
+    const int o = tl.ab[k];
+    if (o >= 0) for (int c = 0; c < 3; ++c) { const double v0 = x[pl.ab + 3 * k + c]; m = fmax(m, fabs(fmin(fmax(v0 - g[o + c], -max_ab), max_ab) - v0)); }
+  }
+  for (int64_t k = tid; k < pl.n_gb; k += nthreads) {
+    const int o = tl.gb[k];
+    if (o >= 0) for (int c = 0; c < 3; ++c) { const double v0 = x[pl.gb + 3 * k + c]; m = fmax(m, fabs(fmin(fmax(v0 - g[o + c], -max_gb), max_gb) - v0)); }
+  }
+  if (tid == 0) {
+    if (tl.tic >= 0) {
+      double a6[6];
+      for (int c = 0; c < 6; ++c) a6[c] = -g[tl.tic + c];
+      Quat dq; double dt[3];
+      se3_exp_dev(a6, &dq, dt);
+      const double* T0 = x + pl.tic;
+      const Quat q{T0[0], T0[1], T0[2], T0[3]};
+      double rt[3]; so3_rotate(q, dt, rt);
+      const Quat r = so3_mul(q, dq);
+      const double T1[7] = {r.x, r.y, r.z, r.w, T0[4] + rt[0], T0[5] + rt[1], T0[6] + rt[2]};
+      for (int c = 0; c < 7; ++c) m = fmax(m, fabs(T1[c] - T0[c]));
+    }
+    auto eucl = [&](int off, int64_t po, int n) { if (off < 0) return; for (int c = 0; c < n; ++c) { const double v0 = x[po + c]; m = fmax(m, fabs((v0 - g[off + c]) - v0)); } };
+    eucl(tl.g, pl.g, 3); eucl(tl.ld, pl.ld, 1); eucl(tl.ai, pl.ai, 6); eucl(tl.gi, pl.gi, 9);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+  if (threadIdx.x == 0 && red[0] > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(&st->gradient_max_norm), (unsigned long long)__double_as_longlong(red[0]));
+}
+
 // out[0] = g . step, out[1] = max |step| (unscaled step = step_s * scale): the slope and the direction norm of the bounds line search
 __global__ void lm_step_slope_kernel(const double* g, const double* step_s, const double* scale, int P, double* out) {
   __shared__ double red[2][1024];
@@ -243,6 +295,11 @@ void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double
 void launch_lm_scale(const NormalEq& ne, const TangentLayout& tl, double* scale, int jacobi, hipStream_t st) {
   if (tl.P == 0) return;
   hipLaunchKernelGGL(lm_scale_kernel, dim3((tl.P + 255) / 256), dim3(256), 0, st, ne, tl, scale, jacobi);
+}
+void launch_lm_projected_gradient(const double* x, const ParamLayout& pl, const TangentLayout& tl, const NormalEq& ne, double max_ab, double max_gb, LmState* s, hipStream_t st) {
+  (void)hipMemsetAsync(&s->gradient_max_norm, 0, sizeof(double), st);
+  int grid = int((pl.total + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(lm_projected_gradient_kernel, dim3(grid), dim3(256), 0, st, x, pl, tl, ne.g(), max_ab, max_gb, s);
 }
 void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st) {
   hipLaunchKernelGGL(lm_gradmax_kernel, dim3(1), dim3(256), 0, st, ne, P, s);

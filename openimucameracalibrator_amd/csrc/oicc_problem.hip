@@ -50,6 +50,7 @@ void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock*
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st);
+void launch_lm_projected_gradient(const double* x, const ParamLayout& pl, const TangentLayout& tl, const NormalEq& ne, double max_ab, double max_gb, LmState* s, hipStream_t st);
 }  // namespace oicc
 
 using namespace oicc;
@@ -173,6 +174,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
@@ -1276,9 +1278,13 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
 
   double t0 = now_s();
   HIPCK(p, hipMemsetAsync(p->d_state.p, 0, sizeof(LmState), st));
-  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
+  const bool projected_gmax = p->opt["projected_gradient_norm"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: is_constrained
+  auto gradient_norm = [&](const double* xbuf, const NormalEq& nq) {   // after a Jacobian pass at xbuf into nq
+    if (projected_gmax) launch_lm_projected_gradient(xbuf, p->pl, tl, nq, p->max_ab, p->max_gb, p->d_state.p, st);
+    else if (!p->gmax_folded) launch_lm_gradmax(nq, P, p->d_state.p, st); };
+  rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, !projected_gmax); if (rc) return rc;
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
-  if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); if (!p->gmax_folded) launch_lm_gradmax(p->ne, P, p->d_state.p, st); }
+  if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); gradient_norm(p->d_x.p, p->ne); }
   rc = read_back(true); if (rc) return rc;
   cost = pin->cost; gmax = pin->st.gradient_max_norm;
   S.seconds_jacobian += now_s() - t0;
@@ -1427,8 +1433,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     const bool speculate = p->opt["debug_sync"] != 3.0;
     HIPCK(p, hipEventRecord(ev[3], st));
     if (speculate) {
-      rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
-      if (!p->gmax_folded) launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+      rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, !projected_gmax); if (rc) return rc;
+      gradient_norm(p->d_xc.p, p->ne2);
     }
     HIPCK(p, hipEventRecord(ev[4], st));
     rc = read_back_wait(); if (rc) return rc;
@@ -1474,8 +1480,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     }
     if (rel_dec > min_rel_dec || inner_useful) {   // IsStepSuccessful
       if (!speculate) {
-        rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
-        if (!p->gmax_folded) launch_lm_gradmax(p->ne2, P, p->d_state.p, st);
+        rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, !projected_gmax); if (rc) return rc;
+        gradient_norm(p->d_xc.p, p->ne2);
       }
       std::swap(p->d_x.p, p->d_xc.p);          // accept: candidate becomes current ...
       std::swap(p->ne.base, p->ne2.base);      // ... and so do its normal equations (already being computed)

@@ -70,6 +70,7 @@ struct Problem {
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["analytic_jacobians"] = 0;
     opt["inner_iterations"] = 0;            // 1: Ceres' use_inner_iterations = true (impl.h:266), ceres_inner.hpp
     opt["inner_iteration_tolerance"] = 1e-3; // Solver::Options default
+    opt["projected_gradient_norm"] = 0;     // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x)
     opt["bounds_line_search"] = 0;          // 1: Ceres' Armijo search along the projected path when bias knots are box bounded
   }
 };
@@ -559,6 +560,22 @@ double ambient_sq(const Problem& p, const Layout& L, const ParamSnapshot* other)
   return s;
 }
 
+// max-norm of the ambient difference to a snapshot over the ACTIVE parameter blocks
+double ambient_max(const Problem& p, const Layout& L, const ParamSnapshot& other) {
+  double m = 0;
+  auto acc = [&](const double* a, const double* b, int n) { for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(a[i] - b[i])); };
+  for (size_t i = 0; i < L.so3.size(); ++i) if (L.so3[i] >= 0) acc(&p.so3[4 * i], &other.so3[4 * i], 4);
+  for (size_t i = 0; i < L.r3.size(); ++i) if (L.r3[i] >= 0) acc(&p.r3[3 * i], &other.r3[3 * i], 3);
+  if (L.other[0] >= 0) acc(p.T_i_c, other.T_i_c, 7);
+  if (L.other[1] >= 0) acc(p.g, other.g, 3);
+  if (L.other[2] >= 0) acc(&p.ld, &other.ld, 1);
+  for (size_t i = 0; i < L.ab.size(); ++i) if (L.ab[i] >= 0) acc(&p.ab[3 * i], &other.ab[3 * i], 3);
+  for (size_t i = 0; i < L.gb.size(); ++i) if (L.gb[i] >= 0) acc(&p.gb[3 * i], &other.gb[3 * i], 3);
+  if (L.other[3] >= 0) acc(p.acc_intr, other.ai, 6);
+  if (L.other[4] >= 0) acc(p.gyr_intr, other.gi, 9);
+  return m;
+}
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #include "ceres_inner.hpp"
@@ -776,7 +793,18 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   std::vector<double> scale(P, 1.0);
   if (p.opt["jacobi_scaling"] != 0)
     for (int i = 0; i < P; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(ne.get(i, i)));
-  auto grad_max = [&]() { double m = 0; for (double v : ne.g) m = std::max(m, std::fabs(v)); return m; };
+  // Ceres' gradient norm of a bounds-constrained program (TrustRegionMinimizer::EvaluateGradientAndJacobian): the max norm of
+  // Plus(x, -g) - x in the AMBIENT space, Plus including the projection onto the bounds; plain max |g| otherwise.
+  const bool projected_gmax = p.opt["projected_gradient_norm"] != 0 && (a.ab || a.gb);
+  auto grad_max = [&]() {
+    double m = 0;
+    if (!projected_gmax) { for (double v : ne.g) m = std::max(m, std::fabs(v)); return m; }
+    ParamSnapshot s0; snapshot(p, &s0);
+    std::vector<double> neg(ne.g.size()); for (size_t i = 0; i < neg.size(); ++i) neg[i] = -ne.g[i];
+    apply_step(&p, L, neg);
+    m = ambient_max(p, L, s0);
+    restore(&p, s0);
+    return m; };
   double gmax = grad_max();
   { oicc_iteration it{0, 1, cost, 0.0, gmax, 0.0, 0.0, radius}; p.trace.push_back(it); }
   if (verbose) std::printf("[oracle] iter 0 cost %.12e gmax %.3e radius %.3e P=%d hb=%d\n", cost, gmax, radius, P, L.hb);

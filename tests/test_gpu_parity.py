@@ -553,6 +553,25 @@ def test_bounds_line_search_matches_the_oracle(cfg, flags, inner):
     assert sp["num_iterations"] != sg["num_iterations"] or abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
 
 
+def test_projected_gradient_norm_of_the_bounded_problem_matches_the_oracle():
+    """With bias knots among the variables the program is bounds constrained and Ceres reports (and tests against its gradient
+    tolerance) the max norm of Plus(x, -g) - x in the ambient space instead of max |g|: a quaternion block contributes at most 2,
+    a bias entry at most its distance to the bound.  Same numbers from the device kernel and the oracle, different from max |g|."""
+    ds = synthetic.make_config("tiny")
+    flags = FLAGS1 | E.IMU_BIASES
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds); cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("projected_gradient_norm", 1)
+    sg = gpu.trajectory_.Optimize(6, flags); sc = cpu.trajectory_.Optimize(6, flags); plain.trajectory_.Optimize(6, flags)
+    ig, ic, ip = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations(), plain.trajectory_.GetIterations()
+    assert len(ig) == len(ic) == len(ip) >= 4
+    for a, b, c in zip(ig, ic, ip):
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"] and abs(a["cost"] - c["cost"]) <= 1e-10 * c["cost"]   # the iterates do not depend on it
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * b["gradient_max_norm"], (a, b)
+    assert ig[0]["gradient_max_norm"] < 0.5 * ip[0]["gradient_max_norm"]
+
+
 # ---- two processes, one GPU: the product's all-reduce hook inside oicc_optimize ---------------------------------------------
 @pytest.mark.parametrize("cfg,flags,ls", [("C1", FLAGS1, 0), ("tiny", FLAGS1 | E.ACC_BIAS, 1)])
 def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, tmp_path):
