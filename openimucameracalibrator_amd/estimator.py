@@ -90,6 +90,13 @@ class SplineTrajectoryEstimator:
     def SetOption(self, name, value):
         self._ck(self._b.set_option(self._h, name.encode(), float(value)))
 
+    def UseReferenceSolverOptions(self, on=True):
+        """The Ceres behaviour the reference's Optimize() runs with (impl.h:255-276): inner iterations (use_inner_iterations = true),
+        and -- implicit in Ceres once the bias knots carry bounds -- the bounds line search and the projected gradient norm.
+        The C++ application sets the same three options; the bare library / this mirror default to plain LM steps."""
+        for name in ("inner_iterations", "bounds_line_search", "projected_gradient_norm"):
+            self.SetOption(name, 1 if on else 0)
+
     def SetStream(self, hip_stream):
         self._ck(self._b.set_stream(self._h, C.c_void_p(int(hip_stream))))
 

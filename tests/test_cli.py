@@ -60,7 +60,7 @@ def test_cli_full_calibration_matches_python_mirror(tmp_path):
         assert k in out
     # same problem through the Python mirror (file round trip quantises timestamps to ns/us)
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
-    cal.trajectory_.SetOption("inner_iterations", 1)   # the application's default, as the reference's Optimize (impl.h:266)
+    cal.trajectory_.UseReferenceSolverOptions()   # the application's defaults, as the reference's Optimize (impl.h:255-276)
     cal.Optimize(50, E.SPLINE | E.T_I_C | E.GRAVITY_DIR)
     T = cal.trajectory_.GetT_i_c()
     q = np.array([out["q_i_c"][c] for c in "xyzw"]); t = np.array([out["t_i_c"][c] for c in "xyz"])
