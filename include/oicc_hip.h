@@ -204,9 +204,8 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * device-side choices (no effect on the result beyond rounding):
  *   solver_algorithm 0 (0 auto, 1 LDS-window band sweep, 2 block cyclic reduction; any geometry neither takes
  *   goes to a global-memory band Cholesky), solver_partitions 0 (time partitions of algorithm 1; 0 = heuristic),
- *   imu_chunk_cells 0 (knot-window cells per IMU work-list chunk of assembly 1; 0 = 1 on small problems, as many as fit on large ones),
- *   assembly 0 (0: time tiles - LDS accumulators + slab merge, 1: one wave per view / IMU chunk with global fp64 atomics,
- *   2: time tiles adding straight into the packed matrix), tile_windows 0 (knot windows per tile; 0 = automatic),
+ *   assembly 0 (0: time tiles - LDS accumulators + slab merge, 2: time tiles adding straight into the packed matrix with
+ *   fp64 atomics), tile_windows 0 (knot windows per tile; 0 = automatic),
  *   wide_cells 1 (IMU samples of neighbouring knot windows share one Gram product).
  * Ceres' inner iterations, which the reference switches on (impl.h:266), change the iterates and are therefore an
  * option of the RESULT, not of the device: inner_iterations 0|1 (1 = Solver::Options::use_inner_iterations with the

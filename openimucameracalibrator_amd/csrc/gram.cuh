@@ -1,5 +1,5 @@
 // Per-cell Gram product [J r]^T [J r] on the matrix pipe and its scatter into the band + arrow normal equations;
-// shared by the residual kernels of the spline problem (kernels_blocks.hip) and of view bundle adjustment (kernels_ba.hip).
+// of the residual kernels of view bundle adjustment (kernels_ba.hip; the spline problem has its own tile version in kernels_tiles.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"

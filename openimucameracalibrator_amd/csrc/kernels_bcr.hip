@@ -501,9 +501,8 @@ static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
 // the factorisation was seen to fail sporadically (NaN pivots in ~10 % of the solves that reuse the damping diagonal after a
 // rejected step, round-2 measurements in DESIGN.md) depending on what the preceding kernel left in LDS; until that is
 // understood such systems go to the band sweep (kernels_cholesky.hip), which takes any arrow width.
-int g_bcr_no_diag_copy = 0;   // debug option debug_bcr_no_diag_copy: reproduces the round-2 failure of wide borders
-int g_bcr_max_border = 32;   // rows of arrow + rhs the solver takes (debug option bcr_max_border of oicc_problem; see the note above)
-bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= g_bcr_max_border; }
+// (the limit travels with the problem: SolveBuffers::bcr_max_border, option bcr_max_border; the workspace is sized for the kernels' own limit)
+bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
@@ -513,7 +512,7 @@ int64_t bcr_workspace_doubles(const TangentLayout& tl) {
 // build + factor + solve; the solution lands in sb.step_s.  Returns 0, or -1 if not applicable.
 int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal,
                      double min_diag, double max_diag, hipStream_t st) {
-  if (!bcr_applicable(tl) || sb.ws == nullptr || sb.ws_doubles < bcr_workspace_doubles(tl)) return -1;
+  if (!bcr_applicable(tl) || tl.a + 1 > sb.bcr_max_border || sb.ws == nullptr || sb.ws_doubles < bcr_workspace_doubles(tl)) return -1;
   const int n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
   BcrArgs A{};
   double* w = sb.ws;
@@ -522,7 +521,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.S = w; w += (int64_t)2 * n * 4096;
   A.Lf = w;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
-  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = g_bcr_no_diag_copy;
+  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = sb.bcr_no_diag_copy;
   A.rtf = (a1 + 15) / 16;
   const int Rp = 192 + 16 * A.rtf;
   A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;

@@ -18,6 +18,7 @@
 //
 // The cost-only pass (candidate point of an LM step) is the same kernel without rows and accumulators.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "oicc_device.h"
 #include "tiles.h"
 #include "block_items.cuh"
@@ -641,17 +642,25 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(int n_doubles) {
   __syncthreads();
   if (lds[(threadIdx.x * 97) % n_doubles] == 0.0) asm volatile("s_nop 0");   // keep the stores
 }
+// HIP function attributes are per device: one flag per device ordinal (atomic: problems on several devices / host threads)
+static void allow_full_lds(const void* fn, std::atomic<uint64_t>& done) {
+  int dev = 0; (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.fetch_or(bit, std::memory_order_release);
+}
 void launch_lds_poison(hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static std::atomic<uint64_t> done{0};
+  allow_full_lds(reinterpret_cast<const void*>(lds_poison_kernel), done);
   hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, st, 160 * 1024 / 8);
 }
 
 // ---- launchers ----
 template <bool JAC, bool DIRECT>
 static void launch_tile_kernel(const TileStatic* dS, const TileDyn& dyn, int n_tiles, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static std::atomic<uint64_t> done{0};
+  allow_full_lds(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT>), done);
   hipLaunchKernelGGL((tile_kernel<JAC, DIRECT>), dim3(n_tiles), dim3(kTileThreads), lds, st, dS, dyn);
 }
 // hS: the host copy of *dS (already uploaded on this stream)

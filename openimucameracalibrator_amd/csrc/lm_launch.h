@@ -16,8 +16,6 @@ void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
                      double max_diag, hipStream_t st);
 int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st);
 int64_t bcr_workspace_doubles(const TangentLayout& tl);
-extern int g_bcr_no_diag_copy;
-extern int g_bcr_max_border;   // arrow + rhs rows the block cyclic reduction takes (kernels_bcr.hip)
 int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                      double max_diag, hipStream_t st);
 // damped system + factorisation + solve (solution in sb.step_s): block cyclic reduction when the

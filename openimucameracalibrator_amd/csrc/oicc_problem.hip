@@ -5,8 +5,8 @@
 // (reference include/OpenCameraCalibrator/core/spline_trajectory_estimator.impl.h):
 //   SetTimes :38-51, InitBiasSplines :54-90, SetFixedParams :93-252, Optimize
 //   :255-276, Add*Measurement :342-613, CalcTimes :764-788, getters :879-1248.
-// The arithmetic of the solve runs in the HIP kernels of kernels_blocks.hip and
-// kernels_solve.hip; this file never computes residuals, Jacobians or solves on
+// The arithmetic of the solve runs in the HIP kernels of kernels_tiles.hip, kernels_bcr.hip,
+// kernels_solve.hip and inner_iterations.hip; this file never computes residuals, Jacobians or solves on
 // the CPU (there is no CPU fallback).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and enums only: the entry points are bound with dlsym at run time
@@ -31,11 +31,7 @@
 #include "line_search.h"
 
 namespace oicc {
-// kernels_blocks.hip
-void launch_view_blocks(const EvalCtx& ctx, const ViewData& vd, bool spline_active, bool jac, hipStream_t st);
-void launch_imu_blocks(int kind, const EvalCtx& ctx, const ImuData& id, bool spline_active, bool bias_active, bool jac, hipStream_t st);
-void launch_all_blocks(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, bool spline_active, bool ab_active,
-                       bool gb_active, bool jac, hipStream_t st);
+// kernels_trajectory.hip
 void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, const int32_t* s_r3, const double* u_so3,
                        const double* u_r3, const int32_t* s_gb, const double* u_gb, const int32_t* s_ab, const double* u_ab,
                        double inv_gb_dt, double inv_ab_dt, double* pose7, double* gyro3, double* accel3, double* gb3, double* ab3,
@@ -158,10 +154,14 @@ struct oicc_problem {
   struct InnerPlan {
     std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<char> group_has_so3; std::vector<int32_t> maps;
     DevBuf<InnerBlock> d_blocks; DevBuf<InnerState> d_states; DevBuf<int32_t> d_maps, d_not_done; DevBuf<double> d_seg;
-    int flags = -2; size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
+    int flags = -2; int64_t layout_gen = -1; bool gs_unit = false;   // what the plan was built from: the tangent layout (make_layout generation) and the GS weighting
+    size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
   } inner;
   // cached layout
-  int layout_flags = -1; HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
+  // layout_flags = -1 invalidates (measurements, knot counts, line delay set by the caller); otherwise the layout and the tiles are
+  // rebuilt only when the flags, the zero-ness of the line delay (active_set) or an option changed since they were built
+  int layout_flags = -1; bool layout_ld_zero = false; int64_t opt_gen = 0, layout_opt_gen = -1, layout_gen = 0;
+  HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
   Active act{};
 
   oicc_problem() {
@@ -176,7 +176,7 @@ struct oicc_problem {
     opt["inner_iteration_tolerance"] = 1e-3;
     opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
-    opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 1: one wave per view / IMU chunk with global fp64 atomics, 2: tiles in direct mode
+    opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 2: tiles in direct mode (fp64 atomics on the packed buffer: the independent accumulation path of the tests)
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
@@ -322,7 +322,6 @@ int build_tiles(oicc_problem* p);
 
 // Tangent layout: the ordering contract of include/oicc_hip.h.
 int make_layout(oicc_problem* p, int flags) {
-  g_bcr_max_border = int(p->opt["bcr_max_border"]); g_bcr_no_diag_copy = int(p->opt["debug_bcr_no_diag_copy"]);
   const Active a = active_set(p, flags);
   // the layout also depends on whether line delay is currently zero (active_set) -> recompute when it might differ
   HostLayout& L = p->L;
@@ -385,8 +384,10 @@ int make_layout(oicc_problem* p, int flags) {
     p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
-  p->layout_flags = flags;
-  return build_tiles(p);
+  p->layout_flags = -1;   // (stays invalid if the tiles cannot be built)
+  const int rc = build_tiles(p);
+  if (rc == OICC_OK) { p->layout_flags = flags; p->layout_ld_zero = p->x[p->pl.ld] == 0.0; p->layout_opt_gen = p->opt_gen; ++p->layout_gen; }
+  return rc;
 }
 
 
@@ -690,6 +691,7 @@ int prepare(oicc_problem* p, int flags) {
   HIPCK(p, hipSetDevice(p->device));
   int rc = sync_measurements(p); if (rc) return rc;
   rc = sync_params_to_device(p); if (rc) return rc;
+  if (p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen) return OICC_OK;   // layout, buffers and tiles are current
   return make_layout(p, flags);
 }
 
@@ -725,7 +727,8 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
 // graph, and Ceres' recursive independent-set ordering (reversed).
 int build_inner_plan(oicc_problem* p, int flags) {
   oicc_problem::InnerPlan& ip = p->inner;
-  if (ip.flags == flags && !ip.blocks.empty()) return OICC_OK;
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  if (ip.flags == flags && ip.layout_gen == p->layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return OICC_OK;
   const HostLayout& L = p->L; const ParamLayout& pl = p->pl;
   struct HB { InnerBlock b; int order; std::vector<int32_t> views, accs, gyrs; };
   std::vector<HB> B;
@@ -734,7 +737,6 @@ int build_inner_plan(oicc_problem* p, int flags) {
     if (off < 0) return -1;
     if (*slot < 0) { HB h; h.b = InnerBlock{kind, idx, dim, amb, xoff}; h.order = int(B.size()); *slot = int(B.size()); B.push_back(h); }
     return *slot; };
-  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
   const size_t nv = p->view_rs.size();
   for (size_t v = 0; v < nv; ++v) {
     if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
@@ -810,7 +812,7 @@ int build_inner_plan(oicc_problem* p, int flags) {
   hipStream_t st = p->stream;
   if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_maps.upload(ip.maps, st) || !ip.d_states.resize(std::max<size_t>(ip.blocks.size(), 1)) || !ip.d_not_done.resize(1) ||
       !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * 17)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
-  ip.flags = flags;
+  ip.flags = flags; ip.layout_gen = p->layout_gen; ip.gs_unit = gs_unit;
   return OICC_OK;
 }
 
@@ -855,20 +857,9 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
               double* cost_out = nullptr) {   // cost_out (tile assembly, cost passes): device address the cost is added to instead of the cost slot
   p->gmax_folded = false;
   hipStream_t st = p->stream;
-  EvalCtx ctx = make_ctx(p, x);
   const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
-  ctx.ne = ne;
-  ctx.dbg_res = dbg_res; ctx.dbg_jac = dbg_jac; ctx.prof = prof;
-  const Active& a = p->act;
   if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
-  if (int(p->opt["assembly"]) == 1) {   // one wave per view / IMU chunk, fp64 atomics on the packed buffer (kernels_blocks.hip)
-    if (jac) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
-    else if (!cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
-    if (only_kind < 0) launch_all_blocks(ctx, view_data(p, force_rs), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), a.spline, a.ab, a.gb, jac, st);
-    if (only_kind == 0) launch_view_blocks(ctx, view_data(p, force_rs), a.spline, jac, st);
-    if (only_kind == 1) launch_imu_blocks(0, ctx, imu_data(p->acc, p->d_acc), a.spline, a.ab, jac, st);
-    if (only_kind == 2) launch_imu_blocks(1, ctx, imu_data(p->gyr, p->d_gyr), a.spline, a.gb, jac, st);
-  } else {                              // time tiles (kernels_tiles.hip): the slab merge writes every entry of the packed buffer
+  {                                     // time tiles (kernels_tiles.hip): the slab merge writes every entry of the packed buffer
     if (jac && (p->tp.direct || p->tp.n_tiles == 0)) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
     else if (!jac && !cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
     const TileParams& tp = p->tp;
@@ -906,11 +897,17 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   HIPCK(p, hipGetLastError());
   if (p->opt["debug_sync"] != 0.0) HIPCK(p, hipStreamSynchronize(st));
   if (p->reduce) {
-    double* cdst = (!jac && cost_out && int(p->opt["assembly"]) != 1) ? cost_out : ne.cost();
+    double* cdst = (!jac && cost_out) ? cost_out : ne.cost();
     int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, cdst, 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   }
   return OICC_OK;
+}
+
+SolveBuffers solve_buffers(oicc_problem* p, long long* prof = nullptr) {
+  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, prof, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  sb.radius = 0.0; sb.bcr_max_border = int(p->opt["bcr_max_border"]); sb.bcr_no_diag_copy = int(p->opt["debug_bcr_no_diag_copy"]);
+  return sb;
 }
 
 int read_cost(oicc_problem* p, double* cost) {
@@ -998,7 +995,9 @@ int oicc_set_stream(oicc_problem* p, void* s) {
   p->stream = reinterpret_cast<hipStream_t>(s); p->own_stream = false; return OICC_OK;
 }
 int oicc_set_option(oicc_problem* p, const char* name, double value) {
-  auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name); it->second = value;
+  auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name);
+  if (it->second != value) ++p->opt_gen;   // layout / tiles / inner plan are rebuilt at the next pass
+  it->second = value;
   if (std::string(name) == "imu_chunk_cells") p->meas_dirty = true;   // the work lists are rebuilt at the next pass
   return OICC_OK;
 }
@@ -1260,8 +1259,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   hipEvent_t* ev = p->ev;
   // The candidate's cost is accumulated in LmState::cand_cost (tile assembly), so that ONE small copy brings back everything the
   // host decides on; the cost slot of the normal equations is only read where a Jacobian pass left the cost there.
-  const bool cost_in_state = int(p->opt["assembly"]) != 1;
-  double* const cand_dst = cost_in_state ? &p->d_state.p->cand_cost : nullptr;
+  constexpr bool cost_in_state = true;
+  double* const cand_dst = &p->d_state.p->cand_cost;
   auto cand_cost_of = [&]() { return cost_in_state ? pin->st.cand_cost : pin->cost; };
   auto read_back = [&](bool with_ne_cost = false) -> int {
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
@@ -1283,7 +1282,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (projected_gmax) launch_lm_projected_gradient(xbuf, p->pl, tl, nq, p->max_ab, p->max_gb, p->d_state.p, st);
     else if (!p->gmax_folded) launch_lm_gradmax(nq, P, p->d_state.p, st); };
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, !projected_gmax); if (rc) return rc;
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  SolveBuffers sb = solve_buffers(p);
   if (P > 0) { launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st); gradient_norm(p->d_x.p, p->ne); }
   rc = read_back(true); if (rc) return rc;
   cost = pin->cost; gmax = pin->st.gradient_max_norm;
@@ -1314,6 +1313,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (iter >= max_iters) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached."); }
     if (radius <= min_radius) { rc = settle_gmax(); if (rc) return rc; return finish(OICC_CONVERGENCE, "Minimum trust region radius reached."); }
     // --- trust-region step: damped solve on the device, retraction, candidate cost
+#ifdef OICC_DEBUG_SOLVER   // host copies / comparisons before every solve (make HIPFLAGS+=-DOICC_DEBUG_SOLVER): not in the shipped library
     if (p->opt["debug_check_ne"] != 0.0) {
       static std::vector<double> keep; static const double* keep_base = nullptr;
       std::vector<double> now(p->ne.total), aux(size_t(3) * std::max(P, 1));
@@ -1338,6 +1338,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       if (w == 6) HIPCK(p, hipMemcpyAsync(sink.data(), sb.diag, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
       HIPCK(p, hipStreamSynchronize(st));
     }
+#endif
     HIPCK(p, hipEventRecord(ev[0], st));
     if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
     if (launch_lm_solve(p->ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
@@ -1512,7 +1513,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  SolveBuffers sb = solve_buffers(p);
   oicc_problem::HostPin* pin = p->pin;
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));
   p->seg_invalidate(p->d_xc.p);
@@ -1533,10 +1534,8 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
           rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
       p->seg_invalidate(p->d_xc.p);
     }
-    const bool cost_in_state = int(p->opt["assembly"]) != 1;   // as in oicc_optimize: the candidate cost comes back inside LmState
-    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cost_in_state ? &p->d_state.p->cand_cost : nullptr); if (rc) return rc;
+    rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, &p->d_state.p->cand_cost); if (rc) return rc;   // as in oicc_optimize: the candidate cost comes back inside LmState
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));
-    if (!cost_in_state) HIPCK(p, hipMemcpyAsync(&pin->cost, p->ne.cost(), sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(p, hipEventRecord(p->ev[5], st));
     rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true); if (rc) return rc;
     if (!p->gmax_folded) launch_lm_gradmax(p->ne2, tl.P, p->d_state.p, st);
@@ -1577,7 +1576,7 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, nullptr, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  SolveBuffers sb = solve_buffers(p);
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
@@ -1610,7 +1609,7 @@ int oicc_debug_solver_profile(oicc_problem* p, int32_t flags, long long out[12])
   rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
   const TangentLayout& tl = p->tl;
   DevBuf<long long> d; if (!d.resize(12)) return OICC_ERR_HIP;
-  SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, d.p, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
+  SolveBuffers sb = solve_buffers(p, d.p);
   launch_lm_scale(p->ne, tl, sb.scale, 1, st);
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = 1e4;
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));

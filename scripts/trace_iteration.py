@@ -3,7 +3,7 @@
 import csv, sys, glob
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-jac = [i for i, r in enumerate(rows) if "all_blocks_kernel<true>" in r["Kernel_Name"]]
+jac = [i for i, r in enumerate(rows) if "tile_kernel<true, false>" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 i0, i1 = jac[k], jac[k + 1]
 t0 = int(rows[i0]["Start_Timestamp"]); prev = t0; busy = 0

@@ -415,12 +415,12 @@ def test_ragged_views_empty_view_and_views_above_64_corners():
     assert gpu.trajectory_.GetMeanReprojectionError() == 0.0 == cpu.trajectory_.GetMeanReprojectionError()
 
 
-# ---- time-tile assembly (kernels_tiles.hip): LDS accumulators + slab merge vs direct atomics vs the one-wave-per-chunk kernels ----
+# ---- time-tile assembly (kernels_tiles.hip): LDS accumulators + slab merge vs direct atomics ----
 @pytest.mark.parametrize("wide", [1, 0])
-@pytest.mark.parametrize("mode,tile_windows", [(0, 0), (0, 1), (0, 3), (0, 7), (0, 64), (2, 0), (2, 5), (1, 0)])
+@pytest.mark.parametrize("mode,tile_windows", [(0, 0), (0, 1), (0, 3), (0, 7), (0, 64), (2, 0), (2, 5)])
 def test_assembly_modes_match_the_oracle(tiny, mode, tile_windows, wide):
     """Every way the normal equations can be assembled gives the oracle's J^T J / J^T r / cost: tiles of 1 ... all windows
-    (halo rows summed by the merge kernel), tiles in direct mode (fp64 atomics), the one-wave-per-view kernels."""
+    (halo rows summed by the merge kernel), tiles in direct mode (fp64 atomics)."""
     ds, _, cpu = tiny
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     gpu.trajectory_.SetOption("assembly", mode); gpu.trajectory_.SetOption("tile_windows", tile_windows); gpu.trajectory_.SetOption("wide_cells", wide)
