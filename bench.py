@@ -177,14 +177,30 @@ def main():
         solve_ms = tr.TimeLinearSolve(flags, repeats=20)
         lay = tr.GetTangentLayout(flags)
         P = lay["P"]; Pb = 3 * int((lay["so3"] >= 0).sum() + (lay["r3"] >= 0).sum()); a = P - Pb
-        # full calibration wall clock on this rank's data (N = 1: the whole C2 problem)
+        # full calibration wall clock (N = 1: the whole C2 problem), twice from the same start: with the solver configuration the
+        # reference runs (impl.h:255-276: use_inner_iterations = true; bounds line search and projected gradient norm implicit in
+        # Ceres) -- the configuration BASELINE's "GoPro9 full calib" is quoted on -- and with plain LM steps (no inner sweeps)
         summ = None
         if world == 1:
-            t1 = time.perf_counter()
-            summ = tr.Optimize(50, flags)
-            reproj = tr.GetMeanReprojectionError()
-            s2 = tr.Optimize(10, E.CAM_LINE_DELAY)
-            full_calib_s = time.perf_counter() - t1
+            def full_calibration(make, reference_options):
+                c = make()
+                if reference_options:
+                    c.trajectory_.UseReferenceSolverOptions()
+                t1 = time.perf_counter()
+                s1 = c.trajectory_.Optimize(50, flags)                      # continuous_time_imu_to_camera_calibration.cc:215-216
+                reproj = c.trajectory_.GetMeanReprojectionError()
+                s2 = c.trajectory_.Optimize(10, E.CAM_LINE_DELAY)            # :217-221
+                secs = time.perf_counter() - t1
+                return dict(seconds=secs, stage1_iterations=s1["num_iterations"], stage1_seconds=s1["seconds_total"], stage2_iterations=s2["num_iterations"],
+                            stage2_seconds=s2["seconds_total"], final_reproj_error_px=reproj, final_cost=s1["final_cost"],
+                            inner_sweeps=s1["inner_sweeps"] + s2["inner_sweeps"], inner_lm_iterations=s1["inner_lm_iterations"] + s2["inner_lm_iterations"],
+                            seconds_inner=s1["seconds_inner"] + s2["seconds_inner"], line_search_steps=s1["line_search_steps"] + s2["line_search_steps"],
+                            seconds_jacobian=s1["seconds_jacobian"] + s2["seconds_jacobian"], seconds_residual=s1["seconds_residual"] + s2["seconds_residual"],
+                            seconds_linear_solver=s1["seconds_linear_solver"] + s2["seconds_linear_solver"]), s1, c
+            make_gpu = lambda: E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds)
+            full_calibration(make_gpu, True)                                   # warm-up: code objects of the inner-iteration kernels
+            full_ref, summ, _ = full_calibration(make_gpu, True)
+            full_plain, _, _ = full_calibration(make_gpu, False)
             hb = summ["half_bandwidth"]
         else:   # no collective may run on rank 0 alone: half bandwidth from the tangent layout (span of the knots of one SO(3) window and the R^3 windows it overlaps)
             so3o, r3o = lay["so3"], lay["r3"]
@@ -221,8 +237,9 @@ def main():
                 if "tile_kernel<true" in line or "slab_merge_kernel" in line or "all_blocks_kernel<true>" in line:
                     tot += float(line.rsplit(",", 1)[1]) * 1024.0
             traffic = tot or None
-        roofline = dict(bound="mfma", kernel=names[dom], achieved=kernels[dom]["fp64_TFLOPs"], peak=78.6, unit="TFLOP/s",
+        roofline = dict(bound="fp64", kernel=names[dom], achieved=kernels[dom]["fp64_TFLOPs"], peak=78.6, unit="TFLOP/s",
                         frac=kernels[dom]["fp64_TFLOPs"] / 78.6, traffic=traffic,
+                        traffic_source=("profiles/" + os.path.basename(pmc) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel pair, not measured in this run)") if traffic else None,
                         hbm=dict(achieved=kernels[dom]["hbm_GBps"], peak=8000.0, unit="GB/s", frac=kernels[dom]["hbm_GBps"] / 8000.0),
                         binds="fp64 datapath of the SIMDs: on MI355X v_mfma_f64_16x16x4_f64 (64 cycles) runs on the vector fp64 lanes, so the Gram MFMAs and "
                               "the spline / Jacobian VALU work of a wave add up (scripts/micro/mfma_lds_rates.hip); peak = 78.6 TFLOP/s for either",
@@ -254,10 +271,8 @@ def main():
                                    allreduce_and_rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms),
                                    allreduce_bytes=int(8 * (Pb * (hb + 1) + a * Pb + a * a + P + 1)))
         if summ is not None:
-            out["full_calibration"] = dict(seconds=full_calib_s, stage1_iterations=summ["num_iterations"], stage1_seconds=summ["seconds_total"],
-                                           stage2_iterations=s2["num_iterations"], final_reproj_error_px=reproj,
-                                           seconds_jacobian=summ["seconds_jacobian"], seconds_residual=summ["seconds_residual"],
-                                           seconds_linear_solver=summ["seconds_linear_solver"])
+            out["full_calibration"] = dict(full_ref, solver_options="reference: inner iterations + bounds line search + projected gradient norm (impl.h:255-276)",
+                                           plain_lm=dict(full_plain, solver_options="plain Levenberg-Marquardt steps (no inner sweeps)"))
         # ---- CPU baseline: the oracle (CPU restatement of the Ceres path) ----------
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -281,7 +296,7 @@ def main():
             t1 = time.perf_counter()
             cs = ccal.trajectory_.Optimize(iters, flags)
             cdt = time.perf_counter() - t1
-            out["cpu_baseline"] = dict(value=n_blocks * cs["num_iterations"] / cdt, unit="blocks/s", cores=nth_best, kind="port",
+            out["cpu_baseline"] = dict(value=n_blocks * cs["num_iterations"] / cdt, unit="blocks/s", cores=nth_best, host_cores=os.cpu_count(), openmp_max_threads=cores, kind="port",
                                        sample="first %d LM iterations of the same C2 problem with the CPU restatement of the Ceres path (forward-mode Jet autodiff in "
                                               "strides of 4, OpenMP over residual blocks, band+arrow Cholesky), best of %s threads: %.2f s" % (
                                                   cs["num_iterations"], "/".join(str(k) for k in sorted(scan)), cdt),
@@ -308,6 +323,20 @@ def main():
                                                    sample="the same %d LM iterations with analytic Jacobians (formulas of the device kernels on the host, OpenMP, "
                                                           "best of 8/16/32/64/%d threads): %.3f s" % (ait, cores, adt),
                                                    ms_per_lm_iteration=1e3 * adt / max(ait, 1))
+            # the FULL calibration on the host cores with the reference's solver options, same start as full_calibration above:
+            # the CPU restatement with Jets (the reference's cost profile) and with the closed-form Jacobians
+            def cpu_full(analytic, nth_):
+                def make():
+                    c_ = E.ImuCameraCalibrator(backend=ob).BatchInitSpline(ds)
+                    c_.trajectory_.SetOption("num_threads", nth_); c_.trajectory_.SetOption("analytic_jacobians", 1 if analytic else 0)
+                    return c_
+                r_, _, _ = full_calibration(make, True)
+                return r_
+            cj = cpu_full(False, nth_best); ca = cpu_full(True, nth)
+            out["cpu_baseline"]["full_calibration_reference_options"] = dict(
+                jets=dict(seconds=cj["seconds"], cores=nth_best, stage1_iterations=cj["stage1_iterations"], inner_sweeps=cj["inner_sweeps"], final_cost=cj["final_cost"]),
+                analytic=dict(seconds=ca["seconds"], cores=nth, stage1_iterations=ca["stage1_iterations"], inner_sweeps=ca["inner_sweeps"], final_cost=ca["final_cost"]),
+                gpu_seconds=full_ref["seconds"], speedup_vs_jets=cj["seconds"] / full_ref["seconds"], speedup_vs_analytic=ca["seconds"] / full_ref["seconds"], kind="port")
         # ---- extra: C5-size Jacobian pass on one GPU --------------------------------
         if not args.no_extra and world == 1:
             try:

@@ -96,6 +96,12 @@ typedef struct oicc_summary {
   double seconds_residual;        /* cost-only passes                           */
   double seconds_linear_solver;   /* damped band+arrow Cholesky solves          */
   char message[128];
+  /* Ceres' optional minimiser stages (options inner_iterations / bounds_line_search; FullReport lines
+   * "Inner iterations" / "Line search steps"): */
+  int32_t inner_sweeps;           /* coordinate-descent sweeps run                       */
+  int32_t line_search_steps;      /* trial step sizes beyond the first                   */
+  int64_t inner_lm_iterations;    /* LM iterations of the per-block solves, all sweeps   */
+  double seconds_inner;           /* wall clock of the sweeps (part of seconds_residual) */
 } oicc_summary;
 
 /* Per-iteration trace (optional, for parity tests): cost, cost change,

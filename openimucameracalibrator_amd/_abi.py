@@ -25,6 +25,8 @@ class Summary(C.Structure):
         ("seconds_total", C.c_double), ("seconds_jacobian", C.c_double),
         ("seconds_residual", C.c_double), ("seconds_linear_solver", C.c_double),
         ("message", C.c_char * 128),
+        ("inner_sweeps", C.c_int32), ("line_search_steps", C.c_int32), ("inner_lm_iterations", C.c_int64),
+        ("seconds_inner", C.c_double),
     ]
 
     def as_dict(self):

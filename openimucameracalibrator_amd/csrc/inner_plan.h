@@ -1,6 +1,6 @@
-// Inner iterations (inner_iterations.hip): parameter blocks of the reduced program, grouped into independent sets, and the
-// device-resident state of each block's Levenberg-Marquardt loop.  Internal, shared by oicc_problem.hip (plan, host loop)
-// and inner_iterations.hip (kernels).
+// Inner iterations (inner_iterations.hip): parameter blocks of the reduced program, grouped into independent sets, the
+// measurements each block depends on and the workgroups that minimise it.  Internal, shared by oicc_problem.hip (plan) and
+// inner_iterations.hip (kernels).
 #pragma once
 #include <cstdint>
 
@@ -8,17 +8,29 @@ namespace oicc {
 
 enum InnerKind { IK_SO3 = 0, IK_R3, IK_TIC, IK_G, IK_LD, IK_AB, IK_GB, IK_AI, IK_GI };
 
+// A run of consecutive items (in the device arrays' order) that depend on one block:
+// kind 0 corners [first, first + count) (their views through ViewData::corner_view), 1 accelerometer samples, 2 gyroscope samples
+struct InnerRun { int32_t kind, first, count, pad; };
+
 struct InnerBlock {
   int32_t kind, idx;      // InnerKind; knot index for the knot kinds
   int32_t dim, ambient;   // tangent / ambient size (SO(3) knot 3 / 4, T_i_c 6 / 7)
   int64_t xoff;           // offset of the block in the parameter vector
+  int32_t run0, nruns;    // its items: runs [run0, run0 + nruns)
+  int32_t n_items;
+  int32_t ctl;            // control block of a block that several workgroups share (InnerCtl index), -1: one workgroup
 };
 
-struct InnerState {
-  double radius, decrease_factor, cost, x_norm, model;
-  double H[81], g[9], scale[9], diag[9], keep[9];
-  double acc_H[81], acc_g[9], acc_cost;    // filled by the evaluation kernels (fp64 atomics)
-  int32_t iter, invalid, done, need_jac, has_candidate, reuse_diagonal, first, pad;
+// one workgroup of a set's launch: part `part` of `nparts` of block `block`
+struct InnerWg { int32_t block, part, nparts, pad; };
+
+// device-resident rendezvous of the workgroups that share one block (all-singleton sets: T_i_c, gravity, line delay, IMU
+// intrinsics, whose items are all views / all samples): partial sums by fp64 atomics, an arrival counter, and the master's
+// command word ((round << 2) | command)
+struct InnerCtl {
+  double acc[56];                 // H (upper, row by row), g, cost
+  unsigned int arrive, word;
+  unsigned int pad[2];
 };
 
 }  // namespace oicc

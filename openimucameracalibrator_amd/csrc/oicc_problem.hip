@@ -142,7 +142,7 @@ struct oicc_problem {
   DevBuf<LmState> d_state; DevBuf<double> d_ls; int64_t line_search_steps = 0;   // d_ls: slope and max norm of the step (bounds line search)
   struct HostPin { LmState st; double cost; double radius; double ls[2]; };
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_tile_rows, h_merge_rows; std::vector<uint8_t> h_row_direct;
   DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src;
@@ -1244,9 +1244,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   const bool verbose = p->opt["verbose"] != 0;
   double decrease_factor = 2.0; bool reuse_diagonal = false;
   double cost = 0.0, gmax = 0.0;
+  const int inner_sweeps0 = p->inner.sweeps; const int64_t inner_lm0 = p->inner.lm_iterations;
   auto finish = [&](int term, const char* msg) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
+    S.inner_sweeps = p->inner.sweeps - inner_sweeps0; S.inner_lm_iterations = p->inner.lm_iterations - inner_lm0; S.line_search_steps = int32_t(p->line_search_steps);
     int r2 = sync_params_to_host(p);
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
 
@@ -1415,7 +1417,9 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       rc = read_back(); if (rc) return rc;
       cand_before_inner = cand_cost_of();
       if (std::isfinite(cand_before_inner)) {
+        HIPCK(p, hipEventRecord(ev[6], st));
         rc = inner_sweep(p, p->d_xc.p); if (rc) return rc;
+        HIPCK(p, hipEventRecord(ev[7], st));
         p->seg_invalidate(p->d_xc.p);
         if (cost_in_state) HIPCK(p, hipMemsetAsync(&p->d_state.p->cand_cost, 0, sizeof(double), st));
         rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, cost_in_state, nullptr, false, nullptr, false, cand_dst); if (rc) return rc;
@@ -1450,6 +1454,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       if (verbose) std::printf("[oicc] iter %d inner iterations: %.12e -> %.12e (%s)\n", iter + 1, cand_before_inner, cand_cost, inner_enabled ? "stay on" : "switched off");
     }
     S.seconds_linear_solver += elapsed_s(ev[0], ev[1]); S.seconds_residual += elapsed_s(ev[1], ev[2]);
+    if (inner_ran) S.seconds_inner += elapsed_s(ev[6], ev[7]);
     if (gmax_pending) {   // gradient of the point accepted in the previous iteration
       gmax = hs.gradient_max_norm; p->trace.back().gradient_max_norm = gmax; gmax_pending = false;
       S.seconds_jacobian += elapsed_s(ev[3], ev[4]);

@@ -782,8 +782,10 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   const int max_invalid = int(p.opt["max_num_consecutive_invalid_steps"]);
   const bool verbose = p.opt["verbose"] != 0;
   double decrease_factor = 2.0; bool reuse_diagonal = false;
+  int64_t inner_lm_iterations = 0; int inner_sweeps = 0, line_search_steps = 0;
   auto finish = [&](int term, const char* msg, double cost) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; std::snprintf(S.message, sizeof(S.message), "%s", msg);
+    S.inner_sweeps = inner_sweeps; S.line_search_steps = line_search_steps; S.inner_lm_iterations = inner_lm_iterations;
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return OICC_OK; };
   if (P == 0) { double c = total_cost(p, L, a); S.initial_cost = c; return finish(OICC_CONVERGENCE, "no variable parameters", c); }
 
@@ -813,11 +815,10 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   std::vector<double> diag(P), D2(P), step_s(P), step(P);
   int iter = 0, invalid = 0;
   // inner iterations (ceres_inner.hpp): set up when the reduced program has at least two parameter blocks
-  inner::Ordering ord; bool inner_enabled = false; int64_t inner_lm_iterations = 0; int inner_sweeps = 0;
+  inner::Ordering ord; bool inner_enabled = false;
   if (p.opt["inner_iterations"] != 0) { inner::build_ordering(p, L, a, &ord); inner_enabled = ord.blocks.size() >= 2; }
   const double inner_tol = p.opt["inner_iteration_tolerance"];
   const bool line_search = p.opt["bounds_line_search"] != 0 && (a.ab || a.gb);   // is_constrained
-  int line_search_steps = 0;
   while (true) {
     if (iter >= max_iters) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.", cost);
     if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.", cost);
@@ -878,7 +879,7 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
       t0 = now_s();
       inner::sweep(p, L, a, ord, num_threads(p), &inner_lm_iterations); ++inner_sweeps;
       const double inner_cost = total_cost(p, L, a);
-      S.seconds_residual += now_s() - t0;
+      S.seconds_residual += now_s() - t0; S.seconds_inner += now_s() - t0;
       model_cost_change += cand_cost - inner_cost;
       inner_useful = inner_cost < cost;
       inner_enabled = 1.0 - inner_cost / cand_cost > inner_tol;

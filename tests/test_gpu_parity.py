@@ -129,6 +129,30 @@ def test_c2_full_size_properties():
     assert ang < np.deg2rad(0.5)
 
 
+def test_c2_lm_iterates_match_the_jet_oracle():
+    """BASELINE config C2 at full size, plain LM, stage 1 and stage 2: every iterate of the HIP path against the oracle's forward-mode
+    Jets (analytic_jacobians = 0: none of the product's closed forms on the checker's side) -- accept / reject sequence, costs,
+    step norms, gradient norms, final extrinsics, gravity, knots, line delay and mean reprojection error."""
+    ds, gpu, cpu = build_pair("C2")
+    cpu.trajectory_.SetOption("analytic_jacobians", 0)
+    sg = gpu.trajectory_.Optimize(50, FLAGS1); sc = cpu.trajectory_.Optimize(50, FLAGS1)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert sg["termination"] == sc["termination"] and sg["num_iterations"] == sc["num_iterations"] >= 3, (sg, sc)
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"], (a, b)
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-6 * max(b["step_norm"], 1e-12), (a, b)
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * max(b["gradient_max_norm"], 1e-9), (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-7
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-6
+    kg, kc = gpu.trajectory_.GetKnots(), cpu.trajectory_.GetKnots()
+    assert np.abs(kg[0] - kc[0]).max() < 1e-7 and np.abs(kg[1] - kc[1]).max() < 1e-7
+    assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-7
+    s2g = gpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY); s2c = cpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
+    assert s2g["num_iterations"] == s2c["num_iterations"] and abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-8 * s2c["final_cost"]
+    assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-3 * 1e-6      # SURVEY 8c: 1e-3 us
+
+
 @pytest.mark.parametrize("algo,parts", [(1, 2), (1, 3), (1, 5), (2, 0)])
 def test_parallel_solvers_match_sequential(algo, parts):
     """The time-partitioned band+arrow Cholesky (algorithm 1: p interior sweeps + reduced
@@ -311,7 +335,9 @@ def test_c4_double_sphere_line_delay_calibration():
     ds = synthetic.make_config("C4")
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
-    cc = cpu.trajectory_.EvaluateCost(FLAGS1)
+    cc, _, gc = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)                  # forward-mode Jets over 80 000 corners + 16 000 IMU blocks
+    cg, _, gg = gpu.trajectory_.Evaluate(FLAGS1, want_H=False)
+    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-9
     assert abs(gpu.trajectory_.EvaluateCost(FLAGS1) - cc) <= 1e-10 * cc
     s1 = gpu.trajectory_.Optimize(50, FLAGS1)
     assert s1["termination"] == 0 and s1["final_cost"] < 0.05 * s1["initial_cost"]
@@ -346,6 +372,10 @@ def test_c5_time_shards_sum_to_the_whole():
         c_sum += c; g_sum += g; blocks += part.num_blocks
     assert blocks == whole.num_blocks
     assert abs(c_sum - c_all) <= 1e-11 * c_all and rel_err(g_sum, g_all) < 1e-10
+    # ... and the whole against the CPU oracle (forward-mode Jets, 410 000 residual blocks, P ~ 90 k): cost and gradient
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    c_cpu, _, g_cpu = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)
+    assert g_cpu.shape == g_all.shape and abs(c_all - c_cpu) <= 1e-10 * c_cpu and rel_err(g_all, g_cpu) < 1e-9
     s = whole.trajectory_.Optimize(1, FLAGS1)
     assert s["num_successful_steps"] == 1 and s["final_cost"] < 0.5 * s["initial_cost"] and s["band_dim"] > 85000
     # at this size the segment tables come once per parameter vector (written by the retraction kernel for the candidate);
@@ -505,24 +535,32 @@ def test_segment_tables_per_parameter_vector_equal_per_tile(cfg, flags, inner):
 
 
 # ---- Ceres' inner iterations (reference impl.h:266), device sweep (inner_iterations.hip) against oracle/ceres_inner.hpp ----
-@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES), ("tiny", FLAGS1 | E.CAM_LINE_DELAY), ("C2", FLAGS1)])
+@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES), ("tiny", FLAGS1 | E.CAM_LINE_DELAY), ("C2", FLAGS1), ("C3", FLAGS1), ("C4", FLAGS1)])
 def test_inner_iterations_match_the_oracle(cfg, flags):
     """use_inner_iterations = true: after every candidate one block coordinate descent sweep over the independent sets of the
     parameter blocks.  Same outer iterate sequence (costs to 1e-7: hundreds of small LM loops whose accept / reject decisions
-    see fp64-atomic summation order) and final extrinsics as the CPU restatement."""
+    see the summation order) and final extrinsics as the CPU restatement with forward-mode Jets (analytic_jacobians = 0), at the
+    full size of BASELINE configs 2-4, followed by the application's stage 2 (line delay only) with the same options."""
     ds = synthetic.make_config(cfg)
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     for c in (gpu, cpu):
         c.trajectory_.SetOption("inner_iterations", 1)
-    cpu.trajectory_.SetOption("analytic_jacobians", 1 if cfg != "tiny" else 0)
+    cpu.trajectory_.SetOption("analytic_jacobians", 0)
     sg = gpu.trajectory_.Optimize(50, flags); sc = cpu.trajectory_.Optimize(50, flags)
     ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     assert sg["num_iterations"] == sc["num_iterations"], ([i["cost"] for i in ig], [i["cost"] for i in ic])
+    assert sg["inner_sweeps"] == sc["inner_sweeps"] >= 1
     for a, b in zip(ig, ic):
         assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
     assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
     assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-5
+    if cfg != "tiny":   # stage 2 of the application (continuous_time_imu_to_camera_calibration.cc:217-221): one parameter block -> Ceres disables the sweep
+        s2g = gpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY); s2c = cpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
+        assert s2g["num_iterations"] == s2c["num_iterations"] and s2g["inner_sweeps"] == s2c["inner_sweeps"] == 0
+        assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-7 * s2c["final_cost"]
+        assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-8
+        assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-6
     # and the sweep changes the trajectory of the solve (it is not a no-op)
     plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
     sp = plain.trajectory_.Optimize(50, flags)
