@@ -33,6 +33,7 @@ struct ViewConst {
   int cam_model; const double* intr;
   bool gs_unit_loss;
   bool spline_active, tic_active, ld_active;
+  bool no_so3_rows = false;   // spline_active, but the caller only takes the R^3-knot columns (inner iterations on an R^3 knot): skip the SO(3) backward pass
 };
 OICC_DEV void view_const_init(ViewConst& C, const double* T_i_c) {
   C.q_ic = Quat{T_i_c[0], T_i_c[1], T_i_c[2], T_i_c[3]};
@@ -95,7 +96,7 @@ OICC_DEV double view_item(const ViewConst& C, const Quat& R0, const SegAcc& SEG,
           for (int cc = 0; cc < 3; ++cc) nB[rr * 3 + cc] = -(a * Rwi[cc * 3] + b * Rwi[cc * 3 + 1] + cz * Rwi[cc * 3 + 2]);   // -M1 R_wi^T
         }
         out.r3(cf, nB);
-        so3_backward_rows_seg<2>(so, SEG, MQ, [&](int j, const double* a) { out.so3(j, a); });
+        if (!C.no_so3_rows) so3_backward_rows_seg<2>(so, SEG, MQ, [&](int j, const double* a) { out.so3(j, a); });
       }
       if (C.tic_active) {
         // d p_c / d(upsilon, omega) = [-I | [p_c]x]; rows scaled by S Jpi
@@ -139,6 +140,7 @@ struct ImuConst {
   double g[3];
   double inv_so3_dt, inv_r3_dt;
   bool spline_active, g_active, bias_active, intr_active;
+  bool no_so3_rows = false;   // as in ViewConst
 };
 template <int KIND>
 OICC_DEV void imu_const_init(ImuConst& C, const double* intr, const double* g) {
@@ -190,7 +192,7 @@ OICC_DEV double imu_item(const ImuConst& C, const Quat& R0, const SegAcc& SEG, c
         if (C.spline_active) out.r3(cf2, gw);
         if (C.g_active) out.grav(gw);
       }
-      if (C.spline_active) {
+      if (C.spline_active && !C.no_so3_rows) {
         // d r/d eps_j = w [vr]x dR/deps_j
         const double L[9] = {0.0, -w * vr[2], w * vr[1], w * vr[2], 0.0, -w * vr[0], -w * vr[1], w * vr[0], 0.0};
         so3_backward_rows_seg<3>(so, SEG, L, [&](int j, const double* a) { out.so3(j, a); });

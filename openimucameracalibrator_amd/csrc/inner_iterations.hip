@@ -8,13 +8,16 @@
 // Levenberg-Marquardt loop with Ceres' default minimiser options.  ONE LAUNCH PER SET (round 3; round 2 ran the blocks of a
 // set in lock step, ~25 launches and a host read-back per set):
 //   * a knot block (SO(3) / R^3 / bias knot: the ~240-360 corners and IMU samples of its six knot windows) is ONE WORKGROUP
-//     that runs the block's WHOLE loop: lane = item -> residual and the Jacobian columns of this one block (block_items.cuh
-//     with a one-block sink), H_bb / g_b / cost_b by wave reductions and per-wave LDS rows (fixed order: deterministic),
-//     thread 0 solves the damped d x d system, writes the candidate in place, all lanes evaluate the cost there, thread 0
-//     accepts / rejects exactly as TrustRegionMinimizer does -- until the block terminates.  No global atomics, no host;
+//     that runs the block's WHOLE loop out of LDS: the items' measurements and the knots / segment tables / calibration
+//     scalars they read are staged once; lane = item -> residual and the Jacobian columns of this one block
+//     (block_items.cuh with a one-block sink), H_bb / g_b / cost_b by DPP row reductions and per-wave LDS rows (fixed
+//     order: deterministic), thread 0 solves the damped d x d system in registers, writes the candidate (LDS copy and
+//     parameter vector), all lanes evaluate the cost there, thread 0 accepts / rejects exactly as TrustRegionMinimizer
+//     does -- until the block terminates.  No global atomics, no host;
 //   * the blocks every view / every sample depends on (T_i_c, gravity, line delay, IMU intrinsics: sets of their own) are
 //     shared by up to one workgroup per CU: partial sums by fp64 atomics on a control block, an arrival counter, the master
-//     workgroup (part 0) advances the loop and publishes the next command (release / acquire at agent scope).
+//     workgroup (part 0) advances the loop and publishes the next command (release / acquire at agent scope); their items
+//     read the parameters from global memory.
 // SO(3) knots change the segment tables (spline_seg.cuh) of their two knot pairs: the block's master rewrites those two
 // entries with every candidate (and restores them on a rejected step), the table stays current across the sets.
 #include <hip/hip_runtime.h>
@@ -24,22 +27,21 @@
 
 namespace oicc {
 
-constexpr int kInnerThreads = 256;    // one workgroup = 4 waves, one per SIMD (the item functions need > 256 VGPRs)
+constexpr int kInnerThreads = 256;               // one workgroup = 4 waves, one per SIMD (the item functions need > 256 VGPRs)
+constexpr int kInnerSlots = 2 * kInnerThreads;   // item slots of a block staged in LDS (two per lane); larger blocks re-read their items
+constexpr int kCapS = 24, kCapR = 16, kCapB = 8; // knots of the block's neighbourhood staged in LDS (SO(3), R^3, each bias spline)
 enum { INNER_CMD_JAC = 0, INNER_CMD_COST = 1, INNER_CMD_DONE = 2 };
-
-struct InnerArgs {
-  EvalCtx ctx;              // ctx.x == xv (the kernels of a sweep change the vector in place)
-  ViewData vd; ImuData ia, ig;
-  double* xv; double* seg;
-  const InnerBlock* blocks; const InnerRun* runs; const InnerWg* wgs; InnerCtl* ctls;
-  unsigned long long* lm_iterations;
-  double max_ab, max_gb;
-};
 
 namespace {
 
-struct GSeg { const double* base; __device__ __forceinline__ const double* operator()(int i) const { return base + i * kSegStride; } };
-struct GR3 { const double* base; __device__ __forceinline__ const double* operator()(int j) const { return base + 3 * j; } };
+// Where the items of a workgroup read the parameters: the LDS copy of the block's neighbourhood, or the parameter vector itself
+// (generic pointers: knot k of the SO(3) spline at so3 + 4 (k - ks0), ...; scal = [T_i_c 7 | g 3 | line delay 1 | accel intr 6 | gyro intr 9]).
+struct ParamView {
+  const double* so3; const double* seg; const double* r3; const double* ab; const double* gb; const double* scal;
+  int ks0, kr0, kab0, kgb0;
+};
+struct PSeg { const double* base; __device__ __forceinline__ const double* operator()(int i) const { return base + i * kSegStride; } };
+struct PR3 { const double* base; __device__ __forceinline__ const double* operator()(int j) const { return base + 3 * j; } };
 
 // Sink of block_items.cuh that keeps the columns of ONE parameter block: J[r][c], r < ROWS, c < dim <= 9, in the lane's
 // column of an LDS array (element e of the lane at J[e * kInnerThreads]: conflict free, and the sums over (x, y) below are
@@ -65,10 +67,20 @@ struct OneBlockSink {
     if (kind == IK_AI || kind == IK_GI) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < n; ++c) J[r * 9 + c] = d[r * n + c]; }
 };
 
+// Sum over the 64 lanes (all active), wave uniform: four DPP row shifts (no LDS traffic) leave the sums of the 16-lane rows in
+// lanes 15, 31, 47, 63; v_readlane brings them together.  ~150 cycles against ~800 for six ds_bpermute steps.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shifted(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;   // lane 0 holds the sum
+  v += dpp_shifted<0x111>(v); v += dpp_shifted<0x112>(v); v += dpp_shifted<0x114>(v); v += dpp_shifted<0x118>(v);   // row_shr:1,2,4,8
+  return (lane_value(v, 15) + lane_value(v, 31)) + (lane_value(v, 47) + lane_value(v, 63));
 }
 
 __device__ __forceinline__ void se3_exp_local(const double a6[6], Quat* q, double t[3]) {   // se3.hpp:761-782
@@ -88,178 +100,294 @@ __device__ __forceinline__ void se3_exp_local(const double a6[6], Quat* q, doubl
   }
   mat3_vec(V, a6, t);
 }
-// x (+) delta of one block (LieLocalParameterization::Plus, then the projection onto the box of a bias knot)
+// x (+) delta of one block (LieLocalParameterization::Plus, then the projection onto the box of a bias knot); x, d in registers
+template <int D>
 __device__ __forceinline__ void block_plus(double* x, int kind, const double* d, double max_ab, double max_gb) {
-  if (kind == IK_SO3) { const Quat r = so3_mul(Quat{x[0], x[1], x[2], x[3]}, so3_exp(d)); x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w; }
-  else if (kind == IK_TIC) {
+  if (D == 3 && kind == IK_SO3) { const Quat r = so3_mul(Quat{x[0], x[1], x[2], x[3]}, so3_exp(d)); x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w; }
+  else if (D == 6 && kind == IK_TIC) {
     Quat dq; double dt[3]; se3_exp_local(d, &dq, dt);
     const Quat q{x[0], x[1], x[2], x[3]};
     double rt[3]; so3_rotate(q, dt, rt);
     const Quat r = so3_mul(q, dq);
     x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w; x[4] += rt[0]; x[5] += rt[1]; x[6] += rt[2];
   } else {
-    const int n = kind == IK_LD ? 1 : (kind == IK_AI ? 6 : (kind == IK_GI ? 9 : 3));
-    for (int c = 0; c < n; ++c) x[c] += d[c];
-    if (kind == IK_AB) for (int c = 0; c < 3; ++c) x[c] = fmin(fmax(x[c], -max_ab), max_ab);
-    if (kind == IK_GB) for (int c = 0; c < 3; ++c) x[c] = fmin(fmax(x[c], -max_gb), max_gb);
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] += d[c];
+    if (D == 3 && kind == IK_AB) for (int c = 0; c < 3; ++c) x[c] = fmin(fmax(x[c], -max_ab), max_ab);
+    if (D == 3 && kind == IK_GB) for (int c = 0; c < 3; ++c) x[c] = fmin(fmax(x[c], -max_gb), max_gb);
   }
 }
 
-// State of one block's Levenberg-Marquardt loop; lives in the LDS of the block's master workgroup, used by its thread 0
-// (arrays indexed at run time: LDS, not scratch).
+// State of one block's Levenberg-Marquardt loop between two evaluations; lives in the LDS of the block's master workgroup.
+// Thread 0 loads what it needs into registers (fixed dimension: static indexing), advances, stores back.
 struct InnerLm {
   double radius, decrease_factor, cost, x_norm, model;
   double H[81], g[9], scale[9], diag[9], keep[9];
-  double M[81], L[81], rhs[9], y[9], step[9];
-  double segkeep[2 * kSegStride];
+  double xcur[9];                                   // the block's current value (mirrors the parameter vector)
+  double qprev[4], qnext[4];                        // SO(3) knot: its two neighbours (fixed while the block is minimised)
+  double segcur[2 * kSegStride], segkeep[2 * kSegStride];   // SO(3) knot: table entries of the pairs (idx - 1, idx), (idx, idx + 1) at xcur / at the kept point
   int iter, invalid, reuse_diagonal, first;
+  int seg_action;                                   // after an advance: 0 none, 1 recompute the two entries (new candidate), 2 write the restored ones
 };
 
-__device__ bool inner_cholesky_solve(int d, InnerLm& S) {   // S.M x = S.rhs -> S.step
-  for (int j = 0; j < d; ++j) {
-    double s = S.M[j * 9 + j]; for (int k = 0; k < j; ++k) s -= S.L[j * 9 + k] * S.L[j * 9 + k];
-    if (!(s > 0.0) || !isfinite(s)) return false;
-    const double l = sqrt(s); S.L[j * 9 + j] = l;
-    for (int i = j + 1; i < d; ++i) { double t = S.M[i * 9 + j]; for (int k = 0; k < j; ++k) t -= S.L[i * 9 + k] * S.L[j * 9 + k]; S.L[i * 9 + j] = t / l; }
+template <int D>
+__device__ __forceinline__ bool inner_cholesky_solve(const double* M, const double* rhs, double* x) {   // M (D x D, stride D) x = rhs, all in registers
+  double L[D * D], y[D];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double s = M[j * D + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * D + k] * L[j * D + k];
+    ok = ok && s > 0.0 && isfinite(s);
+    const double l = sqrt(s);
+    L[j * D + j] = l;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double t = M[i * D + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * D + k] * L[j * D + k];
+      L[i * D + j] = t / l;
+    }
   }
-  for (int i = 0; i < d; ++i) { double t = S.rhs[i]; for (int k = 0; k < i; ++k) t -= S.L[i * 9 + k] * S.y[k]; S.y[i] = t / S.L[i * 9 + i]; }
-  for (int i = d - 1; i >= 0; --i) { double t = S.y[i]; for (int k = i + 1; k < d; ++k) t -= S.L[k * 9 + i] * S.step[k]; S.step[i] = t / S.L[i * 9 + i]; }
-  for (int i = 0; i < d; ++i) if (!isfinite(S.step[i])) return false;
-  return true;
-}
-
-// segment-table entries of the two knot pairs SO(3) knot `idx` belongs to
-__device__ void refresh_segments(const double* so3, int n_so3, int idx, double* seg) {
-  for (int s = idx > 0 ? idx - 1 : 0; s <= idx && s + 1 < n_so3; ++s) {
-    const double* a = so3 + 4 * s;
-    so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, seg + (size_t)s * kSegStride);
+  if (!ok) return false;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    double t = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i * D + k] * y[k];
+    y[i] = t / L[i * D + i];
   }
+#pragma unroll
+  for (int i = D - 1; i >= 0; --i) {
+    double t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < D; ++k) t -= L[k * D + i] * x[k];
+    x[i] = t / L[i * D + i];
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) ok = ok && isfinite(x[i]);
+  return ok;
 }
 
 // Thread 0 of the master workgroup: consume the sums of the evaluation that just finished (`cmd`: Jacobian pass or cost at the
-// candidate), advance the loop, leave the next candidate (or the restored point) in the parameter vector, return the next
-// command.  Mirrors oracle/ceres_inner.hpp solve_block (= TrustRegionMinimizer + LevenbergMarquardtStrategy, default options).
-__device__ int inner_lm_advance(InnerLm& S, const InnerBlock& blk, int cmd, const double* tot, const InnerArgs& A) {
+// candidate), advance the loop, leave the next candidate (or the restored point) in the parameter vector `x` and its LDS copy
+// `xl` (may be null), return the next command.  Mirrors oracle/ceres_inner.hpp solve_block (= TrustRegionMinimizer +
+// LevenbergMarquardtStrategy, default options).  The segment-table entries of an SO(3) knot are updated by the caller (S.seg_action).
+// (a real function call, one per dimension: the unrolled d x d algebra stays out of the register allocation of the evaluation loops)
+template <int D, int NX>
+__device__ __noinline__ int inner_lm_advance(InnerLm& S, int kind, int cmd, const double* tot, double* x, double* xl, double max_ab, double max_gb) {
   constexpr double ftol = 1e-6, ptol = 1e-8, gtol = 1e-10, min_rel_dec = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
-  const int d = blk.dim, nx = blk.ambient, nv = d * (d + 1) / 2 + d + 1;
-  double* x = A.xv + blk.xoff;
-  const bool so3 = blk.kind == IK_SO3;
-  const int s_lo = blk.idx > 0 ? blk.idx - 1 : 0;   // first of the (at most) two segment entries an SO(3) knot owns a share of
-  auto undo = [&]() {
-    for (int i = 0; i < nx; ++i) x[i] = S.keep[i];
-    if (so3) for (int e = 0; e < 2 * kSegStride; ++e) if (s_lo * kSegStride + e < (A.ctx.pl.n_so3 - 1) * kSegStride) A.seg[(size_t)s_lo * kSegStride + e] = S.segkeep[e];
+  constexpr int NV = D * (D + 1) / 2 + D + 1;
+  const bool so3 = D == 3 && kind == IK_SO3;
+  S.seg_action = 0;
+  double xc[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xc[i] = S.xcur[i];
+  auto put = [&](const double* v) {   // the block's value -> state, LDS copy of the neighbourhood, parameter vector
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { S.xcur[i] = v[i]; x[i] = v[i]; if (xl != nullptr) xl[i] = v[i]; }
   };
+  auto undo = [&]() {
+    double k[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) k[i] = S.keep[i];
+    put(k);
+    if (so3) { for (int e = 0; e < 2 * kSegStride; ++e) S.segcur[e] = S.segkeep[e]; S.seg_action = 2; }
+  };
+  double radius = S.radius, decrease_factor = S.decrease_factor;
   if (cmd == INNER_CMD_JAC) {
     int k = 0;
-    for (int i = 0; i < d; ++i) for (int j = i; j < d; ++j) { const double v = tot[k++]; S.H[i * 9 + j] = v; S.H[j * 9 + i] = v; }
-    for (int i = 0; i < d; ++i) S.g[i] = tot[k++];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j) { const double v = tot[k++]; S.H[i * 9 + j] = v; S.H[j * 9 + i] = v; }
+    double gm = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { const double v = tot[k++]; S.g[i] = v; gm = fmax(gm, fabs(v)); }
     if (S.first) {
-      S.cost = tot[nv - 1];
-      for (int i = 0; i < d; ++i) S.scale[i] = 1.0 / (1.0 + sqrt(S.H[i * 9 + i]));
-      double n2 = 0; for (int i = 0; i < nx; ++i) n2 += x[i] * x[i];
+      S.cost = tot[NV - 1];
+#pragma unroll
+      for (int i = 0; i < D; ++i) S.scale[i] = 1.0 / (1.0 + sqrt(S.H[i * 9 + i]));
+      double n2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) n2 += xc[i] * xc[i];
       S.x_norm = sqrt(n2); S.first = 0;
     }
-    double gm = 0; for (int i = 0; i < d; ++i) gm = fmax(gm, fabs(S.g[i]));
     if (gm <= gtol) return INNER_CMD_DONE;
   } else {
-    const double cand = tot[nv - 1];
-    double sn = 0; for (int i = 0; i < nx; ++i) sn += (x[i] - S.keep[i]) * (x[i] - S.keep[i]);
+    const double cand = tot[NV - 1];
+    double sn = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const double dd = xc[i] - S.keep[i]; sn += dd * dd; }
     sn = sqrt(sn);
     const double change = S.cost - cand, rel = change / S.model;
     if (sn <= ptol * (S.x_norm + ptol)) { undo(); return INNER_CMD_DONE; }
     if (fabs(change) <= ftol * S.cost) { undo(); return INNER_CMD_DONE; }
     if (rel > min_rel_dec) {
       S.cost = cand;
-      double n2 = 0; for (int i = 0; i < nx; ++i) n2 += x[i] * x[i];
+      double n2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) n2 += xc[i] * xc[i];
       S.x_norm = sqrt(n2);
-      S.radius = fmin(max_radius, S.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3))); S.decrease_factor = 2.0; S.reuse_diagonal = 0;
+      const double t = 2.0 * rel - 1.0;
+      S.radius = fmin(max_radius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t)); S.decrease_factor = 2.0; S.reuse_diagonal = 0;
       return INNER_CMD_JAC;
     }
-    undo(); S.radius /= S.decrease_factor; S.decrease_factor *= 2.0; S.reuse_diagonal = 1;
+    undo();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = S.keep[i];
+    radius /= decrease_factor; decrease_factor *= 2.0; S.reuse_diagonal = 1;
   }
+  // the damped system in registers
+  double H[D * D], g[D], sc[D], dg[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    g[i] = S.g[i]; sc[i] = S.scale[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j) H[i * D + j] = S.H[i * 9 + j];
+  }
+  if (!S.reuse_diagonal) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) { dg[i] = fmin(fmax(H[i * D + i] * sc[i] * sc[i], min_diag), max_diag); S.diag[i] = dg[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; ++i) dg[i] = S.diag[i];
+  }
+  int iter = S.iter, invalid = S.invalid;
+  int next = INNER_CMD_DONE;
   while (true) {
-    if (S.iter >= 50 || !(S.radius > min_radius)) return INNER_CMD_DONE;
-    ++S.iter;
-    if (!S.reuse_diagonal) for (int i = 0; i < d; ++i) S.diag[i] = fmin(fmax(S.H[i * 9 + i] * S.scale[i] * S.scale[i], min_diag), max_diag);
-    for (int i = 0; i < d; ++i) {
-      S.rhs[i] = -S.g[i] * S.scale[i];
-      for (int j = 0; j < d; ++j) S.M[i * 9 + j] = S.H[i * 9 + j] * S.scale[i] * S.scale[j] + (i == j ? S.diag[i] / S.radius : 0.0);
+    if (iter >= 50 || !(radius > min_radius)) break;
+    ++iter;
+    double M[D * D], rhs[D], step[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      rhs[i] = -g[i] * sc[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) M[i * D + j] = H[i * D + j] * sc[i] * sc[j] + (i == j ? dg[i] / radius : 0.0);
     }
-    bool ok = inner_cholesky_solve(d, S);
+    bool ok = inner_cholesky_solve<D>(M, rhs, step);
     double model = 0.0;
-    if (ok) { for (int i = 0; i < d; ++i) model += 0.5 * S.step[i] * ((S.diag[i] / S.radius) * S.step[i] - S.g[i] * S.scale[i]); ok = model > 0.0; }
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) model += 0.5 * step[i] * ((dg[i] / radius) * step[i] - g[i] * sc[i]);
+      ok = model > 0.0;
+    }
     if (!ok) {
-      if (++S.invalid >= 5) return INNER_CMD_DONE;
-      S.radius /= S.decrease_factor; S.decrease_factor *= 2.0; S.reuse_diagonal = 1;
+      if (++invalid >= 5) break;
+      radius /= decrease_factor; decrease_factor *= 2.0; S.reuse_diagonal = 1;   // (the diagonal is the one in dg already)
       continue;
     }
-    S.invalid = 0; S.model = model;
-    double st[9];
-    for (int i = 0; i < 9; ++i) st[i] = i < d ? S.step[i] * S.scale[i] : 0.0;
-    for (int i = 0; i < nx; ++i) S.keep[i] = x[i];
-    if (so3) for (int e = 0; e < 2 * kSegStride; ++e) if (s_lo * kSegStride + e < (A.ctx.pl.n_so3 - 1) * kSegStride) S.segkeep[e] = A.seg[(size_t)s_lo * kSegStride + e];
-    block_plus(x, blk.kind, st, A.max_ab, A.max_gb);
-    if (so3) refresh_segments(A.xv + A.ctx.pl.so3, A.ctx.pl.n_so3, blk.idx, A.seg);
-    return INNER_CMD_COST;
+    invalid = 0; S.model = model;
+    double st[D], xn[NX];
+#pragma unroll
+    for (int i = 0; i < D; ++i) st[i] = step[i] * sc[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xn[i] = xc[i]; S.keep[i] = xc[i]; }
+    block_plus<D>(xn, kind, st, max_ab, max_gb);
+    put(xn);
+    if (so3) { for (int e = 0; e < 2 * kSegStride; ++e) S.segkeep[e] = S.segcur[e]; S.seg_action = 1; }
+    next = INNER_CMD_COST;
+    break;
+  }
+  S.radius = radius; S.decrease_factor = decrease_factor; S.iter = iter; S.invalid = invalid;
+  return next;
+}
+
+// What an item contributes that no parameter block changes: its knot windows and measurement.  Gathered once per block
+// (runs -> corner -> view -> ... is a chain of four dependent global loads) into the lane's column of an LDS array.
+struct ItemRec {
+  int kind;              // 0 corner, 1 accelerometer sample, 2 gyroscope sample, -1 none
+  int s_so3, s_r3, sx;   // knot windows; sx: rolling-shutter flag (corner) / bias window (IMU)
+  double d[10];          // corner: u_so3 u_r3 obs_u obs_v 1/sx 1/sy X[4];  IMU: u_so3 u_r3 u_b m[3] w
+};
+
+// slot i of the block: every run of items starts at a multiple of 64 slots, so that a wave evaluates items of one family only
+__device__ __forceinline__ void inner_load_item(const InnerArgs& A, const InnerBlock& blk, int i, ItemRec& R) {
+  R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
+  if (i >= blk.n_slots) return;
+  int idx = 0, off = i;
+  for (int r = 0; r < blk.nruns; ++r) {
+    const InnerRun run = A.runs[blk.run0 + r];
+    if (R.kind < 0 && off >= 0 && off < run.count) { R.kind = run.kind; idx = run.first + off; }
+    off -= (run.count + 63) & ~63;
+  }
+  if (R.kind == 0) {
+    const ViewData& vd = A.vd;
+    const int v = vd.corner_view[idx];
+    R.s_so3 = vd.view_s_so3[v]; R.s_r3 = vd.view_s_r3[v]; R.sx = vd.view_rs[v] != 0;
+    R.d[0] = vd.view_u_so3[v]; R.d[1] = vd.view_u_r3[v]; R.d[2] = vd.corner_u[idx]; R.d[3] = vd.corner_v[idx]; R.d[4] = vd.corner_isx[idx]; R.d[5] = vd.corner_isy[idx];
+    const double* X = A.ctx.pts + 4 * (int64_t)vd.corner_pt[idx];
+    R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
+  } else if (R.kind > 0) {
+    const ImuData& id = R.kind == 1 ? A.ia : A.ig;
+    R.s_so3 = id.s_so3[idx]; R.s_r3 = R.kind == 1 ? id.s_r3[idx] : 0; R.sx = id.s_b[idx];
+    R.d[0] = id.u_so3[idx]; R.d[1] = R.kind == 1 ? id.u_r3[idx] : 0.0; R.d[2] = id.u_b[idx]; R.d[3] = id.mx[idx]; R.d[4] = id.my[idx]; R.d[5] = id.mz[idx]; R.d[6] = id.w[idx];
   }
 }
 
-// residual (+ the Jacobian columns of block `blk`) of item `idx` of family `kind` (0 corner, 1 accelerometer, 2 gyroscope)
+// residual (+ the Jacobian columns of block `blk`) of one item
 template <bool JAC>
-__device__ __forceinline__ int inner_eval_item(const InnerArgs& A, const InnerBlock& blk, int kind, int idx, const LaneCol& J, const LaneCol& r) {
-  const EvalCtx& ctx = A.ctx; const double* xv = A.xv;
-  if (kind == 0) {
-    const ViewData& vd = A.vd;
-    const int v = vd.corner_view[idx];
-    const int s_so3 = vd.view_s_so3[v], s_r3 = vd.view_s_r3[v];
+__device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneCol& J, const LaneCol& r) {
+  const EvalCtx& ctx = A.ctx;
+  const int s_so3 = R.s_so3, s_r3 = R.s_r3;
+  const double* q0 = P.so3 + 4 * (s_so3 - P.ks0);
+  const PSeg sg{P.seg + (s_so3 - P.ks0) * kSegStride}; const PR3 kr{P.r3 + 3 * (s_r3 - P.kr0)};
+  if (R.kind == 0) {
     ViewConst vc;
-    view_const_init(vc, xv + ctx.pl.tic);
-    vc.ld = xv[ctx.pl.ld];
+    view_const_init(vc, P.scal);
+    vc.ld = P.scal[10];
     vc.sh_s = ctx.rs_time_in_seconds ? ctx.inv_so3_dt : 1.0; vc.sh_r = ctx.rs_time_in_seconds ? ctx.inv_r3_dt : 1.0;
     vc.inv_so3_dt = ctx.inv_so3_dt; vc.inv_r3_dt = ctx.inv_r3_dt; vc.cam_model = ctx.cam_model; vc.intr = ctx.intr; vc.gs_unit_loss = ctx.gs_unit_loss != 0;
-    vc.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; vc.tic_active = blk.kind == IK_TIC; vc.ld_active = blk.kind == IK_LD;
-    const double* q0 = xv + ctx.pl.so3 + 4 * (int64_t)s_so3;
+    vc.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; vc.no_so3_rows = blk.kind == IK_R3; vc.tic_active = blk.kind == IK_TIC; vc.ld_active = blk.kind == IK_LD;
     const OneBlockSink<2> sink{blk.kind, blk.kind == IK_SO3 ? blk.idx - s_so3 : (blk.kind == IK_R3 ? blk.idx - s_r3 : 0), J, r};
-    const GSeg sg{A.seg + (size_t)s_so3 * kSegStride}; const GR3 kr{xv + ctx.pl.r3 + 3 * (int64_t)s_r3};
-    view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, vd.view_u_so3[v], vd.view_u_r3[v], vd.view_rs[v] != 0, vd.corner_u[idx], vd.corner_v[idx],
-                   vd.corner_isx[idx], vd.corner_isy[idx], ctx.pts + 4 * (int64_t)vd.corner_pt[idx], sink);
-    return 2;
+    const double X[4] = {R.d[6], R.d[7], R.d[8], R.d[9]};
+    view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], R.sx != 0, R.d[2], R.d[3], R.d[4], R.d[5], X, sink);
+    return;
   }
-  const bool accel = kind == 1;
-  const ImuData& id = accel ? A.ia : A.ig;
-  const int s_so3 = id.s_so3[idx], s_r3 = accel ? id.s_r3[idx] : 0, s_b = id.s_b[idx];
+  const bool accel = R.kind == 1;
+  const int s_b = R.sx;
   ImuConst ic;
   ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
-  ic.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; ic.g_active = blk.kind == IK_G;
+  ic.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; ic.no_so3_rows = blk.kind == IK_R3; ic.g_active = blk.kind == IK_G;
   ic.bias_active = blk.kind == IK_AB || blk.kind == IK_GB; ic.intr_active = blk.kind == IK_AI || blk.kind == IK_GI;
   const int jj = blk.kind == IK_SO3 ? blk.idx - s_so3 : (blk.kind == IK_R3 ? blk.idx - s_r3 : ((blk.kind == IK_AB || blk.kind == IK_GB) ? blk.idx - s_b : 0));
   const OneBlockSink<3> sink{blk.kind, jj, J, r};
-  const double* q0 = xv + ctx.pl.so3 + 4 * (int64_t)s_so3;
-  const GSeg sg{A.seg + (size_t)s_so3 * kSegStride}; const GR3 kr{xv + ctx.pl.r3 + 3 * (int64_t)s_r3};
-  const double m[3] = {id.mx[idx], id.my[idx], id.mz[idx]};
-  const double* bk = xv + (accel ? ctx.pl.ab : ctx.pl.gb) + 3 * (int64_t)s_b;
-  if (accel) { imu_const_init<0>(ic, xv + ctx.pl.ai, xv + ctx.pl.g); imu_item<0, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, id.u_so3[idx], id.u_r3[idx], id.u_b[idx], bk, m, id.w[idx], sink); }
-  else { imu_const_init<1>(ic, xv + ctx.pl.gi, xv + ctx.pl.g); imu_item<1, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, id.u_so3[idx], 0.0, id.u_b[idx], bk, m, id.w[idx], sink); }
-  return 3;
+  const double m[3] = {R.d[3], R.d[4], R.d[5]};
+  const double* bk = accel ? P.ab + 3 * (s_b - P.kab0) : P.gb + 3 * (s_b - P.kgb0);
+  if (accel) { imu_const_init<0>(ic, P.scal + 11, P.scal + 7); imu_item<0, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], R.d[2], bk, m, R.d[6], sink); }
+  else { imu_const_init<1>(ic, P.scal + 17, P.scal + 7); imu_item<1, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], 0.0, R.d[2], bk, m, R.d[6], sink); }
+}
+
+// lane's item record <-> its column of the LDS staging arrays (slot = round * kInnerThreads + tid)
+__device__ __forceinline__ void item_store(const ItemRec& R, int* si, double* sd, int slot) {
+  si[slot] = R.kind; si[kInnerSlots + slot] = R.s_so3; si[2 * kInnerSlots + slot] = R.s_r3; si[3 * kInnerSlots + slot] = R.sx;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) sd[k * kInnerSlots + slot] = R.d[k];
+}
+__device__ __forceinline__ void item_fetch(ItemRec& R, const int* si, const double* sd, int slot) {
+  R.kind = si[slot]; R.s_so3 = si[kInnerSlots + slot]; R.s_r3 = si[2 * kInnerSlots + slot]; R.sx = si[3 * kInnerSlots + slot];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) R.d[k] = sd[k * kInnerSlots + slot];
 }
 
 // all items of the block that fall to this workgroup: sums into the wave's LDS row [H upper | g | cost]
 template <bool JAC>
-__device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const InnerBlock& blk, int part, int nparts, double* row /* this wave's [56] */, double* s_J /* [30][kInnerThreads] */) {
+__device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, int part, int nparts, bool staged, const int* si, const double* sd,
+                                                 double* row /* this wave's [56] */, double* s_J /* [30][kInnerThreads] */) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int d = blk.dim, nv = d * (d + 1) / 2 + d + 1;
   const LaneCol J{s_J + tid}, res{s_J + 27 * kInnerThreads + tid};
-  for (int base = part * kInnerThreads; base < blk.n_items; base += nparts * kInnerThreads) {
-    const int i = base + tid;
-    int kind = -1, idx = 0, off = i;
-    for (int r = 0; r < blk.nruns; ++r) {
-      const InnerRun run = A.runs[blk.run0 + r];
-      if (kind < 0 && off >= 0 && off < run.count) { kind = run.kind; idx = run.first + off; }
-      off -= run.count;
-    }
+  int slot = tid;
+  for (int base = part * kInnerThreads; base < blk.n_slots; base += nparts * kInnerThreads, slot += kInnerThreads) {
+    ItemRec R;
+    if (staged) item_fetch(R, si, sd, slot); else inner_load_item(A, blk, base + tid, R);
+    if (__ballot(R.kind >= 0) == 0ull) continue;   // (padding slots of the last wave of a run)
     if (JAC) for (int k = 0; k < 27; ++k) J[k] = 0.0;
     res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
-    if (i < blk.n_items && kind >= 0) inner_eval_item<JAC>(A, blk, kind, idx, J, res);
+    if (R.kind >= 0) inner_eval_item<JAC>(A, blk, P, R, J, res);
     const double r0 = res[0], r1 = res[1], r2 = res[2];
     const double c = wave_sum(0.5 * (r0 * r0 + r1 * r1 + r2 * r2));
     if (lane == 0) row[nv - 1] += c;
@@ -290,27 +418,83 @@ __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
 // workgroup = (block of the set, part): the block's whole Levenberg-Marquardt loop
 __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
   __shared__ double s_J[30 * kInnerThreads];       // per lane: Jacobian columns of the block (3 x 9) and the residuals
+  __shared__ double s_item_d[10 * kInnerSlots];    // per lane and round: the item's measurement (ItemRec)
+  __shared__ int s_item_i[4 * kInnerSlots];
+  __shared__ double s_so3[4 * kCapS], s_seg[kSegStride * kCapS], s_r3[3 * kCapR], s_ab[3 * kCapB], s_gb[3 * kCapB], s_scal[26];   // the block's neighbourhood
   __shared__ double s_part[kInnerThreads / 64][56];
   __shared__ double s_tot[56];
   __shared__ InnerLm S;
   __shared__ int s_cmd;
   const InnerWg wg = A.wgs[blockIdx.x];
   const InnerBlock blk = A.blocks[wg.block];
+  const ParamLayout& pl = A.ctx.pl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nwaves = kInnerThreads / 64;
   const bool master = wg.part == 0;
   InnerCtl* const ctl = blk.ctl >= 0 ? A.ctls + blk.ctl : nullptr;
   const int d = blk.dim, nv = d * (d + 1) / 2 + d + 1;
-  if (master && tid == 0) {
-    S.radius = 1e4; S.decrease_factor = 2.0; S.cost = 0.0; S.x_norm = 0.0; S.model = 0.0;
-    S.iter = 0; S.invalid = 0; S.reuse_diagonal = 0; S.first = 1;
+  const bool so3 = blk.kind == IK_SO3;
+  const int n_pairs = pl.n_so3 - 1, s_lo = blk.idx > 0 ? blk.idx - 1 : 0;   // SO(3) knot: table entries s_lo, s_lo + 1; it owns the pairs idx - 1 and idx
+  // ---- the block's neighbourhood: knots, segment tables and scalars its items read -> LDS (one workgroup per block and the
+  // ranges fit), else the items read the parameter vector
+  const bool local = ctl == nullptr && blk.nks <= kCapS && blk.nkr <= kCapR && blk.nkab <= kCapB && blk.nkgb <= kCapB;
+  ParamView P;
+  if (local) {
+    for (int e = tid; e < 4 * blk.nks; e += kInnerThreads) s_so3[e] = A.xv[pl.so3 + 4 * (int64_t)blk.ks0 + e];
+    for (int e = tid; e < kSegStride * (blk.nks - 1); e += kInnerThreads) s_seg[e] = A.seg[(size_t)blk.ks0 * kSegStride + e];
+    for (int e = tid; e < 3 * blk.nkr; e += kInnerThreads) s_r3[e] = A.xv[pl.r3 + 3 * (int64_t)blk.kr0 + e];
+    for (int e = tid; e < 3 * blk.nkab; e += kInnerThreads) s_ab[e] = A.xv[pl.ab + 3 * (int64_t)blk.kab0 + e];
+    for (int e = tid; e < 3 * blk.nkgb; e += kInnerThreads) s_gb[e] = A.xv[pl.gb + 3 * (int64_t)blk.kgb0 + e];
+    if (tid < 26) s_scal[tid] = A.xv[pl.tic + tid];
+    P = ParamView{s_so3, s_seg, s_r3, s_ab, s_gb, s_scal, blk.ks0, blk.kr0, blk.kab0, blk.kgb0};
+  } else {
+    P = ParamView{A.xv + pl.so3, A.seg, A.xv + pl.r3, A.xv + pl.ab, A.xv + pl.gb, A.xv + pl.tic, 0, 0, 0, 0};
   }
+  // the block's value inside the LDS copy (the master writes candidates to both)
+  double* xl = nullptr;
+  if (local) {
+    switch (blk.kind) {
+      case IK_SO3: xl = s_so3 + 4 * (blk.idx - blk.ks0); break;
+      case IK_R3: xl = s_r3 + 3 * (blk.idx - blk.kr0); break;
+      case IK_AB: xl = s_ab + 3 * (blk.idx - blk.kab0); break;
+      case IK_GB: xl = s_gb + 3 * (blk.idx - blk.kgb0); break;
+      default: xl = s_scal + (blk.xoff - pl.tic); break;
+    }
+  }
+  // ---- items of this workgroup -> LDS (the lane that evaluates an item loads it: no barrier needed)
+  const bool staged = (blk.n_slots + wg.nparts * kInnerThreads - 1) / (wg.nparts * kInnerThreads) <= kInnerSlots / kInnerThreads;
+  if (staged) {
+    int slot = tid;
+    for (int base = wg.part * kInnerThreads; base < blk.n_slots; base += wg.nparts * kInnerThreads, slot += kInnerThreads) {
+      ItemRec R; inner_load_item(A, blk, base + tid, R); item_store(R, s_item_i, s_item_d, slot);
+    }
+  }
+  if (master) {
+    if (tid == 0) {
+      S.radius = 1e4; S.decrease_factor = 2.0; S.cost = 0.0; S.x_norm = 0.0; S.model = 0.0;
+      S.iter = 0; S.invalid = 0; S.reuse_diagonal = 0; S.first = 1; S.seg_action = 0;
+    }
+    if (tid < blk.ambient) S.xcur[tid] = A.xv[blk.xoff + tid];
+    if (so3) {
+      const double* q = A.xv + pl.so3;
+      if (tid >= 16 && tid < 20) S.qprev[tid - 16] = blk.idx > 0 ? q[4 * (int64_t)(blk.idx - 1) + (tid - 16)] : 0.0;
+      if (tid >= 20 && tid < 24) S.qnext[tid - 20] = blk.idx + 1 < pl.n_so3 ? q[4 * (int64_t)(blk.idx + 1) + (tid - 20)] : 0.0;
+      if (tid >= 64 && tid < 64 + 2 * kSegStride) { const int e = tid - 64; S.segcur[e] = s_lo * kSegStride + e < n_pairs * kSegStride ? A.seg[(size_t)s_lo * kSegStride + e] : 0.0; }
+    }
+  }
+  __syncthreads();
   int cmd = INNER_CMD_JAC;
   unsigned round = 0;
+  const bool prof = A.prof != nullptr && blockIdx.x == 0 && tid == 0;
+  int nprof = 0;
+#define INNER_MARK() do { if (prof && nprof < 62) A.prof[1 + nprof++] = clock64(); } while (0)
+  INNER_MARK();
   while (true) {
     if (lane < 56) s_part[wave][lane] = 0.0;
-    if (cmd == INNER_CMD_JAC) inner_eval_items<true>(A, blk, wg.part, wg.nparts, s_part[wave], s_J);
-    else inner_eval_items<false>(A, blk, wg.part, wg.nparts, s_part[wave], s_J);
+    if (cmd == INNER_CMD_JAC) inner_eval_items<true>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    else inner_eval_items<false>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    INNER_MARK();
     __syncthreads();
+    INNER_MARK();
     if (tid < nv) {
       double t = 0.0;
       for (int w = 0; w < nwaves; ++w) t += s_part[w][tid];
@@ -320,30 +504,66 @@ __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
       __threadfence(); __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (master) {
-        if (tid == 0) { const unsigned want = (unsigned)wg.nparts * (round + 1); while (__hip_atomic_load(&ctl->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2); }
+        if (tid == 0) { const unsigned want = (unsigned)wg.nparts * (round + 1); while (__hip_atomic_load(&ctl->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1); }
         __syncthreads(); __threadfence();
         if (tid < nv) s_tot[tid] = __hip_atomic_exchange(&ctl->acc[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read and clear for the next round
       }
     }
     __syncthreads();
     if (master) {
-      if (tid == 0) s_cmd = inner_lm_advance(S, blk, cmd, s_tot, A);
+      if (tid == 0) {
+        double* x = A.xv + blk.xoff;
+        int nc = INNER_CMD_DONE;
+        switch (blk.kind) {
+          case IK_SO3: nc = inner_lm_advance<3, 4>(S, IK_SO3, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_TIC: nc = inner_lm_advance<6, 7>(S, IK_TIC, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_LD: nc = inner_lm_advance<1, 1>(S, IK_LD, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_AI: nc = inner_lm_advance<6, 6>(S, IK_AI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_GI: nc = inner_lm_advance<9, 9>(S, IK_GI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          default: nc = inner_lm_advance<3, 3>(S, blk.kind, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;   // R^3 knot, gravity, bias knots
+        }
+        s_cmd = nc;
+      }
+      INNER_MARK();
+      if (so3) {   // the knot's two segment-table entries: recomputed for a new candidate (two lanes of different waves), or the kept ones restored
+        __syncthreads();
+        const int act = S.seg_action;
+        if (act == 1 && (tid == 0 || tid == 64)) {
+          const int e = tid >> 6, pair = s_lo + e;
+          if (pair < n_pairs && pair <= blk.idx) {
+            const double* a4 = pair == blk.idx ? S.xcur : S.qprev;
+            const double* b4 = pair == blk.idx ? S.qnext : S.xcur;
+            so3_segment_prepare(Quat{a4[0], a4[1], a4[2], a4[3]}, Quat{b4[0], b4[1], b4[2], b4[3]}, S.segcur + e * kSegStride);
+          }
+        }
+        if (act == 1) __syncthreads();
+        if (act != 0 && tid < 2 * kSegStride) {
+          const int pair = s_lo + tid / kSegStride;
+          if (pair < n_pairs && pair <= blk.idx) {
+            A.seg[(size_t)s_lo * kSegStride + tid] = S.segcur[tid];
+            if (local) s_seg[(s_lo - blk.ks0) * kSegStride + tid] = S.segcur[tid];
+          }
+        }
+      }
       if (ctl) {
         __threadfence(); __syncthreads();
         if (tid == 0) __hip_atomic_store(&ctl->word, ((round + 1) << 2) | (unsigned)s_cmd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (tid == 0) {
       unsigned w;
-      while (((w = __hip_atomic_load(&ctl->word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != round + 1) __builtin_amdgcn_s_sleep(2);
+      while (((w = __hip_atomic_load(&ctl->word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 2) != round + 1) __builtin_amdgcn_s_sleep(1);
       s_cmd = int(w & 3u);
     }
     __syncthreads();
+    INNER_MARK();
     if (ctl) __threadfence();   // the candidate the master wrote is visible to every lane
     cmd = s_cmd;
     ++round;
     if (cmd == INNER_CMD_DONE) break;
   }
   if (master && tid == 0 && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
+  if (prof) A.prof[0] = nprof;
+#undef INNER_MARK
 }
 
 // ambient step norm ||x - xc||^2 over the active blocks after the sweep (the retraction kernel's value is stale then)

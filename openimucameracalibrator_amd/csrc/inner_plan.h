@@ -3,6 +3,7 @@
 // inner_iterations.hip (kernels).
 #pragma once
 #include <cstdint>
+#include "oicc_device.h"
 
 namespace oicc {
 
@@ -18,7 +19,11 @@ struct InnerBlock {
   int64_t xoff;           // offset of the block in the parameter vector
   int32_t run0, nruns;    // its items: runs [run0, run0 + nruns)
   int32_t n_items;
+  int32_t n_slots;        // item slots: every run padded to a multiple of 64 (a wave evaluates one residual family)
   int32_t ctl;            // control block of a block that several workgroups share (InnerCtl index), -1: one workgroup
+  // knots its items read (what a one-workgroup block stages in LDS): SO(3) [ks0, ks0 + nks), R^3, accelerometer / gyroscope bias
+  int32_t ks0, nks, kr0, nkr, kab0, nkab, kgb0, nkgb;
+  int32_t pad;
 };
 
 // one workgroup of a set's launch: part `part` of `nparts` of block `block`
@@ -31,6 +36,17 @@ struct InnerCtl {
   double acc[56];                 // H (upper, row by row), g, cost
   unsigned int arrive, word;
   unsigned int pad[2];
+};
+
+// kernel arguments of one set's launch (inner_set_kernel)
+struct InnerArgs {
+  EvalCtx ctx;              // ctx.x == xv (the kernels of a sweep change the vector in place)
+  ViewData vd; ImuData ia, ig;
+  double* xv; double* seg;
+  const InnerBlock* blocks; const InnerRun* runs; const InnerWg* wgs; InnerCtl* ctls;
+  unsigned long long* lm_iterations;
+  double max_ab, max_gb;
+  long long* prof;          // debug (option debug_inner_profile): shader clock of workgroup 0 / thread 0 at every phase boundary, [0] = count
 };
 
 }  // namespace oicc

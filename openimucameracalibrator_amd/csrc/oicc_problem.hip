@@ -39,9 +39,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
 int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st);
 void launch_lds_poison(hipStream_t st);
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
-void launch_inner_eval(const EvalCtx& ctx, const ViewData& vd, const ImuData& ia, const ImuData& ig, const double* seg, const InnerBlock* blocks, InnerState* states,
-                       const int32_t* map_view, const int32_t* map_acc, const int32_t* map_gyr, bool jac, hipStream_t st);
-void launch_inner_step(double* xv, const InnerBlock* blocks, InnerState* states, int b0, int b1, int phase, double max_ab, double max_gb, int32_t* not_done, hipStream_t st);
+void launch_inner_set(const InnerArgs& A, int n_wgs, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
@@ -152,8 +150,8 @@ struct oicc_problem {
   bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
   // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
   struct InnerPlan {
-    std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<char> group_has_so3; std::vector<int32_t> maps;
-    DevBuf<InnerBlock> d_blocks; DevBuf<InnerState> d_states; DevBuf<int32_t> d_maps, d_not_done; DevBuf<double> d_seg;
+    std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0;   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
+    DevBuf<InnerBlock> d_blocks; DevBuf<InnerRun> d_runs; DevBuf<InnerWg> d_wgs; DevBuf<InnerCtl> d_ctls; DevBuf<unsigned long long> d_lm_iterations; DevBuf<double> d_seg; int n_ctls = 0;
     int flags = -2; int64_t layout_gen = -1; bool gs_unit = false;   // what the plan was built from: the tangent layout (make_layout generation) and the GS weighting
     size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
   } inner;
@@ -174,6 +172,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["debug_inner_profile"] = 0;   // g + 1: print the phase clocks of workgroup 0 of independent set g after every sweep
     opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 2: tiles in direct mode (fp64 atomics on the packed buffer: the independent accumulation path of the tests)
@@ -735,49 +734,53 @@ int build_inner_plan(oicc_problem* p, int flags) {
   std::vector<int> id_so3(pl.n_so3, -1), id_r3(pl.n_r3, -1), id_ab(pl.n_ab, -1), id_gb(pl.n_gb, -1); int id_o[5] = {-1, -1, -1, -1, -1};
   auto get = [&](int kind, int idx, int dim, int amb, int off, int64_t xoff, int* slot) -> int {
     if (off < 0) return -1;
-    if (*slot < 0) { HB h; h.b = InnerBlock{kind, idx, dim, amb, xoff}; h.order = int(B.size()); *slot = int(B.size()); B.push_back(h); }
+    if (*slot < 0) { HB h; h.b = InnerBlock{}; h.b.kind = kind; h.b.idx = idx; h.b.dim = dim; h.b.ambient = amb; h.b.xoff = xoff; h.b.ctl = -1; h.order = int(B.size()); *slot = int(B.size()); B.push_back(h); }
     return *slot; };
+  // Hessian graph: an edge between two blocks that share a residual block.  Consecutive samples of one sensor (and views of one
+  // window) depend on the same blocks: the clique of an id list is only added when it differs from the previous list of its family.
+  std::vector<std::vector<int>> adj;
+  auto clique = [&](const std::vector<int>& ids, std::vector<int>* last) {
+    if (ids == *last) return;
+    *last = ids;
+    if (adj.size() < B.size()) adj.resize(B.size());
+    for (int x : ids) if (x >= 0) for (int y : ids) if (y >= 0 && x != y) adj[x].push_back(y); };
+  std::vector<int> last_v, last_a, last_g, ids;
   const size_t nv = p->view_rs.size();
   for (size_t v = 0; v < nv; ++v) {
     if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
-    std::vector<int> ids;
+    ids.clear();
     const int ss = p->view_s_so3[v], sr = p->view_s_r3[v];
     for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
     for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
     ids.push_back(get(IK_TIC, 0, 6, 7, L.other[0], pl.tic, &id_o[0]));
     if (p->view_rs[v]) ids.push_back(get(IK_LD, 0, 1, 1, L.other[2], pl.ld, &id_o[2]));
     for (int id : ids) if (id >= 0) B[id].views.push_back(int32_t(v));
+    clique(ids, &last_v);
   }
   const size_t na = p->acc.size(), ng = p->gyr.size();
   for (size_t i = 0; i < std::max(na, ng); ++i) {
     if (i < na) {
-      std::vector<int> ids; const int ss = p->acc.s_so3[i], sr = p->acc.s_r3[i], sb = p->acc.s_b[i];
+      ids.clear(); const int ss = p->acc.s_so3[i], sr = p->acc.s_r3[i], sb = p->acc.s_b[i];
       for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
       for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
       for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_AB, sb + k, 3, 3, L.ab[sb + k], pl.ab + 3 * int64_t(sb + k), &id_ab[sb + k]));
       ids.push_back(get(IK_G, 0, 3, 3, L.other[1], pl.g, &id_o[1]));
       ids.push_back(get(IK_AI, 0, 6, 6, L.other[3], pl.ai, &id_o[3]));
       for (int id : ids) if (id >= 0) B[id].accs.push_back(int32_t(i));
+      clique(ids, &last_a);
     }
     if (i < ng) {
-      std::vector<int> ids; const int ss = p->gyr.s_so3[i], sb = p->gyr.s_b[i];
+      ids.clear(); const int ss = p->gyr.s_so3[i], sb = p->gyr.s_b[i];
       for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
       for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_GB, sb + k, 3, 3, L.gb[sb + k], pl.gb + 3 * int64_t(sb + k), &id_gb[sb + k]));
       ids.push_back(get(IK_GI, 0, 9, 9, L.other[4], pl.gi, &id_o[4]));
       for (int id : ids) if (id >= 0) B[id].gyrs.push_back(int32_t(i));
+      clique(ids, &last_g);
     }
   }
   const int n = int(B.size());
-  std::vector<std::vector<int>> adj(n);
-  {
-    std::vector<std::vector<int>> ofv(nv), ofa(na), ofg(ng);
-    for (int b = 0; b < n; ++b) { for (int v : B[b].views) ofv[v].push_back(b); for (int v : B[b].accs) ofa[v].push_back(b); for (int v : B[b].gyrs) ofg[v].push_back(b); }
-    auto clique = [&](const std::vector<int>& ids) { for (int x : ids) for (int y : ids) if (x != y) adj[x].push_back(y); };
-    for (auto& ids : ofv) clique(ids);
-    for (auto& ids : ofa) clique(ids);
-    for (auto& ids : ofg) clique(ids);
-    for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
-  }
+  adj.resize(n);
+  for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
   std::vector<char> removed(n, 0);
   std::vector<std::vector<int>> rounds;
   for (int covered = 0; covered < n;) {
@@ -791,63 +794,94 @@ int build_inner_plan(oicc_problem* p, int flags) {
     covered += int(set.size());
     rounds.push_back(set);
   }
-  // processing order: last set first; blocks of a set contiguous
-  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.group_has_so3.clear();
-  ip.n_items = nv + na + ng;
-  const size_t ngroups = rounds.size();
-  ip.maps.assign(ngroups * ip.n_items, -1);
-  size_t g = 0;
-  for (auto it = rounds.rbegin(); it != rounds.rend(); ++it, ++g) {
-    char has = 0;
-    for (int v : *it) {
-      const int nb = int(ip.blocks.size());
-      ip.blocks.push_back(B[v].b); has |= B[v].b.kind == IK_SO3;
-      int32_t* m = ip.maps.data() + g * ip.n_items;
-      for (int x : B[v].views) m[x] = nb;
-      for (int x : B[v].accs) m[nv + x] = nb;
-      for (int x : B[v].gyrs) m[nv + na + x] = nb;
+  // processing order: last set first; blocks of a set contiguous.  Per block: the runs of consecutive items that depend on it
+  // (time-sorted measurements: one run of corners, one of accelerometer and one of gyroscope samples) and its workgroups --
+  // one for a knot block; the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on
+  // each other: all of them must be resident, so a set's shared blocks split the CUs and come first in the launch).
+  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.n_ctls = 0;
+  constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
+  auto add_runs = [&](int kind, const std::vector<int32_t>& idx, InnerBlock* b) {
+    for (int32_t x : idx) {
+      const int32_t first = kind == 0 ? int32_t(p->view_c0[x]) : x, count = kind == 0 ? int32_t(p->view_c0[x + 1] - p->view_c0[x]) : 1;
+      if (count == 0) continue;
+      if (b->nruns > 0 && ip.runs.back().kind == kind && ip.runs.back().first + ip.runs.back().count == first) ip.runs.back().count += count;
+      else { ip.runs.push_back(InnerRun{kind, first, count, 0}); ++b->nruns; }
+      b->n_items += count;
     }
-    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_has_so3.push_back(has);
+    b->n_slots = 0;
+    for (int r = 0; r < b->nruns; ++r) b->n_slots += (ip.runs[size_t(b->run0) + r].count + 63) & ~63;
+  };
+  // knots the items of a block read
+  auto knot_ranges = [&](const HB& h, InnerBlock* b) {
+    int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1;
+    for (int32_t v : h.views) { s0 = std::min(s0, p->view_s_so3[v]); s1 = std::max(s1, p->view_s_so3[v] + kN); r0 = std::min(r0, p->view_s_r3[v]); r1 = std::max(r1, p->view_s_r3[v] + kN); }
+    for (int32_t i : h.accs) { s0 = std::min(s0, p->acc.s_so3[i]); s1 = std::max(s1, p->acc.s_so3[i] + kN); r0 = std::min(r0, p->acc.s_r3[i]); r1 = std::max(r1, p->acc.s_r3[i] + kN);
+                               a0 = std::min(a0, p->acc.s_b[i]); a1 = std::max(a1, p->acc.s_b[i] + kNb); }
+    for (int32_t i : h.gyrs) { s0 = std::min(s0, p->gyr.s_so3[i]); s1 = std::max(s1, p->gyr.s_so3[i] + kN); g0 = std::min(g0, p->gyr.s_b[i]); g1 = std::max(g1, p->gyr.s_b[i] + kNb); }
+    b->ks0 = s1 >= 0 ? s0 : 0; b->nks = s1 >= 0 ? s1 - s0 : 0; b->kr0 = r1 >= 0 ? r0 : 0; b->nkr = r1 >= 0 ? r1 - r0 : 0;
+    b->kab0 = a1 >= 0 ? a0 : 0; b->nkab = a1 >= 0 ? a1 - a0 : 0; b->kgb0 = g1 >= 0 ? g0 : 0; b->nkgb = g1 >= 0 ? g1 - g0 : 0;
+  };
+  for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
+    const int b0 = int(ip.blocks.size());
+    int n_shared = 0;
+    for (int v : *it) {
+      InnerBlock b = B[v].b;
+      b.run0 = int32_t(ip.runs.size()); b.nruns = 0; b.n_items = 0; b.ctl = -1;
+      add_runs(0, B[v].views, &b); add_runs(1, B[v].accs, &b); add_runs(2, B[v].gyrs, &b);
+      knot_ranges(B[v], &b);
+      if (b.n_slots > kSharedAbove) ++n_shared;
+      ip.blocks.push_back(b);
+    }
+    const int b1 = int(ip.blocks.size());
+    const int cap = std::max(1, p->n_cu / std::max(n_shared, 1));
+    for (int pass = 0; pass < 2; ++pass)        // shared blocks first
+      for (int b = b0; b < b1; ++b) {
+        InnerBlock& blk = ip.blocks[b];
+        const bool shared = blk.n_slots > kSharedAbove;
+        if (shared != (pass == 0)) continue;
+        const int nparts = shared ? std::min(cap, (blk.n_slots + kThreads - 1) / kThreads) : 1;
+        if (nparts > 1) blk.ctl = ip.n_ctls++;
+        for (int q = 0; q < nparts; ++q) ip.wgs.push_back(InnerWg{b, q, nparts, 0});
+      }
+    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size()));
   }
   hipStream_t st = p->stream;
-  if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_maps.upload(ip.maps, st) || !ip.d_states.resize(std::max<size_t>(ip.blocks.size(), 1)) || !ip.d_not_done.resize(1) ||
-      !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * 17)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
+  if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_runs.upload(ip.runs, st) || !ip.d_wgs.upload(ip.wgs, st) || !ip.d_ctls.resize(std::max(ip.n_ctls, 1)) || !ip.d_lm_iterations.resize(1) ||
+      !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
+  HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
+  HIPCK(p, hipStreamSynchronize(st));   // (the host vectors may be rebuilt right away)
   ip.flags = flags; ip.layout_gen = p->layout_gen; ip.gs_unit = gs_unit;
   return OICC_OK;
 }
 
-// One sweep of coordinate descent on the parameter vector `xv` (device, modified in place).
+// One sweep of coordinate descent on the parameter vector `xv` (device, modified in place): the segment tables of xv, then ONE
+// launch per independent set (inner_iterations.hip); nothing comes back to the host.
 int inner_sweep(oicc_problem* p, double* xv) {
   oicc_problem::InnerPlan& ip = p->inner;
   hipStream_t st = p->stream;
-  EvalCtx ctx = make_ctx(p, xv);
-  const ViewData vd = view_data(p); const ImuData ia = imu_data(p->acc, p->d_acc), ig = imu_data(p->gyr, p->d_gyr);
-  const size_t nv = p->view_rs.size(), na = p->acc.size();
-  const int n_pairs = std::max(p->pl.n_so3 - 1, 0);
+  InnerArgs A{};
+  A.ctx = make_ctx(p, xv); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
+  A.xv = xv; A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.wgs = nullptr; A.ctls = ip.d_ctls.p;
+  A.lm_iterations = ip.d_lm_iterations.p; A.max_ab = p->max_ab; A.max_gb = p->max_gb;
   ++ip.sweeps;
-  for (size_t g = 0; g + 1 < ip.group_first.size(); ++g) {
-    const int b0 = ip.group_first[g], b1 = ip.group_first[g + 1];
-    const int32_t* m = ip.d_maps.p + g * ip.n_items;
-    launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 0, p->max_ab, p->max_gb, ip.d_not_done.p, st);
-    launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
-    for (int rounds = 0; rounds < 56;) {
-      for (int r = 0; r < 4; ++r, ++rounds) {
-        if (ip.group_has_so3[g] && rounds > 0) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
-        launch_inner_eval(ctx, vd, ia, ig, ip.d_seg.p, ip.d_blocks.p, ip.d_states.p, m, m + nv, m + nv + na, true, st);
-        launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 1, p->max_ab, p->max_gb, ip.d_not_done.p, st);
-        if (ip.group_has_so3[g]) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);
-        launch_inner_eval(ctx, vd, ia, ig, ip.d_seg.p, ip.d_blocks.p, ip.d_states.p, m, m + nv, m + nv + na, false, st);
-        if (r == 3) HIPCK(p, hipMemsetAsync(ip.d_not_done.p, 0, sizeof(int32_t), st));
-        launch_inner_step(xv, ip.d_blocks.p, ip.d_states.p, b0, b1, 2, p->max_ab, p->max_gb, ip.d_not_done.p, st);
-      }
-      int32_t nd = 0;
-      HIPCK(p, hipMemcpyAsync(&nd, ip.d_not_done.p, sizeof(nd), hipMemcpyDeviceToHost, st));
-      HIPCK(p, hipStreamSynchronize(st));
-      if (nd == 0) break;
-    }
-    if (ip.group_has_so3[g]) launch_inner_seg(xv + p->pl.so3, n_pairs, ip.d_seg.p, st);   // rejected candidates were undone after the last evaluation
+  launch_inner_seg(xv + p->pl.so3, std::max(p->pl.n_so3 - 1, 0), ip.d_seg.p, st);
+  if (ip.n_ctls > 0) HIPCK(p, hipMemsetAsync(ip.d_ctls.p, 0, size_t(ip.n_ctls) * sizeof(InnerCtl), st));
+  const int prof_set = int(p->opt["debug_inner_profile"]) - 1;   // debug: phase clocks of workgroup 0 of this set
+  DevBuf<long long> d_prof;
+  for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
+    A.wgs = ip.d_wgs.p + ip.group_wg0[g];
+    A.prof = nullptr;
+    if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); A.prof = d_prof.p; }
+    launch_inner_set(A, ip.group_wg0[g + 1] - ip.group_wg0[g], st);
   }
   HIPCK(p, hipGetLastError());
+  if (prof_set >= 0 && d_prof.p) {
+    long long h[64];
+    HIPCK(p, hipMemcpyAsync(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
+    std::printf("[oicc] inner profile, set %d (%d workgroups), workgroup 0 / thread 0, cycles between marks [eval | barrier | advance | publish]:", prof_set, ip.group_wg0[prof_set + 1] - ip.group_wg0[prof_set]);
+    for (int k = 1; k < int(h[0]); ++k) std::printf(" %lld", h[1 + k] - h[k]);
+    std::printf("\n");
+  }
   return OICC_OK;
 }
 
@@ -1248,8 +1282,12 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   auto finish = [&](int term, const char* msg) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
+    unsigned long long lm_total = 0;   // (cumulative device counter of the per-block loops)
+    const bool swept = p->inner.sweeps > inner_sweeps0 && p->inner.d_lm_iterations.p != nullptr;
+    if (swept) (void)hipMemcpyAsync(&lm_total, p->inner.d_lm_iterations.p, sizeof(lm_total), hipMemcpyDeviceToHost, p->stream);
+    int r2 = sync_params_to_host(p);   // (drains the stream)
+    if (swept) p->inner.lm_iterations = int64_t(lm_total);
     S.inner_sweeps = p->inner.sweeps - inner_sweeps0; S.inner_lm_iterations = p->inner.lm_iterations - inner_lm0; S.line_search_steps = int32_t(p->line_search_steps);
-    int r2 = sync_params_to_host(p);
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
 
   // Host <-> device traffic of the loop: per LM iteration ONE 8-byte radius write, ONE zeroing of the

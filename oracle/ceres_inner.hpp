@@ -255,9 +255,10 @@ inline void sweep(Problem& p, const Layout& L, const Active& a, const Ordering& 
 
   for (const std::vector<int>& set : ord.groups) {
     const int64_t n = int64_t(set.size());
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total)
-    for (int64_t i = 0; i < n; ++i) total += solve_block(p, L, a, ord.blocks[set[i]]);
-    if (std::getenv("OICC_ORACLE_TRACE_SWEEP")) std::printf("[oracle] sweep: set of %lld blocks (first kind %d) -> cost %.9e\n", (long long)n, ord.blocks[set[0]].kind, total_cost(p, L, a));
+    int most = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total) reduction(max : most)
+    for (int64_t i = 0; i < n; ++i) { const int it = solve_block(p, L, a, ord.blocks[set[i]]); total += it; most = std::max(most, it); }
+    if (std::getenv("OICC_ORACLE_TRACE_SWEEP")) std::printf("[oracle] sweep: set of %lld blocks (first kind %d), at most %d LM iterations per block -> cost %.9e\n", (long long)n, ord.blocks[set[0]].kind, most, total_cost(p, L, a));
   }
   if (lm_iterations) *lm_iterations += total;
 }

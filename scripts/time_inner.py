@@ -1,0 +1,14 @@
+"""Inner sweeps of one configuration (GPU box): python scripts/time_inner.py C2 [repeats] -- wall clock of the reference-option solve and its sweeps."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openimucameracalibrator_amd import synthetic, estimator as E
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ds = synthetic.make_config(cfg)
+flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
+for r in range(reps):
+    cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cal.trajectory_.UseReferenceSolverOptions()
+    t = time.perf_counter(); s = cal.trajectory_.Optimize(50, flags); dt = time.perf_counter() - t
+    print("%s run %d: %.3f ms, %d LM iterations, %d sweeps, %d inner LM iterations, sweeps %.3f ms (%.3f ms each), final cost %.9e" % (
+        cfg, r, 1e3 * dt, s["num_iterations"], s["inner_sweeps"], s["inner_lm_iterations"], 1e3 * s["seconds_inner"], 1e3 * s["seconds_inner"] / max(s["inner_sweeps"], 1), s["final_cost"]), flush=True)
