@@ -40,6 +40,7 @@ struct BcrArgs {
   long long* prof;   // optional cycle counters of block 0 / wave 0 (debug)
   int n, a, Pb, rtf, LD;
   int no_diag_copy;            // debug: panel waves read the diagonal block in place (the hazard described in the panel factorisation)
+  int delay;                   // debug: panel waves > 0 sleep this many x ~1000 cycles before they read a panel (makes that hazard deterministic)
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
 };
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
       // The 8x8 diagonal block is read by lanes 0..7 of EVERY panel wave and rewritten in place by wave 0 at the end of its
       // panel: a wave that starts late (two panel waves share a SIMD once the border has three 16-row tiles, a + 1 > 32) could
       // read factored entries.  The waves therefore read the block from a copy the previous trailing update left in `dg`.
+      if (A.delay > 0 && wave > 0) for (int k = 0; k < A.delay; ++k) __builtin_amdgcn_s_sleep(16);   // (tests: a panel wave that starts late)
       const bool from_copy = lane < 8 && !A.no_diag_copy;
       const double* colp = from_copy ? dg + lane : W + j0 * LD + (act ? rho : 0);
       const int cstride = from_copy ? 8 : LD;
@@ -497,10 +499,10 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
 
 // ---- host ------------------------------------------------------------------
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
-// Arrow limit: the kernels are written for up to 63 arrow columns, but with three or four 16-row border tiles (a + 1 > 32)
-// the factorisation was seen to fail sporadically (NaN pivots in ~10 % of the solves that reuse the damping diagonal after a
-// rejected step, round-2 measurements in DESIGN.md) depending on what the preceding kernel left in LDS; until that is
-// understood such systems go to the band sweep (kernels_cholesky.hip), which takes any arrow width.
+// Arrow limit: the kernels take up to 63 arrow columns (four 16-row border tiles).  Round 2 saw sporadic NaN pivots with more than
+// two border tiles; the cause was the in-place read of the panel's diagonal block by waves that start a panel late (see the panel
+// factorisation and tests/test_gpu_parity.py::test_bcr_wide_borders_and_the_panel_hazard, which makes it deterministic); with the
+// `dg` copy the limit is the kernels' own.
 // (the limit travels with the problem: SolveBuffers::bcr_max_border, option bcr_max_border; the workspace is sized for the kernels' own limit)
 bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
@@ -521,7 +523,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.S = w; w += (int64_t)2 * n * 4096;
   A.Lf = w;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
-  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = sb.bcr_no_diag_copy;
+  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = sb.bcr_no_diag_copy; A.delay = sb.bcr_delay;
   A.rtf = (a1 + 15) / 16;
   const int Rp = 192 + 16 * A.rtf;
   A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;

@@ -107,8 +107,9 @@ struct SolveBuffers {
   int force_p;     // > 0: force this many partitions (tests); 0: heuristic
   int algo;        // 0: auto, 1: time-partitioned band sweep, 2: block cyclic reduction
   double radius;   // trust-region radius of this step (kernel argument, no host->device copy)
-  int bcr_max_border = 32;      // arrow + rhs rows the block cyclic reduction accepts (per problem: option bcr_max_border)
+  int bcr_max_border = 64;      // arrow + rhs rows the block cyclic reduction accepts (per problem: option bcr_max_border)
   int bcr_no_diag_copy = 0;     // debug: panel waves read the diagonal block in place (option debug_bcr_no_diag_copy)
+  int bcr_delay = 0;            // debug: panel waves other than wave 0 start every panel this many ~1000-cycle sleeps late (option debug_bcr_delay)
 };
 
 }  // namespace oicc

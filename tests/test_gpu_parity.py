@@ -177,12 +177,12 @@ def test_parallel_solvers_match_sequential(algo, parts):
     assert np.abs(k1[0] - k2[0]).max() < 1e-9 and (np.abs(k1[1] - k2[1]) / (1 + np.abs(k1[1]))).max() < 1e-9
 
 
-@pytest.mark.parametrize("algo", [1, 2])
-def test_bias_and_intrinsics_active_lm_matches_oracle(algo):
-    """IMU_BIASES | IMU_INTRINSICS: 27+15 arrow columns, box-bounded bias knots (band sweep); IMU_BIASES alone, 27 arrow
-    columns = two border tiles, for the block cyclic reduction (limited to 31 arrow columns, kernels_bcr.hip)."""
+@pytest.mark.parametrize("algo,intrinsics", [(1, 1), (2, 0), (2, 1), (0, 1)])
+def test_bias_and_intrinsics_active_lm_matches_oracle(algo, intrinsics):
+    """IMU_BIASES | IMU_INTRINSICS: 27+15 arrow columns, box-bounded bias knots, through the band sweep (1), the block cyclic
+    reduction (2: three border tiles; IMU_BIASES alone: two) and the automatic choice (0 = BCR)."""
     ds = synthetic.make_config("tiny")
-    flags = FLAGS1 | E.IMU_BIASES | (E.IMU_INTRINSICS if algo == 1 else 0)
+    flags = FLAGS1 | E.IMU_BIASES | (E.IMU_INTRINSICS if intrinsics else 0)
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     gpu.trajectory_.SetOption("solver_algorithm", algo)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
@@ -197,6 +197,37 @@ def test_bias_and_intrinsics_active_lm_matches_oracle(algo):
     assert np.abs(ag).max() <= 1.0 and np.abs(gg2).max() <= 0.1          # impl.h:213-218,235-240 bounds
     ig, ic = gpu.trajectory_.GetIMUIntrinsics(), cpu.trajectory_.GetIMUIntrinsics()
     assert np.abs(ig[0] - ic[0]).max() < 1e-6 and np.abs(ig[1] - ic[1]).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "C1"])
+def test_bcr_wide_borders_and_the_panel_hazard(cfg):
+    """Block cyclic reduction with three and four 16-row border tiles (biases + IMU intrinsics: > 31 arrow columns, a fifth panel
+    wave), LDS poisoned before every pass and solve, over accepted and rejected steps: the iterates of the band sweep.  And the
+    hazard behind round 2's sporadic NaN pivots, made deterministic: panel waves that start a panel late (debug_bcr_delay) read
+    the 8 x 8 diagonal block AFTER wave 0 has overwritten it with its factor when they read it in place
+    (debug_bcr_no_diag_copy = 1: the round-2 code) -- wrong factors; with the copy the trailing update leaves for them (`dg`,
+    kernels_bcr.hip) the same delay changes nothing."""
+    ds = synthetic.make_config(cfg)
+    flags = FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS
+
+    def run(algo, **opts):
+        c = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        c.trajectory_.SetOption("solver_algorithm", algo); c.trajectory_.SetOption("bcr_max_border", 64); c.trajectory_.SetOption("debug_poison_lds", 1)
+        for k, v in opts.items():
+            c.trajectory_.SetOption(k, v)
+        s_ = c.trajectory_.Optimize(12, flags)
+        return s_, c.trajectory_.GetIterations()
+
+    s_ref, it_ref = run(1)
+    assert 31 < s_ref["arrow_dim"] < 64 and s_ref["num_unsuccessful_steps"] + s_ref["num_successful_steps"] >= 4
+
+    def same(it):
+        return len(it) == len(it_ref) and all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(it, it_ref))
+    for opts in ({}, {"debug_bcr_delay": 3}, {"debug_bcr_delay": 9}):
+        s_, it = run(2, **opts)
+        assert s_["termination"] == s_ref["termination"] and same(it), (opts, [i["cost"] for i in it], [i["cost"] for i in it_ref])
+    s_bad, it_bad = run(2, debug_bcr_delay=3, debug_bcr_no_diag_copy=1)
+    assert not same(it_bad)                      # the in-place read of a late wave sees wave 0's factor
 
 
 @pytest.mark.parametrize("unit_loss", [0, 1])
