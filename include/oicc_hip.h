@@ -246,6 +246,14 @@ int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user);
  * Replaces any hook installed with oicc_set_allreduce; oicc_destroy releases the communicator. */
 int oicc_rccl_get_unique_id(uint8_t id[128]);
 int oicc_rccl_init(oicc_problem* p, int32_t nranks, int32_t rank, const uint8_t id[128]);
+/* Inner iterations (the reference's use_inner_iterations = true, impl.h:266) on a time-sharded problem: the coordinate
+ * descent sweep minimises every parameter block over ALL residual blocks that depend on it, so a rank that holds only its
+ * shard cannot run it.  `whole` is a second problem on the same device with the same spline, calibration and options that
+ * holds EVERY rank's measurements (a few MB even at BASELINE config 5); the sweeps of oicc_optimize(p) then run on p's
+ * candidate over whole's measurements, identically (replicated) on every rank, with no collective; with the native RCCL
+ * path rank 0's swept candidate is broadcast afterwards so that all ranks continue from identical bits.  The Jacobian and
+ * cost passes of p stay sharded.  NULL removes the source.  `whole` must outlive p's solves. */
+int oicc_set_inner_iteration_source(oicc_problem* p, oicc_problem* whole);
 /* Tell this rank about measurements held by OTHER ranks (timestamps only), so
  * that every rank derives the same tangent layout (which knots are in the
  * problem, bandwidth, which parameter blocks exist).

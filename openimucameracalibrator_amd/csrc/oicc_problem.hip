@@ -115,6 +115,7 @@ struct oicc_problem {
   oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
   void* rccl_comm = nullptr;   // ncclComm_t of oicc_rccl_init
   int rccl_nranks = 1;
+  oicc_problem* inner_src = nullptr;   // time-sharded ranks: the problem whose measurements (all ranks') the inner-iteration sweeps run over
   // device
   DevBuf<double> d_x, d_xc, d_pts;
   // segment tables (spline_seg.cuh) of the SO(3) knot pairs of the two parameter buffers, keyed by the buffer's address (d_x.p and
@@ -857,9 +858,8 @@ int build_inner_plan(oicc_problem* p, int flags) {
 
 // One sweep of coordinate descent on the parameter vector `xv` (device, modified in place): the segment tables of xv, then ONE
 // launch per independent set (inner_iterations.hip); nothing comes back to the host.
-int inner_sweep(oicc_problem* p, double* xv) {
+int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the problem whose measurements and plan are used (xv may belong to another problem with the same spline)
   oicc_problem::InnerPlan& ip = p->inner;
-  hipStream_t st = p->stream;
   InnerArgs A{};
   A.ctx = make_ctx(p, xv); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
   A.xv = xv; A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.wgs = nullptr; A.ctls = ip.d_ctls.p;
@@ -1037,6 +1037,7 @@ int oicc_set_option(oicc_problem* p, const char* name, double value) {
   return OICC_OK;
 }
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user) { p->reduce = fn; p->reduce_user = user; return OICC_OK; }
+int oicc_set_inner_iteration_source(oicc_problem* p, oicc_problem* whole) { ARG(p, whole != p, "a problem cannot be its own inner iteration source"); p->inner_src = whole; return OICC_OK; }
 
 int oicc_rccl_get_unique_id(uint8_t id[128]) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -1279,16 +1280,17 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   const bool verbose = p->opt["verbose"] != 0;
   double decrease_factor = 2.0; bool reuse_diagonal = false;
   double cost = 0.0, gmax = 0.0;
-  const int inner_sweeps0 = p->inner.sweeps; const int64_t inner_lm0 = p->inner.lm_iterations;
+  const int inner_sweeps0 = (p->inner_src ? p->inner_src : p)->inner.sweeps; const int64_t inner_lm0 = (p->inner_src ? p->inner_src : p)->inner.lm_iterations;
   auto finish = [&](int term, const char* msg) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
     unsigned long long lm_total = 0;   // (cumulative device counter of the per-block loops)
-    const bool swept = p->inner.sweeps > inner_sweeps0 && p->inner.d_lm_iterations.p != nullptr;
-    if (swept) (void)hipMemcpyAsync(&lm_total, p->inner.d_lm_iterations.p, sizeof(lm_total), hipMemcpyDeviceToHost, p->stream);
+    oicc_problem* const qs = p->inner_src ? p->inner_src : p;
+    const bool swept = qs->inner.sweeps > inner_sweeps0 && qs->inner.d_lm_iterations.p != nullptr;
+    if (swept) (void)hipMemcpyAsync(&lm_total, qs->inner.d_lm_iterations.p, sizeof(lm_total), hipMemcpyDeviceToHost, p->stream);
     int r2 = sync_params_to_host(p);   // (drains the stream)
-    if (swept) p->inner.lm_iterations = int64_t(lm_total);
-    S.inner_sweeps = p->inner.sweeps - inner_sweeps0; S.inner_lm_iterations = p->inner.lm_iterations - inner_lm0; S.line_search_steps = int32_t(p->line_search_steps);
+    if (swept) qs->inner.lm_iterations = int64_t(lm_total);
+    S.inner_sweeps = qs->inner.sweeps - inner_sweeps0; S.inner_lm_iterations = qs->inner.lm_iterations - inner_lm0; S.line_search_steps = int32_t(p->line_search_steps);
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
 
   // Host <-> device traffic of the loop: per LM iteration ONE 8-byte radius write, ONE zeroing of the
@@ -1337,10 +1339,20 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   p->seg_invalidate(p->d_xc.p);
   int iter = 0, invalid = 0;
   bool inner_enabled = false;
+  oicc_problem* const q = p->inner_src ? p->inner_src : p;   // whose measurements the sweeps run over (a time-sharded rank: the problem with every rank's measurements)
   if (p->opt["inner_iterations"] != 0.0) {
-    if (p->reduce) { p->err = "inner iterations are not available with an all-reduce hook (time-sharded problems)"; return OICC_ERR_UNSUPPORTED; }
-    rc = build_inner_plan(p, flags); if (rc) return rc;
-    inner_enabled = p->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
+    if (p->reduce && q == p) { p->err = "inner iterations on a time-sharded problem need oicc_set_inner_iteration_source (a sweep minimises a block over ALL its residual blocks)"; return OICC_ERR_UNSUPPORTED; }
+    if (q != p) {
+      if (q->device != p->device || q->pl.total != p->pl.total || q->pl.n_so3 != p->pl.n_so3 || q->pl.n_r3 != p->pl.n_r3 || q->dt_so3 != p->dt_so3 || q->dt_r3 != p->dt_r3 || q->start_ns != p->start_ns) {
+        p->err = "inner iteration source: different device or spline"; return OICC_ERR_INVALID_ARG; }
+      for (const char* name : {"gs_unit_loss", "rs_time_in_seconds"}) q->opt[name] = p->opt[name];
+      q->cam_model = p->cam_model; q->n_intr = p->n_intr; std::memcpy(q->intr, p->intr, sizeof(q->intr));
+      q->x[q->pl.ld] = p->x[p->pl.ld];   // (active_set looks at the zero-ness of the line delay)
+      rc = prepare(q, flags); if (rc) { p->err = "inner iteration source: " + q->err; return rc; }
+      if (q->L.P != p->L.P || q->L.Pb != p->L.Pb) { p->err = "inner iteration source: its measurements give a different tangent layout (declare the remote measurements on the shard)"; return OICC_ERR_STATE; }
+    }
+    rc = build_inner_plan(q, flags); if (rc) { if (q != p) p->err = q->err; return rc; }
+    inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
   }
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
   bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
@@ -1457,13 +1469,14 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       cand_before_inner = cand_cost_of();
       if (std::isfinite(cand_before_inner)) {
         HIPCK(p, hipEventRecord(ev[6], st));
-        rc = inner_sweep(p, p->d_xc.p); if (rc) return rc;
+        rc = inner_sweep(q, p->d_xc.p, st); if (rc) { if (q != p) p->err = q->err; return rc; }
+        if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0) { p->err = "broadcast of the swept candidate failed"; return OICC_ERR_STATE; }   // (the shared blocks of a sweep sum with atomics: rank 0's bits for everyone)
         HIPCK(p, hipEventRecord(ev[7], st));
         p->seg_invalidate(p->d_xc.p);
         if (cost_in_state) HIPCK(p, hipMemsetAsync(&p->d_state.p->cand_cost, 0, sizeof(double), st));
         rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, cost_in_state, nullptr, false, nullptr, false, cand_dst); if (rc) return rc;
         HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, sizeof(double), st));
-        launch_inner_diff_norm(p->d_x.p, p->d_xc.p, p->inner.d_blocks.p, int(p->inner.blocks.size()), &p->d_state.p->step_norm_sq, st);
+        launch_inner_diff_norm(p->d_x.p, p->d_xc.p, q->inner.d_blocks.p, int(q->inner.blocks.size()), &p->d_state.p->step_norm_sq, st);
         inner_ran = true;
       }
     }

@@ -97,6 +97,12 @@ class SplineTrajectoryEstimator:
         for name in ("inner_iterations", "bounds_line_search", "projected_gradient_norm"):
             self.SetOption(name, 1 if on else 0)
 
+    def SetInnerIterationSource(self, whole):
+        """Time-sharded ranks: `whole` (a SplineTrajectoryEstimator on the same device holding every rank's measurements) supplies the
+        residual blocks of the inner-iteration sweeps (oicc_set_inner_iteration_source); None removes it."""
+        self._inner_source = whole          # keep it alive
+        self._ck(self._b.set_inner_iteration_source(self._h, whole._h if whole is not None else None))
+
     def SetStream(self, hip_stream):
         self._ck(self._b.set_stream(self._h, C.c_void_p(int(hip_stream))))
 

@@ -1,7 +1,9 @@
 """Worker of test_two_processes_on_one_gpu_reduce_through_the_hook: rank r of WORLD_SIZE processes, ALL on GPU 0, holds the
 r-th time shard of a problem and runs oicc_optimize with an all-reduce hook that stages through host memory and gloo
 (RCCL refuses two ranks on one device; the hook is the product path under test, the transport is not).
-usage: python mp_shard_worker.py <cfg> <flags> <iterations> <bounds_line_search> <out.json>   (RANK / WORLD_SIZE / MASTER_* from the env)"""
+usage: python mp_shard_worker.py <cfg> <flags> <iterations> <bounds_line_search> <out.json> [inner_iterations]   (RANK / WORLD_SIZE / MASTER_* from the env)
+With inner_iterations = 1 every rank also builds the WHOLE problem on the device and hands it to its shard as the source of the
+inner-iteration sweeps (oicc_set_inner_iteration_source): the reference's solver configuration on time-sharded ranks."""
 import ctypes, json, os, sys
 import numpy as np
 import torch
@@ -12,6 +14,7 @@ from openimucameracalibrator_amd import synthetic, estimator as E
 
 def main():
     cfg, flags, iters, ls, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    inner = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hip = ctypes.CDLL("libamdhip64.so")
@@ -30,13 +33,16 @@ def main():
     ds = synthetic.make_config(cfg)
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
     tr = cal.trajectory_
-    tr.SetOption("bounds_line_search", ls)
+    tr.SetOption("bounds_line_search", ls); tr.SetOption("inner_iterations", inner)
     if world > 1:
         tr.SetAllReduce(allreduce)
+        if inner:
+            whole = E.ImuCameraCalibrator().BatchInitSpline(ds)
+            tr.SetInnerIterationSource(whole.trajectory_)
     s = tr.Optimize(iters, flags)
     it = tr.GetIterations()
     res = dict(rank=rank, blocks=cal.num_blocks, iterations=[dict(cost=i["cost"], ok=i["step_is_successful"], gmax=i["gradient_max_norm"]) for i in it],
-               final_cost=s["final_cost"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"])
+               final_cost=s["final_cost"], inner_sweeps=s["inner_sweeps"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"])
     json.dump(res, open(out, "w"))
     dist.barrier()
     dist.destroy_process_group()
