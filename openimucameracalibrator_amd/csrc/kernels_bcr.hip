@@ -21,6 +21,13 @@
 //   After ceil(log2 n) levels block 0 is alone: its workgroup also factors the arrow
 //   corner, solves it and starts the back substitution, which then runs level by level
 //   in reverse, again one workgroup per pivot.
+//
+// PARALLEL cyclic reduction (round 3) for systems of at most one block per CU (n <= 256: BASELINE configs 2-4): every
+// level eliminates EVERY block against its neighbours at distance s (same kernels, all n blocks as pivots), which
+// decouples the blocks after ceil(log2 n) levels and needs no back substitution through the levels: the arrow columns
+// and the right-hand side ride along as a1 right-hand sides, a final launch solves D_i X_i = R_i per block, sums
+// E^T B^-1 [E | g] into the corner, and the last workgroup to finish solves the corner and writes the step.
+// 11 dependent launches instead of 17 for C2 (no bcr_backward launches), the idle CUs pay for the extra eliminations.
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"
 
@@ -43,6 +50,13 @@ struct BcrArgs {
   int delay;                   // debug: panel waves > 0 sleep this many x ~1000 cycles before they read a panel (makes that hazard deterministic)
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
+  // parallel cyclic reduction: every block is a pivot at every level; the coupling of the pair (k, k + s) is stored twice,
+  // slot 2k with k's variables as the column index ("k major") and slot 2k + 1 with those of k + s
+  int pcr;
+  const double* F0;            // [n][64*a1] border rows as built (arrow columns E_i and rhs before the levels changed them)
+  double* X;                   // [n][a1][64] solutions of D_i X_i = R_i after the last level
+  double* Cacc;                // [a1*a1] sum_i E_i^T X_i
+  unsigned int* counter;       // workgroups of the final launch that have finished
 };
 
 __device__ __forceinline__ void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -59,8 +73,50 @@ __device__ __forceinline__ void tri10(int t, int& xt, int& yt) {
   yt = t - (xt * (xt + 1)) / 2;
 }
 
-template <int LD, bool LAST, bool PROF>
+// Arrow corner (a x a, with the rhs as row / column a) held as Cq(r, c) = W[c*LD + 64 + r]: Cholesky, forward and backward
+// substitution; the arrow part of the step lands in da[0..a).  ONE WAVE, lane = row (a + 1 <= 64): per column the pivot comes
+// by v_readlane, the rank-1 update of the remaining columns runs over LDS without a workgroup barrier (round 2 spent three
+// 1024-thread barriers per column here).  Called by all threads; ends with a workgroup barrier.
+template <int LD>
+__device__ __forceinline__ void bcr_corner_solve(double* W, double* da, int* failp, int a, int tid, int wave, int lane) {
+  const int a1 = a + 1;
+  if (wave == 0) {
+    bool bad = false;
+    for (int c = 0; c < a; ++c) {
+      double* col = W + c * LD + 64;
+      const double mine = lane < a1 ? col[lane] : 0.0;
+      double piv = bcr_readlane(mine, c);
+      if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+      const double d = sqrt(piv);
+      const double l = lane == c ? d : (lane > c ? mine / d : 0.0);
+      if (lane >= c && lane < a1) col[lane] = l;
+      for (int c2 = c + 1; c2 < a; ++c2) {
+        const double l2 = bcr_readlane(l, c2);
+        if (lane >= c2 && lane < a1) W[c2 * LD + 64 + lane] -= l * l2;
+      }
+    }
+    if (bad && lane == 0) *failp = 1;
+    // back substitution of the corner, lane = arrow column: z_q = Cq(a, q), L_c^T x_a = z
+    double z = lane < a ? W[lane * LD + 64 + a] : 0.0;
+    const double dc = lane < a ? 1.0 / W[lane * LD + 64 + lane] : 0.0;
+    double xq_mine = 0.0;
+    for (int q = a - 1; q >= 0; --q) {
+      const double xq = bcr_readlane(z * dc, q);
+      if (lane == q) xq_mine = xq;
+      const double l = lane < q ? W[lane * LD + 64 + q] : 0.0;    // L_c(q, lane)
+      z = fma(-l, xq, z);
+    }
+    if (lane < a) da[lane] = xq_mine;
+  }
+  __syncthreads();
+}
+
+// MODE 0: a pivot of a level;  1: block 0 after the last level of the cyclic reduction (+ corner + its back substitution);
+// 2: final launch of the parallel cyclic reduction (a decoupled block with its a1 right-hand sides; the last workgroup
+//    to finish also solves the corner and writes the step)
+template <int LD, int MODE, bool PROF>
 __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
+  constexpr bool LAST = MODE == 1;
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,13 +130,13 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
   double* const dg = da + 64 + 8;        // [8][8] copy of the current panel's diagonal block (column major), see the panel factorisation
 
   const int s = A.s;
-  const int i = LAST ? 0 : s * (2 * (int)blockIdx.x + 1);
+  const int i = LAST ? 0 : ((A.pcr || MODE == 2) ? (int)blockIdx.x : s * (2 * (int)blockIdx.x + 1));
   const int il = i - s, ir = i + s;
-  const bool hasL = !LAST, hasR = !LAST && ir < A.n;
+  const bool hasL = MODE == 0 && il >= 0, hasR = MODE == 0 && ir < A.n;
   const double* Dg = A.D + (int64_t)i * 4096;
   const double* Fg = A.F + (int64_t)i * 64 * a1;
-  const double* SL = hasL ? A.S + (A.offS_in + il / s) * 4096 : nullptr;
-  const double* SR = hasR ? A.S + (A.offS_in + i / s) * 4096 : nullptr;
+  const double* SL = hasL ? A.S + (A.offS_in + (A.pcr ? 2 * il + 1 : il / s)) * 4096 : nullptr;   // (pcr: the pair (il, i) with i's variables as columns)
+  const double* SR = hasR ? A.S + (A.offS_in + (A.pcr ? 2 * i : i / s)) * 4096 : nullptr;         // (pcr: the pair (i, ir), again i major)
 
   const bool prof = PROF && A.prof != nullptr && blockIdx.x == 0 && wave == 0;
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -123,6 +179,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
     int rem = wave + 16 * k, ct = 0;
     while (ct < 4 && rem >= nrt - ct) { rem -= nrt - ct; ++ct; }
     t_ok[k] = ct < 4; t_ct[k] = t_ok[k] ? ct : 0; t_rt[k] = t_ok[k] ? ct + rem : 0;
+    if (MODE == 2 && t_rt[k] >= 4 && t_rt[k] < 12) t_ok[k] = false;   // no neighbours: the left / right rows are zero
     const double* src = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
     acc[k][0] = src[0]; acc[k][1] = src[4 * LD]; acc[k][2] = src[8 * LD]; acc[k][3] = src[12 * LD];
   }
@@ -133,7 +190,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
     // ---- panel factorisation, in place in W
     if (wave < NAW) {
       const int rho = lane < 8 ? j0 + lane : 8 + wave * 56 + (lane - 8);
-      const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru);
+      const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru && !(MODE == 2 && rho >= 64 && rho < 192));
       // eight reads off one base address (LD is a compile-time constant: immediate offsets); inactive lanes
       // read row 0 and are masked afterwards
       // The 8x8 diagonal block is read by lanes 0..7 of EVERY panel wave and rewritten in place by wave 0 at the end of its
@@ -217,7 +274,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
   }
 
   // ---- factor rows to global memory (row major; diagonal slot = 1/L_ii, upper part zero)
-  if (!LAST) {
+  if (MODE == 0) {
     double* Lg = A.Lf + (int64_t)i * Ru * 64;
     for (int e = tid; e < Ru * 64; e += kBcrThreads) {
       const int r = e >> 6, c = e & 63;
@@ -228,11 +285,90 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
   }
   BCR_MARK(5);
 
-  if (!LAST) {
+  if (MODE == 0) {
     // the Schur complement of the border rows is formed by bcr_schur_kernel from the factor rows just written
     __syncthreads();
     if (tid == 0 && *failp) atomicOr(A.fail, 1);
     if (PROF && prof && lane == 0) for (int k = 0; k < 8; ++k) A.prof[k] = pc[k];
+    return;
+  }
+
+  if (MODE == 2) {
+    // ---------------- final launch of the parallel cyclic reduction: X_i = D_i^-1 R_i for the a1 right-hand sides
+    // (the factorisation left Y = L^-1 R in the border rows; back substitution per column, one wave each)
+    __syncthreads();
+    for (int q = wave; q < a1; q += kBcrThreads / 64) {
+      double z = W[lane * LD + 192 + q];
+      double xv = 0.0;
+      const double dv = dinvs[lane];
+      for (int jb = 56; jb >= 0; jb -= 8) {
+        double l8[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) l8[t] = lane < jb + t ? -W[lane * LD + jb + t] : 0.0;   // L(jb+t, lane)
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+          const double xj = bcr_readlane(z * dv, jb + t);
+          if (lane == jb + t) xv = xj;
+          z = fma(l8[t], xj, z);
+        }
+      }
+      W[q * LD + 64 + lane] = xv;          // X(lane, q) in the unused left rows
+    }
+    __syncthreads();
+    for (int e = tid; e < a1 * 64; e += kBcrThreads) { const int q = e >> 6, r = e & 63; A.X[((int64_t)i * a1 + q) * 64 + r] = W[q * LD + 64 + r]; }
+    // E_i^T X_i (arrow columns of the block as built) into the shared corner sum: E_i staged in the unused right rows
+    // (W[q*LD + 128 + r] = E_i(r, q)), coalesced, before the 64-term sums
+    const double* F0 = A.F0 + (int64_t)i * 64 * a1;
+    for (int e = tid; e < 64 * a1; e += kBcrThreads) { const int r = e / a1, q = e - r * a1; W[q * LD + 128 + r] = F0[e]; }
+    __syncthreads();
+    for (int e = tid; e < a * a1; e += kBcrThreads) {
+      const int q1 = e / a1, q2 = e - q1 * a1;
+      double v0 = 0.0, v1 = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < 64; r += 2) { v0 = fma(W[q1 * LD + 128 + r], W[q2 * LD + 64 + r], v0); v1 = fma(W[q1 * LD + 128 + r + 1], W[q2 * LD + 64 + r + 1], v1); }
+      const double v = v0 + v1;
+      if (v != 0.0) unsafeAtomicAdd(A.Cacc + q1 * a1 + q2, v);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      if (*failp) atomicOr(A.fail, 1);
+      const unsigned ticket = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      failp[1] = ticket == (unsigned)A.n - 1u;
+    }
+    __syncthreads();
+    if (!failp[1]) return;
+    // ---- last workgroup: reduced corner C - E^T B^-1 E with the rhs as row / column a, its solution, then the band part
+    __threadfence();
+    if (tid == 0) *failp = 0;
+    for (int e = tid; e < a1 * a1; e += kBcrThreads) {
+      const int c = e / a1, r = e - c * a1;
+      double v = A.Mc[r * a1 + c];
+      const int q1 = r < a ? r : c, q2 = r < a ? c : a;                  // row a (the rhs): by symmetry of B^-1 the sum stored at (c, a)
+      if (q1 < a) v -= __hip_atomic_load(A.Cacc + q1 * a1 + q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      W[c * LD + 64 + r] = v;
+    }
+    __syncthreads();
+    bcr_corner_solve<LD>(W, da, failp, a, tid, wave, lane);
+    for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
+    for (int e = tid; e < A.n * 64; e += kBcrThreads) {
+      if (e >= A.Pb) break;
+      const int blk = e >> 6, r = e & 63;
+      const double* Xb = A.X + (int64_t)blk * a1 * 64 + r;
+      double v = Xb[a * 64];
+      int q = 0;
+      for (; q + 8 <= a; q += 8) {          // eight loads in flight before the dependent sum
+        double t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t8[k] = Xb[(q + k) * 64];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v = fma(-t8[k], da[q + k], v);
+      }
+      for (; q < a; ++q) v = fma(-Xb[q * 64], da[q], v);
+      A.x[e] = v;
+    }
+    __syncthreads();
+    if (tid == 0 && *failp) atomicOr(A.fail, 1);
     return;
   }
 
@@ -250,34 +386,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
     W[c * LD + 64 + r] = v0 + v1;
   }
   __syncthreads();
-  for (int c = 0; c < a; ++c) {
-    double* col = W + c * LD + 64;
-    if (tid == 0) { double piv = col[c]; if (!(piv > 0.0)) { *failp = 1; piv = 1.0; } col[c] = sqrt(piv); }
-    __syncthreads();
-    const double d = col[c];
-    for (int r = c + 1 + tid; r < a1; r += kBcrThreads) col[r] /= d;
-    __syncthreads();
-    const int nrem = a1 - (c + 1);
-    for (int e = tid; e < nrem * nrem; e += kBcrThreads) {
-      const int c2 = c + 1 + e / nrem, r = c + 1 + e % nrem;
-      if (r >= c2 && c2 < a) W[c2 * LD + 64 + r] -= col[r] * col[c2];
-    }
-    __syncthreads();
-  }
-  if (wave == 0) {
-    // back substitution of the corner, lane = arrow column: z_q = Cq(a, q), L_c^T x_a = z
-    double z = lane < a ? W[lane * LD + 64 + a] : 0.0;
-    const double dc = lane < a ? 1.0 / W[lane * LD + 64 + lane] : 0.0;
-    double xq_mine = 0.0;
-    for (int q = a - 1; q >= 0; --q) {
-      const double xq = bcr_readlane(z * dc, q);
-      if (lane == q) xq_mine = xq;
-      const double l = lane < q ? W[lane * LD + 64 + q] : 0.0;    // L_c(q, lane)
-      z = fma(-l, xq, z);
-    }
-    if (lane < a) da[lane] = xq_mine;
-  }
-  __syncthreads();
+  bcr_corner_solve<LD>(W, da, failp, a, tid, wave, lane);
   for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
   if (wave == 0) {
     double z = W[lane * LD + 192 + a];
@@ -313,18 +422,18 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(BcrArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int a1 = A.a + 1, rtf = A.rtf, Ru = 192 + a1, s = A.s;
-  const int i = s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
-  const bool hasR = ir < A.n;
-  const int nRL = hasR ? 16 : 0, nLL = 10, nRR = hasR ? 10 : 0;
-  const int nFL = 4 * rtf, nFR = hasR ? 4 * rtf : 0, nFF = (rtf * (rtf + 1)) / 2;
+  const int i = A.pcr ? (int)blockIdx.y : s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
+  const bool hasL = il >= 0, hasR = ir < A.n;                       // (cyclic reduction: a pivot always has its left neighbour)
+  const int nRL = (hasL && hasR) ? 16 : 0, nLL = hasL ? 10 : 0, nRR = hasR ? 10 : 0;
+  const int nFL = hasL ? 4 * rtf : 0, nFR = hasR ? 4 * rtf : 0, nFF = A.pcr ? 0 : (rtf * (rtf + 1)) / 2;   // (pcr: the corner is formed once, by the final launch)
   const int ntot = nRL + nLL + nRR + nFL + nFR + nFF;
   const int t = (int)blockIdx.x * 4 + wave;
   if (t >= ntot) return;
   // orientation of the new coupling (il, ir): the pivot of the next level is the one at an odd position
-  const bool il_is_pivot = ((il / (2 * s)) & 1) != 0;
+  const bool il_is_pivot = A.pcr || ((il / (2 * s)) & 1) != 0;
   double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)ir * 4096;
   double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)ir * 64 * a1;
-  double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
+  double* So = A.S + (A.offS_out + (A.pcr ? 2 * il : il / (2 * s))) * 4096;
   const double* Lg = A.Lf + (int64_t)i * Ru * 64;
   int kind, xt, yt, u = t;
   if (u < nRL) { kind = 0; xt = u >> 2; yt = u & 3; }
@@ -353,7 +462,7 @@ __global__ __launch_bounds__(256) void bcr_schur_kernel(BcrArgs A) {
   for (int r = 0; r < 4; ++r) {
     const double v = -g[r];
     if (kind == 0) {
-      if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; }       // Q[c = il var][r = ir var]
+      if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; if (A.pcr) So[4096 + x * 64 + y] = v; }   // Q[c = il var][r = ir var] (pcr: and the ir-major copy in the next slot)
       else       { const int y = 16 * yt + li, x = 16 * xt + lq + 4 * r; So[x * 64 + y] = v; }       // Q[c = ir var][r = il var]
     } else if (kind == 1 || kind == 2) {
       const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
@@ -436,6 +545,10 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
   const double radius = sb.radius;
+  if (A.pcr) {
+    for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) A.Cacc[e] = 0.0;
+    if (tid == 0) *A.counter = 0u;
+  }
   if (tid == 0) {   // results of the step that starts here
     sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
   }
@@ -466,7 +579,7 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
       }
       A.D[e] = v;
     }
-    if (blk < n - 1) {
+    if (blk < n - 1 && !A.pcr) {
       // coupling (blk, blk+1): the pivot of level 0 is the odd one
       const bool right = (blk & 1) != 0;     // pivot = blk, neighbour = blk+1 (its right)
       const int64_t gr = (int64_t)(blk + 1) * 64 + (right ? r : c);
@@ -476,6 +589,16 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
       if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
       A.S[e] = v;
     }
+    if (blk < n - 1 && A.pcr) {
+      // coupling (blk, blk+1) in both orientations: slot 2 blk with blk's variables as the column index c, slot 2 blk + 1 with those of blk + 1
+      for (int o = 0; o < 2; ++o) {
+        const int64_t gc = (int64_t)blk * 64 + (o == 0 ? c : r), gr = (int64_t)(blk + 1) * 64 + (o == 0 ? r : c);
+        const int64_t k = gr - gc;
+        double v = 0.0;
+        if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
+        A.S[(A.offS_in + 2 * blk + o) * 4096 + (e & 4095)] = v;
+      }
+    }
   }
   // border rows: arrow + rhs
   for (int64_t e = tid; e < (int64_t)n * 64 * a1; e += nthreads) {
@@ -483,6 +606,7 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
     double v = 0.0;
     if (gi < Pb) v = q < a ? ne.Et()[(int64_t)q * Pb + gi] * sb.scale[gi] * sb.scale[Pb + q] : -ne.g()[gi] * sb.scale[gi];
     A.F[e] = v;
+    if (A.pcr) const_cast<double*>(A.F0)[e] = v;
   }
   // corner (same format as lm_build_kernel's Mc)
   for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) {
@@ -505,10 +629,12 @@ static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
 // `dg` copy the limit is the kernels' own.
 // (the limit travels with the problem: SolveBuffers::bcr_max_border, option bcr_max_border; the workspace is sized for the kernels' own limit)
 bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
+constexpr int kPcrMaxBlocks = 256;   // parallel cyclic reduction while every block has its own CU (one round per level)
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
-  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64;
+  const int64_t pcr = n <= kPcrMaxBlocks ? 2 * n * 4096 + n * 64 * a1 + n * a1 * 64 + a1 * a1 + 8 : 0;   // second coupling buffer (two orientations, ping-pong), F0, X, Cacc, counter
+  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64 + pcr;
 }
 
 // build + factor + solve; the solution lands in sb.step_s.  Returns 0, or -1 if not applicable.
@@ -521,10 +647,21 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.D = w; w += (int64_t)n * 4096;
   A.F = w; w += (int64_t)n * 64 * a1;
   A.S = w; w += (int64_t)2 * n * 4096;
-  A.Lf = w;
+  // algorithm 0 / 2: cyclic reduction, 3: parallel cyclic reduction (measured on C2-C4: the same or more time -- every level costs more
+  // with all blocks as pivots and the final launch is a level of its own --, kept as an independent solver for the tests)
+  A.pcr = sb.algo == 3 && n <= kPcrMaxBlocks ? 1 : 0;
+  if (sb.algo == 3 && !A.pcr) return -1;
+  if (A.pcr) w += (int64_t)2 * n * 4096;     // second coupling buffer right behind the first (the levels ping-pong between them)
+  A.Lf = w; w += (int64_t)n * (192 + a1) * 64 + 64;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
   A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = sb.bcr_no_diag_copy; A.delay = sb.bcr_delay;
   A.rtf = (a1 + 15) / 16;
+  if (A.pcr) {
+    A.F0 = w; w += (int64_t)n * 64 * a1;
+    A.X = w; w += (int64_t)n * a1 * 64;
+    A.Cacc = w; w += (int64_t)a1 * a1;
+    A.counter = reinterpret_cast<unsigned int*>(w);
+  }
   const int Rp = 192 + 16 * A.rtf;
   A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;
   const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8 + 64) * sizeof(double);
@@ -536,17 +673,32 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
   }
   using KernelFn = void (*)(BcrArgs);
-  KernelFn k_level = nullptr, k_last = nullptr, k_prof = nullptr;
+  KernelFn k_level = nullptr, k_last = nullptr, k_prof = nullptr, k_final = nullptr;
   switch (A.LD) {
-    case 209: k_level = bcr_eliminate_kernel<209, false, false>; k_last = bcr_eliminate_kernel<209, true, false>; k_prof = bcr_eliminate_kernel<209, false, true>; break;
-    case 241: k_level = bcr_eliminate_kernel<241, false, false>; k_last = bcr_eliminate_kernel<241, true, false>; k_prof = k_level; break;
-    case 273: k_level = bcr_eliminate_kernel<273, false, false>; k_last = bcr_eliminate_kernel<273, true, false>; k_prof = k_level; break;
+    case 209: k_level = bcr_eliminate_kernel<209, 0, false>; k_last = bcr_eliminate_kernel<209, 1, false>; k_prof = bcr_eliminate_kernel<209, 0, true>; k_final = bcr_eliminate_kernel<209, 2, false>; break;
+    case 241: k_level = bcr_eliminate_kernel<241, 0, false>; k_last = bcr_eliminate_kernel<241, 1, false>; k_prof = k_level; k_final = bcr_eliminate_kernel<241, 2, false>; break;
+    case 273: k_level = bcr_eliminate_kernel<273, 0, false>; k_last = bcr_eliminate_kernel<273, 1, false>; k_prof = k_level; k_final = bcr_eliminate_kernel<273, 2, false>; break;
     default: return -1;
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_last), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int schur_groups = (36 + 8 * A.rtf + (A.rtf * (A.rtf + 1)) / 2 + 3) / 4;
+  if (A.pcr) {
+    // every level: all n blocks against their neighbours at distance s; the couplings ping-pong between the two buffers
+    // (offsets in 4096-double blocks from A.S)
+    int64_t in = 0, out = (int64_t)2 * n;
+    for (int s = 1; s < n; s *= 2) {
+      A.s = s; A.offS_in = in; A.offS_out = out;
+      hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(n), dim3(kBcrThreads), lds, st, A);
+      hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, n), dim3(256), 0, st, A);
+      std::swap(in, out);
+    }
+    A.s = 0;
+    hipLaunchKernelGGL(k_final, dim3(n), dim3(kBcrThreads), lds, st, A);
+    return 0;
+  }
   // forward: levels while more than one block is active
   int strides[40]; int npivs[40]; int nlev = 0;
   int64_t off = 0;

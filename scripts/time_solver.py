@@ -9,10 +9,10 @@ tr = cal.trajectory_
 F = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
 for algo in algos:
     tr.SetOption("solver_algorithm", algo)
-    for p in ([0] if algo == 2 else [1, 0]):
+    for p in ([1, 0] if algo == 1 else [0]):
         tr.SetOption("solver_partitions", p)
         try:
-            print(cfg, "algorithm", {1: "band sweep", 2: "block cyclic reduction"}[algo], "partitions", p if p else "auto",
+            print(cfg, "algorithm", {1: "band sweep", 2: "block cyclic reduction", 3: "parallel block cyclic reduction", 0: "automatic"}[algo], "partitions", p if p else "auto",
                   "solve ms", round(tr.TimeLinearSolve(F, 10), 4), flush=True)
         except Exception as e:
             print(algo, p, "failed", e)
