@@ -168,6 +168,15 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = n_blocks * args.steps / dt
 
+    # N > 1: the all-reduce of the packed system, timed by HIP events on the library's stream (a collective: every rank runs it)
+    allreduce_ms, allreduce_bytes = None, None
+    if use_dist:
+        try:
+            allreduce_ms, allreduce_bytes = tr.TimeAllReduce(flags, repeats=10)
+        except Exception as e:
+            sys.stderr.write("rank %d: all-reduce timing failed (%s)\n" % (rank, e))
+        barrier()
+
     out = None
     if rank == 0:
         # ---- per-kernel HIP-event timings (library stream) and roofline ----------
@@ -266,10 +275,10 @@ def main():
             "jacobian_pass_ms": pass_ms,
             "roofline": roofline,
         }
-        if world > 1:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
+        if use_dist:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
             out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
-                                   allreduce_and_rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms),
-                                   allreduce_bytes=int(8 * (Pb * (hb + 1) + a * Pb + a * a + P + 1)))
+                                   allreduce_ms=allreduce_ms, allreduce_bytes=allreduce_bytes, allreduce_timing="HIP events around 10 all-reduces of the packed normal equations on the library's stream (%s)" % reduce_path,
+                                   rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms - (allreduce_ms or 0.0)))
         if summ is not None:
             out["full_calibration"] = dict(full_ref, solver_options="reference: inner iterations + bounds line search + projected gradient norm (impl.h:255-276)",
                                            plain_lm=dict(full_plain, solver_options="plain Levenberg-Marquardt steps (no inner sweeps)"))

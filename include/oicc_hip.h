@@ -255,6 +255,10 @@ int oicc_rccl_init(oicc_problem* p, int32_t nranks, int32_t rank, const uint8_t 
  * path rank 0's swept candidate is broadcast afterwards so that all ranks continue from identical bits.  The Jacobian and
  * cost passes of p stay sharded.  NULL removes the source.  `whole` must outlive p's solves. */
 int oicc_set_inner_iteration_source(oicc_problem* p, oicc_problem* whole);
+/* Measurement: `repeats` reductions of the packed normal-equation buffer through the installed hook / the native RCCL path,
+ * timed with HIP events on the library's stream (every rank must call it with the same arguments: it is a collective).
+ * ms_per_call: average; bytes: size of the reduced buffer.  OICC_ERR_STATE without a reduction path. */
+int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes);
 /* Tell this rank about measurements held by OTHER ranks (timestamps only), so
  * that every rank derives the same tangent layout (which knots are in the
  * problem, bandwidth, which parameter blocks exist).

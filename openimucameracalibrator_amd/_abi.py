@@ -109,6 +109,7 @@ DEVICE_ONLY = {
     "rccl_get_unique_id": (C.c_int, [c_u8p]),
     "rccl_init": (C.c_int, [H, C.c_int32, C.c_int32, c_u8p]),
     "set_inner_iteration_source": (C.c_int, [H, H]),
+    "time_allreduce": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_i64p]),
     "sew_knot_spacing_and_variance": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, c_dp, c_dp, C.c_double, C.c_double, C.c_double,
                                                 c_dp, c_dp, c_i32p]),
 }

@@ -1650,6 +1650,23 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   return OICC_OK;
 }
 
+int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  if (!p->reduce) { p->err = "no reduction path installed (oicc_rccl_init / oicc_set_allreduce)"; return OICC_ERR_STATE; }
+  hipStream_t st = p->stream;
+  HIPCK(p, hipMemsetAsync(p->d_ne2.p, 0, p->ne.total * sizeof(double), st));   // (the second buffer: the current system stays intact)
+  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  if (p->reduce(p->reduce_user, p->d_ne2.p, p->ne.total, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }   // warm-up (connection set-up)
+  HIPCK(p, hipEventRecord(e0, st));
+  for (int i = 0; i < repeats; ++i) if (p->reduce(p->reduce_user, p->d_ne2.p, p->ne.total, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+  HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_call) *ms_per_call = double(ms) / std::max(repeats, 1);
+  if (bytes) *bytes = int64_t(p->ne.total) * int64_t(sizeof(double));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return OICC_OK;
+}
+
 // Test hook (host only, no device): next trial step size of the bounds line search from [x, value, slope] triples; prev may be NULL.
 double oicc_debug_ls_next_step_size(const double init[3], const double* prev, int32_t prev_has_slope, const double cur[3], int32_t cur_has_slope) {
   LsSample i, q, c;

@@ -97,6 +97,12 @@ class SplineTrajectoryEstimator:
         for name in ("inner_iterations", "bounds_line_search", "projected_gradient_norm"):
             self.SetOption(name, 1 if on else 0)
 
+    def TimeAllReduce(self, flags, repeats=10):
+        """(ms per all-reduce of the packed normal equations, bytes) through the installed reduction path; a collective: every rank calls it."""
+        ms = C.c_double(0.0); nb = C.c_int64(0)
+        self._ck(self._b.time_allreduce(self._h, int(flags), int(repeats), C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
     def SetInnerIterationSource(self, whole):
         """Time-sharded ranks: `whole` (a SplineTrajectoryEstimator on the same device holding every rank's measurements) supplies the
         residual blocks of the inner-iteration sweeps (oicc_set_inner_iteration_source); None removes it."""
