@@ -178,6 +178,7 @@ struct oicc_problem {
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 2: tiles in direct mode (fp64 atomics on the packed buffer: the independent accumulation path of the tests)
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
+    opt["view_unit_items"] = 0; opt["accel_unit_items"] = 0; opt["gyro_unit_items"] = 0;   // items per unit of the tile pass (0: as many as fit the wave's row buffer); smaller units = more waves per tile busy on one-round problems
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
     opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
@@ -565,7 +566,8 @@ int build_tiles(oicc_problem* p) {
   int rb = std::max(need(p->fv, max_nc), std::max(need(p->fa, 32), need(p->fg, 32)));
   rb = std::min(rb, 3456);   // 27 KB per wave: a 50-corner view in one piece
   rb = std::max(rb, 512);
-  row_fmt_capacity(p->fv, rb, 64); row_fmt_capacity(p->fa, rb, 64); row_fmt_capacity(p->fg, rb, 64);
+  auto unit_cap = [&](const char* name) { const int v = int(p->opt[name]); return v > 0 ? std::min(v, 64) : 64; };
+  row_fmt_capacity(p->fv, rb, unit_cap("view_unit_items")); row_fmt_capacity(p->fa, rb, unit_cap("accel_unit_items")); row_fmt_capacity(p->fg, rb, unit_cap("gyro_unit_items"));
   if (p->fv.cap < 1 || p->fa.cap < 1 || p->fg.cap < 1) { p->err = "row buffer too small for this parameter set"; return OICC_ERR_UNSUPPORTED; }
   tp.rb_doubles = rb; tp.wave_doubles = 96 + rb;
   const int64_t dt_fine = std::min(p->dt_so3, p->dt_r3);

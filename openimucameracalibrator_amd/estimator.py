@@ -304,9 +304,10 @@ class SplineTrajectoryEstimator:
         self._ck(self._b.evaluate_blocks(self._h, int(flags), int(kind), _dp(r), _dp(J) if want_jac else None))
         return r, J
 
-    def TimeJacobianPass(self, flags, repeats=10):
+    def TimeJacobianPass(self, flags, repeats=10, families=True):
+        """(ms per full pass, ms of the passes restricted to views / accelerometer / gyroscope); families=False: full passes only"""
         ms = C.c_double(0); k = np.zeros(3)
-        self._ck(self._b.time_jacobian_pass(self._h, int(flags), int(repeats), C.byref(ms), _dp(k)))
+        self._ck(self._b.time_jacobian_pass(self._h, int(flags), int(repeats), C.byref(ms), _dp(k) if families else None))
         return ms.value, k
 
     def RunLmIterations(self, flags, steps):
