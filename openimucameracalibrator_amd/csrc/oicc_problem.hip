@@ -732,107 +732,125 @@ int build_inner_plan(oicc_problem* p, int flags) {
   oicc_problem::InnerPlan& ip = p->inner;
   const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
   if (ip.flags == flags && ip.layout_gen == p->layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return OICC_OK;
+  const double t_plan0 = now_s(); double t_plan1 = 0, t_plan2 = 0, t_plan3 = 0;
   const HostLayout& L = p->L; const ParamLayout& pl = p->pl;
-  struct HB { InnerBlock b; int order; std::vector<int32_t> views, accs, gyrs; };
+  // Parameter blocks in the order the reference's AddResidualBlock calls create them (views in time order, then accelerometer /
+  // gyroscope samples in turn, imu_camera_calibrator.cc:90-120), each with the RUNS of consecutive items that depend on it and the
+  // knot ranges those items read.  Consecutive samples of a sensor share their knot windows: a group of them is handled at once.
+  struct HB { InnerBlock b; int order; std::vector<InnerRun> runs; int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1; };
   std::vector<HB> B;
   std::vector<int> id_so3(pl.n_so3, -1), id_r3(pl.n_r3, -1), id_ab(pl.n_ab, -1), id_gb(pl.n_gb, -1); int id_o[5] = {-1, -1, -1, -1, -1};
   auto get = [&](int kind, int idx, int dim, int amb, int off, int64_t xoff, int* slot) -> int {
     if (off < 0) return -1;
     if (*slot < 0) { HB h; h.b = InnerBlock{}; h.b.kind = kind; h.b.idx = idx; h.b.dim = dim; h.b.ambient = amb; h.b.xoff = xoff; h.b.ctl = -1; h.order = int(B.size()); *slot = int(B.size()); B.push_back(h); }
     return *slot; };
-  // Hessian graph: an edge between two blocks that share a residual block.  Consecutive samples of one sensor (and views of one
-  // window) depend on the same blocks: the clique of an id list is only added when it differs from the previous list of its family.
+  // Hessian graph: an edge between two blocks that share a residual block (one clique per group of items)
   std::vector<std::vector<int>> adj;
-  auto clique = [&](const std::vector<int>& ids, std::vector<int>* last) {
-    if (ids == *last) return;
-    *last = ids;
+  struct Group { std::vector<int> ids; int32_t first = 0, count = 0, ss = 0, sr = -1, sb = -1; bool open = false; };
+  auto flush = [&](int kind, Group& gq) {
+    if (!gq.open) return;
+    gq.open = false;
     if (adj.size() < B.size()) adj.resize(B.size());
-    for (int x : ids) if (x >= 0) for (int y : ids) if (y >= 0 && x != y) adj[x].push_back(y); };
-  std::vector<int> last_v, last_a, last_g, ids;
+    for (int x : gq.ids) {
+      if (x < 0) continue;
+      HB& h = B[x];
+      if (gq.count > 0) {
+        if (!h.runs.empty() && h.runs.back().kind == kind && h.runs.back().first + h.runs.back().count == gq.first) h.runs.back().count += gq.count;
+        else h.runs.push_back(InnerRun{kind, gq.first, gq.count, 0});
+      }
+      h.s0 = std::min(h.s0, int(gq.ss)); h.s1 = std::max(h.s1, int(gq.ss) + kN);
+      if (gq.sr >= 0) { h.r0 = std::min(h.r0, int(gq.sr)); h.r1 = std::max(h.r1, int(gq.sr) + kN); }
+      if (kind == 1) { h.a0 = std::min(h.a0, int(gq.sb)); h.a1 = std::max(h.a1, int(gq.sb) + kNb); }
+      if (kind == 2) { h.g0 = std::min(h.g0, int(gq.sb)); h.g1 = std::max(h.g1, int(gq.sb) + kNb); }
+      for (int y : gq.ids) if (y >= 0 && x != y) adj[x].push_back(y);
+    }
+  };
   const size_t nv = p->view_rs.size();
-  for (size_t v = 0; v < nv; ++v) {
-    if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
-    ids.clear();
-    const int ss = p->view_s_so3[v], sr = p->view_s_r3[v];
-    for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
-    for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
-    ids.push_back(get(IK_TIC, 0, 6, 7, L.other[0], pl.tic, &id_o[0]));
-    if (p->view_rs[v]) ids.push_back(get(IK_LD, 0, 1, 1, L.other[2], pl.ld, &id_o[2]));
-    for (int id : ids) if (id >= 0) B[id].views.push_back(int32_t(v));
-    clique(ids, &last_v);
+  {
+    Group gq;
+    for (size_t v = 0; v < nv; ++v) {
+      if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
+      gq.ids.clear();
+      const int ss = p->view_s_so3[v], sr = p->view_s_r3[v];
+      for (int k = 0; k < kN; ++k) gq.ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+      for (int k = 0; k < kN; ++k) gq.ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
+      gq.ids.push_back(get(IK_TIC, 0, 6, 7, L.other[0], pl.tic, &id_o[0]));
+      if (p->view_rs[v]) gq.ids.push_back(get(IK_LD, 0, 1, 1, L.other[2], pl.ld, &id_o[2]));
+      gq.first = int32_t(p->view_c0[v]); gq.count = int32_t(p->view_c0[v + 1] - p->view_c0[v]); gq.ss = ss; gq.sr = sr; gq.sb = -1; gq.open = true;
+      flush(0, gq);
+    }
   }
   const size_t na = p->acc.size(), ng = p->gyr.size();
-  for (size_t i = 0; i < std::max(na, ng); ++i) {
-    if (i < na) {
-      ids.clear(); const int ss = p->acc.s_so3[i], sr = p->acc.s_r3[i], sb = p->acc.s_b[i];
-      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
-      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
-      for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_AB, sb + k, 3, 3, L.ab[sb + k], pl.ab + 3 * int64_t(sb + k), &id_ab[sb + k]));
-      ids.push_back(get(IK_G, 0, 3, 3, L.other[1], pl.g, &id_o[1]));
-      ids.push_back(get(IK_AI, 0, 6, 6, L.other[3], pl.ai, &id_o[3]));
-      for (int id : ids) if (id >= 0) B[id].accs.push_back(int32_t(i));
-      clique(ids, &last_a);
+  {
+    Group ga, gg;
+    for (size_t i = 0; i < std::max(na, ng); ++i) {
+      if (i < na) {
+        const int ss = p->acc.s_so3[i], sr = p->acc.s_r3[i], sb = p->acc.s_b[i];
+        if (ga.open && ga.ss == ss && ga.sr == sr && ga.sb == sb && ga.first + ga.count == int32_t(i)) ++ga.count;
+        else {
+          flush(1, ga);
+          ga.ids.clear();
+          for (int k = 0; k < kN; ++k) ga.ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+          for (int k = 0; k < kN; ++k) ga.ids.push_back(get(IK_R3, sr + k, 3, 3, L.r3[sr + k], pl.r3 + 3 * int64_t(sr + k), &id_r3[sr + k]));
+          for (int k = 0; k < kNb; ++k) ga.ids.push_back(get(IK_AB, sb + k, 3, 3, L.ab[sb + k], pl.ab + 3 * int64_t(sb + k), &id_ab[sb + k]));
+          ga.ids.push_back(get(IK_G, 0, 3, 3, L.other[1], pl.g, &id_o[1]));
+          ga.ids.push_back(get(IK_AI, 0, 6, 6, L.other[3], pl.ai, &id_o[3]));
+          ga.first = int32_t(i); ga.count = 1; ga.ss = ss; ga.sr = sr; ga.sb = sb; ga.open = true;
+        }
+      }
+      if (i < ng) {
+        const int ss = p->gyr.s_so3[i], sb = p->gyr.s_b[i];
+        if (gg.open && gg.ss == ss && gg.sb == sb && gg.first + gg.count == int32_t(i)) ++gg.count;
+        else {
+          flush(2, gg);
+          gg.ids.clear();
+          for (int k = 0; k < kN; ++k) gg.ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
+          for (int k = 0; k < kNb; ++k) gg.ids.push_back(get(IK_GB, sb + k, 3, 3, L.gb[sb + k], pl.gb + 3 * int64_t(sb + k), &id_gb[sb + k]));
+          gg.ids.push_back(get(IK_GI, 0, 9, 9, L.other[4], pl.gi, &id_o[4]));
+          gg.first = int32_t(i); gg.count = 1; gg.ss = ss; gg.sr = -1; gg.sb = sb; gg.open = true;
+        }
+      }
     }
-    if (i < ng) {
-      ids.clear(); const int ss = p->gyr.s_so3[i], sb = p->gyr.s_b[i];
-      for (int k = 0; k < kN; ++k) ids.push_back(get(IK_SO3, ss + k, 3, 4, L.so3[ss + k], pl.so3 + 4 * int64_t(ss + k), &id_so3[ss + k]));
-      for (int k = 0; k < kNb; ++k) ids.push_back(get(IK_GB, sb + k, 3, 3, L.gb[sb + k], pl.gb + 3 * int64_t(sb + k), &id_gb[sb + k]));
-      ids.push_back(get(IK_GI, 0, 9, 9, L.other[4], pl.gi, &id_o[4]));
-      for (int id : ids) if (id >= 0) B[id].gyrs.push_back(int32_t(i));
-      clique(ids, &last_g);
-    }
+    flush(1, ga); flush(2, gg);
   }
   const int n = int(B.size());
   adj.resize(n);
+  t_plan1 = now_s();
   for (auto& v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // Ceres' recursive independent-set ordering: round after round the greedy maximal independent set of what is left, vertices in
+  // order of increasing degree (ties: creation order); degrees are kept up to date as vertices leave
   std::vector<char> removed(n, 0);
+  std::vector<int> deg(n, 0);
+  for (int v = 0; v < n; ++v) deg[v] = int(adj[v].size());
   std::vector<std::vector<int>> rounds;
+  std::vector<int> queue; queue.reserve(n);
+  std::vector<char> color(n, 0);
   for (int covered = 0; covered < n;) {
-    std::vector<int> deg(n, 0), queue;
-    for (int v = 0; v < n; ++v) if (!removed[v]) { queue.push_back(v); for (int w : adj[v]) if (!removed[w]) ++deg[v]; }
+    queue.clear();
+    for (int v = 0; v < n; ++v) if (!removed[v]) { queue.push_back(v); color[v] = 0; }
     std::sort(queue.begin(), queue.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : B[x].order < B[y].order; });
-    std::vector<char> color(n, 0);
     std::vector<int> set;
     for (int v : queue) { if (color[v]) continue; set.push_back(v); color[v] = 2; for (int w : adj[v]) if (!removed[w]) color[w] = 1; }
-    for (int v : set) removed[v] = 1;
+    for (int v : set) { removed[v] = 1; for (int w : adj[v]) if (!removed[w]) --deg[w]; }
     covered += int(set.size());
     rounds.push_back(set);
   }
-  // processing order: last set first; blocks of a set contiguous.  Per block: the runs of consecutive items that depend on it
-  // (time-sorted measurements: one run of corners, one of accelerometer and one of gyroscope samples) and its workgroups --
-  // one for a knot block; the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on
-  // each other: all of them must be resident, so a set's shared blocks split the CUs and come first in the launch).
+  t_plan2 = now_s();
+  // processing order: last set first; blocks of a set contiguous.  Per block its runs and its workgroups -- one for a knot block;
+  // the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on each other: all of them
+  // must be resident, so a set's shared blocks split the CUs and come first in the launch).
   ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.n_ctls = 0;
   constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
-  auto add_runs = [&](int kind, const std::vector<int32_t>& idx, InnerBlock* b) {
-    for (int32_t x : idx) {
-      const int32_t first = kind == 0 ? int32_t(p->view_c0[x]) : x, count = kind == 0 ? int32_t(p->view_c0[x + 1] - p->view_c0[x]) : 1;
-      if (count == 0) continue;
-      if (b->nruns > 0 && ip.runs.back().kind == kind && ip.runs.back().first + ip.runs.back().count == first) ip.runs.back().count += count;
-      else { ip.runs.push_back(InnerRun{kind, first, count, 0}); ++b->nruns; }
-      b->n_items += count;
-    }
-    b->n_slots = 0;
-    for (int r = 0; r < b->nruns; ++r) b->n_slots += (ip.runs[size_t(b->run0) + r].count + 63) & ~63;
-  };
-  // knots the items of a block read
-  auto knot_ranges = [&](const HB& h, InnerBlock* b) {
-    int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1;
-    for (int32_t v : h.views) { s0 = std::min(s0, p->view_s_so3[v]); s1 = std::max(s1, p->view_s_so3[v] + kN); r0 = std::min(r0, p->view_s_r3[v]); r1 = std::max(r1, p->view_s_r3[v] + kN); }
-    for (int32_t i : h.accs) { s0 = std::min(s0, p->acc.s_so3[i]); s1 = std::max(s1, p->acc.s_so3[i] + kN); r0 = std::min(r0, p->acc.s_r3[i]); r1 = std::max(r1, p->acc.s_r3[i] + kN);
-                               a0 = std::min(a0, p->acc.s_b[i]); a1 = std::max(a1, p->acc.s_b[i] + kNb); }
-    for (int32_t i : h.gyrs) { s0 = std::min(s0, p->gyr.s_so3[i]); s1 = std::max(s1, p->gyr.s_so3[i] + kN); g0 = std::min(g0, p->gyr.s_b[i]); g1 = std::max(g1, p->gyr.s_b[i] + kNb); }
-    b->ks0 = s1 >= 0 ? s0 : 0; b->nks = s1 >= 0 ? s1 - s0 : 0; b->kr0 = r1 >= 0 ? r0 : 0; b->nkr = r1 >= 0 ? r1 - r0 : 0;
-    b->kab0 = a1 >= 0 ? a0 : 0; b->nkab = a1 >= 0 ? a1 - a0 : 0; b->kgb0 = g1 >= 0 ? g0 : 0; b->nkgb = g1 >= 0 ? g1 - g0 : 0;
-  };
   for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
     const int b0 = int(ip.blocks.size());
     int n_shared = 0;
     for (int v : *it) {
-      InnerBlock b = B[v].b;
-      b.run0 = int32_t(ip.runs.size()); b.nruns = 0; b.n_items = 0; b.ctl = -1;
-      add_runs(0, B[v].views, &b); add_runs(1, B[v].accs, &b); add_runs(2, B[v].gyrs, &b);
-      knot_ranges(B[v], &b);
+      const HB& h = B[v];
+      InnerBlock b = h.b;
+      b.run0 = int32_t(ip.runs.size()); b.nruns = int32_t(h.runs.size()); b.n_items = 0; b.n_slots = 0; b.ctl = -1;
+      for (const InnerRun& r : h.runs) { ip.runs.push_back(r); b.n_items += r.count; b.n_slots += (r.count + 63) & ~63; }
+      b.ks0 = h.s1 >= 0 ? h.s0 : 0; b.nks = h.s1 >= 0 ? h.s1 - h.s0 : 0; b.kr0 = h.r1 >= 0 ? h.r0 : 0; b.nkr = h.r1 >= 0 ? h.r1 - h.r0 : 0;
+      b.kab0 = h.a1 >= 0 ? h.a0 : 0; b.nkab = h.a1 >= 0 ? h.a1 - h.a0 : 0; b.kgb0 = h.g1 >= 0 ? h.g0 : 0; b.nkgb = h.g1 >= 0 ? h.g1 - h.g0 : 0;
       if (b.n_slots > kSharedAbove) ++n_shared;
       ip.blocks.push_back(b);
     }
@@ -849,11 +867,14 @@ int build_inner_plan(oicc_problem* p, int flags) {
       }
     ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size()));
   }
+  t_plan3 = now_s();
   hipStream_t st = p->stream;
   if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_runs.upload(ip.runs, st) || !ip.d_wgs.upload(ip.wgs, st) || !ip.d_ctls.resize(std::max(ip.n_ctls, 1)) || !ip.d_lm_iterations.resize(1) ||
       !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
   HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
   HIPCK(p, hipStreamSynchronize(st));   // (the host vectors may be rebuilt right away)
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + cliques %.3f, adjacency + independent sets %.3f, runs + workgroups %.3f, device buffers %.3f\n",
+                                           ip.blocks.size(), ip.group_first.size() - 1, ip.wgs.size(), 1e3 * (t_plan1 - t_plan0), 1e3 * (t_plan2 - t_plan1), 1e3 * (t_plan3 - t_plan2), 1e3 * (now_s() - t_plan3));
   ip.flags = flags; ip.layout_gen = p->layout_gen; ip.gs_unit = gs_unit;
   return OICC_OK;
 }
