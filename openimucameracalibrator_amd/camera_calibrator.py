@@ -275,9 +275,9 @@ class CameraCalibrator:
         views = []
         for key in sorted(scene_json["views"]):                            # nlohmann::json (std::map) iterates the keys in string order
             ip = scene_json["views"][key]["image_points"]
-            if len(ip) < 4:
+            ip = {k: v for k, v in ip.items() if int(k) in index}              # ids without a board point are skipped while loading, as in the C++ loader ...
+            if len(ip) < 4:                                                     # ... so the minimum count applies to the usable correspondences
                 continue
-            ip = {k: v for k, v in ip.items() if int(k) in index}              # ids without a board point are skipped, as in the C++ loader
             pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
             uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
             ok, R, C, f = planar_init.initialize_view(points, pid, uv - [px, py])
@@ -492,9 +492,9 @@ class PoseEstimator:
         self.px_obs_ = []
         for key in sorted(scene_json["views"]):                              # nlohmann::json (std::map) key order
             ip = scene_json["views"][key]["image_points"]
-            if len(ip) < min_num_points:                                     # pose_estimator.cc:131-135
+            ip = {k: v for k, v in ip.items() if int(k) in index}            # (an id without a board point would dereference a null track in the reference, :129)
+            if len(ip) < min_num_points:                                     # pose_estimator.cc:131-135, on the usable correspondences
                 continue
-            ip = {k: v for k, v in ip.items() if int(k) in index}
             pid = np.array([index[int(k)] for k in ip], dtype=np.int32)
             uv = np.array([ip[k][:2] for k in ip], dtype=np.float64)
             xy = planar_init.pixel_to_normalized(model, intrinsics, uv)      # camera.PixelToNormalizedCoordinates, :119-121
