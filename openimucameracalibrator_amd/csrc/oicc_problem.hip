@@ -737,7 +737,8 @@ int build_inner_plan(oicc_problem* p, int flags) {
   // Parameter blocks in the order the reference's AddResidualBlock calls create them (views in time order, then accelerometer /
   // gyroscope samples in turn, imu_camera_calibrator.cc:90-120), each with the RUNS of consecutive items that depend on it and the
   // knot ranges those items read.  Consecutive samples of a sensor share their knot windows: a group of them is handled at once.
-  struct HB { InnerBlock b; int order; std::vector<InnerRun> runs; int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1; };
+  struct HB { InnerBlock b; int order; std::vector<InnerRun> runs; int last_run[3] = {-1, -1, -1};   // last_run: the block's latest run of each residual family (the families' groups arrive interleaved)
+              int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1; };
   std::vector<HB> B;
   std::vector<int> id_so3(pl.n_so3, -1), id_r3(pl.n_r3, -1), id_ab(pl.n_ab, -1), id_gb(pl.n_gb, -1); int id_o[5] = {-1, -1, -1, -1, -1};
   auto get = [&](int kind, int idx, int dim, int amb, int off, int64_t xoff, int* slot) -> int {
@@ -755,8 +756,9 @@ int build_inner_plan(oicc_problem* p, int flags) {
       if (x < 0) continue;
       HB& h = B[x];
       if (gq.count > 0) {
-        if (!h.runs.empty() && h.runs.back().kind == kind && h.runs.back().first + h.runs.back().count == gq.first) h.runs.back().count += gq.count;
-        else h.runs.push_back(InnerRun{kind, gq.first, gq.count, 0});
+        const int lr = h.last_run[kind];
+        if (lr >= 0 && h.runs[lr].first + h.runs[lr].count == gq.first) h.runs[lr].count += gq.count;
+        else { h.last_run[kind] = int(h.runs.size()); h.runs.push_back(InnerRun{kind, gq.first, gq.count, 0}); }
       }
       h.s0 = std::min(h.s0, int(gq.ss)); h.s1 = std::max(h.s1, int(gq.ss) + kN);
       if (gq.sr >= 0) { h.r0 = std::min(h.r0, int(gq.sr)); h.r1 = std::max(h.r1, int(gq.sr) + kN); }
