@@ -27,8 +27,19 @@
 
 namespace oicc {
 
-constexpr int kInnerThreads = 256;               // one workgroup = 4 waves, one per SIMD (the item functions need > 256 VGPRs)
-constexpr int kInnerSlots = 2 * kInnerThreads;   // item slots of a block staged in LDS (two per lane); larger blocks re-read their items
+// Two builds of the kernel.  General: 256 threads = 4 waves, one per SIMD (the item functions with the SO(3) backward pass need
+// > 256 VGPRs), two item slots per lane staged in LDS.  R3ONLY, for sets that hold nothing but R^3 knots (six of the 19 sets of C2,
+// 45 % of a sweep when they ran on the general build: a knot's ~360 items are six waves = two rounds there): the blocks' Jacobian
+// columns are coefficient x 3-vector of the FORWARD pass, so the backward pass and every other parameter group compile away, the
+// kernel fits 256 VGPRs and runs 512 threads = 8 waves -- all items of a knot in one round.
+template <bool R3ONLY>
+struct InnerCfg {
+  static constexpr int T = R3ONLY ? 512 : 256;      // threads of a workgroup
+  static constexpr int SLOTS = 512;                  // item slots of a block staged in LDS; larger blocks re-read their items
+  static constexpr int JS = R3ONLY ? 3 : 9;          // columns kept per Jacobian row of the block
+  static constexpr int NJ = 3 * JS + 3;              // per lane: 3 rows x JS columns, then the residuals
+};
+constexpr int kInnerThreads = InnerCfg<false>::T;
 constexpr int kCapS = 24, kCapR = 16, kCapB = 8; // knots of the block's neighbourhood staged in LDS (SO(3), R^3, each bias spline)
 enum { INNER_CMD_JAC = 0, INNER_CMD_COST = 1, INNER_CMD_DONE = 2 };
 
@@ -46,25 +57,28 @@ struct PR3 { const double* base; __device__ __forceinline__ const double* operat
 // Sink of block_items.cuh that keeps the columns of ONE parameter block: J[r][c], r < ROWS, c < dim <= 9, in the lane's
 // column of an LDS array (element e of the lane at J[e * kInnerThreads]: conflict free, and the sums over (x, y) below are
 // plain run-time loops instead of 54 unrolled register reductions).
-struct LaneCol { double* p; __device__ __forceinline__ double& operator[](int e) const { return p[e * kInnerThreads]; } };
-template <int ROWS>
+template <int T>
+struct LaneColT { double* p; __device__ __forceinline__ double& operator[](int e) const { return p[e * T]; } };
+template <int ROWS, class CFG>
 struct OneBlockSink {
+  using LaneCol = LaneColT<CFG::T>;
+  static constexpr int JS = CFG::JS;
   int kind, jj;          // block kind (InnerKind) and, for knots, the knot's index inside the item's window
   LaneCol J;             // ROWS x 9
   LaneCol r_out;         // ROWS
   __device__ __forceinline__ void res(const double* r) const { for (int i = 0; i < ROWS; ++i) r_out[i] = r[i]; }
-  __device__ __forceinline__ void zero() const { for (int i = 0; i < ROWS * 9; ++i) J[i] = 0.0; }
+  __device__ __forceinline__ void zero() const { for (int i = 0; i < ROWS * JS; ++i) J[i] = 0.0; }
   __device__ __forceinline__ void so3(int j, const double* a) const {
-    if (kind == IK_SO3 && j == jj) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * 9 + c] = a[r * 3 + c]; }
+    if (kind == IK_SO3 && j == jj) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * JS + c] = a[r * 3 + c]; }
   __device__ __forceinline__ void r3(const double* cf, const double* b) const {
-    if (kind == IK_R3) { double c_ = 0.0; for (int j = 0; j < 6; ++j) c_ = j == jj ? cf[j] : c_; for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * 9 + c] = c_ * b[r * 3 + c]; } }
-  __device__ __forceinline__ void tic(const double* t) const { if (kind == IK_TIC) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 6; ++c) J[r * 9 + c] = t[r * 6 + c]; }
-  __device__ __forceinline__ void ld(const double* l) const { if (kind == IK_LD) for (int r = 0; r < ROWS; ++r) J[r * 9] = l[r]; }
-  __device__ __forceinline__ void grav(const double* b) const { if (kind == IK_G) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * 9 + c] = b[r * 3 + c]; }
+    if (kind == IK_R3) { double c_ = 0.0; for (int j = 0; j < 6; ++j) c_ = j == jj ? cf[j] : c_; for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * JS + c] = c_ * b[r * 3 + c]; } }
+  __device__ __forceinline__ void tic(const double* t) const { if (JS >= 6 && kind == IK_TIC) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 6; ++c) J[r * JS + c] = t[r * 6 + c]; }
+  __device__ __forceinline__ void ld(const double* l) const { if (kind == IK_LD) for (int r = 0; r < ROWS; ++r) J[r * JS] = l[r]; }
+  __device__ __forceinline__ void grav(const double* b) const { if (kind == IK_G) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * JS + c] = b[r * 3 + c]; }
   __device__ __forceinline__ void bias(const double* cb, const double* m) const {
-    if (kind == IK_AB || kind == IK_GB) { double c_ = 0.0; for (int j = 0; j < 3; ++j) c_ = j == jj ? cb[j] : c_; for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * 9 + c] = c_ * m[r * 3 + c]; } }
+    if (kind == IK_AB || kind == IK_GB) { double c_ = 0.0; for (int j = 0; j < 3; ++j) c_ = j == jj ? cb[j] : c_; for (int r = 0; r < ROWS; ++r) for (int c = 0; c < 3; ++c) J[r * JS + c] = c_ * m[r * 3 + c]; } }
   __device__ __forceinline__ void intr(int n, const double* d) const {
-    if (kind == IK_AI || kind == IK_GI) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < n; ++c) J[r * 9 + c] = d[r * n + c]; }
+    if (JS >= 9 && (kind == IK_AI || kind == IK_GI)) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < n; ++c) J[r * JS + c] = d[r * n + c]; }
 };
 
 // Sum over the 64 lanes (all active), wave uniform: four DPP row shifts (no LDS traffic) leave the sums of the 16-lane rows in
@@ -329,8 +343,9 @@ __device__ __forceinline__ void inner_load_item(const InnerArgs& A, const InnerB
 }
 
 // residual (+ the Jacobian columns of block `blk`) of one item
-template <bool JAC>
-__device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneCol& J, const LaneCol& r) {
+template <bool JAC, class CFG>
+__device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneColT<CFG::T>& J, const LaneColT<CFG::T>& r) {
+  constexpr bool R3ONLY = CFG::JS == 3;   // every block of the set is an R^3 knot: the activity flags below are compile-time constants
   const EvalCtx& ctx = A.ctx;
   const int s_so3 = R.s_so3, s_r3 = R.s_r3;
   const double* q0 = P.so3 + 4 * (s_so3 - P.ks0);
@@ -341,8 +356,10 @@ __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerB
     vc.ld = P.scal[10];
     vc.sh_s = ctx.rs_time_in_seconds ? ctx.inv_so3_dt : 1.0; vc.sh_r = ctx.rs_time_in_seconds ? ctx.inv_r3_dt : 1.0;
     vc.inv_so3_dt = ctx.inv_so3_dt; vc.inv_r3_dt = ctx.inv_r3_dt; vc.cam_model = ctx.cam_model; vc.intr = ctx.intr; vc.gs_unit_loss = ctx.gs_unit_loss != 0;
-    vc.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; vc.no_so3_rows = blk.kind == IK_R3; vc.tic_active = blk.kind == IK_TIC; vc.ld_active = blk.kind == IK_LD;
-    const OneBlockSink<2> sink{blk.kind, blk.kind == IK_SO3 ? blk.idx - s_so3 : (blk.kind == IK_R3 ? blk.idx - s_r3 : 0), J, r};
+    vc.spline_active = R3ONLY || blk.kind == IK_SO3 || blk.kind == IK_R3; vc.no_so3_rows = R3ONLY || blk.kind == IK_R3;
+    vc.tic_active = !R3ONLY && blk.kind == IK_TIC; vc.ld_active = !R3ONLY && blk.kind == IK_LD;
+    const int bkind = R3ONLY ? int(IK_R3) : blk.kind;
+    const OneBlockSink<2, CFG> sink{bkind, bkind == IK_SO3 ? blk.idx - s_so3 : (bkind == IK_R3 ? blk.idx - s_r3 : 0), J, r};
     const double X[4] = {R.d[6], R.d[7], R.d[8], R.d[9]};
     view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], R.sx != 0, R.d[2], R.d[3], R.d[4], R.d[5], X, sink);
     return;
@@ -351,43 +368,47 @@ __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerB
   const int s_b = R.sx;
   ImuConst ic;
   ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
-  ic.spline_active = blk.kind == IK_SO3 || blk.kind == IK_R3; ic.no_so3_rows = blk.kind == IK_R3; ic.g_active = blk.kind == IK_G;
-  ic.bias_active = blk.kind == IK_AB || blk.kind == IK_GB; ic.intr_active = blk.kind == IK_AI || blk.kind == IK_GI;
-  const int jj = blk.kind == IK_SO3 ? blk.idx - s_so3 : (blk.kind == IK_R3 ? blk.idx - s_r3 : ((blk.kind == IK_AB || blk.kind == IK_GB) ? blk.idx - s_b : 0));
-  const OneBlockSink<3> sink{blk.kind, jj, J, r};
+  const int bkind = R3ONLY ? int(IK_R3) : blk.kind;
+  ic.spline_active = R3ONLY || bkind == IK_SO3 || bkind == IK_R3; ic.no_so3_rows = R3ONLY || bkind == IK_R3; ic.g_active = !R3ONLY && bkind == IK_G;
+  ic.bias_active = !R3ONLY && (bkind == IK_AB || bkind == IK_GB); ic.intr_active = !R3ONLY && (bkind == IK_AI || bkind == IK_GI);
+  const int jj = bkind == IK_SO3 ? blk.idx - s_so3 : (bkind == IK_R3 ? blk.idx - s_r3 : ((bkind == IK_AB || bkind == IK_GB) ? blk.idx - s_b : 0));
+  const OneBlockSink<3, CFG> sink{bkind, jj, J, r};
   const double m[3] = {R.d[3], R.d[4], R.d[5]};
   const double* bk = accel ? P.ab + 3 * (s_b - P.kab0) : P.gb + 3 * (s_b - P.kgb0);
   if (accel) { imu_const_init<0>(ic, P.scal + 11, P.scal + 7); imu_item<0, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], R.d[2], bk, m, R.d[6], sink); }
   else { imu_const_init<1>(ic, P.scal + 17, P.scal + 7); imu_item<1, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], 0.0, R.d[2], bk, m, R.d[6], sink); }
 }
 
-// lane's item record <-> its column of the LDS staging arrays (slot = round * kInnerThreads + tid)
+// lane's item record <-> its column of the LDS staging arrays (slot = round * threads + tid)
+template <int SLOTS>
 __device__ __forceinline__ void item_store(const ItemRec& R, int* si, double* sd, int slot) {
-  si[slot] = R.kind; si[kInnerSlots + slot] = R.s_so3; si[2 * kInnerSlots + slot] = R.s_r3; si[3 * kInnerSlots + slot] = R.sx;
+  si[slot] = R.kind; si[SLOTS + slot] = R.s_so3; si[2 * SLOTS + slot] = R.s_r3; si[3 * SLOTS + slot] = R.sx;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) sd[k * kInnerSlots + slot] = R.d[k];
+  for (int k = 0; k < 10; ++k) sd[k * SLOTS + slot] = R.d[k];
 }
+template <int SLOTS>
 __device__ __forceinline__ void item_fetch(ItemRec& R, const int* si, const double* sd, int slot) {
-  R.kind = si[slot]; R.s_so3 = si[kInnerSlots + slot]; R.s_r3 = si[2 * kInnerSlots + slot]; R.sx = si[3 * kInnerSlots + slot];
+  R.kind = si[slot]; R.s_so3 = si[SLOTS + slot]; R.s_r3 = si[2 * SLOTS + slot]; R.sx = si[3 * SLOTS + slot];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) R.d[k] = sd[k * kInnerSlots + slot];
+  for (int k = 0; k < 10; ++k) R.d[k] = sd[k * SLOTS + slot];
 }
 
 // all items of the block that fall to this workgroup: sums into the wave's LDS row [H upper | g | cost]
-template <bool JAC>
+template <bool JAC, class CFG>
 __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, int part, int nparts, bool staged, const int* si, const double* sd,
-                                                 double* row /* this wave's [56] */, double* s_J /* [30][kInnerThreads] */) {
+                                                 double* row /* this wave's [56] */, double* s_J /* [CFG::NJ][CFG::T] */) {
+  constexpr int T = CFG::T, JS = CFG::JS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int d = blk.dim, nv = d * (d + 1) / 2 + d + 1;
-  const LaneCol J{s_J + tid}, res{s_J + 27 * kInnerThreads + tid};
+  const LaneColT<T> J{s_J + tid}, res{s_J + 3 * JS * T + tid};
   int slot = tid;
-  for (int base = part * kInnerThreads; base < blk.n_slots; base += nparts * kInnerThreads, slot += kInnerThreads) {
+  for (int base = part * T; base < blk.n_slots; base += nparts * T, slot += T) {
     ItemRec R;
-    if (staged) item_fetch(R, si, sd, slot); else inner_load_item(A, blk, base + tid, R);
+    if (staged) item_fetch<CFG::SLOTS>(R, si, sd, slot); else inner_load_item(A, blk, base + tid, R);
     if (__ballot(R.kind >= 0) == 0ull) continue;   // (padding slots of the last wave of a run)
-    if (JAC) for (int k = 0; k < 27; ++k) J[k] = 0.0;
+    if (JAC) for (int k = 0; k < 3 * JS; ++k) J[k] = 0.0;
     res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
-    if (R.kind >= 0) inner_eval_item<JAC>(A, blk, P, R, J, res);
+    if (R.kind >= 0) inner_eval_item<JAC, CFG>(A, blk, P, R, J, res);
     const double r0 = res[0], r1 = res[1], r2 = res[2];
     const double c = wave_sum(0.5 * (r0 * r0 + r1 * r1 + r2 * r2));
     if (lane == 0) row[nv - 1] += c;
@@ -395,11 +416,11 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const Inner
       int k = 0;
       for (int x = 0; x < d; ++x)
         for (int y = x; y < d; ++y, ++k) {
-          const double h = wave_sum(J[x] * J[y] + J[9 + x] * J[9 + y] + J[18 + x] * J[18 + y]);
+          const double h = wave_sum(J[x] * J[y] + J[JS + x] * J[JS + y] + J[2 * JS + x] * J[2 * JS + y]);
           if (lane == 0) row[k] += h;
         }
       for (int x = 0; x < d; ++x, ++k) {
-        const double g = wave_sum(J[x] * r0 + J[9 + x] * r1 + J[18 + x] * r2);
+        const double g = wave_sum(J[x] * r0 + J[JS + x] * r1 + J[2 * JS + x] * r2);
         if (lane == 0) row[k] += g;
       }
     }
@@ -416,8 +437,11 @@ __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
 }
 
 // workgroup = (block of the set, part): the block's whole Levenberg-Marquardt loop
-__global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
-  __shared__ double s_J[30 * kInnerThreads];       // per lane: Jacobian columns of the block (3 x 9) and the residuals
+template <bool R3ONLY>
+__global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArgs A) {
+  using CFG = InnerCfg<R3ONLY>;
+  constexpr int kInnerThreads = CFG::T, kInnerSlots = CFG::SLOTS;
+  __shared__ double s_J[CFG::NJ * kInnerThreads];  // per lane: Jacobian columns of the block (3 x JS) and the residuals
   __shared__ double s_item_d[10 * kInnerSlots];    // per lane and round: the item's measurement (ItemRec)
   __shared__ int s_item_i[4 * kInnerSlots];
   __shared__ double s_so3[4 * kCapS], s_seg[kSegStride * kCapS], s_r3[3 * kCapR], s_ab[3 * kCapB], s_gb[3 * kCapB], s_scal[26];   // the block's neighbourhood
@@ -432,7 +456,7 @@ __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
   const bool master = wg.part == 0;
   InnerCtl* const ctl = blk.ctl >= 0 ? A.ctls + blk.ctl : nullptr;
   const int d = blk.dim, nv = d * (d + 1) / 2 + d + 1;
-  const bool so3 = blk.kind == IK_SO3;
+  const bool so3 = !R3ONLY && blk.kind == IK_SO3;
   const int n_pairs = pl.n_so3 - 1, s_lo = blk.idx > 0 ? blk.idx - 1 : 0;   // SO(3) knot: table entries s_lo, s_lo + 1; it owns the pairs idx - 1 and idx
   // ---- the block's neighbourhood: knots, segment tables and scalars its items read -> LDS (one workgroup per block and the
   // ranges fit), else the items read the parameter vector
@@ -465,7 +489,7 @@ __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
   if (staged) {
     int slot = tid;
     for (int base = wg.part * kInnerThreads; base < blk.n_slots; base += wg.nparts * kInnerThreads, slot += kInnerThreads) {
-      ItemRec R; inner_load_item(A, blk, base + tid, R); item_store(R, s_item_i, s_item_d, slot);
+      ItemRec R; inner_load_item(A, blk, base + tid, R); item_store<kInnerSlots>(R, s_item_i, s_item_d, slot);
     }
   }
   if (master) {
@@ -490,8 +514,8 @@ __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
   INNER_MARK();
   while (true) {
     if (lane < 56) s_part[wave][lane] = 0.0;
-    if (cmd == INNER_CMD_JAC) inner_eval_items<true>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
-    else inner_eval_items<false>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    if (cmd == INNER_CMD_JAC) inner_eval_items<true, CFG>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    else inner_eval_items<false, CFG>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
     INNER_MARK();
     __syncthreads();
     INNER_MARK();
@@ -514,7 +538,8 @@ __global__ void __launch_bounds__(kInnerThreads) inner_set_kernel(InnerArgs A) {
       if (tid == 0) {
         double* x = A.xv + blk.xoff;
         int nc = INNER_CMD_DONE;
-        switch (blk.kind) {
+        if (R3ONLY) nc = inner_lm_advance<3, 3>(S, IK_R3, cmd, s_tot, x, xl, A.max_ab, A.max_gb);
+        else switch (blk.kind) {
           case IK_SO3: nc = inner_lm_advance<3, 4>(S, IK_SO3, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_TIC: nc = inner_lm_advance<6, 7>(S, IK_TIC, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_LD: nc = inner_lm_advance<1, 1>(S, IK_LD, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
@@ -581,8 +606,10 @@ __global__ void inner_diff_norm_kernel(const double* x, const double* xc, const 
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st) {
   if (n_pairs > 0) hipLaunchKernelGGL(inner_seg_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, so3, n_pairs, seg);
 }
-void launch_inner_set(const InnerArgs& A, int n_wgs, hipStream_t st) {
-  if (n_wgs > 0) hipLaunchKernelGGL(inner_set_kernel, dim3(n_wgs), dim3(kInnerThreads), 0, st, A);
+void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 512 item slots
+  if (n_wgs <= 0) return;
+  if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, A);
+  else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, A);
 }
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st) {
   if (nb > 0) hipLaunchKernelGGL(inner_diff_norm_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, x, xc, blocks, nb, step_norm_sq);

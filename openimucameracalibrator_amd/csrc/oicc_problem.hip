@@ -39,7 +39,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
 int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st);
 void launch_lds_poison(hipStream_t st);
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
-void launch_inner_set(const InnerArgs& A, int n_wgs, hipStream_t st);
+void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
@@ -151,7 +151,7 @@ struct oicc_problem {
   bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
   // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
   struct InnerPlan {
-    std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0;   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
+    std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0; std::vector<char> group_r3only;   // set g holds nothing but R^3 knots of at most 512 item slots: the 8-wave build of the kernel   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
     DevBuf<InnerBlock> d_blocks; DevBuf<InnerRun> d_runs; DevBuf<InnerWg> d_wgs; DevBuf<InnerCtl> d_ctls; DevBuf<unsigned long long> d_lm_iterations; DevBuf<double> d_seg; int n_ctls = 0;
     int flags = -2; int64_t layout_gen = -1; bool gs_unit = false;   // what the plan was built from: the tangent layout (make_layout generation) and the GS weighting
     size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
@@ -173,6 +173,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["debug_inner_general_kernel"] = 0;   // 1: sets of R^3 knots run on the general 4-wave build of the inner kernel too (tests: both builds give the same sweep)
     opt["debug_inner_profile"] = 0;   // g + 1: print the phase clocks of workgroup 0 of independent set g after every sweep
     opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
@@ -841,7 +842,7 @@ int build_inner_plan(oicc_problem* p, int flags) {
   // processing order: last set first; blocks of a set contiguous.  Per block its runs and its workgroups -- one for a knot block;
   // the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on each other: all of them
   // must be resident, so a set's shared blocks split the CUs and come first in the launch).
-  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.n_ctls = 0;
+  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.n_ctls = 0;
   constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
   for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
     const int b0 = int(ip.blocks.size());
@@ -867,7 +868,9 @@ int build_inner_plan(oicc_problem* p, int flags) {
         if (nparts > 1) blk.ctl = ip.n_ctls++;
         for (int q = 0; q < nparts; ++q) ip.wgs.push_back(InnerWg{b, q, nparts, 0});
       }
-    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size()));
+    char r3only = p->opt["debug_inner_general_kernel"] == 0.0;
+    for (int b = b0; b < b1; ++b) r3only = r3only && ip.blocks[b].kind == IK_R3 && ip.blocks[b].n_slots <= 512;
+    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only);
   }
   t_plan3 = now_s();
   hipStream_t st = p->stream;
@@ -898,7 +901,7 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the probl
     A.wgs = ip.d_wgs.p + ip.group_wg0[g];
     A.prof = nullptr;
     if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); A.prof = d_prof.p; }
-    launch_inner_set(A, ip.group_wg0[g + 1] - ip.group_wg0[g], st);
+    launch_inner_set(A, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st);
   }
   HIPCK(p, hipGetLastError());
   if (prof_set >= 0 && d_prof.p) {

@@ -614,6 +614,23 @@ def test_inner_iterations_match_the_oracle(cfg, flags):
     assert abs(sp["final_cost"] - sg["final_cost"]) > 1e-9 * sg["final_cost"]
 
 
+def test_both_builds_of_the_inner_kernel_give_the_same_sweeps():
+    """Sets that hold nothing but R^3 knots run on the 8-wave build of inner_set_kernel (forward pass only, all items of a knot in
+    one round); option debug_inner_general_kernel sends them through the general 4-wave build: same iterates (the per-wave partial
+    sums are grouped differently: 1e-9)."""
+    ds = synthetic.make_config("C2")
+    out = []
+    for general in (0, 1):
+        c = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        c.trajectory_.SetOption("inner_iterations", 1); c.trajectory_.SetOption("debug_inner_general_kernel", general)
+        s_ = c.trajectory_.Optimize(50, FLAGS1)
+        out.append((s_, c.trajectory_.GetIterations(), c.trajectory_.GetT_i_c()))
+    (s0, i0, t0), (s1, i1, t1) = out
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["inner_sweeps"] == s1["inner_sweeps"] >= 1 and s0["inner_lm_iterations"] == s1["inner_lm_iterations"]
+    assert all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(i0, i1))
+    assert np.abs(t0 - t1).max() < 1e-8
+
+
 # ---- Ceres' bounds line search (box-bounded bias knots, impl.h:206-240): host-driven Armijo search of oicc_optimize ----
 @pytest.mark.parametrize("cfg,flags,inner", [("C1", FLAGS1 | E.ACC_BIAS, 0), ("C1", FLAGS1 | E.ACC_BIAS, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1)])
 def test_bounds_line_search_matches_the_oracle(cfg, flags, inner):
