@@ -35,11 +35,11 @@ namespace oicc {
 template <bool R3ONLY>
 struct InnerCfg {
   static constexpr int T = R3ONLY ? 512 : 256;      // threads of a workgroup
-  static constexpr int SLOTS = 512;                  // item slots of a block staged in LDS; larger blocks re-read their items
+  static constexpr int SLOTS = R3ONLY ? 1024 : 512;  // item slots of a block staged in LDS (two per lane); larger blocks re-read their items
   static constexpr int JS = R3ONLY ? 3 : 9;          // columns kept per Jacobian row of the block
   static constexpr int NJ = 3 * JS + 3;              // per lane: 3 rows x JS columns, then the residuals
 };
-constexpr int kInnerThreads = InnerCfg<false>::T;
+
 constexpr int kCapS = 24, kCapR = 16, kCapB = 8; // knots of the block's neighbourhood staged in LDS (SO(3), R^3, each bias spline)
 enum { INNER_CMD_JAC = 0, INNER_CMD_COST = 1, INNER_CMD_DONE = 2 };
 
@@ -606,7 +606,7 @@ __global__ void inner_diff_norm_kernel(const double* x, const double* xc, const 
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st) {
   if (n_pairs > 0) hipLaunchKernelGGL(inner_seg_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, so3, n_pairs, seg);
 }
-void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 512 item slots
+void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 1024 item slots
   if (n_wgs <= 0) return;
   if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, A);
   else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, A);
