@@ -170,11 +170,17 @@ class SplineTrajectoryEstimator {
     ck(oicc_add_gyroscope_measurements(h_, int64_t(t_ns.size()), t_ns.data(), gyro_xyz.data(), w_gyro, ok_gyro->data()));
   }
 
+  // time-sharded ranks: the estimator that holds every rank's measurements supplies the residual blocks of the inner-iteration sweeps
+  void SetInnerIterationSource(SplineTrajectoryEstimator* whole) { ck(oicc_set_inner_iteration_source(h_, whole ? whole->h_ : nullptr)); }
+
   oicc_summary Optimize(int max_iters, int flags) {   // impl.h:255-276
     oicc_summary s; ck(oicc_optimize(h_, max_iters, flags, &s));
     std::cout << "Solver: " << s.message << "  iterations " << s.num_iterations << " (" << s.num_successful_steps << " successful)  cost "
               << s.initial_cost << " -> " << s.final_cost << "  time " << s.seconds_total << " s (jacobian " << s.seconds_jacobian
-              << ", residual " << s.seconds_residual << ", linear solver " << s.seconds_linear_solver << ")\n";
+              << ", residual " << s.seconds_residual << ", linear solver " << s.seconds_linear_solver << ")";
+    if (s.inner_sweeps > 0 || s.line_search_steps > 0)   // Ceres FullReport: "Inner iterations", "Line search steps"
+      std::cout << "  inner sweeps " << s.inner_sweeps << " (" << s.inner_lm_iterations << " block LM iterations, " << s.seconds_inner << " s)  line search steps " << s.line_search_steps;
+    std::cout << "\n";
     return s;
   }
 
