@@ -208,9 +208,11 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  *   rs_time_in_seconds 0 (1: documented fix of quirk Q1),
  *   verbose 0;
  * device-side choices (no effect on the result beyond rounding):
- *   solver_algorithm 0 (0 auto = 2 where it applies, 1 LDS-window band sweep, 2 block cyclic reduction, 3 its parallel form -- every
- *   block a pivot at every level, no back substitution levels, up to 256 blocks of 64 band columns --; any geometry neither takes
- *   goes to a global-memory band Cholesky), solver_partitions 0 (time partitions of algorithm 1; 0 = heuristic),
+ *   solver_algorithm 0 (0 auto = 4 where it applies, 1 LDS-window band sweep, 2 block cyclic reduction with the Cholesky factor of
+ *   every pivot block and its border rows, 3 its parallel form -- every block a pivot at every level, no back substitution levels,
+ *   up to 256 blocks of 64 band columns --, 4 block cyclic reduction through the explicit inverses of the 64 x 64 pivot blocks:
+ *   the border rows leave the serial factorisation and become matrix products; any geometry none of them takes goes to a
+ *   global-memory band Cholesky), solver_partitions 0 (time partitions of algorithm 1; 0 = heuristic),
  *   assembly 0 (0: time tiles - LDS accumulators + slab merge, 2: time tiles adding straight into the packed matrix with
  *   fp64 atomics), tile_windows 0 (knot windows per tile; 0 = automatic),
  *   wide_cells 1 (IMU samples of neighbouring knot windows share one Gram product).

@@ -73,17 +73,67 @@ __device__ __forceinline__ void tri10(int t, int& xt, int& yt) {
   yt = t - (xt * (xt + 1)) / 2;
 }
 
-// Arrow corner (a x a, with the rhs as row / column a) held as Cq(r, c) = W[c*LD + 64 + r]: Cholesky, forward and backward
+// Arrow corner (a x a, with the rhs as row / column a) held as Cq(r, c) = C[c*LD + r]: Cholesky, forward and backward
 // substitution; the arrow part of the step lands in da[0..a).  ONE WAVE, lane = row (a + 1 <= 64): per column the pivot comes
 // by v_readlane, the rank-1 update of the remaining columns runs over LDS without a workgroup barrier (round 2 spent three
 // 1024-thread barriers per column here).  Called by all threads; ends with a workgroup barrier.
 template <int LD>
-__device__ __forceinline__ void bcr_corner_solve(double* W, double* da, int* failp, int a, int tid, int wave, int lane) {
+__device__ __forceinline__ void bcr_corner_solve(double* C, double* da, int* failp, int a, int tid, int wave, int lane) {
   const int a1 = a + 1;
+  if (a1 <= 16) {
+    // up to 15 arrow columns (T_i_c, gravity, line delay: 9-10): the columns stay in registers -- per column the pivot chain of
+    // the panel factorisation and v_readlane broadcasts instead of a read-modify-write of LDS per remaining column; LDS only
+    // transposes the factor for the back substitution
+    if (wave == 0) {
+      double av[16], dinv = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) av[c] = (c < a && lane < a1 && lane >= c) ? C[c * LD + lane] : 0.0;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c < a) {
+          const double piv = bcr_readlane(av[c], c);
+          bad |= !(piv > 0.0);
+          const double y0 = __builtin_amdgcn_rsq(piv);
+          const double g0 = piv * y0, h0 = 0.5 * y0;
+          const double r0 = fma(-g0, h0, 0.5);
+          const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+          const double r1 = fma(-g1, h1, 0.5);
+          const double u = (av[c] + av[c]) * h1;
+          const double l = fma(u, r1, u);
+          av[c] = l;
+          if (lane == c) { const double y1 = h1 + h1; dinv = fma(y1, r1, y1); }
+#pragma unroll
+          for (int c2 = c + 1; c2 < 16; ++c2) {
+            const double lc2 = bcr_readlane(l, c2);
+            av[c2] = fma(-l, lc2, av[c2]);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < a && lane < a1 && lane >= c) C[c * LD + lane] = av[c];
+      double lt[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) lt[q] = (q < a && lane < q) ? C[lane * LD + q] : 0.0;      // L(q, lane)
+      double z = lane < a ? C[lane * LD + a] : 0.0, xq_mine = 0.0;                               // L(a, lane): the forward-substituted rhs
+#pragma unroll
+      for (int q = 15; q >= 0; --q) {
+        if (q < a) {
+          const double xq = bcr_readlane(z * dinv, q);
+          if (lane == q) xq_mine = xq;
+          z = fma(-lt[q], xq, z);
+        }
+      }
+      if (lane < a) da[lane] = xq_mine;
+      if (bad && lane == 0) *failp = 1;
+    }
+    __syncthreads();
+    return;
+  }
   if (wave == 0) {
     bool bad = false;
     for (int c = 0; c < a; ++c) {
-      double* col = W + c * LD + 64;
+      double* col = C + c * LD;
       const double mine = lane < a1 ? col[lane] : 0.0;
       double piv = bcr_readlane(mine, c);
       if (!(piv > 0.0)) { bad = true; piv = 1.0; }
@@ -92,18 +142,18 @@ __device__ __forceinline__ void bcr_corner_solve(double* W, double* da, int* fai
       if (lane >= c && lane < a1) col[lane] = l;
       for (int c2 = c + 1; c2 < a; ++c2) {
         const double l2 = bcr_readlane(l, c2);
-        if (lane >= c2 && lane < a1) W[c2 * LD + 64 + lane] -= l * l2;
+        if (lane >= c2 && lane < a1) C[c2 * LD + lane] -= l * l2;
       }
     }
     if (bad && lane == 0) *failp = 1;
     // back substitution of the corner, lane = arrow column: z_q = Cq(a, q), L_c^T x_a = z
-    double z = lane < a ? W[lane * LD + 64 + a] : 0.0;
-    const double dc = lane < a ? 1.0 / W[lane * LD + 64 + lane] : 0.0;
+    double z = lane < a ? C[lane * LD + a] : 0.0;
+    const double dc = lane < a ? 1.0 / C[lane * LD + lane] : 0.0;
     double xq_mine = 0.0;
     for (int q = a - 1; q >= 0; --q) {
       const double xq = bcr_readlane(z * dc, q);
       if (lane == q) xq_mine = xq;
-      const double l = lane < q ? W[lane * LD + 64 + q] : 0.0;    // L_c(q, lane)
+      const double l = lane < q ? C[lane * LD + q] : 0.0;    // L_c(q, lane)
       z = fma(-l, xq, z);
     }
     if (lane < a) da[lane] = xq_mine;
@@ -349,7 +399,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
       W[c * LD + 64 + r] = v;
     }
     __syncthreads();
-    bcr_corner_solve<LD>(W, da, failp, a, tid, wave, lane);
+    bcr_corner_solve<LD>(W + 64, da, failp, a, tid, wave, lane);
     for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
     for (int e = tid; e < A.n * 64; e += kBcrThreads) {
       if (e >= A.Pb) break;
@@ -386,7 +436,7 @@ __global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
     W[c * LD + 64 + r] = v0 + v1;
   }
   __syncthreads();
-  bcr_corner_solve<LD>(W, da, failp, a, tid, wave, lane);
+  bcr_corner_solve<LD>(W + 64, da, failp, a, tid, wave, lane);
   for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
   if (wave == 0) {
     double z = W[lane * LD + 192 + a];
@@ -538,11 +588,410 @@ __global__ __launch_bounds__(64 * kBackWaves) void bcr_backward_kernel(BcrArgs A
   }
 }
 
+// =====================================================================================================================
+// Cyclic reduction through the INVERSE of the pivot blocks (round 3, solver_algorithm 4).
+//
+// The levels above spend their time in ONE workgroup per pivot that factors D_i with its 128 + a1 border rows hanging
+// below the panel (202 rows x 64 columns through one CU's LDS and MFMA pipe, 58 register tiles).  Only the 64 x 64
+// diagonal block is inherently serial.  Here a level is
+//   bcri_invert_kernel   one workgroup per pivot: right-looking Cholesky of [D_i ; I] (128 rows, 20 tiles), which leaves
+//                        X = L^-T below the factor, then Z_i = X X^T = D_i^-1 on MFMA               -> global
+//   bcri_schur_kernel    12 + 3 rtf workgroups per pivot: T = B Z_i for one 16-row tile of the border rows B = [S_left ;
+//                        S_right ; arrow rows ; rhs] (kept for the back substitution), then the Schur tiles -T B^T onto
+//                        the neighbours, their coupling, the arrow rows and the corner
+//   bcri_backward_kernel x_i = T_rhs - T_left^T x_il - T_right^T x_ir - T_arrow^T x_arrow: a matrix-vector product, no
+//                        triangular solve on the way back
+// Block 0 after the last level still goes through bcr_eliminate_kernel<LD, 1> (factor + corner + its back substitution).
+// Error: forward errors of B D^-1 B^T through the explicit inverse and through the Cholesky factor are both
+// O(cond(D_i) eps); the LM tests hold both to the oracle's steps.
+// =====================================================================================================================
+constexpr int kInvWaves = 16;   // (measured: 13.3 us per pivot against 14.5 with 8 waves, 17 with 4)
+constexpr int kInvLD = 145;   // 128 rows, + 16 (two panels' rows of one wave land in different banks), + 1
+
+// Z tile (xt, yt), xt >= yt, of X X^T: X(r, k) = 0 for k < r, the sum starts at the tile of the later rows
+template <int XT>
+__device__ __forceinline__ bcr_v4d bcri_z_tile(const double* W, int yt, int li, int lq) {
+  constexpr int LD = kInvLD, K0 = 4 * XT, NK = 16 - K0;
+  const double* py = W + lq * LD + 64 + 16 * yt + li;
+  const double* px = W + lq * LD + 64 + 16 * XT + li;
+  double vy[NK], vx[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) { vy[kk] = py[4 * (K0 + kk) * LD]; vx[kk] = px[4 * (K0 + kk) * LD]; }
+  asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
+  bcr_v4d g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) g = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk], vx[kk], g, 0, 0, 0);
+  return g;   // g[r] <-> (x row 16 XT + li, y row 16 yt + lq + 4 r)
+}
+
+// What follows the factorisation of [D_i ; I] (all waves, after a workgroup barrier): Z = X X^T, and for block 0 (LAST) the arrow
+// corner and the first back substitution.
+template <bool LAST>
+__device__ __forceinline__ void bcri_tail(const BcrArgs& A, double* W, double* da, int* failp, const double* Fs, double* Zg, int tid, int wave, int lane, bool report) {
+  constexpr int LD = kInvLD, NW = kInvWaves, NT = 64 * NW, FLD = 65;
+  const int li = lane & 15, lq = lane >> 4;
+  const int a = A.a, a1 = a + 1;
+  // ---- Z = X X^T (X = L^-T in rows 64..127): to global, or (LAST) into rows 0..63, where the factor is no longer needed
+  for (int t = wave; t < 10; t += NW) {
+    int xt, yt; tri10(t, xt, yt);
+    const bcr_v4d g = xt == 0 ? bcri_z_tile<0>(W, yt, li, lq) : (xt == 1 ? bcri_z_tile<1>(W, yt, li, lq) : (xt == 2 ? bcri_z_tile<2>(W, yt, li, lq) : bcri_z_tile<3>(W, yt, li, lq)));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
+      if (LAST) { W[y * LD + x] = g[r]; if (xt != yt) W[x * LD + y] = g[r]; }
+      else { Zg[y * 64 + x] = g[r]; if (xt != yt) Zg[x * 64 + y] = g[r]; }
+    }
+  }
+  __syncthreads();
+  if (!LAST) {
+    if (report && tid == 0 && *failp) atomicOr(A.fail, 1);
+    return;
+  }
+  // ---------------- LAST: T = F_0 Z into rows 64.. (T(q, c) = W[c*LD + 64 + q]; X is no longer needed)
+  const int rtf = A.rtf;
+  if (wave < 4 * rtf) {
+    const int t = wave >> 2, w = wave & 3;
+    const double* pf = Fs + lq * FLD + 16 * t + li;
+    const double* pz = W + lq * LD + 16 * w + li;
+    double vf[16], vz[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { vf[kk] = pf[4 * kk * FLD]; vz[kk] = pz[4 * kk * LD]; }
+    asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
+    bcr_v4d tq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) tq = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[kk], vz[kk], tq, 0, 0, 0);
+    // tq[r] <-> (column 16 w + li, border row 16 t + lq + 4 r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[(16 * w + li) * LD + 64 + 16 * t + lq + 4 * r] = tq[r];
+  }
+  __syncthreads();
+  // corner Cq(r, c) = Mc - T F_0^T at W[c*LD + r] (rows 0..63: the inverse is no longer needed), lower tiles t1 >= t2
+  if (wave < (rtf * (rtf + 1)) / 2) {
+    int t1 = 0, u = wave; while (u >= t1 + 1) { u -= t1 + 1; ++t1; }
+    const int t2 = u;
+    const double* pt = W + lq * LD + 64 + 16 * t1 + li;
+    const double* pf = Fs + lq * FLD + 16 * t2 + li;
+    double vt[16], vf[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { vt[kk] = pt[4 * kk * LD]; vf[kk] = pf[4 * kk * FLD]; }
+    asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
+    bcr_v4d g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) g = __builtin_amdgcn_mfma_f64_16x16x4f64(vf[kk], vt[kk], g, 0, 0, 0);
+    // g[r] <-> (row q1 = 16 t1 + li, column q2 = 16 t2 + lq + 4 r)
+    double mc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int q1 = 16 * t1 + li, q2 = 16 * t2 + lq + 4 * r; mc[r] = (q1 < a1 && q2 < a1) ? A.Mc[q1 * a1 + q2] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int q1 = 16 * t1 + li, q2 = 16 * t2 + lq + 4 * r; if (q1 < a1 && q2 < a1) W[q2 * LD + q1] = mc[r] - g[r]; }
+  }
+  __syncthreads();
+  bcr_corner_solve<LD>(W, da, failp, a, tid, wave, lane);
+  for (int q = tid; q < a; q += NT) A.x[A.Pb + q] = da[q];
+  if (wave == 0) {
+    const double* tc = W + lane * LD + 64;
+    double v = tc[a];
+    for (int q = 0; q < a; q += 8) {            // eight loads in flight before the dependent sum
+      double t8[8], d8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const bool ok = q + k < a; t8[k] = ok ? tc[q + k] : 0.0; d8[k] = ok ? da[q + k] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v = fma(-t8[k], d8[k], v);
+    }
+    if (lane < A.Pb) A.x[lane] = v;
+  }
+  __syncthreads();
+  if (tid == 0 && *failp) atomicOr(A.fail, 1);
+}
+
+
+// LAST: block 0 after the last level -- the inverse stays in LDS, T = F_0 Z, the arrow corner minus T F_0^T, its solution and
+// x_0 = T_rhs - T_arrow^T x_arrow, all in this workgroup
+template <bool LAST, bool PROF, class LoadD>
+__device__ __forceinline__ void bcri_invert_body(const BcrArgs& A, const int i, LoadD load_d, const bool report = true) {
+  constexpr int LD = kInvLD, NW = kInvWaves, NT = 64 * NW, NTILE = 20, SLOTS = (NTILE + NW - 1) / NW, RU = 128, NAW = 3, FLD = 65;
+  static_assert(NW == 16, "the corner phases of block 0 take one tile per wave");
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  double* const W = lds;                 // [64][LD] column major: rows 0..63 D_i -> L, rows 64..127 I -> L^-T
+  double* const da = W + 64 * LD;        // [64] arrow solution (LAST)
+  int* const failp = reinterpret_cast<int*>(da + 64);
+  double* const dg = da + 64 + 8;        // [16][16] copy of the current panel's diagonal tile (column major; see bcr_eliminate_kernel)
+  double* const Fs = dg + 256;           // LAST: [64][FLD] border rows of block 0, Fs[k * FLD + q]
+  const int a1 = A.a + 1;
+  double* Zg = A.Lf + (int64_t)i * (192 + a1) * 64;
+  const bool prof = PROF && A.prof != nullptr && blockIdx.x == 0 && wave == 0;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = prof ? clock64() : 0;
+#define BCR_MARK(k) do { if (PROF && prof) { const long long tn_ = clock64(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
+  if (tid == 0) *failp = 0;
+  {
+    constexpr int PER = 4096 / NT;
+    double gd[PER], gf[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + k * NT;
+      gd[k] = load_d(e);
+      if (LAST) { const int c = e >> 6, q = e & 63; gf[k] = q < a1 ? A.F[c * a1 + q] : 0.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + k * NT;
+      const int c = e >> 6, r = e & 63;
+      W[c * LD + r] = r >= c ? gd[k] : 0.0;
+      if (c < 16 && r < 16) dg[c * 16 + r] = r >= c ? gd[k] : 0.0;
+      W[c * LD + 64 + r] = r == c ? 1.0 : 0.0;
+      if (LAST) Fs[c * FLD + r] = gf[k];
+    }
+  }
+  __syncthreads();
+  // ---- static tile ownership: tiles 0..9 the lower triangle of D_i, 10..19 the upper triangle of X (X(r, c) = 0 for c < r)
+  int t_rt[SLOTS], t_ct[SLOTS]; bool t_ok[SLOTS];
+  bcr_v4d acc[SLOTS];
+#pragma unroll
+  for (int k = 0; k < SLOTS; ++k) {
+    const int t = wave + NW * k;
+    t_ok[k] = t < NTILE;
+    int xt, yt; tri10(t < 10 ? t : (t < NTILE ? t - 10 : 0), xt, yt);
+    if (t < 10) { t_rt[k] = xt; t_ct[k] = yt; } else { t_rt[k] = 4 + yt; t_ct[k] = xt; }
+    const double* src = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
+    acc[k][0] = src[0]; acc[k][1] = src[4 * LD]; acc[k][2] = src[8 * LD]; acc[k][3] = src[12 * LD];
+  }
+  BCR_MARK(0);
+  // Panels of 16 columns = one tile column (four LDS round trips and eight barriers per block instead of eight and sixteen).
+  // Panel waves: lanes 0..15 the panel's diagonal rows (from `dg`, redundantly in every panel wave), lanes 16..63 one row each.
+  const int prow = 16 + wave * 48 + (lane - 16);
+  for (int p = 0; p < 4; ++p) {
+    const int j0 = 16 * p;
+    if (wave < NAW) {
+      const int rho = lane < 16 ? j0 + lane : prow;
+      // rows of X below the panel's last column are still zero
+      const bool act = lane < 16 || (rho >= j0 + 16 && rho < RU && !(rho >= 64 && rho - 64 > j0 + 15));
+      if (A.delay > 0 && wave > 0) for (int k = 0; k < A.delay; ++k) __builtin_amdgcn_s_sleep(16);
+      const double* colp = lane < 16 ? dg + lane : W + j0 * LD + (act ? rho : 0);
+      const int cstride = lane < 16 ? 16 : LD;
+      double av[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { const double v = colp[c * cstride]; av[c] = (act && (lane >= 16 || lane >= c)) ? v : 0.0; }
+      if (PROF && prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      BCR_MARK(6);
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = bcr_readlane(av[c], c);
+        bad |= !(piv > 0.0);
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double g0 = piv * y0, h0 = 0.5 * y0;
+        const double r0 = fma(-g0, h0, 0.5);
+        const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+        const double r1 = fma(-g1, h1, 0.5);
+        const double u = (av[c] + av[c]) * h1;
+        const double l = fma(u, r1, u);
+        av[c] = l;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double lc2 = bcr_readlane(l, c2);
+          av[c2] = fma(-l, lc2, av[c2]);
+        }
+      }
+      if (PROF && prof) { asm volatile("s_nop 0" :: "v"(av[15])); }
+      BCR_MARK(7);
+      if (act && (lane >= 16 || wave == 0)) {
+        double* cp = W + j0 * LD + rho;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cp[c * LD] = av[c];
+      }
+      if (bad && lane == 0) *failp = 1;
+    }
+    BCR_MARK(1);
+    bcr_lds_barrier();
+    BCR_MARK(2);
+    if (p < 3) {
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        // tiles right of the panel; an X tile whose rows start below the panel's last column has a zero operand
+        if (t_ok[k] && t_ct[k] > p && (t_rt[k] < 4 || t_rt[k] - 4 <= p)) {
+          const double* pa = W + (j0 + lq) * LD + 16 * t_ct[k] + li;
+          const double* pb = W + (j0 + lq) * LD + 16 * t_rt[k] + li;
+          double va[4], vb[4];
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) { va[kq] = pa[4 * kq * LD]; vb[kq] = -pb[4 * kq * LD]; }
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], vb[kq], acc[k], 0, 0, 0);
+          if (t_ct[k] == p + 1) {   // the next panel's columns go back to LDS
+            double* dst = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
+            dst[0] = acc[k][0]; dst[4 * LD] = acc[k][1]; dst[8 * LD] = acc[k][2]; dst[12 * LD] = acc[k][3];
+            if (t_rt[k] == t_ct[k]) { dg[lq * 16 + li] = acc[k][0]; dg[(lq + 4) * 16 + li] = acc[k][1]; dg[(lq + 8) * 16 + li] = acc[k][2]; dg[(lq + 12) * 16 + li] = acc[k][3]; }
+          }
+        }
+      }
+    }
+    BCR_MARK(3);
+    bcr_lds_barrier();
+    BCR_MARK(4);
+  }
+  BCR_MARK(4);
+  bcri_tail<LAST>(A, W, da, failp, Fs, Zg, tid, wave, lane, report);
+  BCR_MARK(5);
+  if (PROF && prof && lane == 0) for (int k = 0; k < 8; ++k) A.prof[k] = pc[k];
+#undef BCR_MARK
+}
+
+template <bool LAST, bool PROF>
+__global__ __launch_bounds__(64 * kInvWaves) void bcri_invert_kernel(BcrArgs A) {
+  const int i = LAST ? 0 : A.s * (2 * (int)blockIdx.x + 1);
+  const double* Dg = A.D + (int64_t)i * 4096;
+  bcri_invert_body<LAST, PROF>(A, i, [Dg](int e) { return Dg[e]; });
+}
+
+// one workgroup (4 waves) per (pivot, 16-row tile x of the border rows, group of up to four column tiles y)
+__global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
+  __shared__ double Ts[16][68];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int a1 = A.a + 1, rtf = A.rtf, s = A.s;
+  const int i = s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
+  const bool hasR = ir < A.n;                       // (a pivot always has its left neighbour)
+  // group -> row tile (kind xk: 0 left, 1 right, 2 arrow rows / rhs; index xt), column tiles (kind yk, ny of them), and who stores T
+  int g = (int)blockIdx.x, xk, xt, yk, ny; bool store_t;
+  if (g < 4) { xk = 0; xt = g; yk = 0; ny = g + 1; store_t = true; }
+  else if (g < 8) { xk = 1; xt = g - 4; yk = 0; ny = 4; store_t = false; }
+  else if (g < 12) { xk = 1; xt = g - 8; yk = 1; ny = xt + 1; store_t = true; }
+  else { g -= 12; yk = g / rtf; xt = g - yk * rtf; xk = 2; ny = yk < 2 ? 4 : xt + 1; store_t = yk == 0; }
+  if ((xk == 1 || yk == 1) && !hasR) return;
+  const double* SL = A.S + (A.offS_in + il / s) * 4096;
+  const double* SR = A.S + (A.offS_in + i / s) * 4096;
+  const double* Fg = A.F + (int64_t)i * 64 * a1;
+  double* Zg = A.Lf + (int64_t)i * (192 + a1) * 64;
+  double* Tg = Zg + 4096;
+  // border rows as MFMA operands: element (row 16 t + li, pivot variable k = 4 kk + lq)
+  auto border_ptr = [&](int kind, int t, int& stride, bool& ok) -> const double* {
+    if (kind == 0) { stride = 64; ok = true; return SL + lq * 64 + 16 * t + li; }
+    if (kind == 1) { stride = 64; ok = true; return SR + lq * 64 + 16 * t + li; }
+    const int q = 16 * t + li; ok = q < a1; stride = a1; return Fg + lq * a1 + (ok ? q : 0);
+  };
+  int sx, sy; bool okx, oky;
+  const double* px = border_ptr(xk, xt, sx, okx);
+  const double* py = border_ptr(yk, wave < ny ? wave : 0, sy, oky);
+  const double* pz = Zg + lq * 64 + 16 * wave + li;
+  double vx[16], vz[16], vy[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { vx[kk] = px[4 * kk * sx]; vz[kk] = pz[4 * kk * 64]; }
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
+  asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
+  // T(x rows, columns 16 wave ..) = B_x Z: two accumulators, the dependent chain is 8 MFMAs
+  bcr_v4d tq = {0.0, 0.0, 0.0, 0.0}, tq2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 2) {
+    tq = __builtin_amdgcn_mfma_f64_16x16x4f64(okx ? vx[kk] : 0.0, vz[kk], tq, 0, 0, 0);
+    tq2 = __builtin_amdgcn_mfma_f64_16x16x4f64(okx ? vx[kk + 1] : 0.0, vz[kk + 1], tq2, 0, 0, 0);
+  }
+  tq += tq2;
+  // tq[r] <-> (column 16 wave + li, row lq + 4 r of the tile)
+  const int trow0 = xk == 0 ? 16 * xt : (xk == 1 ? 64 + 16 * xt : 128 + 16 * xt);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lq + 4 * r;
+    Ts[row][16 * wave + li] = tq[r];
+    if (store_t && (xk != 2 || 16 * xt + row < a1)) Tg[(int64_t)(trow0 + row) * 64 + 16 * wave + li] = tq[r];
+  }
+  __syncthreads();
+  if (wave >= ny) return;
+  const int yt = wave;
+  // orientation of the new coupling (il, ir): the pivot of the next level is the one at an odd position
+  const bool il_is_pivot = ((il / (2 * s)) & 1) != 0;
+  const bool swap = xk == 1 && yk == 0 && !il_is_pivot;
+  double vt[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) vt[kk] = Ts[li][4 * kk + lq];
+  asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
+  bcr_v4d gq = {0.0, 0.0, 0.0, 0.0}, gq2 = {0.0, 0.0, 0.0, 0.0};
+  if (swap) {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      gq = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk], vy[kk], gq, 0, 0, 0);
+      gq2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk + 1], vy[kk + 1], gq2, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      gq = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk], vt[kk], gq, 0, 0, 0);
+      gq2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk + 1], vt[kk + 1], gq2, 0, 0, 0);
+    }
+  }
+  gq += gq2;
+  // not swapped: gq[r] <-> (x row li, y row lq + 4 r); swapped: (y row li, x row lq + 4 r)
+  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)ir * 4096;
+  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)ir * 64 * a1;
+  double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double v = -gq[r];
+    if (xk == 1 && yk == 0) {
+      if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; }    // Q[c = il var][r = ir var]
+      else       { const int y = 16 * yt + li, x = 16 * xt + lq + 4 * r; So[x * 64 + y] = v; }    // Q[c = ir var][r = il var]
+    } else if (xk < 2) {
+      const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
+      if (x >= y && v != 0.0) unsafeAtomicAdd((xk == 0 ? Dl : Dr) + y * 64 + x, v);
+    } else if (yk < 2) {
+      const int q = 16 * xt + li, y = 16 * yt + lq + 4 * r;
+      if (q < a1 && v != 0.0) unsafeAtomicAdd((yk == 0 ? Fl : Fr) + y * a1 + q, v);
+    } else {
+      const int q1 = 16 * xt + li, q2 = 16 * yt + lq + 4 * r;
+      if (q1 < a1 && q2 <= q1 && v != 0.0) {
+        unsafeAtomicAdd(A.Mc + q1 * a1 + q2, v);
+        if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
+      }
+    }
+  }
+}
+
+// back substitution of the pivots of one level: lane = column of T, the 128 + a rows spread over the waves
+__global__ __launch_bounds__(64 * kBackWaves) void bcri_backward_kernel(BcrArgs A) {
+  __shared__ double xs[192];
+  __shared__ double part[kBackWaves][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = A.a, a1 = a + 1, s = A.s;
+  const int i = s * (2 * (int)blockIdx.x + 1), il = i - s, ir = i + s;
+  const bool hasR = ir < A.n;
+  const double* Tg = A.Lf + (int64_t)i * (192 + a1) * 64 + 4096;
+  constexpr int RW = 192 / kBackWaves;
+  double lv[RW];
+#pragma unroll
+  for (int k = 0; k < RW; ++k) {
+    const int r = wave + kBackWaves * k;
+    const bool ok = r < 128 + a && (hasR || r < 64 || r >= 128);
+    lv[k] = ok ? Tg[r * 64 + lane] : 0.0;
+  }
+  const double yv = wave == 0 ? Tg[(128 + a) * 64 + lane] : 0.0;
+  double xin = 0.0;
+  if (tid < 64) { const int gi = il * 64 + tid; xin = gi < A.Pb ? A.x[gi] : 0.0; }
+  else if (tid < 128) { const int gi = ir * 64 + (tid - 64); xin = (hasR && gi < A.Pb) ? A.x[gi] : 0.0; }
+  else if (tid < 128 + a) xin = A.x[A.Pb + (tid - 128)];
+  if (tid < 192) xs[tid] = xin;
+  __syncthreads();
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < RW; ++k) { const int r = wave + kBackWaves * k; sum = fma(lv[k], r < 128 + a ? xs[r] : 0.0, sum); }
+  part[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBackWaves; ++w) acc += part[w][lane];
+    const int gi = i * 64 + lane;
+    if (gi < A.Pb) A.x[gi] = yv - acc;
+  }
+}
+
 // ---- damped, scaled system in block form:  M = S H S + clamp(diag)/radius, rhs = -S g -----
-__global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal, double min_diag,
-                                 double max_diag, BcrArgs A) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
+                                               double max_diag, const BcrArgs& A, const int64_t tid, const int64_t nthreads) {
   const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
   const double radius = sb.radius;
   if (A.pcr) {
@@ -621,6 +1070,38 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
   }
 }
 
+__global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal, double min_diag,
+                                 double max_diag, BcrArgs A) {
+  bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// The build and the first level's inversions in ONE launch (cyclic reduction through the inverses): the workgroups of the
+// pivots of level 0 (the odd blocks) take their D_i straight from the band of the normal equations -- same expressions as
+// the build, which still writes every block for the later levels -- while the other workgroups build the system.
+__global__ __launch_bounds__(64 * kInvWaves) void bcri_build_invert_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
+                                                                           double min_diag, double max_diag, BcrArgs A) {
+  const int npiv = A.n / 2;
+  if ((int)blockIdx.x >= npiv) {
+    bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)((int)blockIdx.x - npiv) * blockDim.x + threadIdx.x, (int64_t)((int)gridDim.x - npiv) * blockDim.x);
+    return;
+  }
+  const int i = 2 * (int)blockIdx.x + 1;
+  const int Pb = tl.Pb, Wd = tl.W, hb = tl.hb;
+  const double radius = sb.radius;
+  const double* band = ne.band();
+  bcri_invert_body<false, false>(A, i, [&](int e) -> double {
+    const int c = e >> 6, r = e & 63, k = r - c;
+    const int64_t gc = (int64_t)i * 64 + c, gr = (int64_t)i * 64 + r;
+    if (k < 0) return 0.0;
+    if (gr >= Pb) return (gc >= Pb && k == 0) ? 1.0 : 0.0;   // identity padding of the last block
+    const double sc = sb.scale[gc];
+    double v = k <= hb ? band[gc * Wd + k] * sc * sb.scale[gr] : 0.0;
+    if (k == 0) v += (reuse_diagonal ? sb.diag[gc] : fmin(fmax(band[gc * Wd] * sc * sc, min_diag), max_diag)) / radius;
+    return v;
+  }, false);   // the build workgroups of this launch reset the failure flag: a non-positive pivot here is not reported but poisons
+               // (NaN) the inverse, the Schur complements of every later level and finally block 0, whose kernel reports it
+}
+
 // ---- host ------------------------------------------------------------------
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
 // Arrow limit: the kernels take up to 63 arrow columns (four 16-row border tiles).  Round 2 saw sporadic NaN pivots with more than
@@ -666,11 +1147,20 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;
   const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8 + 64) * sizeof(double);
   if (lds > 160 * 1024 - 64) return -1;
+  const bool inv = !A.pcr && (sb.algo == 0 || sb.algo == 4);   // (2: the factor-based levels, kept as an independent solver)
+  const size_t lds_inv = ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double), lds_inv_last = lds_inv + (size_t)64 * 65 * sizeof(double);
+  const bool fused_build = inv && n >= 2 && A.prof == nullptr;    // build + the inversions of level 0 in one launch
   {
     int64_t work = (int64_t)n * 4096;
-    int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
     A.s = 1; A.offS_in = 0; A.offS_out = 0;
-    hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+    if (fused_build) {
+      int grid = int((work + 1023) / 1024); if (grid > 1024) grid = 1024;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcri_build_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv);
+      hipLaunchKernelGGL(bcri_build_invert_kernel, dim3(n / 2 + grid), dim3(64 * kInvWaves), lds_inv, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+    } else {
+      int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
+      hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+    }
   }
   using KernelFn = void (*)(BcrArgs);
   KernelFn k_level = nullptr, k_last = nullptr, k_prof = nullptr, k_final = nullptr;
@@ -699,6 +1189,13 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     hipLaunchKernelGGL(k_final, dim3(n), dim3(kBcrThreads), lds, st, A);
     return 0;
   }
+  // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel); 5 / 6: the same with 16 / 4 waves per pivot (measurements)
+  KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>, k_inv_last = bcri_invert_kernel<true, false>;
+  if (inv) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_last), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv_last);
+  }
+  const int inv_threads = 64 * kInvWaves;
   // forward: levels while more than one block is active
   int strides[40]; int npivs[40]; int nlev = 0;
   int64_t off = 0;
@@ -706,16 +1203,23 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     const int m = (n + s - 1) / s;          // active blocks
     const int npiv = m / 2;
     A.s = s; A.offS_in = off; A.offS_out = off + (m - 1);
-    hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(npiv), dim3(kBcrThreads), lds, st, A);
-    hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, npiv), dim3(256), 0, st, A);
+    if (inv) {
+      BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
+      if (!(fused_build && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(inv_threads), lds_inv, st, Ai);
+      hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv), dim3(256), 0, st, A);
+    } else {
+      hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(npiv), dim3(kBcrThreads), lds, st, A);
+      hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, npiv), dim3(256), 0, st, A);
+    }
     strides[nlev] = s; npivs[nlev] = npiv; ++nlev;
     off += m - 1;
   }
   A.s = 0; A.offS_in = 0; A.offS_out = 0;
-  hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
+  if (inv) hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(inv_threads), lds_inv_last, st, A);
+  else hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
   for (int l = nlev - 1; l >= 0; --l) {
     A.s = strides[l];
-    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
+    hipLaunchKernelGGL(inv ? bcri_backward_kernel : bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
   }
   return 0;
 }

@@ -24,7 +24,7 @@ static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, c
                                   double min_diag, double max_diag, hipStream_t st) {
   SolveBuffers sb = sb_in; sb.radius = radius;
   if (sb.algo != 1 && launch_bcr_solve(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st) == 0) return 0;
-  if ((sb.algo == 2 || sb.algo == 3) && tl.Pb > 0) return -1;
+  if (sb.algo >= 2 && tl.Pb > 0) return -1;
   launch_lm_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, st);
   return launch_band_arrow_cholesky(tl, sb, st);
 }

@@ -13,5 +13,5 @@ tr.SetOption("solver_algorithm", algo)
 tr.SetOption("solver_partitions", int(sys.argv[2]) if len(sys.argv)>2 else 0)
 rc=f(tr._h, E.SPLINE|E.T_I_C|E.GRAVITY_DIR, out)
 v=list(out)
-names = ["load","A_store","bar1","update","bar2","lfac","A_ldsload","A_chain"] if algo == 2 else ["init","phaseC","barC","phaseO_A","barO","x5","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"]
+names = ["load","A_store","bar1","update","bar2","lfac","A_ldsload","A_chain"] if algo in (2, 4, 5, 6) else ["init","phaseC","barC","phaseO_A","barO","x5","tile_load","tile_mfma","Bpublish","Bborderpub","Brest","tile_store"]
 print(rc, dict(zip(names,v)), sum(v))

@@ -12,7 +12,7 @@ for algo in algos:
     for p in ([1, 0] if algo == 1 else [0]):
         tr.SetOption("solver_partitions", p)
         try:
-            print(cfg, "algorithm", {1: "band sweep", 2: "block cyclic reduction", 3: "parallel block cyclic reduction", 0: "automatic"}[algo], "partitions", p if p else "auto",
+            print(cfg, "algorithm", {1: "band sweep", 2: "block cyclic reduction", 3: "parallel block cyclic reduction", 0: "automatic"}.get(algo, "cyclic reduction through pivot inverses (%d)" % algo), "partitions", p if p else "auto",
                   "solve ms", round(tr.TimeLinearSolve(F, 10), 4), flush=True)
         except Exception as e:
             print(algo, p, "failed", e)

@@ -10,8 +10,8 @@ python - "$F" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sel = [r for r in rows if "bcr_" in r["Kernel_Name"]]
-idx = [i for i, r in enumerate(sel) if "bcr_build" in r["Kernel_Name"]]
+sel = [r for r in rows if "bcr" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(sel) if "build" in r["Kernel_Name"]]
 sw = sel[idx[-2]:idx[-1]]
 t0 = int(sw[0]["Start_Timestamp"])
 for r in sw:
