@@ -224,11 +224,11 @@ def main():
         # Kernel groups of one LM iteration.  "blocks" is the fused residual+Jacobian+Gram launch the
         # metric is named after (ONE launch per pass: all_blocks_kernel<true>); view/accel/gyro are its
         # three residual families timed as stand-alone launches; "solve" is the 17-launch block cyclic
-        # reduction (bcr_build/eliminate/schur/backward), a dependent-latency chain, reported as a group.
+        # reduction through the pivot inverses (bcri_build_invert / invert / schur / backward), a dependent-latency chain, reported as a group.
         times = dict(blocks=pass_ms, view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
         names = dict(blocks="tile_kernel<true, false> + slab_merge_kernel", view="tile_kernel<true, false> (views only) + slab_merge_kernel",
                      accel="tile_kernel<true, false> (accelerometer only) + slab_merge_kernel", gyro="tile_kernel<true, false> (gyroscope only) + slab_merge_kernel",
-                     solve="bcr_build_kernel + bcr_eliminate_kernel + bcr_schur_kernel + bcr_backward_kernel")
+                     solve="bcri_build_invert_kernel + bcri_invert_kernel + bcri_schur_kernel + bcri_backward_kernel")
         kernels = {k: dict(kernel=names[k], ms=times[k], alg_bytes=b_alg[k], alg_flops=f_alg[k],
                            hbm_GBps=b_alg[k] / (times[k] * 1e-3) / 1e9 if times[k] > 0 else 0.0,
                            fp64_TFLOPs=f_alg[k] / (times[k] * 1e-3) / 1e12 if times[k] > 0 else 0.0) for k in times}
@@ -258,8 +258,8 @@ def main():
                              "the newest profiles/r*_pmc_hbm_C2.csv (%s)." % os.path.basename(pmc),
                         step_share=dict(blocks_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
                                         solve_group=dict(kernels=names["solve"], ms=solve_ms, fp64_frac=kernels["solve"]["fp64_TFLOPs"] / 78.6,
-                                                         why="dependent chain: ceil(log2 n)+1 block eliminations of 64 columns each (pivot recurrences at ~40 cycles "
-                                                             "per dependent fp64 operation) and one kernel boundary per tree level")),
+                                                         why="dependent chain: ceil(log2 n)+1 inversions of 64 x 64 pivot blocks (pivot recurrences at ~200 cycles per column), "
+                                                             "each followed by a Schur launch, and a back substitution launch per tree level: three kernel boundaries per level")),
                         kernels=kernels)
         out = {
             "metric": "residual+Jacobian blocks/sec; wall-clock per LM iter, GoPro9 full calib",
