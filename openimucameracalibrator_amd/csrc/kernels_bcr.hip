@@ -50,6 +50,7 @@ struct BcrArgs {
   int delay;                   // debug: panel waves > 0 sleep this many x ~1000 cycles before they read a panel (makes that hazard deterministic)
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
+  int top;                     // bcri_invert_kernel<LAST>: the one pivot of the top level (> 0), whose back substitution block 0's workgroup does as well
   // parallel cyclic reduction: every block is a pivot at every level; the coupling of the pair (k, k + s) is stored twice,
   // slot 2k with k's variables as the column index ("k major") and slot 2k + 1 with those of k + s
   int pcr;
@@ -627,7 +628,8 @@ __device__ __forceinline__ bcr_v4d bcri_z_tile(const double* W, int yt, int li, 
 // What follows the factorisation of [D_i ; I] (all waves, after a workgroup barrier): Z = X X^T, and for block 0 (LAST) the arrow
 // corner and the first back substitution.
 template <bool LAST>
-__device__ __forceinline__ void bcri_tail(const BcrArgs& A, double* W, double* da, int* failp, const double* Fs, double* Zg, int tid, int wave, int lane, bool report) {
+__device__ __forceinline__ void bcri_tail(const BcrArgs& A, double* W, double* da, int* failp, const double* Fs, double* Zg, int tid, int wave, int lane, bool report,
+                                          const double (&ttop)[12], const double ytop, double* x0s) {
   constexpr int LD = kInvLD, NW = kInvWaves, NT = 64 * NW, FLD = 65;
   const int li = lane & 15, lq = lane >> 4;
   const int a = A.a, a1 = a + 1;
@@ -699,9 +701,30 @@ __device__ __forceinline__ void bcri_tail(const BcrArgs& A, double* W, double* d
       for (int k = 0; k < 8; ++k) v = fma(-t8[k], d8[k], v);
     }
     if (lane < A.Pb) A.x[lane] = v;
+    x0s[lane] = lane < A.Pb ? v : 0.0;
   }
   __syncthreads();
   if (tid == 0 && *failp) atomicOr(A.fail, 1);
+  if (A.top > 0) {
+    // the one pivot of the top level (left neighbour block 0, no right neighbour): x = T_rhs - T_left^T x_0 - T_arrow^T x_arrow;
+    // its rows of T were loaded when the kernel started
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int r = wave + NW * k;
+      const double xv = r < 64 ? x0s[r] : ((r >= 128 && r < 128 + a) ? da[r - 128] : 0.0);
+      sum = fma(ttop[k], xv, sum);
+    }
+    W[wave * 64 + lane] = sum;            // (W is free: NW x 64 partial sums)
+    __syncthreads();
+    if (wave == 0) {
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc += W[w * 64 + lane];
+      const int gi = A.top * 64 + lane;
+      if (gi < A.Pb) A.x[gi] = ytop - acc;
+    }
+  }
 }
 
 
@@ -727,6 +750,16 @@ __device__ __forceinline__ void bcri_invert_body(const BcrArgs& A, const int i, 
   long long tprev = prof ? clock64() : 0;
 #define BCR_MARK(k) do { if (PROF && prof) { const long long tn_ = clock64(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
   if (tid == 0) *failp = 0;
+  double ttop[12], ytop = 0.0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) ttop[k] = 0.0;
+  if (LAST && A.top > 0) {
+    const double* Tt = A.Lf + (int64_t)A.top * (192 + a1) * 64 + 4096;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { const int r = wave + NW * k; if (r < 64 || (r >= 128 && r < 128 + A.a)) ttop[k] = Tt[r * 64 + lane]; }
+    if (wave == 0) ytop = Tt[(128 + A.a) * 64 + lane];
+    asm volatile("" ::: "memory");   // (issued here, used after the corner: the loads must not sink to their use)
+  }
   {
     constexpr int PER = 4096 / NT;
     double gd[PER], gf[PER];
@@ -833,7 +866,7 @@ __device__ __forceinline__ void bcri_invert_body(const BcrArgs& A, const int i, 
     BCR_MARK(4);
   }
   BCR_MARK(4);
-  bcri_tail<LAST>(A, W, da, failp, Fs, Zg, tid, wave, lane, report);
+  bcri_tail<LAST>(A, W, da, failp, Fs, Zg, tid, wave, lane, report, ttop, ytop, dg);
   BCR_MARK(5);
   if (PROF && prof && lane == 0) for (int k = 0; k < 8; ++k) A.prof[k] = pc[k];
 #undef BCR_MARK
@@ -986,6 +1019,95 @@ __global__ __launch_bounds__(64 * kBackWaves) void bcri_backward_kernel(BcrArgs 
     for (int w = 0; w < kBackWaves; ++w) acc += part[w][lane];
     const int gi = i * 64 + lane;
     if (gi < A.Pb) A.x[gi] = yv - acc;
+  }
+}
+
+// Two levels of the back substitution in one launch: a workgroup takes a pivot j of the upper level (stride 2 s) and then, eight
+// waves each, its two neighbours j - s and j + s, which are pivots of the lower level (stride s) and need x_j -- it stays in LDS.
+// Every row of T the three products read is in flight before the first barrier.  A lower pivot whose upper neighbour lies beyond
+// the last block (at most one) gets a workgroup of its own behind the others.
+__global__ __launch_bounds__(1024) void bcri_backward2_kernel(BcrArgs A, int npiv_upper, int orphan) {
+  constexpr int NW = 16, RW1 = 192 / NW, RW2 = 192 / (NW / 2);
+  __shared__ double xs[4][64];            // x of j - 2 s, j, j + 2 s, the arrow part
+  __shared__ double part[NW][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = A.a, a1 = a + 1, s = A.s, n = A.n;
+  const int64_t ru64 = (int64_t)(192 + a1) * 64;
+  const bool lone = (int)blockIdx.x >= npiv_upper;                  // the orphan: only a "left child", its right neighbour does not exist
+  const int j = lone ? orphan + s : 2 * s * (2 * (int)blockIdx.x + 1);
+  const int jl = j - 2 * s, jr = j + 2 * s;
+  const bool has_jr = !lone && jr < n;
+  // lower pivots: half 0 = j - s (neighbours jl, j), half 1 = j + s (neighbours j, jr)
+  const int half = wave >> 3, hw = wave & 7;
+  const int ci = half == 0 ? j - s : j + s;
+  const bool child = half == 0 ? true : (!lone && ci < n);
+  const bool child_hasR = half == 0 ? !lone : jr < n;
+  auto xin = [&](int blk, int r) { const int gi = blk * 64 + r; return gi < A.Pb ? A.x[gi] : 0.0; };
+  if (tid < 64) xs[0][tid] = xin(jl, tid);
+  else if (tid < 128) xs[2][tid - 64] = has_jr ? xin(jr, tid - 64) : 0.0;
+  else if (tid < 192) xs[3][tid - 128] = tid - 128 < a ? A.x[A.Pb + (tid - 128)] : 0.0;
+  else if (tid < 256 && lone) xs[1][tid - 192] = 0.0;
+  double l1[RW1], l2[RW2], y1 = 0.0, y2 = 0.0;
+  {
+    const double* T1 = A.Lf + j * ru64 + 4096;
+#pragma unroll
+    for (int k = 0; k < RW1; ++k) {
+      const int r = wave + NW * k;
+      const bool ok = !lone && r < 128 + a && (has_jr || r < 64 || r >= 128);
+      l1[k] = ok ? T1[r * 64 + lane] : 0.0;
+    }
+    if (wave == 0 && !lone) y1 = T1[(128 + a) * 64 + lane];
+    const double* T2 = A.Lf + ci * ru64 + 4096;
+#pragma unroll
+    for (int k = 0; k < RW2; ++k) {
+      const int r = hw + 8 * k;
+      const bool ok = child && r < 128 + a && (child_hasR || r < 64 || r >= 128);
+      l2[k] = ok ? T2[r * 64 + lane] : 0.0;
+    }
+    if (hw == 0 && child) y2 = T2[(128 + a) * 64 + lane];
+  }
+  __syncthreads();
+  if (!lone) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < RW1; ++k) {
+      const int r = wave + NW * k;
+      const double xv = r < 64 ? xs[0][r] : (r < 128 ? xs[2][r - 64] : (r < 128 + a ? xs[3][r - 128] : 0.0));
+      sum = fma(l1[k], xv, sum);
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0) {
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc += part[w][lane];
+      const double xv = y1 - acc;
+      const int gi = j * 64 + lane;
+      xs[1][lane] = gi < A.Pb ? xv : 0.0;
+      if (gi < A.Pb) A.x[gi] = xv;
+    }
+    __syncthreads();
+  }
+  {
+    const double* xl = half == 0 ? xs[0] : xs[1];
+    const double* xr = half == 0 ? xs[1] : xs[2];
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < RW2; ++k) {
+      const int r = hw + 8 * k;
+      const double xv = r < 64 ? xl[r] : (r < 128 ? xr[r - 64] : (r < 128 + a ? xs[3][r - 128] : 0.0));
+      sum = fma(l2[k], xv, sum);
+    }
+    part[wave][lane] = sum;
+    __syncthreads();
+    if (hw == 0 && child) {
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) acc += part[8 * half + w][lane];
+      const int gi = ci * 64 + lane;
+      if (gi < A.Pb) A.x[gi] = y2 - acc;
+    }
   }
 }
 
@@ -1215,11 +1337,25 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     off += m - 1;
   }
   A.s = 0; A.offS_in = 0; A.offS_out = 0;
+  A.top = (inv && nlev >= 1) ? strides[nlev - 1] : 0;     // (the top level has one pivot, block `stride`)
   if (inv) hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(inv_threads), lds_inv_last, st, A);
   else hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
+  if (inv) {
+    // back substitution below the top level: two levels per launch from the bottom up (an odd count: the uppermost alone, first)
+    int l = nlev - 2;        // (the top level went with block 0)
+    if (l >= 0 && !(l & 1)) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); --l; }
+    for (; l >= 1; l -= 2) {
+      const int s = strides[l - 1];
+      int orphan = -1;      // the lower pivot s (2 c + 1), c even, whose upper neighbour would be block >= n
+      if (npivs[l - 1] > 2 * npivs[l]) orphan = s * (2 * (npivs[l - 1] - 1) + 1);    // (4 q + 2 active blocks at the lower level)
+      A.s = s;
+      hipLaunchKernelGGL(bcri_backward2_kernel, dim3(npivs[l] + (orphan >= 0 ? 1 : 0)), dim3(1024), 0, st, A, npivs[l], orphan);
+    }
+    return 0;
+  }
   for (int l = nlev - 1; l >= 0; --l) {
     A.s = strides[l];
-    hipLaunchKernelGGL(inv ? bcri_backward_kernel : bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
+    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
   }
   return 0;
 }
