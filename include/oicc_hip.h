@@ -306,6 +306,11 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps);
 /* Same for the damped band+arrow solve of the last assembled system. */
 int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats,
                            double* ms_per_solve);
+/* Verification of the linear solver at any size: one damped solve (SPARSE_NORMAL_CHOLESKY step of ceres::Solve, called at
+ * spline_trajectory_estimator.impl.h:272) at the current point with trust-region radius `radius`, then the residual of the step against
+ * the packed normal equations themselves: out = {||M d - rhs|| / ||rhs||, ||rhs||, factorisation failure flag},
+ * M = S JtJ S + clamp(diag)/radius, rhs = -S Jtr (S: Jacobi scaling). */
+int oicc_solve_residual(oicc_problem* p, int32_t flags, double radius, double out[3]);
 
 /* ---- read-back: mirrors the getters ------------------------------------- */
 int oicc_get_T_i_c(const oicc_problem* p, double q_xyzw_t_xyz[7]);  /* impl.h:1133 */

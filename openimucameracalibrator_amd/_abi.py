@@ -103,6 +103,7 @@ DEVICE_ONLY = {
     "set_allreduce": (C.c_int, [H, ALLREDUCE_FN, C.c_void_p]),
     "time_jacobian_pass": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_dp]),
     "time_linear_solve": (C.c_int, [H, C.c_int32, C.c_int32, c_dp]),
+    "solve_residual": (C.c_int, [H, C.c_int32, C.c_double, c_dp]),
     "run_lm_iterations": (C.c_int, [H, C.c_int32, C.c_int32]),
     "estimate_imu_to_camera_rotation": (C.c_int, [C.c_int32, C.c_int64, c_dp, c_dp, C.c_int64, c_dp, c_dp, C.c_double, C.c_int32,
                                                   c_dp, c_dp, c_dp, c_dp, c_i32p]),

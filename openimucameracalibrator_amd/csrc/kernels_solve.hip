@@ -19,6 +19,7 @@
 // arrow row) ride along, so the Schur complement C - Y^T Y and L^-1(-g) come out
 // of the same sweep.  A backward sweep in 8-row blocks yields the step.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "oicc_device.h"
 #include "spline_math.cuh"
 #include "spline_seg.cuh"
@@ -289,6 +290,52 @@ __global__ void lm_step_slope_kernel(const double* g, const double* step_s, cons
 }
 
 // ---- launchers ----------------------------------------------------------------
+// Residual of the damped, scaled system the solvers just solved, straight from the packed normal equations (none of the
+// solvers' own data): r = (S H S + D^2 / radius) delta_s + S g.  Band rows: one thread per row (lower band by columns:
+// band[j*W + k] = H(j + k, j)); each also adds its share of the arrow rows' sums to acc[2 + q].  out: acc[0] = sum r^2,
+// acc[1] = sum rhs^2 (band rows here, arrow rows by lm_solve_residual_arrow_kernel).
+__global__ void lm_solve_residual_band_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, double* acc) {
+  __shared__ double red[2][256];
+  const int Pb = tl.Pb, a = tl.a, W = tl.W, hb = tl.hb;
+  const double* band = ne.band(); const double* Et = ne.Et(); const double* g = ne.g();
+  double r2 = 0.0, b2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Pb; i += (int64_t)gridDim.x * blockDim.x) {
+    const double si = sb.scale[i], di = sb.step_s[i];
+    double v = sb.D2[i] * di;
+    for (int k = 0; k <= hb && i + k < Pb; ++k) v += band[i * W + k] * si * sb.scale[i + k] * sb.step_s[i + k];
+    for (int k = 1; k <= hb && i - k >= 0; ++k) v += band[(i - k) * W + k] * si * sb.scale[i - k] * sb.step_s[i - k];
+    for (int q = 0; q < a; ++q) {
+      const double e = Et[(int64_t)q * Pb + i] * si * sb.scale[Pb + q];
+      v += e * sb.step_s[Pb + q];
+      if (e != 0.0) unsafeAtomicAdd(acc + 2 + q, e * di);
+    }
+    const double rhs = -g[i] * si;
+    r2 += (v - rhs) * (v - rhs); b2 += rhs * rhs;
+  }
+  red[0][threadIdx.x] = r2; red[1][threadIdx.x] = b2;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { unsafeAtomicAdd(acc, red[0][0]); unsafeAtomicAdd(acc + 1, red[1][0]); }
+}
+__global__ void lm_solve_residual_arrow_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, double* acc) {
+  const int Pb = tl.Pb, a = tl.a, q = threadIdx.x;
+  if (q >= a) return;
+  const double sq = sb.scale[Pb + q];
+  double v = sb.D2[Pb + q] * sb.step_s[Pb + q] + acc[2 + q];
+  for (int q2 = 0; q2 < a; ++q2) v += ne.C()[q * a + q2] * sq * sb.scale[Pb + q2] * sb.step_s[Pb + q2];
+  const double rhs = -ne.g()[Pb + q] * sq;
+  unsafeAtomicAdd(acc, (v - rhs) * (v - rhs)); unsafeAtomicAdd(acc + 1, rhs * rhs);
+}
+// acc: 2 + a doubles, zeroed here
+void launch_lm_solve_residual(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, double* acc, hipStream_t st) {
+  (void)hipMemsetAsync(acc, 0, (2 + (size_t)tl.a) * sizeof(double), st);
+  if (tl.Pb > 0) hipLaunchKernelGGL(lm_solve_residual_band_kernel, dim3(std::min(1024, (tl.Pb + 255) / 256)), dim3(256), 0, st, ne, tl, sb, acc);
+  if (tl.a > 0) hipLaunchKernelGGL(lm_solve_residual_arrow_kernel, dim3(1), dim3(64), 0, st, ne, tl, sb, acc);
+}
+
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st) {
   hipLaunchKernelGGL(lm_step_slope_kernel, dim3(1), dim3(1024), 0, st, g, sb.step_s, sb.scale, P, out);
 }

@@ -15,6 +15,7 @@ void launch_lm_gradmax(const NormalEq& ne, int P, LmState* s, hipStream_t st);
 void launch_lm_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                      double max_diag, hipStream_t st);
 int launch_band_arrow_cholesky(const TangentLayout& tl, const SolveBuffers& sb, hipStream_t st);
+void launch_lm_solve_residual(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, double* acc, hipStream_t st);
 int64_t bcr_workspace_doubles(const TangentLayout& tl);
 int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                      double max_diag, hipStream_t st);

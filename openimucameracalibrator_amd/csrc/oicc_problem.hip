@@ -1678,6 +1678,29 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   return OICC_OK;
 }
 
+// One damped solve of the system at the current point, checked against the packed normal equations themselves:
+// out = {||M delta - rhs||_2 / ||rhs||_2, ||rhs||_2, Cholesky failure flag} with M = S H S + D^2 / radius, rhs = -S g.
+int oicc_solve_residual(oicc_problem* p, int32_t flags, double radius, double out[3]) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
+  const TangentLayout& tl = p->tl;
+  if (tl.P == 0) { out[0] = out[1] = out[2] = 0.0; return OICC_OK; }
+  SolveBuffers sb = solve_buffers(p);
+  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+  HIPCK(p, hipMemsetAsync(p->d_state.p, 0, sizeof(LmState), st));
+  if (launch_lm_solve(p->ne, tl, sb, radius, 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+  DevBuf<double> acc; if (!acc.resize(2 + size_t(tl.a))) return OICC_ERR_HIP;
+  launch_lm_solve_residual(p->ne, tl, sb, acc.p, st);
+  double h[2] = {0, 0}; LmState hs;
+  HIPCK(p, hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipStreamSynchronize(st));
+  out[1] = std::sqrt(h[1]); out[0] = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : std::sqrt(h[0]); out[2] = double(hs.chol_failed);
+  return OICC_OK;
+}
+
 int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes) {
   int rc = prepare(p, flags); if (rc) return rc;
   if (!p->reduce) { p->err = "no reduction path installed (oicc_rccl_init / oicc_set_allreduce)"; return OICC_ERR_STATE; }

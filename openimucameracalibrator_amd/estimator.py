@@ -322,6 +322,12 @@ class SplineTrajectoryEstimator:
         self._ck(self._b.time_linear_solve(self._h, int(flags), int(repeats), C.byref(ms)))
         return ms.value
 
+    def SolveResidual(self, flags, radius=1e4):
+        """One damped solve at the current point, checked against the packed normal equations: (relative residual, ||rhs||, failed)."""
+        out = (C.c_double * 3)()
+        self._ck(self._b.solve_residual(self._h, int(flags), float(radius), out))
+        return out[0], out[1], bool(out[2])
+
     # ---- getters ------------------------------------------------------------
     def GetNumSO3Knots(self):
         return int(self._b.get_num_so3_knots(self._h))

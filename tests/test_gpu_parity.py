@@ -304,6 +304,22 @@ def test_block_cyclic_reduction_deep_tree_c4():
     assert all(np.allclose(costs[0], c, rtol=1e-9, atol=0) for c in costs[1:])
 
 
+@pytest.mark.parametrize("cfg", ["C2", "C4", "C5"])
+def test_linear_solvers_leave_a_small_residual_at_full_size(cfg):
+    """A size-independent check of the linear solvers, at the full size of BASELINE's configurations (C5: 90 k band columns, 1406
+    blocks, 11 reduction levels): one damped solve, then ||M d - rhs|| / ||rhs|| from the packed normal equations themselves (no
+    solver data).  The Cholesky-based solvers (band sweep, factor-based cyclic reduction) are backward stable: ~5e-16.  The cyclic
+    reduction through the explicit inverses of the pivot blocks (the automatic choice) and the parallel cyclic reduction pay a
+    factor of 10-150, still 1e-14 -- five orders below the tolerance of the LM iterate comparisons."""
+    ds = synthetic.make_config(cfg)
+    for algo, bound in ((1, 2e-14), (2, 2e-14), (0, 1e-12), (4, 1e-12)) + (((3, 1e-12),) if cfg == "C2" else ()):
+        cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        cal.trajectory_.SetOption("solver_algorithm", algo)
+        for radius in (1e4, 1e16):       # Ceres' initial radius; (almost) no damping: the normal equations as they are
+            res, rhs_norm, failed = cal.trajectory_.SolveResidual(FLAGS1, radius)
+            assert not failed and rhs_norm > 0 and res < bound, (cfg, algo, radius, res)
+
+
 def test_parallel_cyclic_reduction_on_c3():
     """C3 (606 + 306 knots: 43 blocks, 6 levels of the parallel cyclic reduction) against the partitioned band sweep, with LDS
     poisoned before every solve and through rejected steps (a start far from the valley)."""
