@@ -368,6 +368,7 @@ int make_layout(oicc_problem* p, int flags) {
   }
   L.hb = hb;
   p->act = a;
+  const bool timing = p->opt["verbose"] >= 2.0; const double tl0 = now_s();
   // device copies
   hipStream_t st = p->stream;
   if (!p->d_tl_so3.upload(L.so3, st) || !p->d_tl_r3.upload(L.r3, st) || !p->d_tl_ab.upload(L.ab, st) || !p->d_tl_gb.upload(L.gb, st)) {
@@ -388,7 +389,9 @@ int make_layout(oicc_problem* p, int flags) {
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   p->layout_flags = -1;   // (stays invalid if the tiles cannot be built)
+  const double tl1 = now_s();
   const int rc = build_tiles(p);
+  if (timing) std::printf("[oicc] layout: uploads + buffers %.3f ms, tiles %.3f ms\n", 1e3 * (tl1 - tl0), 1e3 * (now_s() - tl1));
   if (rc == OICC_OK) { p->layout_flags = flags; p->layout_ld_zero = p->x[p->pl.ld] == 0.0; p->layout_opt_gen = p->opt_gen; ++p->layout_gen; }
   return rc;
 }
@@ -693,10 +696,16 @@ int prepare(oicc_problem* p, int flags) {
   ARG(p, p->pl.n_so3 > 0, "oicc_set_times has not been called");
   ARG(p, !(flags & OICC_POINTS), "OICC_POINTS (board point refinement) is not supported on this path");
   HIPCK(p, hipSetDevice(p->device));
+  const bool timing = p->opt["verbose"] >= 2.0;
+  const double t0 = now_s();
   int rc = sync_measurements(p); if (rc) return rc;
+  const double t1 = now_s();
   rc = sync_params_to_device(p); if (rc) return rc;
+  const double t2 = now_s();
   if (p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen) return OICC_OK;   // layout, buffers and tiles are current
-  return make_layout(p, flags);
+  rc = make_layout(p, flags);
+  if (timing) std::printf("[oicc] prepare: measurements %.3f ms, parameters %.3f ms, layout + buffers + tiles %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
+  return rc;
 }
 
 EvalCtx make_ctx(oicc_problem* p, const double* x) {
@@ -749,10 +758,16 @@ int build_inner_plan(oicc_problem* p, int flags) {
   // Hessian graph: an edge between two blocks that share a residual block (one clique per group of items)
   std::vector<std::vector<int>> adj;
   struct Group { std::vector<int> ids; int32_t first = 0, count = 0, ss = 0, sr = -1, sb = -1; bool open = false; };
+  // consecutive groups of a residual family share all but one or two of their blocks: a pair of blocks that was together in the
+  // family's previous group already has its edge (the lists are made unique below; this only keeps them short)
+  std::vector<int> in_prev[3]; int serial[3] = {0, 0, 0};
   auto flush = [&](int kind, Group& gq) {
     if (!gq.open) return;
     gq.open = false;
     if (adj.size() < B.size()) adj.resize(B.size());
+    std::vector<int>& prev = in_prev[kind];
+    if (prev.size() < B.size()) prev.resize(B.size(), -1);
+    const int cur = ++serial[kind];
     for (int x : gq.ids) {
       if (x < 0) continue;
       HB& h = B[x];
@@ -765,8 +780,10 @@ int build_inner_plan(oicc_problem* p, int flags) {
       if (gq.sr >= 0) { h.r0 = std::min(h.r0, int(gq.sr)); h.r1 = std::max(h.r1, int(gq.sr) + kN); }
       if (kind == 1) { h.a0 = std::min(h.a0, int(gq.sb)); h.a1 = std::max(h.a1, int(gq.sb) + kNb); }
       if (kind == 2) { h.g0 = std::min(h.g0, int(gq.sb)); h.g1 = std::max(h.g1, int(gq.sb) + kNb); }
-      for (int y : gq.ids) if (y >= 0 && x != y) adj[x].push_back(y);
+      const bool x_old = prev[x] == cur - 1;
+      for (int y : gq.ids) if (y >= 0 && x != y && !(x_old && prev[y] == cur - 1)) adj[x].push_back(y);
     }
+    for (int x : gq.ids) if (x >= 0) prev[x] = cur;
   };
   const size_t nv = p->view_rs.size();
   {
