@@ -29,6 +29,8 @@
 // E^T B^-1 [E | g] into the corner, and the last workgroup to finish solves the corner and writes the step.
 // 11 dependent launches instead of 17 for C2 (no bcr_backward launches), the idle CUs pay for the extra eliminations.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 #include "oicc_device.h"
 
 namespace oicc {
@@ -1225,6 +1227,23 @@ __global__ __launch_bounds__(64 * kInvWaves) void bcri_build_invert_kernel(Norma
 }
 
 // ---- host ------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): set once per pair, not once per solve
+// (a solve is a dozen launches of ~10 us; the attribute calls were a measurable part of its host time)
+static void bcr_allow_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, uint64_t> done;
+  int dev = 0; (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    uint64_t& mask = done[fn];
+    if (dev < 64 && (mask & bit)) return;
+    mask |= bit;
+  }
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
 // Arrow limit: the kernels take up to 63 arrow columns (four 16-row border tiles).  Round 2 saw sporadic NaN pivots with more than
 // two border tiles; the cause was the in-place read of the panel's diagonal block by waves that start a panel late (see the panel
@@ -1277,7 +1296,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     A.s = 1; A.offS_in = 0; A.offS_out = 0;
     if (fused_build) {
       int grid = int((work + 1023) / 1024); if (grid > 1024) grid = 1024;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcri_build_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv);
+      bcr_allow_lds(reinterpret_cast<const void*>(bcri_build_invert_kernel), lds_inv);
       hipLaunchKernelGGL(bcri_build_invert_kernel, dim3(n / 2 + grid), dim3(64 * kInvWaves), lds_inv, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
     } else {
       int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
@@ -1292,10 +1311,10 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     case 273: k_level = bcr_eliminate_kernel<273, 0, false>; k_last = bcr_eliminate_kernel<273, 1, false>; k_prof = k_level; k_final = bcr_eliminate_kernel<273, 2, false>; break;
     default: return -1;
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_level), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_last), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prof), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  bcr_allow_lds(reinterpret_cast<const void*>(k_level), lds);
+  bcr_allow_lds(reinterpret_cast<const void*>(k_last), lds);
+  bcr_allow_lds(reinterpret_cast<const void*>(k_prof), lds);
+  bcr_allow_lds(reinterpret_cast<const void*>(k_final), lds);
   const int schur_groups = (36 + 8 * A.rtf + (A.rtf * (A.rtf + 1)) / 2 + 3) / 4;
   if (A.pcr) {
     // every level: all n blocks against their neighbours at distance s; the couplings ping-pong between the two buffers
@@ -1314,8 +1333,8 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel); 5 / 6: the same with 16 / 4 waves per pivot (measurements)
   KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>, k_inv_last = bcri_invert_kernel<true, false>;
   if (inv) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_last), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv_last);
+    bcr_allow_lds(reinterpret_cast<const void*>(k_inv), lds_inv);
+    bcr_allow_lds(reinterpret_cast<const void*>(k_inv_last), lds_inv_last);
   }
   const int inv_threads = 64 * kInvWaves;
   // forward: levels while more than one block is active
