@@ -621,9 +621,13 @@ __device__ __forceinline__ bcr_v4d bcri_z_tile(const double* W, int yt, int li, 
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { vy[kk] = py[4 * (K0 + kk) * LD]; vx[kk] = px[4 * (K0 + kk) * LD]; }
   asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
-  bcr_v4d g = {0.0, 0.0, 0.0, 0.0};
+  bcr_v4d g = {0.0, 0.0, 0.0, 0.0}, g2 = {0.0, 0.0, 0.0, 0.0};   // (two accumulators: the dependent chain is NK / 2 MFMAs)
 #pragma unroll
-  for (int kk = 0; kk < NK; ++kk) g = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk], vx[kk], g, 0, 0, 0);
+  for (int kk = 0; kk < NK; kk += 2) {
+    g = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk], vx[kk], g, 0, 0, 0);
+    g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk + 1], vx[kk + 1], g2, 0, 0, 0);
+  }
+  g += g2;
   return g;   // g[r] <-> (x row 16 XT + li, y row 16 yt + lq + 4 r)
 }
 
