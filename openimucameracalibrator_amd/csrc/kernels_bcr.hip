@@ -1294,7 +1294,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   if (lds > 160 * 1024 - 64) return -1;
   const bool inv = !A.pcr && (sb.algo == 0 || sb.algo == 4);   // (2: the factor-based levels, kept as an independent solver)
   const size_t lds_inv = ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double), lds_inv_last = lds_inv + (size_t)64 * 65 * sizeof(double);
-  const bool fused_build = inv && n >= 2 && A.prof == nullptr;    // build + the inversions of level 0 in one launch
+  const bool fused_build = inv && n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
   {
     int64_t work = (int64_t)n * 4096;
     A.s = 1; A.offS_in = 0; A.offS_out = 0;
