@@ -223,7 +223,7 @@ def main():
         b_alg, f_alg = algorithmic_model(cal, ds, (P, Pb, a, hb))
         # Kernel groups of one LM iteration.  "blocks" is the fused residual+Jacobian+Gram launch the
         # metric is named after (ONE launch per pass: all_blocks_kernel<true>); view/accel/gyro are its
-        # three residual families timed as stand-alone launches; "solve" is the 17-launch block cyclic
+        # three residual families timed as stand-alone launches; "solve" is the 13-launch block cyclic
         # reduction through the pivot inverses (bcri_build_invert / invert / schur / backward), a dependent-latency chain, reported as a group.
         times = dict(blocks=pass_ms, view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
         names = dict(blocks="tile_kernel<true, false> + slab_merge_kernel", view="tile_kernel<true, false> (views only) + slab_merge_kernel",
