@@ -22,6 +22,11 @@
 //   corner, solves it and starts the back substitution, which then runs level by level
 //   in reverse, again one workgroup per pivot.
 //
+// The DEFAULT since round 3 is the same reduction through the explicit INVERSES of the pivot blocks (bcri_* kernels in the second
+// half of this file, solver_algorithm 4 = automatic): only the 64 x 64 diagonal block of a pivot is factored in one workgroup, its
+// border rows become matrix products on other CUs and the back substitution a matrix-vector product.  What follows first is the
+// factor-based formulation of rounds 1-2 (solver_algorithm 2), kept as an independent solver for the tests.
+//
 // PARALLEL cyclic reduction (round 3) for systems of at most one block per CU (n <= 256: BASELINE configs 2-4): every
 // level eliminates EVERY block against its neighbours at distance s (same kernels, all n blocks as pivots), which
 // decouples the blocks after ceil(log2 n) levels and needs no back substitution through the levels: the arrow columns
