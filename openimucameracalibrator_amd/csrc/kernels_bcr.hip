@@ -1339,7 +1339,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     hipLaunchKernelGGL(k_final, dim3(n), dim3(kBcrThreads), lds, st, A);
     return 0;
   }
-  // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel); 5 / 6: the same with 16 / 4 waves per pivot (measurements)
+  // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel)
   KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>, k_inv_last = bcri_invert_kernel<true, false>;
   if (inv) {
     bcr_allow_lds(reinterpret_cast<const void*>(k_inv), lds_inv);
