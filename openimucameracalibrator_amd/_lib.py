@@ -10,7 +10,7 @@ import os
 from ._abi import Bound, BoundBa
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liboicc_hip.so")
+LIB_PATH = os.environ.get("OICC_DEV_LIB") or os.path.join(_HERE, "csrc", "liboicc_hip.so")   # OICC_DEV_LIB: another BUILD of the same library (developer A/B timing, scripts/build_variant.sh)
 _bound = None
 _bound_ba = None
 

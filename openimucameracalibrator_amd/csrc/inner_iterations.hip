@@ -566,7 +566,9 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
           const int pair = s_lo + tid / kSegStride;
           if (pair < n_pairs && pair <= blk.idx) {
             A.seg[(size_t)s_lo * kSegStride + tid] = S.segcur[tid];
-            if (local) s_seg[(s_lo - blk.ks0) * kSegStride + tid] = S.segcur[tid];
+            // the LDS mirror holds the pairs [ks0, ks0 + nks - 1) only: pair idx - 1 lies in front of it when no item's window starts before
+            // the knot itself (ks0 == idx: the first touched knot, or the first knot after a gap in the measurements)
+            if (local && pair >= blk.ks0 && pair - blk.ks0 < blk.nks - 1) s_seg[(pair - blk.ks0) * kSegStride + (tid - (pair - s_lo) * kSegStride)] = S.segcur[tid];
           }
         }
       }
@@ -610,6 +612,13 @@ void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t s
   if (n_wgs <= 0) return;
   if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, A);
   else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, A);
+}
+// Workgroups of the general build that are resident at the same time on `n_cu` compute units (occupancy query, not an assumption: the
+// workgroups that share a block spin on each other, so a set's shared parts must all fit next to whatever else runs on the device)
+int inner_set_resident_capacity(int n_cu) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inner_set_kernel<false>, InnerCfg<false>::T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return per_cu * n_cu;
 }
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st) {
   if (nb > 0) hipLaunchKernelGGL(inner_diff_norm_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, x, xc, blocks, nb, step_norm_sq);

@@ -336,6 +336,35 @@ void launch_lm_solve_residual(const NormalEq& ne, const TangentLayout& tl, const
   if (tl.a > 0) hipLaunchKernelGGL(lm_solve_residual_arrow_kernel, dim3(1), dim3(64), 0, st, ne, tl, sb, acc);
 }
 
+// Rank consistency on the all-reduce HOOK path (no broadcast primitive there): every rank packs [candidate | step scalars | 1],
+// the hook sums the pack, and every rank takes the mean -- identical bits everywhere, each rank's own value up to rounding.
+//   pack[0 .. n) = x,  pack[n .. n + 3) = model cost change, |step|^2, |x|^2,  pack[n + 3] = Cholesky failed,  pack[n + 4] = 1
+__global__ void rank_pack_kernel(const double* x, int64_t n, const LmState* s, double* pack) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + 5; i += (int64_t)gridDim.x * blockDim.x) {
+    double v;
+    if (i < n) v = x[i];
+    else if (s == nullptr) v = i == n + 4 ? 1.0 : 0.0;
+    else v = i == n ? s->model_cost_change : i == n + 1 ? s->step_norm_sq : i == n + 2 ? s->x_norm_sq : i == n + 3 ? double(s->chol_failed != 0) : 1.0;
+    pack[i] = v;
+  }
+}
+__global__ void rank_unpack_kernel(double* x, int64_t n, LmState* s, const double* pack) {
+  const double inv = 1.0 / pack[n + 4];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + 4; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n) x[i] = pack[i] * inv;
+    else if (s != nullptr) {
+      if (i == n) s->model_cost_change = pack[i] * inv; else if (i == n + 1) s->step_norm_sq = pack[i] * inv; else if (i == n + 2) s->x_norm_sq = pack[i] * inv;
+      else s->chol_failed = pack[i] > 0.0 ? 1 : 0;
+    }
+  }
+}
+void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st) {
+  hipLaunchKernelGGL(rank_pack_kernel, dim3(int(std::min<int64_t>(1024, (n + 5 + 255) / 256))), dim3(256), 0, st, x, n, s, pack);
+}
+void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hipStream_t st) {
+  hipLaunchKernelGGL(rank_unpack_kernel, dim3(int(std::min<int64_t>(1024, (n + 4 + 255) / 256))), dim3(256), 0, st, x, n, s, pack);
+}
+
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st) {
   hipLaunchKernelGGL(lm_step_slope_kernel, dim3(1), dim3(1024), 0, st, g, sb.step_s, sb.scale, P, out);
 }

@@ -2,18 +2,21 @@
 // Design: tiles.h.  What Ceres does per residual block (Evaluate -> J * plus-Jacobian -> block sparse J^T J,
 // reference spline_trajectory_estimator.impl.h:255-276 -> ceres::Solve) is fused into one launch:
 //
-//   workgroup = one tile of consecutive knot windows, 4 waves
-//     P0  knots, tangent offsets, accumulator rows of the knots and the tile's unit descriptors -> LDS (one round trip: the knot
+//   workgroup = one CHAIN of consecutive tiles (tiles.h), walked in time order; per tile of consecutive knot windows:
+//     P0  knots, tangent offsets, ring slots of the knots and the tile's unit descriptors -> LDS (one round trip: the knot
 //         range is predicted from the tile index while the descriptor is in flight); per knot pair the segment table (log, axis,
-//         Jr^-1: spline_seg.cuh), loaded from the table of this parameter vector or, on one-round problems, computed here
+//         Jr^-1: spline_seg.cuh), loaded from the table of this parameter vector or, on one-round problems, computed here;
+//         the accumulator rows of the knots this tile is the first of the chain to touch are zeroed
 //     P1  every wave pulls units from the tile's queue:  lane = item (corner / IMU sample)
 //           spline evaluation, residual, analytic Jacobian rows (block_items.cuh) -> compact rows in the wave's LDS buffer
 //           per CELL (a view, or the samples sharing one set of knot windows) the augmented Gram matrix [J r]^T [J r]
 //           as 16x16 v_mfma_f64_16x16x4_f64 tiles, operands expanded from the compact rows while they are loaded
-//           tiles -> the tile's band accumulator in LDS (ds_add_f64)
-//     P2  interior rows (no other tile has them) -> the packed normal equations; halo rows + arrow corner -> the tile's slab in
-//         HBM; plain coalesced stores either way
-//   slab_merge_kernel: halo rows of the packed normal equations = sum of the slab rows that hold them (fixed order), max |g|.
+//           tiles -> the band accumulator in LDS (ds_add_f64)
+//     P2  the rows of the knots no later tile of the chain touches leave the CU: into the packed normal equations (no other
+//         chain has them: final), or into the chain's slab (the ~50 rows at each end of a chain); plain stores either way
+//     after the last tile: the arrow corner -> the chain's slab
+//   slab_merge_kernel: chain-boundary rows of the packed normal equations = sum of the slab rows that hold them (fixed order),
+//   arrow corner = sum over the chains, max |g|.
 //   Problem-constant arguments live in device memory (TileStatic): by value they cost a 9k-cycle spill prologue per workgroup.
 //
 // The cost-only pass (candidate point of an LM step) is the same kernel without rows and accumulators.
@@ -312,14 +315,20 @@ __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLa
 
 }  // namespace
 
-template <bool JAC, bool DIRECT>
-__global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __restrict__ S, TileDyn dyn) {
+// One tile of a chain: P0 staging, P1 units, P2 stores (see the header of this file).  Returns the cost of the items this thread
+// evaluated.  (As a real function call -- OICC_TILE_BODY_ATTR = __noinline__ -- the pass is 7 % slower at C5 and 5 % at C2: measured
+// on one box against the inlined build, scripts/ab_pass.sh.)
+#ifndef OICC_TILE_BODY_ATTR
+#define OICC_TILE_BODY_ATTR __forceinline__
+#endif
+template <bool JAC, bool DIRECT, int MAXW>
+__device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S, const TileDyn& dyn, const int tile, const int tile0, const int tile1, long long* prof) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const EvalCtx& ctx = S->ctx; const ViewData& vd = S->vd; const ImuData& ia = S->ia; const ImuData& ig = S->ig;
   const RowFmt& fv = S->fmt[0]; const RowFmt& fa_ = S->fmt[1]; const RowFmt& fg = S->fmt[2]; const TileParams& tp = S->tp;
   const double* __restrict__ xg = dyn.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const TileDesc td = tp.tiles[blockIdx.x];   // (issued here, first needed after the staging below)
+  const int kTileThreads = blockDim.x, kTileWaves = kTileThreads >> 6;   // (run-time: TileParams::n_waves)
   double* acc = lds + tp.o_acc;
   double* l_so3 = lds + tp.o_so3;
   double* l_r3 = lds + tp.o_r3;
@@ -332,85 +341,88 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
   double* l_zero = lds + tp.o_zero;                            // an all-zero item record (rows past a cell)
   int* colinfo = reinterpret_cast<int*>(lds + tp.o_wave + (size_t)wave * tp.wave_doubles);   // [64][3] of the wave's current cell
   double* rb = lds + tp.o_wave + (size_t)wave * tp.wave_doubles + 96;
-
-  const bool prof_on = JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && wave == 0;
-  long long* prof = prof_on ? dyn.prof : nullptr;
+  int* const l_slot_so3 = l_tl_so3 + 2 * kMaxTileKnots; int* const l_slot_r3 = l_tl_r3 + 2 * kMaxTileKnots;   // ring slot of every staged knot
+  int* const l_todo_so3 = l_tl_so3 + 4 * kMaxTileKnots; int* const l_todo_r3 = l_tl_r3 + 4 * kMaxTileKnots;   // TileDesc::rows_off, table `todo`
+  int* const l_tdb = reinterpret_cast<int*>(lds + tp.o_misc + 12);   // descriptors of the chain's later tiles, [tile & 1][12 ints]
+  Target T;
+  T.acc = acc; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
+  double cost_local = 0.0;
   const long long tp0 = prof ? clock64() : 0;
-  // ---- P0: knots, tangent offsets, segment tables, zeroed accumulator ----
-  // (what does not depend on the tile descriptor comes first: it overlaps the descriptor's load)
-  if (JAC) {
-    if (!DIRECT) {
-      const int nacc = tp.acc_rows * tp.Wl + tp.corner;
-      for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0;
-    }
-    if (tid < 192) {
-      const int kind = __builtin_amdgcn_readfirstlane(tid >> 6), col = tid & 63;   // (wave-uniform: the format's fields are scalar loads)
-      int ba, fa, grp;
-      const RowFmt fk = S->fmt[kind];   // (by value: a few wide scalar loads instead of one per field)
-      column_table_entry(fk, col, ba, fa, grp);
-      l_ct[tid] = ba; l_ct[192 + tid] = fa; l_ct[384 + tid] = grp;
-    }
-    if (tid < 128) l_zero[tid] = 0.0;
-  }
+  // the tile's descriptor: the chain's first one straight from memory (issued here, first needed after the staging below), the
+  // later ones were fetched into LDS behind the units of the tile before
+  TileDesc td;
+  if (tile == tile0) td = tp.tiles[tile0]; else td = *reinterpret_cast<const TileDesc*>(l_tdb + 12 * (tile & 1));
+  int td_prefetch = 0;
+  if (tile + 1 < tile1 && tid < 12) td_prefetch = reinterpret_cast<const int*>(tp.tiles + tile + 1)[tid];
+  // ---- P0: knots, tangent offsets, segment tables, ring slots; the rows of new knots zeroed ----
   // Knots and their tangent offsets: loaded for the knot ranges the affine model of TileParams predicts (clamped to the knot
   // vectors) without waiting for the descriptor, and once more for the few tiles whose descriptor says otherwise.
-  // (at most kMaxTileKnots knots of a kind: one element per thread and array, all four loads in flight before the first LDS store)
-  static_assert(4 * kMaxTileKnots <= kTileThreads, "one staged element per thread");
+  // (all loads of a pass in flight before the first LDS store; a pass covers every array with 256 threads, fewer threads loop)
   auto stage_knots = [&](int ks0, int nks, int kr0, int nkr) {
-    const bool ha = tid < nks * 4, hb = tid < nkr * 3, hc = JAC && tid < nks, hd = JAC && tid < nkr;
-    const double va = ha ? xg[ctx.pl.so3 + (int64_t)ks0 * 4 + tid] : 0.0;
-    const double vb = hb ? xg[ctx.pl.r3 + (int64_t)kr0 * 3 + tid] : 0.0;
-    const int vc = hc ? ctx.tl.so3[ks0 + tid] : 0;
-    const int vd_ = hd ? ctx.tl.r3[kr0 + tid] : 0;
-    // segment tables of the staged knot pairs: kSegStride doubles per pair, precomputed for this parameter vector
-    constexpr int kSegPerThread = (kMaxTileKnots * kSegStride + kTileThreads - 1) / kTileThreads;
     const int nseg = dyn.seg != nullptr ? (nks - 1) * kSegStride : 0;
     const double* sg = dyn.seg + (int64_t)ks0 * kSegStride;
-    double vs[kSegPerThread];
+    for (int base = 0; base < 4 * kMaxTileKnots; base += kTileThreads) {
+      const int i = base + tid;
+      const bool ha = i < nks * 4, hb = i < nkr * 3, hc = JAC && i < nks, hd = JAC && i < nkr;
+      const double va = ha ? xg[ctx.pl.so3 + (int64_t)ks0 * 4 + i] : 0.0;
+      const double vb = hb ? xg[ctx.pl.r3 + (int64_t)kr0 * 3 + i] : 0.0;
+      const int vc = hc ? ctx.tl.so3[ks0 + i] : 0;
+      const int vd_ = hd ? ctx.tl.r3[kr0 + i] : 0;
+      // segment tables of the staged knot pairs: kSegStride doubles per pair, precomputed for this parameter vector
+      constexpr int kSegPerPass = (kMaxTileKnots * kSegStride + 4 * kMaxTileKnots - 1) / (4 * kMaxTileKnots);
+      double vs[kSegPerPass];
 #pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j) { const int i = tid + j * kTileThreads; vs[j] = i < nseg ? sg[i] : 0.0; }
-    if (ha) l_so3[tid] = va;
-    if (hb) l_r3[tid] = vb;
-    if (hc) l_tl_so3[tid] = vc;
-    if (hd) l_tl_r3[tid] = vd_;
+      for (int j = 0; j < kSegPerPass; ++j) { const int q = i + j * 4 * kMaxTileKnots; vs[j] = q < nseg ? sg[q] : 0.0; }
+      if (ha) l_so3[i] = va;
+      if (hb) l_r3[i] = vb;
+      if (hc) l_tl_so3[i] = vc;
+      if (hd) l_tl_r3[i] = vd_;
 #pragma unroll
-    for (int j = 0; j < kSegPerThread; ++j) { const int i = tid + j * kTileThreads; if (i < nseg) l_seg[i] = vs[j]; }
+      for (int j = 0; j < kSegPerPass; ++j) { const int q = i + j * 4 * kMaxTileKnots; if (q < nseg) l_seg[q] = vs[j]; }
+    }
   };
   int g_ks0 = -1, g_nks = 0, g_kr0 = -1, g_nkr = 0;
   if (tp.affine) {
-    const int b = blockIdx.x;
+    const int b = tile;
     g_ks0 = tp.td0.ks0 + b * tp.tds.ks0; g_nks = tp.td0.nks + b * tp.tds.nks; g_kr0 = tp.td0.kr0 + b * tp.tds.kr0; g_nkr = tp.td0.nkr + b * tp.tds.nkr;
     const bool sane = g_ks0 >= 0 && g_nks >= 0 && g_nks <= kMaxTileKnots && g_ks0 + g_nks <= (int)ctx.pl.n_so3 && g_kr0 >= 0 && g_nkr >= 0 && g_nkr <= kMaxTileKnots && g_kr0 + g_nkr <= (int)ctx.pl.n_r3;
     if (sane) stage_knots(g_ks0, g_nks, g_kr0, g_nkr); else g_ks0 = -1;
   }
   if (td.ks0 != g_ks0 || td.nks != g_nks || td.kr0 != g_kr0 || td.nkr != g_nkr) stage_knots(td.ks0, td.nks, td.kr0, td.nkr);
+  const int nk_tile = td.nks + td.nkr;   // staged knots: [0, nks) SO(3), [nks, nk_tile) R^3
   {   // the tile's unit descriptors (4 ints each): the waves read them from LDS instead of a dependent global load per unit
     const int* src = reinterpret_cast<const int*>(tp.units + td.unit0);
     for (int i = tid; i < 4 * (td.unit1 - td.unit0); i += kTileThreads) l_units[i] = src[i];
-    if (JAC && !DIRECT) {   // accumulator row of every staged knot
+    if (JAC && !DIRECT) {   // ring slot of every staged knot and what is to be done with its rows in this tile
       const int* ar = tp.tile_rows + td.rows_off;
-      if (tid < td.nks) l_tl_so3[2 * kMaxTileKnots + tid] = ar[tid];
-      else if (tid >= 64 && tid - 64 < td.nkr) l_tl_r3[2 * kMaxTileKnots + tid - 64] = ar[td.nks + tid - 64];
+      for (int k = tid; k < nk_tile; k += kTileThreads) {
+        const int sl = ar[k], todo = ar[nk_tile + k];
+        if (k < td.nks) { l_slot_so3[k] = sl; l_todo_so3[k] = todo; } else { l_slot_r3[k - td.nks] = sl; l_todo_r3[k - td.nks] = todo; }
+      }
     }
   }
   if (tid == 0) l_queue[0] = 0;
-  if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   __syncthreads();
+  if (JAC && !DIRECT && tile != tile0) {   // rows of the knots that enter the chain with this tile
+    const int n3 = 3 * tp.Wl;
+    for (int k = wave; k < nk_tile; k += kTileWaves) {
+      const int todo = k < td.nks ? l_todo_so3[k] : l_todo_r3[k - td.nks];
+      if (!(todo & kTileTodoZero)) continue;
+      double* row = acc + (k < td.nks ? l_slot_so3[k] : l_slot_r3[k - td.nks]) * tp.Wl;
+      for (int e = lane; e < n3; e += 64) row[e] = 0.0;
+    }
+  }
   const long long tp1 = prof ? clock64() : 0;
   if (dyn.seg == nullptr) {   // small problems (one round of tiles): the tables are computed here, 1.2 us, rather than by a ~13 us chain in the retraction
     for (int i = tid; i < td.nks - 1; i += kTileThreads) {
       const double* a = l_so3 + 4 * i;
       so3_segment_prepare(Quat{a[0], a[1], a[2], a[3]}, Quat{a[4], a[5], a[6], a[7]}, l_seg + i * kSegStride);
     }
-    __syncthreads();
   }
-
-  Target T;
-  T.acc = acc; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
+  if (dyn.seg == nullptr || (JAC && !DIRECT && tile != tile0)) __syncthreads();
   const long long tp2 = prof ? clock64() : 0;
 
   // ---- P1: units ----
-  double cost_local = 0.0;
   while (true) {
     int u = 0;
     if (lane == 0) u = atomicAdd(l_queue, 1);
@@ -509,44 +521,85 @@ __global__ void __launch_bounds__(kTileThreads) tile_kernel(const TileStatic* __
     }
   }
 
-  if (!JAC) {   // cost pass: one atomic per tile (the cost slot is a single address: thousands of atomics on it serialise)
+  // ---- P2: the rows of the knots that leave the chain with this tile ----
+  const long long tp3 = prof ? clock64() : 0;
+  if (JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0 && tile + 1 == tile1) { dyn.prof[8 + (wave & 3)] = clock64(); if (wave == 0) dyn.prof[12] = tp0; }   // when each wave ran out of units (last tile of the chain)
+  if (JAC && !DIRECT) {
+    __syncthreads();
+    // A knot no later tile of the chain touches is complete as far as this chain goes.  If no other chain touches it either its
+    // three rows are final: band rows (one contiguous piece of the packed band), arrow columns and gradient entries go straight
+    // into the packed normal equations; else they go to the chain's slab for the merge.
+    double* slab = tp.slabs + (int64_t)blockIdx.x * tp.slab_stride;
+    const int Wl = tp.Wl, W = T.W, a = T.a, Pb = T.Pb;
+    for (int k = wave; k < nk_tile; k += kTileWaves) {
+      const int todo = k < td.nks ? l_todo_so3[k] : l_todo_r3[k - td.nks];
+      if (!(todo & kTileTodoStore)) continue;
+      const double* row = acc + (k < td.nks ? l_slot_so3[k] : l_slot_r3[k - td.nks]) * Wl;
+      const int srow = (todo >> 2) - 1;
+      if (srow >= 0) { double* dst = slab + (int64_t)srow * Wl; for (int e = lane; e < 3 * Wl; e += 64) dst[e] = row[e]; }
+      else {
+        const int g = k < td.nks ? l_tl_so3[k] : l_tl_r3[k - td.nks];   // the knot's first tangent row
+        double* band = T.ne.band() + (int64_t)g * W;
+        for (int e = lane; e < 3 * W; e += 64) { const int r = (e >= W) + (e >= 2 * W); band[e] = row[r * Wl + (e - r * W)]; }
+        for (int e = lane; e < 3 * (a + 1); e += 64) {
+          const int c = e / 3, r = e - 3 * c;
+          (c < a ? T.ne.Et() + (int64_t)c * Pb : T.ne.g())[g + r] = row[r * Wl + W + c];
+        }
+      }
+    }
+  }
+  if (prof && lane == 0) {   // [4] staging, [5] segment tables, [6] the wave's units, [7] wait for the other waves + stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp4 = clock64();
+    prof[4] += tp1 - tp0; prof[5] += tp2 - tp1; prof[6] += tp3 - tp2; prof[7] += tp4 - tp3;
+  }
+  if (tile + 1 < tile1) { if (tid < 12) l_tdb[12 * ((tile + 1) & 1) + tid] = td_prefetch; __syncthreads(); }   // the next tile's staging overwrites the knot tables
+  return cost_local;
+}
+
+// CHAINED = false: every chain is one tile (one-round problems); the tile loop and its loop-carried state compile away
+// (inside the loop the kernel spills twice as many SGPRs: +2 us per C2 pass, measured with scripts/ab_kstats.sh).
+template <bool JAC, bool DIRECT, int MAXW, bool CHAINED>
+__global__ void __launch_bounds__(64 * MAXW) tile_kernel(const TileStatic* __restrict__ S, TileDyn dyn) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const TileParams& tp = S->tp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kTileThreads = blockDim.x, kTileWaves = kTileThreads >> 6;   // (run-time: TileParams::n_waves)
+  const int tile0 = CHAINED ? blockIdx.x * tp.chain_len : blockIdx.x, tile1 = CHAINED ? min(tile0 + tp.chain_len, tp.n_tiles) : tile0 + 1;   // the chain
+  double* acc = lds + tp.o_acc;
+  const bool prof_on = JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && wave == 0;
+  long long* prof = prof_on ? dyn.prof : nullptr;
+  // ---- once per chain: column tables, the zero record, the accumulator ----
+  if (JAC) {
+    int* l_ct = reinterpret_cast<int*>(lds + tp.o_ct);
+    double* l_zero = lds + tp.o_zero;
+    if (!DIRECT) { const int nacc = tp.acc_rows * tp.Wl + tp.corner; for (int i = tid; i < nacc; i += kTileThreads) acc[i] = 0.0; }   // (every slot: the first tile's knots need no pass of their own, and this overlaps the descriptor's load)
+    for (int i = tid; i < 192; i += kTileThreads) {
+      const int kind = __builtin_amdgcn_readfirstlane(i >> 6), col = i & 63;   // (wave-uniform: the format's fields are scalar loads)
+      int ba, fa, grp;
+      const RowFmt fk = S->fmt[kind];   // (by value: a few wide scalar loads instead of one per field)
+      column_table_entry(fk, col, ba, fa, grp);
+      l_ct[i] = ba; l_ct[192 + i] = fa; l_ct[384 + i] = grp;
+    }
+    for (int i = tid; i < 128; i += kTileThreads) l_zero[i] = 0.0;
+  }
+  if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
+  double cost_local = 0.0;
+  for (int tile = tile0; tile < tile1; ++tile) cost_local += tile_body<JAC, DIRECT, MAXW>(S, dyn, tile, tile0, tile1, prof);
+
+
+  if (!JAC) {   // cost pass: one atomic per chain (the cost slot is a single address: thousands of atomics on it serialise)
     const double s = wave_sum_d(cost_local);
     double* part = lds + tp.o_misc + 2;
     if (lane == 0) part[wave] = s;
     __syncthreads();
-    if (tid == 0) { const double t = (part[0] + part[1]) + (part[2] + part[3]); if (t != 0.0) unsafeAtomicAdd(dyn.cost_out, t); }
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < kTileWaves; ++w) t += part[w]; if (t != 0.0) unsafeAtomicAdd(dyn.cost_out, t); }
     return;
   }
-  // ---- P2: accumulator -> slab ----
-  const long long tp3 = prof ? clock64() : 0;
-  if (JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0) { dyn.prof[8 + wave] = clock64(); if (wave == 0) dyn.prof[12] = tp0; }   // when each wave ran out of units
-  if (!DIRECT) {
+  if (!DIRECT) {   // the arrow corner [C | g_arrow ; . | 2 cost] accumulated over the whole chain
     __syncthreads();
-    // Rows no other tile touches ([x0, x1): the tile's interior) are final: their band rows are one contiguous piece of the
-    // packed band, their arrow columns and gradient entries contiguous pieces of Et / g -- flat, coalesced stores.  The halo
-    // rows and the arrow corner go to the slab for the merge.
     double* slab = tp.slabs + (int64_t)blockIdx.x * tp.slab_stride;
-    const int Wl = tp.Wl, W = T.W, a = T.a, Pb = T.Pb, x0 = td.x0, x1 = td.x1, nown = x1 - x0;
-    for (int i = tid; i < x0 * Wl; i += kTileThreads) slab[i] = acc[i];
-    for (int i = x1 * Wl + tid; i < td.nrows * Wl; i += kTileThreads) slab[i] = acc[i];
-    if (nown > 0) {
-      const unsigned magic = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);     // idx / W for idx < 2^16
-      double* band = T.ne.band() + (int64_t)td.g0 * W;
-      for (int idx = tid; idx < nown * W; idx += kTileThreads) {
-        const int r = int(__umulhi((unsigned)idx, magic)), e = idx - r * W;
-        band[idx] = acc[(x0 + r) * Wl + e];
-      }
-      for (int c = wave; c <= a; c += kTileWaves) {
-        double* dst = (c < a ? T.ne.Et() + (int64_t)c * Pb : T.ne.g()) + td.g0;
-        for (int r = lane; r < nown; r += 64) dst[r] = acc[(x0 + r) * Wl + W + c];
-      }
-    }
-    for (int i = tid; i < tp.corner; i += kTileThreads) slab[tp.acc_rows * tp.Wl + i] = acc[tp.acc_rows * tp.Wl + i];
-  }
-  if (prof && lane == 0) {   // [4] staging, [5] segment tables, [6] the wave's units, [7] wait for the other waves + slab stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long tp4 = clock64();
-    prof[4] += tp1 - tp0; prof[5] += tp2 - tp1; prof[6] += tp3 - tp2; prof[7] += tp4 - tp3;
+    for (int i = tid; i < tp.corner; i += kTileThreads) slab[(int64_t)tp.slab_rows * tp.Wl + i] = acc[tp.acc_rows * tp.Wl + i];
   }
 }
 
@@ -622,7 +675,7 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
   const int p = ent / a1, q = ent - p * a1;
   if (p > q) return;
   double s = 0.0;
-  for (int t = threadIdx.x; t < tp.n_tiles; t += 256) s += tp.slabs[(int64_t)t * tp.slab_stride + (int64_t)tp.acc_rows * tp.Wl + ent];
+  for (int t = threadIdx.x; t < tp.n_chains; t += 256) s += tp.slabs[(int64_t)t * tp.slab_stride + (int64_t)tp.slab_rows * tp.Wl + ent];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
@@ -657,20 +710,29 @@ void launch_lds_poison(hipStream_t st) {
 }
 
 // ---- launchers ----
-template <bool JAC, bool DIRECT>
-static void launch_tile_kernel(const TileStatic* dS, const TileDyn& dyn, int n_tiles, size_t lds, hipStream_t st) {
+template <bool JAC, bool DIRECT, int MAXW, bool CHAINED>
+static void launch_tile_kernel_c(const TileStatic* dS, const TileDyn& dyn, int n_chains, int n_waves, size_t lds, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
-  allow_full_lds(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT>), done);
-  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT>), dim3(n_tiles), dim3(kTileThreads), lds, st, dS, dyn);
+  allow_full_lds(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT, MAXW, CHAINED>), done);
+  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT, MAXW, CHAINED>), dim3(n_chains), dim3(64 * n_waves), lds, st, dS, dyn);
+}
+template <bool JAC, bool DIRECT, int MAXW>
+static void launch_tile_kernel(const TileStatic* dS, const TileDyn& dyn, int n_chains, int n_waves, size_t lds, hipStream_t st, bool chained) {
+  if (chained) launch_tile_kernel_c<JAC, DIRECT, MAXW, true>(dS, dyn, n_chains, n_waves, lds, st);
+  else launch_tile_kernel_c<JAC, DIRECT, MAXW, false>(dS, dyn, n_chains, n_waves, lds, st);
 }
 // hS: the host copy of *dS (already uploaded on this stream)
 int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st) {
   const TileParams& tp = hS.tp;
   if (tp.n_tiles == 0) return 0;
+  const int nw = tp.n_waves;
+  const bool chained = tp.chain_len > 1;
+  if (nw < 1 || nw > kTileMaxWaves) return -1;
   if (jac) {
-    if (tp.direct) launch_tile_kernel<true, true>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
+    if (tp.direct) launch_tile_kernel<true, true, 4>(dS, dyn, tp.n_chains, std::min(nw, 4), tp.lds_bytes, st, chained);
     else {
-      launch_tile_kernel<true, false>(dS, dyn, tp.n_tiles, tp.lds_bytes, st);
+      if (nw <= 4) launch_tile_kernel<true, false, 4>(dS, dyn, tp.n_chains, nw, tp.lds_bytes, st, chained);
+      else launch_tile_kernel<true, false, 8>(dS, dyn, tp.n_chains, nw, tp.lds_bytes, st, chained);
       const int64_t entries = (int64_t)tp.n_merge_rows * (hS.ctx.tl.W + hS.ctx.tl.a);
       const int U = entries > (int64_t)256 * 2048 * 4 ? 4 : 1;           // several entries per thread only when there are enough workgroups to fill the chip anyway
       const int nb_rows = int((entries + 256 * U - 1) / (256 * U));
@@ -683,7 +745,7 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
       else hipLaunchKernelGGL(slab_merge_kernel<1>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
     }
   } else {
-    launch_tile_kernel<false, false>(dS, dyn, tp.n_tiles, (size_t)tp.o_acc * sizeof(double), st);   // knots, tables and the queue only
+    launch_tile_kernel<false, false, 4>(dS, dyn, tp.n_chains, std::min(nw, 4), (size_t)tp.o_acc * sizeof(double), st, chained);   // knots, tables and the queue only
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -40,6 +40,9 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
 void launch_lds_poison(hipStream_t st);
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
 void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st);
+int inner_set_resident_capacity(int n_cu);
+void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st);
+void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
@@ -135,6 +138,7 @@ struct oicc_problem {
   ImuDev d_acc, d_gyr;
   DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
   DevBuf<double> d_ws;
+  DevBuf<double> d_rank_pack;   // all-reduce hook path: [candidate | step scalars | rank count] (make_rank_consistent)
   DevBuf<double> d_ne2;   // second normal-equation buffer: the Jacobian pass at the candidate runs while the host decides
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
@@ -173,12 +177,15 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["inner_shared_residency"] = 0.5;     // share of the device's resident workgroups the parts of a set's shared blocks (T_i_c, gravity, line delay, IMU intrinsics) may take together
     opt["debug_inner_general_kernel"] = 0;   // 1: sets of R^3 knots run on the general 4-wave build of the inner kernel too (tests: both builds give the same sweep)
     opt["debug_inner_profile"] = 0;   // g + 1: print the phase clocks of workgroup 0 of independent set g after every sweep
     opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 2: tiles in direct mode (fp64 atomics on the packed buffer: the independent accumulation path of the tests)
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
+    opt["chain_tiles"] = 0;     // consecutive tiles one workgroup walks with its ring accumulator (tiles.h); 0: automatic = ceil(tiles / compute units)
+    opt["accumulation"] = 0;    // 1 = deterministic: one wave per chain, every sum of the Jacobian pass in a fixed order (bit-identical runs; slower)
     opt["view_unit_items"] = 0; opt["accel_unit_items"] = 0; opt["gyro_unit_items"] = 0;   // items per unit of the tile pass (0: as many as fit the wave's row buffer); smaller units = more waves per tile busy on one-round problems
     opt["wide_cells"] = 1;      // IMU samples of several consecutive SO(3) windows share one Gram product (as many as fit the 16-column blocks)
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
@@ -586,11 +593,15 @@ int build_tiles(oicc_problem* p) {
   auto carve = [&](int nks, int nkr, int nunits, int acc_doubles) {   // returns total doubles
     int o = 0;
     tp.o_so3 = o; o += nks * 4; tp.o_r3 = o; o += std::max(nkr, 1) * 3; tp.o_seg = o; o += std::max(nks - 1, 1) * 17;
-    tp.o_tl = o; o += 2 * kMaxTileKnots; /* int tables: tangent offsets [so3 | r3], accumulator rows [so3 | r3] */ tp.o_misc = o; o += 8; tp.o_units = o; o += 2 * std::max(nunits, 1); tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += kTileWaves * tp.wave_doubles;
+    tp.o_tl = o; o += 3 * kMaxTileKnots; /* int tables [so3 | r3] each: tangent offsets, ring slots, what to do with the knot's rows in this tile */ tp.o_misc = o; o += 24; /* queue | per-wave cost partials | two tile descriptors */ tp.o_units = o; o += 2 * std::max(nunits, 1); tp.o_ct = o; o += 288; tp.o_zero = o; o += 128; tp.o_acc = o; o += acc_doubles; tp.o_wave = o; o += tp.n_waves * tp.wave_doubles;
     return o;
   };
   TileBuild tb;
   tp.direct = mode == 2 ? 1 : 0;
+  // waves per workgroup: one per SIMD; option accumulation = 1 ("deterministic"): ONE wave per chain takes the units in their fixed
+  // order, so the LDS additions (and with the fixed chain order of the merge every sum of the pass) happen in one order: two runs
+  // give the same bits (for bisecting a parity failure; slower)
+  tp.n_waves = p->opt["accumulation"] != 0.0 ? 1 : 4;
   auto try_T = [&](int t) {   // builds the tiles for t windows; true if they fit
     make_tiles(p, t, &tb);
     if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;
@@ -606,7 +617,7 @@ int build_tiles(oicc_problem* p) {
   int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); if (n_cu < 1) n_cu = 256;
   p->n_cu = n_cu;
   const double work_cycles = 800.0 * double(p->corner_view.size()) + 1300.0 * double(p->acc.size()) + 800.0 * double(p->gyr.size());
-  const double w_us = std::min(50.0, std::max(1.0, 1.15 * work_cycles / double(std::max<int64_t>(n_windows, 1)) / kTileWaves / 2400.0));
+  const double w_us = std::min(50.0, std::max(1.0, 1.15 * work_cycles / double(std::max<int64_t>(n_windows, 1)) / 4 / 2400.0));
   bool fits = false;
   while (true) {
     int t = std::max(T, 1);
@@ -635,38 +646,79 @@ int build_tiles(oicc_problem* p) {
   tp.lds_bytes = carve(tb.max_nks, tb.max_nkr, tb.max_units, tp.direct ? 0 : tb.max_rows * tp.Wl + tp.corner) * int(sizeof(double));
   p->h_tiles.swap(tb.tiles); p->h_units.swap(tb.units);
   tp.n_tiles = int32_t(p->h_tiles.size()); tp.n_units = int32_t(p->h_units.size());
-  tp.slab_stride = int64_t(tp.acc_rows) * tp.Wl + tp.corner;
-  // Which tiles hold which band row: (tile, accumulator row) lists in tile order.  Rows of exactly one tile that are consecutive
-  // in the layout form the tile's interior (TileDesc::x0, x1, g0): stored by the tile itself; every other row is merged from slabs.
-  p->h_tile_rows.swap(tb.knot_rows);
-  std::vector<std::vector<std::pair<int32_t, int32_t>>> holders(std::max(tl.Pb, 1));
-  if (!tp.direct) for (int32_t t = 0; t < tp.n_tiles; ++t)
-    for (int r = 0; r < p->h_tiles[t].nrows; ++r) holders[tb.row_of[size_t(tb.row_of_off[t]) + r]].push_back({t, r});
-  p->h_row_direct.assign(std::max(tl.Pb, 1), 0);
-  for (int32_t t = 0; t < tp.n_tiles; ++t) {
-    TileDesc& td = p->h_tiles[t];
-    td.x0 = td.x1 = 0; td.g0 = 0;
-    if (tp.direct || p->opt["debug_no_direct_rows"] != 0.0) continue;
-    const int32_t* g = tb.row_of.data() + tb.row_of_off[t];
-    int best0 = 0, best1 = 0, run0 = -1;
-    for (int r = 0; r <= td.nrows; ++r) {
-      const bool own = r < td.nrows && holders[g[r]].size() == 1;
-      const bool cont = own && run0 >= 0 && g[r] == g[r - 1] + 1;
-      if (run0 >= 0 && !cont) { if (r - run0 > best1 - best0) { best0 = run0; best1 = r; } run0 = -1; }
-      if (own && run0 < 0) run0 = r;
-    }
-    td.x0 = best0; td.x1 = best1; td.g0 = best1 > best0 ? g[best0] : 0;
-    for (int r = td.x0; r < td.x1; ++r) p->h_row_direct[g[r]] = 1;
+  // Chains: workgroup c walks tiles [c L, (c + 1) L), L = the number of rounds the tiles would need as workgroups of their own.
+  tp.chain_len = std::max(1, int(p->opt["chain_tiles"]) > 0 ? int(p->opt["chain_tiles"]) : (tp.n_tiles + n_cu - 1) / n_cu);
+  tp.n_chains = (tp.n_tiles + tp.chain_len - 1) / tp.chain_len;
+  // Which chains touch which knot (a knot = 3 consecutive tangent rows): a knot of exactly one chain is stored by that chain (final),
+  // every other knot goes through the slabs of its chains and the merge.  Inside a chain a knot lives in one ring slot from the first
+  // to the last tile that stages it (tiles and knots ascend in time, so a knot's tiles are consecutive).
+  const int32_t n_s = int32_t(p->pl.n_so3), n_r = int32_t(p->pl.n_r3);
+  std::vector<int32_t> first_chain(size_t(n_s) + n_r, -1), last_chain(size_t(n_s) + n_r, -1), slot_of(size_t(n_s) + n_r, -1);   // by knot: SO(3) knot i at i, R^3 knot j at n_s + j
+  auto knot_id = [&](const TileDesc& td, int k) { return k < td.nks ? td.ks0 + k : n_s + td.kr0 + (k - td.nks); };
+  auto knot_off = [&](int id) { return !a.spline ? -1 : (id < n_s ? p->L.so3[id] : p->L.r3[id - n_s]); };
+  if (!tp.direct) for (int32_t t = 0; t < tp.n_tiles; ++t) {
+    const TileDesc& td = p->h_tiles[t]; const int32_t c = t / tp.chain_len;
+    for (int k = 0; k < td.nks + td.nkr; ++k) { const int id = knot_id(td, k); if (first_chain[id] < 0) first_chain[id] = c; last_chain[id] = c; }
   }
-  p->h_merge_rows.clear();
-  for (int i = 0; i < tl.Pb; ++i) if (!p->h_row_direct[i]) p->h_merge_rows.push_back(i);
+  const bool all_slab = p->opt["debug_no_direct_rows"] != 0.0;
+  p->h_row_direct.assign(std::max(tl.Pb, 1), 0);
+  struct Held { int32_t row, chain, slab_row; };
+  std::vector<Held> held;                                              // rows that go through slabs, generated in chain order
+  std::vector<int32_t> tables;                                         // per tile [slot | todo] over its staged knots (TileDesc::rows_off)
+  std::vector<int32_t> free_slots;
+  tp.slab_rows = 0;
+  if (!tp.direct) for (int32_t c = 0; c < tp.n_chains; ++c) {
+    const int32_t t0 = c * tp.chain_len, t1 = std::min(tp.n_tiles, t0 + tp.chain_len);
+    free_slots.clear();                                                // knot slots (units of 3 rows), lowest first
+    for (int sl = tp.acc_rows / 3 - 1; sl >= 0; --sl) free_slots.push_back(sl);
+    int32_t slab_row = 0;
+    for (int32_t t = t0; t < t1; ++t) {
+      TileDesc& td = p->h_tiles[t];
+      const int nk = td.nks + td.nkr;
+      const int32_t off0 = int32_t(tables.size());
+      tables.resize(tables.size() + 2 * size_t(nk), -1);
+      int32_t* slot = tables.data() + off0; int32_t* todo = slot + nk;
+      const TileDesc* tn = t + 1 < t1 ? &p->h_tiles[t + 1] : nullptr;
+      auto staged_next = [&](int k) {   // the ranges of consecutive tiles ascend
+        if (!tn) return false;
+        return k < td.nks ? (td.ks0 + k >= tn->ks0 && td.ks0 + k < tn->ks0 + tn->nks) : (td.kr0 + (k - td.nks) >= tn->kr0 && td.kr0 + (k - td.nks) < tn->kr0 + tn->nkr); };
+      for (int k = 0; k < nk; ++k) {
+        todo[k] = 0;
+        const int id = knot_id(td, k), o = knot_off(id);
+        if (o < 0) continue;
+        if (slot_of[id] < 0) {
+          if (free_slots.empty()) { p->err = "tile ring: no free accumulator slot (internal)"; return OICC_ERR_STATE; }
+          slot_of[id] = free_slots.back(); free_slots.pop_back();
+          todo[k] |= kTileTodoZero;
+        }
+        slot[k] = 3 * slot_of[id];
+        if (!staged_next(k)) {
+          todo[k] |= kTileTodoStore;
+          if (all_slab || first_chain[id] != c || last_chain[id] != c) { todo[k] |= (slab_row + 1) << 2; for (int r = 0; r < 3; ++r) held.push_back(Held{o + r, c, slab_row + r}); slab_row += 3; }
+          else for (int r = 0; r < 3; ++r) p->h_row_direct[o + r] = 1;
+        }
+      }
+      for (int k = nk - 1; k >= 0; --k) if (todo[k] & kTileTodoStore) { const int id = knot_id(td, k); free_slots.push_back(slot_of[id]); slot_of[id] = -1; }   // free for the next tile
+      td.rows_off = off0;
+    }
+    tp.slab_rows = std::max(tp.slab_rows, slab_row);
+  }
+  p->h_tile_rows.swap(tables);
+  tp.slab_stride = int64_t(tp.slab_rows) * tp.Wl + tp.corner;
+  std::stable_sort(held.begin(), held.end(), [](const Held& x, const Held& y) { return x.row < y.row; });   // (chain order kept inside a row: the merge's fixed summation order)
+  p->h_merge_rows.clear(); p->h_merge_ptr.assign(1, 0); p->h_merge_src.clear();
+  for (size_t i = 0; i < held.size(); ++i) {
+    if (i == 0 || held[i].row != held[i - 1].row) { if (i) p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size())); p->h_merge_rows.push_back(held[i].row); }
+    p->h_merge_src.push_back(int64_t(held[i].chain) * tp.slab_stride + int64_t(held[i].slab_row) * tp.Wl);
+  }
+  if (!held.empty()) p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size()));
+  tp.n_merge_rows = int32_t(p->h_merge_rows.size());
+  // band rows nobody touches (knots in the layout without a measurement on this rank: multi-GPU shards) are merge rows with no source: the merge writes zeros
+  for (int i = 0; i < tl.Pb; ++i) if (!p->h_row_direct[i] && !tp.direct) {
+    if (!std::binary_search(p->h_merge_rows.begin(), p->h_merge_rows.begin() + tp.n_merge_rows, i)) { p->h_merge_rows.push_back(i); p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size())); }
+  }
   tp.n_merge_rows = int32_t(p->h_merge_rows.size());
   if (p->h_merge_rows.empty()) p->h_merge_rows.push_back(0);
-  p->h_merge_ptr.assign(1, 0); p->h_merge_src.clear();
-  if (!tp.direct) for (int32_t h = 0; h < tp.n_merge_rows; ++h) {
-    for (const auto& tr : holders[p->h_merge_rows[h]]) p->h_merge_src.push_back(int64_t(tr.first) * tp.slab_stride + int64_t(tr.second) * tp.Wl);
-    p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size()));
-  }
   if (p->h_merge_src.empty()) p->h_merge_src.push_back(0);
   if (p->h_tile_rows.empty()) p->h_tile_rows.push_back(0);
   // affine guess of the knot ranges (see TileParams): fitted on two interior tiles, used if at least half of the tiles follow it
@@ -684,9 +736,9 @@ int build_tiles(oicc_problem* p) {
   }
   hipStream_t st = p->stream;
   if (!p->d_tiles.upload(p->h_tiles, st) || !p->d_units.upload(p->h_units, st) || !p->d_tile_rows.upload(p->h_tile_rows, st) || !p->d_merge_rows.upload(p->h_merge_rows, st) || !p->d_merge_ptr.upload(p->h_merge_ptr, st) || !p->d_merge_src.upload(p->h_merge_src, st) || !p->d_row_direct.upload(p->h_row_direct, st) ||
-      !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_tiles) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
-  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows, %d units, accumulator %d rows x %d (+%d), row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
-                                           tp.n_tiles, T, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
+      !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_chains) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows in %d chains of %d, %d waves, %d units, accumulator %d rows x %d (+%d), slab %d rows, %d of %d rows merged, row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
+                                           tp.n_tiles, T, tp.n_chains, tp.chain_len, tp.n_waves, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, tp.slab_rows, tp.n_merge_rows, tl.Pb, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
   tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.tile_rows = p->d_tile_rows.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.row_direct = p->d_row_direct.p;
   return OICC_OK;
 }
@@ -875,7 +927,10 @@ int build_inner_plan(oicc_problem* p, int flags) {
       ip.blocks.push_back(b);
     }
     const int b1 = int(ip.blocks.size());
-    const int cap = std::max(1, p->n_cu / std::max(n_shared, 1));
+    // (all parts of a set's shared blocks together take at most `inner_shared_residency` (default one half) of the workgroups the
+    // occupancy query says are resident at once: a second problem on the same device -- another rank, another stream -- that runs
+    // the same kind of set at the same time still fits next to it, so neither can strand the other's spinning parts)
+    const int cap = std::max(1, int(double(inner_set_resident_capacity(p->n_cu)) * std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"]))) / std::max(n_shared, 1));
     for (int pass = 0; pass < 2; ++pass)        // shared blocks first
       for (int b = b0; b < b1; ++b) {
         InnerBlock& blk = ip.blocks[b];
@@ -894,6 +949,7 @@ int build_inner_plan(oicc_problem* p, int flags) {
   if (!ip.d_blocks.upload(ip.blocks, st) || !ip.d_runs.upload(ip.runs, st) || !ip.d_wgs.upload(ip.wgs, st) || !ip.d_ctls.resize(std::max(ip.n_ctls, 1)) || !ip.d_lm_iterations.resize(1) ||
       !ip.d_seg.resize(size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
   HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
+  ip.lm_iterations = 0;                 // host mirror of the device counter that was just cleared (oicc_optimize reports the difference)
   HIPCK(p, hipStreamSynchronize(st));   // (the host vectors may be rebuilt right away)
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + cliques %.3f, adjacency + independent sets %.3f, runs + workgroups %.3f, device buffers %.3f\n",
                                            ip.blocks.size(), ip.group_first.size() - 1, ip.wgs.size(), 1e3 * (t_plan1 - t_plan0), 1e3 * (t_plan2 - t_plan1), 1e3 * (t_plan3 - t_plan2), 1e3 * (now_s() - t_plan3));
@@ -1034,6 +1090,24 @@ int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stre
 // rank 0's copy to every rank, in place (candidate parameters and the step's scalars: all ranks continue from identical bits)
 int rccl_broadcast_from_root(oicc_problem* p, void* device_ptr, int64_t count_doubles, hipStream_t stream) {
   return rccl_api().Broadcast(device_ptr, device_ptr, size_t(count_doubles), ncclDouble, 0, static_cast<ncclComm_t>(p->rccl_comm), stream) == ncclSuccess ? 0 : -1;
+}
+// All ranks continue from identical bits: `xv` (a parameter vector) and, with `with_state`, the step scalars of LmState.
+// Native RCCL: rank 0's copy is broadcast.  All-reduce hook (no broadcast there): the mean over the ranks of a pack that the hook
+// sums (kernels_solve.hip) -- the ranks' values differ in the last bits only (fp64 atomics of their own solves / sweeps).
+int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st) {
+  if (p->rccl_comm != nullptr) {
+    if (p->rccl_nranks <= 1) return OICC_OK;
+    if (rccl_broadcast_from_root(p, xv, p->pl.total, st) != 0 || (with_state && rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) {
+      p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+    return OICC_OK;
+  }
+  if (p->reduce == nullptr) return OICC_OK;
+  const int64_t n = p->pl.total;
+  if (!p->d_rank_pack.resize(size_t(n + 5))) { p->err = "hipMalloc rank pack"; return OICC_ERR_HIP; }
+  launch_rank_pack(xv, n, with_state ? p->d_state.p : nullptr, p->d_rank_pack.p, st);
+  if (p->reduce(p->reduce_user, p->d_rank_pack.p, n + 5, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+  launch_rank_unpack(xv, n, with_state ? p->d_state.p : nullptr, p->d_rank_pack.p, st);
+  return OICC_OK;
 }
 }  // namespace
 // ================================= C API =======================================
@@ -1325,7 +1399,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   const bool verbose = p->opt["verbose"] != 0;
   double decrease_factor = 2.0; bool reuse_diagonal = false;
   double cost = 0.0, gmax = 0.0;
-  const int inner_sweeps0 = (p->inner_src ? p->inner_src : p)->inner.sweeps; const int64_t inner_lm0 = (p->inner_src ? p->inner_src : p)->inner.lm_iterations;
+  const int inner_sweeps0 = (p->inner_src ? p->inner_src : p)->inner.sweeps; int64_t inner_lm0 = (p->inner_src ? p->inner_src : p)->inner.lm_iterations;
   auto finish = [&](int term, const char* msg) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
@@ -1390,13 +1464,15 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (q != p) {
       if (q->device != p->device || q->pl.total != p->pl.total || q->pl.n_so3 != p->pl.n_so3 || q->pl.n_r3 != p->pl.n_r3 || q->dt_so3 != p->dt_so3 || q->dt_r3 != p->dt_r3 || q->start_ns != p->start_ns) {
         p->err = "inner iteration source: different device or spline"; return OICC_ERR_INVALID_ARG; }
-      for (const char* name : {"gs_unit_loss", "rs_time_in_seconds"}) q->opt[name] = p->opt[name];
+      for (const char* name : {"gs_unit_loss", "rs_time_in_seconds", "inner_iteration_tolerance", "inner_shared_residency"}) q->opt[name] = p->opt[name];
+      q->max_ab = p->max_ab; q->max_gb = p->max_gb;   // the box of the bias knots the sweeps project onto
       q->cam_model = p->cam_model; q->n_intr = p->n_intr; std::memcpy(q->intr, p->intr, sizeof(q->intr));
       q->x[q->pl.ld] = p->x[p->pl.ld];   // (active_set looks at the zero-ness of the line delay)
       rc = prepare(q, flags); if (rc) { p->err = "inner iteration source: " + q->err; return rc; }
       if (q->L.P != p->L.P || q->L.Pb != p->L.Pb) { p->err = "inner iteration source: its measurements give a different tangent layout (declare the remote measurements on the shard)"; return OICC_ERR_STATE; }
     }
     rc = build_inner_plan(q, flags); if (rc) { if (q != p) p->err = q->err; return rc; }
+    inner_lm0 = q->inner.lm_iterations;   // (a rebuilt plan restarts the device counter)
     inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
   }
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
@@ -1451,9 +1527,9 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     // Several ranks: every rank solved the same (all-reduced) system, but the fp64 atomics of its own solve leave last-bit
     // differences in the step.  Rank 0's candidate parameters (<= 0.9 MB at C5) and its step scalars (model cost change, step
     // norms, Cholesky flag) are broadcast, so that all ranks evaluate, decide and continue from bit-identical state.
-    if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
-      if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 || rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) {
-        p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+    // (all-reduce hook without RCCL: the mean over the ranks instead, make_rank_consistent)
+    if (p->reduce != nullptr && !(p->rccl_comm != nullptr && p->rccl_nranks <= 1)) {
+      rc = make_rank_consistent(p, p->d_xc.p, true, st); if (rc) return rc;
       p->seg_invalidate(p->d_xc.p);   // rank 0's knots replaced this rank's
     }
     HIPCK(p, hipEventRecord(ev[1], st));
@@ -1478,8 +1554,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
           HIPCK(p, hipMemsetAsync(&p->d_state.p->step_norm_sq, 0, 3 * sizeof(double), st));   // step_norm_sq, x_norm_sq, cand_cost
           launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, alpha, 0);
           p->seg_invalidate(p->d_xc.p);
-          if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
-              rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+          if (p->reduce != nullptr) { int rr = make_rank_consistent(p, p->d_xc.p, true, st); if (rr) return rr; }
           int r = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cand_dst); if (r) return r;
           r = read_back(); if (r) return r;
           *value = cand_cost_of(); return OICC_OK; };
@@ -1515,7 +1590,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       if (std::isfinite(cand_before_inner)) {
         HIPCK(p, hipEventRecord(ev[6], st));
         rc = inner_sweep(q, p->d_xc.p, st); if (rc) { if (q != p) p->err = q->err; return rc; }
-        if (p->rccl_comm != nullptr && p->rccl_nranks > 1 && rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0) { p->err = "broadcast of the swept candidate failed"; return OICC_ERR_STATE; }   // (the shared blocks of a sweep sum with atomics: rank 0's bits for everyone)
+        if (p->reduce != nullptr) { rc = make_rank_consistent(p, p->d_xc.p, false, st); if (rc) return rc; }   // (the shared blocks of a sweep sum with atomics: the ranks' swept candidates differ in the last bits)
         HIPCK(p, hipEventRecord(ev[7], st));
         p->seg_invalidate(p->d_xc.p);
         if (cost_in_state) HIPCK(p, hipMemsetAsync(&p->d_state.p->cand_cost, 0, sizeof(double), st));
@@ -1631,9 +1706,8 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
       launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, (sgt && p->seg_precomputed()) ? sgt->buf.p : nullptr);
       if (sgt) sgt->valid = p->seg_precomputed();
     }
-    if (p->rccl_comm != nullptr && p->rccl_nranks > 1) {
-      if (rccl_broadcast_from_root(p, p->d_xc.p, p->pl.total, st) != 0 ||
-          rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0) { p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
+    if (p->reduce != nullptr && !(p->rccl_comm != nullptr && p->rccl_nranks <= 1)) {
+      rc = make_rank_consistent(p, p->d_xc.p, true, st); if (rc) return rc;
       p->seg_invalidate(p->d_xc.p);
     }
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, &p->d_state.p->cand_cost); if (rc) return rc;   // as in oicc_optimize: the candidate cost comes back inside LmState

@@ -1,13 +1,17 @@
 // Time tiles of the Jacobian / normal-equation pass (internal, shared by oicc_problem.hip and kernels_tiles.hip).
 //
-// The measurements are cut into TILES of consecutive knot windows.  One workgroup (4 waves) owns a tile: it stages the
-// tile's knots and per-knot-pair segment tables in LDS, its waves pull UNITS (one camera view, or a run of IMU samples)
-// from a queue, evaluate them lane-per-item into compact rows in LDS, form each cell's Gram product on the matrix pipe
-// and add it into the tile's band accumulator IN LDS (ds_add_f64).  The accumulator -- the tile's rows of the band,
-// their arrow columns and gradient entries, plus the arrow corner -- leaves the CU once, with plain coalesced stores:
-// the rows no other tile has go straight into the packed normal equations, the halo rows and the corner into the tile's
-// SLAB; slab_merge_kernel sums the (few) slab rows of every halo row.  No global atomics, no memset of the normal
-// equations, a fixed summation order between tiles.
+// The measurements are cut into TILES of consecutive knot windows, the tiles into CHAINS of consecutive tiles.  One workgroup
+// owns a chain and walks its tiles in time order: per tile it stages the tile's knots and per-knot-pair segment tables in LDS,
+// its waves pull UNITS (one camera view, or a run of IMU samples) from a queue, evaluate them lane-per-item into compact rows
+// in LDS, form each cell's Gram product on the matrix pipe and add it into the band accumulator IN LDS (ds_add_f64).
+// The accumulator is a RING of knot slots (3 tangent rows each: band, arrow columns, gradient entry): a knot's rows are zeroed
+// in the first tile of the chain that stages the knot, stay where they are while the chain moves on (neighbouring tiles share
+// 5 of 6 knots per spline: nothing is copied, nothing leaves the CU) and are stored ONCE, when the last tile that touches the
+// knot is done -- straight into the packed normal equations if no other chain touches the knot (all but the ~50 rows at each
+// end of a chain), else into the chain's SLAB; slab_merge_kernel sums the slab rows of those boundary rows and the arrow
+// corners of the chains.  No global atomics, no memset of the normal equations, a fixed summation order between chains.
+// Round 4: chains.  Rounds 2-3 gave every tile its own workgroup and slab (C5: 2000 tiles in 8 rounds, two thirds of all
+// rows written to slabs by 2-3 tiles and read back by the merge: 2.6x the algorithmic traffic).
 // Geometries whose accumulator does not fit in LDS run the same kernel in DIRECT mode (fp64 atomics on the packed buffer).
 #pragma once
 #include <cstdint>
@@ -15,22 +19,24 @@
 
 namespace oicc {
 
-constexpr int kTileWaves = 4;
-constexpr int kTileThreads = 64 * kTileWaves;
+constexpr int kTileMaxWaves = 8;      // waves of a workgroup: TileParams::n_waves (4 = one per SIMD ... 8 = two per SIMD; 1: option accumulation = deterministic)
 constexpr int kSegDoubles = 17;       // = kSegStride of spline_seg.cuh (checked in kernels_tiles.hip): doubles of one knot pair's segment table
 constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 / r3)
 
 struct TileDesc {
   int32_t unit0, unit1;   // units [unit0, unit1)
-  int32_t lo, nrows;      // the accumulator has nrows rows: the tangent rows of the tile's ACTIVE staged knots in ascending order (lo = the first one);
+  int32_t lo, nrows;      // the tile touches nrows accumulator rows: the tangent rows of its ACTIVE staged knots (lo = the first one in the layout);
                           // rows of other knots that lie between them in the layout (the R^3 windows reach further in time) are not stored
   int32_t ks0, nks;       // SO(3) knots staged: [ks0, ks0 + nks)
   int32_t kr0, nkr;       // R^3 knots staged
-  int32_t x0, x1;         // accumulator rows [x0, x1) belong to no other tile AND are consecutive rows g0, g0 + 1, ... of the layout:
-                          // they go straight into the packed normal equations, the rest into the slab
-  int32_t g0;             // tangent row of accumulator row x0
-  int32_t rows_off;       // TileParams::tile_rows + rows_off: accumulator row of each staged knot's first component ([nks] SO(3), [nkr] R^3; -1 inactive)
+  int32_t rows_off;       // TileParams::tile_rows + rows_off: two tables over the staged knots ([nks] SO(3), then [nkr] R^3):
+                          //   slot[k]  accumulator row (ring slot) of the knot's first tangent component, -1 inactive
+                          //   todo[k]  bit 0: zero the knot's rows before the tile's units run (first tile of the chain that stages it)
+                          //            bit 1: store them after the units (last tile of the chain that stages it): into the packed normal
+                          //            equations if (todo >> 2) == 0, else into row (todo >> 2) - 1 of the chain's slab
+  int32_t pad[3];
 };
+constexpr int kTileTodoZero = 1, kTileTodoStore = 2;
 struct UnitDesc {
   int32_t kind;           // 0 view (items = corners of ONE view), 1 accelerometer samples, 2 gyroscope samples
   int32_t first, count;   // item range
@@ -61,23 +67,26 @@ struct RowFmt {
 struct TileParams {
   const TileDesc* tiles; const UnitDesc* units;
   int32_t n_tiles, n_units;
+  int32_t n_chains, chain_len;   // workgroup c walks tiles [c * chain_len, min((c + 1) * chain_len, n_tiles))
+  int32_t n_waves;         // waves per workgroup (blockDim.x / 64)
   int32_t direct;          // 1: no LDS accumulator, fp64 atomics on the packed normal equations
   int32_t Wl;              // accumulator row length = W + a + 1   [band | arrow columns | gradient]
-  int32_t acc_rows;        // accumulator rows (max over tiles)
+  int32_t acc_rows;        // accumulator rows = ring slots (max over tiles of the rows a tile touches)
+  int32_t slab_rows;       // rows of a chain's slab (max over chains)
   int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
   // LDS carve (in doubles from the start of dynamic LDS)
   int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_units, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets and accumulator rows of the knots | queue | the tile's unit descriptors | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
   int32_t rb_doubles;
   int32_t lds_bytes;
-  double* slabs; int64_t slab_stride;   // slab of tile t at slabs + t * slab_stride: [acc_rows x Wl | corner]
+  double* slabs; int64_t slab_stride;   // slab of chain c at slabs + c * slab_stride: [slab_rows x Wl | corner]
   double* gmax;            // not null: the merge kernel also leaves max |g| there (LmState::gradient_max_norm), reset by the tile kernel
   // Regular problems: lo / nrows / ks0 / nks / kr0 / nkr of tile t are td0 + t * tds for (almost) every tile.  The kernel starts its
   // knot loads from this guess while the descriptor itself is still on its way and repeats them only for the tiles that differ.
   TileDesc td0, tds; int32_t affine;
   const int32_t* tile_rows;                           // see TileDesc::rows_off
-  const int32_t* merge_rows; int32_t n_merge_rows;   // the band rows the merge kernel sums from slabs (every row that is not some tile's interior row)
-  const int32_t* merge_ptr; const int64_t* merge_src; // CSR over merge_rows: offsets (in doubles) of the slab rows to add, in tile order
-  const uint8_t* row_direct;                          // per band row: 1 = stored by its tile
+  const int32_t* merge_rows; int32_t n_merge_rows;   // the band rows the merge kernel sums from slabs (every row that more than one chain touches)
+  const int32_t* merge_ptr; const int64_t* merge_src; // CSR over merge_rows: offsets (in doubles) of the slab rows to add, in chain order
+  const uint8_t* row_direct;                          // per band row: 1 = stored by its chain
 };
 
 // Arguments of tile_kernel.  Everything that only changes with the problem (layouts, measurement arrays, row formats, tile
