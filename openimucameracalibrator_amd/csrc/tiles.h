@@ -70,6 +70,7 @@ struct TileParams {
   int32_t n_chains, chain_len;   // workgroup c walks tiles [c * chain_len, min((c + 1) * chain_len, n_tiles))
   int32_t n_waves;         // waves per workgroup (blockDim.x / 64)
   int32_t direct;          // 1: no LDS accumulator, fp64 atomics on the packed normal equations
+  int32_t rowsplit;        // 1: the wave's row buffer holds one Jacobian row of every item at a time (RowFmt::rows_per_item = 1; kernels_tiles.hip RowSink)
   int32_t Wl;              // accumulator row length = W + a + 1   [band | arrow columns | gradient]
   int32_t acc_rows;        // accumulator rows = ring slots (max over tiles of the rows a tile touches)
   int32_t slab_rows;       // rows of a chain's slab (max over chains)

@@ -3,8 +3,10 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openimucameracalibrator_amd import synthetic, estimator as E
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C5"
-kinds = [int(a) for a in sys.argv[2:]] or [-1]
+kinds = [int(a) for a in sys.argv[2:] if "=" not in a] or [-1]
 cal = E.ImuCameraCalibrator().BatchInitSpline(synthetic.make_config(cfg))
+for a in sys.argv[2:]:                                             # option=value ...
+    if "=" in a: cal.trajectory_.SetOption(a.split("=")[0], float(a.split("=")[1]))
 tr = cal.trajectory_
 f = tr._b.lib.oicc_debug_tile_profile
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_longlong)]
