@@ -137,145 +137,6 @@ struct TileSink {
   }
 };
 
-// Row-split sink (round 4, the 8-wave build): the wave's LDS buffer holds ONE Jacobian row of every item at a time, so that eight
-// waves fit where four did -- record of item m (RowFmt with rows_per_item = 1): value idx at [idx], the factors, the constant 1,
-// a zero slot, (IMU) the item's SO(3) window.  Row 0 goes to the record as it is produced; rows 1, 2 wait in registers (`H`, a
-// fixed layout so that every index is a compile-time constant: so3 0..17 | v 18..20 | tic 21..26 | ld 27 | m 28..30 | intr 31..39 |
-// res 40) and are written into the record when their Gram pass comes (rs_write_row).
-constexpr int kRsHeld = 41;
-template <int KINDSEL>
-struct RowSink {
-  static constexpr int ROWS = KINDSEL == 0 ? 2 : 3;
-  static constexpr int DW = KINDSEL == 0 ? 43 : (KINDSEL == 1 ? 54 : 36);
-  const RowFmt& f; double* rec; double* H;   // H: [(ROWS - 1)][kRsHeld] in registers
-  double* dres; double* djac;
-  __device__ __forceinline__ RowSink(const RowFmt& f_, double* record, double* held, int s_so3_rel, double* dres_, double* djac_) : f(f_), rec(record), H(held), dres(dres_), djac(djac_) {
-    record[f.nbase + f.nfac] = 1.0; record[f.nbase + f.nfac + 1] = 0.0;
-    if (KINDSEL != 0) reinterpret_cast<int*>(record + f.nbase + f.nfac + 2)[0] = s_so3_rel;
-  }
-  __device__ __forceinline__ void res(const double* r) const {
-    rec[f.b_res] = r[0];
-#pragma unroll
-    for (int i = 1; i < ROWS; ++i) H[(i - 1) * kRsHeld + 40] = r[i];
-    if (dres) for (int i = 0; i < ROWS; ++i) dres[i] = r[i];
-  }
-  __device__ __forceinline__ void zero() const {
-    for (int k = 0; k < f.b_res; ++k) rec[k] = 0.0;
-    for (int k = 0; k < f.nfac; ++k) rec[f.nbase + k] = 0.0;
-#pragma unroll
-    for (int i = 0; i < ROWS - 1; ++i)
-#pragma unroll
-      for (int k = 0; k < 40; ++k) H[i * kRsHeld + k] = 0.0;
-  }
-  __device__ __forceinline__ void so3(int j, const double* a) const {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      rec[f.b_s + 3 * j + c] = a[c];
-#pragma unroll
-      for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 3 * j + c] = a[r * 3 + c];
-      if (djac) for (int r = 0; r < ROWS; ++r) djac[r * DW + 3 * j + c] = a[r * 3 + c];
-    }
-  }
-  __device__ __forceinline__ void vec3(const double* b) const {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      rec[f.b_v + c] = b[c];
-#pragma unroll
-      for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 18 + c] = b[r * 3 + c];
-    }
-  }
-  __device__ __forceinline__ void r3(const double* cf, const double* b) const {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) rec[f.nbase + f.f_cf + j] = cf[j];
-    vec3(b);
-    if (djac) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) djac[r * DW + 18 + 3 * j + c] = cf[j] * b[r * 3 + c];
-    }
-  }
-  __device__ __forceinline__ void tic(const double* t) const {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      rec[f.b_t + c] = t[c];
-#pragma unroll
-      for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 21 + c] = t[r * 6 + c];
-      if (djac) for (int r = 0; r < ROWS; ++r) djac[r * DW + 36 + c] = t[r * 6 + c];
-    }
-  }
-  __device__ __forceinline__ void ld(const double* l) const {
-    rec[f.b_l] = l[0];
-#pragma unroll
-    for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 27] = l[r];
-    if (djac) for (int r = 0; r < ROWS; ++r) djac[r * DW + 42] = l[r];
-  }
-  __device__ __forceinline__ void grav(const double* b) const {
-    vec3(b);
-    if (djac) for (int c = 0; c < 3; ++c) for (int r = 0; r < ROWS; ++r) djac[r * DW + 36 + c] = b[r * 3 + c];
-  }
-  __device__ __forceinline__ void bias(const double* cb, const double* m) const {
-    constexpr int o = KINDSEL == 1 ? 39 : 18;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) rec[f.nbase + f.f_cb + k] = cb[k];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      rec[f.b_m + c] = m[c];
-#pragma unroll
-      for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 28 + c] = m[r * 3 + c];
-    }
-    if (djac) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) djac[r * DW + o + 3 * k + c] = cb[k] * m[r * 3 + c];
-    }
-  }
-  __device__ __forceinline__ void intr(int n, const double* d) const {   // n = 6 (accelerometer) / 9 (gyroscope): a constant at every call site
-    constexpr int o = KINDSEL == 1 ? 48 : 27;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) if (c < n) {
-      rec[f.b_i + c] = d[c];
-#pragma unroll
-      for (int r = 1; r < ROWS; ++r) H[(r - 1) * kRsHeld + 31 + c] = d[r * n + c];
-      if (djac) for (int r = 0; r < ROWS; ++r) djac[r * DW + o + c] = d[r * n + c];
-    }
-  }
-};
-// row r >= 1 of the lane's item from the registers into its record (the values of the row before are overwritten)
-template <int KINDSEL>
-__device__ __forceinline__ void rs_write_row(const RowFmt& f, double* rec, const double* Hr) {
-  if (f.b_s >= 0) {
-#pragma unroll
-    for (int j = 0; j < 18; ++j) rec[f.b_s + j] = Hr[j];
-  }
-  if (f.b_v >= 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rec[f.b_v + c] = Hr[18 + c];
-  }
-  if (KINDSEL == 0) {
-    if (f.b_t >= 0) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) rec[f.b_t + c] = Hr[21 + c];
-    }
-    if (f.b_l >= 0) rec[f.b_l] = Hr[27];
-  } else {
-    if (f.b_m >= 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) rec[f.b_m + c] = Hr[28 + c];
-    }
-    if (f.b_i >= 0) {
-#pragma unroll
-      for (int c = 0; c < (KINDSEL == 1 ? 6 : 9); ++c) rec[f.b_i + c] = Hr[31 + c];
-    }
-  }
-  rec[f.b_res] = Hr[40];
-}
-
 // ---- per-tile column tables (LDS, built once per tile from the row formats): for each residual family and Gram column
 //   ct_ba   offset of the column's value inside an item's record (idx * rows), the record's zero slot for padding columns
 //   ct_fa   offset of its factor (the constant-one slot for columns stored expanded)
@@ -433,100 +294,6 @@ __device__ __forceinline__ void gram_cell(const RowFmt& f, const int* ct_ba, con
   if (prof && lane == 0) { const long long t2 = clock64(); prof[2] += t1 - t0; prof[3] += t2 - t1; }
 }
 
-// scatter of the upper block triangle of a cell's Gram matrix (the second half of gram_cell, shared with the row-split build)
-template <int NT, bool DIRECT, bool WIDE, class V4>
-__device__ __forceinline__ void gram_scatter(const V4* acc, const int* colinfo, const Target& T, int lane) {
-  const int li = lane & 15, lq = lane >> 4;
-  int oj[NT], b1j[NT], b2j[NT], oi[NT][4], b1i[NT][4], b2i[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int cj = 16 * t + li;
-    oj[t] = colinfo[3 * cj]; b1j[t] = colinfo[3 * cj + 1]; b2j[t] = colinfo[3 * cj + 2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const int ci = 16 * t + lq + 4 * r; oi[t][r] = colinfo[3 * ci]; b1i[t][r] = colinfo[3 * ci + 1]; b2i[t][r] = colinfo[3 * ci + 2]; }
-  }
-  int idx = 0;
-#pragma unroll
-  for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-    for (int tj = ti; tj < NT; ++tj) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = 16 * ti + lq + 4 * r, cj = 16 * tj + li;
-        const int x = oi[ti][r], y = oj[tj];
-        if (ci <= cj && x >= 0 && y >= 0) {
-          const bool sw = x > y;
-          const int j = sw ? x : y, i = sw ? y : x;
-          if (WIDE && j < T.Pb && j - i >= T.W) continue;     // knots of different windows of a wide cell that no sample shares: exact zero, outside the band
-          if (DIRECT) target_add_direct(T, i, j, acc[idx][r]);
-          else {
-            const int b1 = sw ? b1j[tj] : b1i[ti][r], b2 = sw ? b2j[tj] : b2i[ti][r];
-            unsafeAtomicAdd(T.acc + (j < T.Pb ? b1 : b2) + j, acc[idx][r]);          // ds_add_f64
-          }
-        }
-      }
-      ++idx;
-    }
-}
-
-// Row-split Gram product of one cell (items [l0, l1) of the wave's unit): ROWS passes over the cell's records, one Jacobian row of
-// every item each (K index = item; a K step of the MFMA = 4 items), all into the same result tiles; `write_row(r)` makes the cell's
-// lanes overwrite their records with row r before pass r >= 1.  One scatter at the end.  Operands one K step ahead.
-template <int NT, bool DIRECT, bool WIDE, int ROWS, class WriteRow>
-__device__ __forceinline__ void gram_cell_rs(const RowFmt& f, const int* ct_ba, const int* ct_fa, const int* ct_grp, const double* rb, const double* zero_rec,
-                                             int l0, int l1, int s_cell, const int* colinfo, const Target& T, int lane, const WriteRow& write_row, long long* prof) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  constexpr int NP = NT * (NT + 1) / 2;
-  v4d acc[NP];
-#pragma unroll
-  for (int t = 0; t < NP; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int li = lane & 15, lq = lane >> 4;
-  const int S = f.item_stride;
-  int ba[NT], fa[NT]; bool is_s[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { ba[t] = ct_ba[16 * t + li]; fa[t] = ct_fa[16 * t + li]; is_s[t] = WIDE && (ct_grp[16 * t + li] & 15) == GRP_S; }
-  const int s_lo = f.b_s, zoff = f.nbase + f.nfac + 1, woff = zoff + 1;   // SO(3) values, zero slot, window slot of a record
-  const long long t0 = prof ? clock64() : 0;
-  auto load = [&](int kb, double (&v)[NT], double (&q)[NT]) {
-    const int item = kb + lq;
-    const double* rec = item < l1 ? rb + __umul24(item, S) : zero_rec;
-    if (WIDE) {
-      const int d = item < l1 ? (reinterpret_cast<const int*>(rec + woff)[0] - s_cell) * 3 : 0;    // the item's window inside the cell
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int o = ba[t] - d;
-        const bool in = !is_s[t] || (unsigned)(o - s_lo) < 18u;
-        v[t] = rec[in ? (is_s[t] ? o : ba[t]) : zoff]; q[t] = rec[fa[t]];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { v[t] = rec[ba[t]]; q[t] = rec[fa[t]]; }
-    }
-  };
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {   // (unrolled: the rows in registers are indexed by constants)
-    if (r > 0) { wave_sync(); write_row(r); }   // (every lane has read row r - 1)
-    wave_sync();
-    double v[NT], q[NT], a[NT];
-    load(l0, v, q);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a[t] = v[t] * q[t];
-    for (int kb = l0; kb < l1; kb += 4) {
-      load(kb + 4, v, q);          // (past the cell: the zero record)
-      int idx = 0;
-#pragma unroll
-      for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = ti; tj < NT; ++tj) { acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], a[tj], acc[idx], 0, 0, 0); ++idx; }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) a[t] = v[t] * q[t];
-    }
-  }
-  const long long t1 = prof ? clock64() : 0;
-  gram_scatter<NT, DIRECT, WIDE>(acc, colinfo, T, lane);
-  if (prof && lane == 0) { const long long t2 = clock64(); prof[2] += t1 - t0; prof[3] += t2 - t1; }
-}
-
 // {extended tangent offset or -1, base1, base2} of Gram column `lane` of a cell with knot windows (s_so3, s_r3 relative to the
 // staged knots; s_b); sensor: 0 view, 1 accelerometer, 2 gyroscope
 __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLayout& tl, const Target& T, int sensor, const int* l_tl_so3,
@@ -548,38 +315,13 @@ __device__ __forceinline__ void cell_column_info(int grp_packed, const TangentLa
 
 }  // namespace
 
-// Row-split build: the cells of a unit (a view's corners / the IMU samples that share one set of knot windows), one Gram product
-// and one scatter each.  `key`: the lane's view (views), unused otherwise.  H: the lane's rows 1.. in registers (RowSink).
-template <int KINDSEL, bool DIRECT>
-__device__ __forceinline__ void rs_cells(const RowFmt& f, const int* cba, const int* cfa, const int* cgr, double* rb, const double* l_zero, int count, bool valid, int lane,
-                                         int s_so3, int s_r3, int s_b, int key, const TangentLayout& tl, const Target& T, const int* l_tl_so3, const int* l_tl_r3,
-                                         int* colinfo, const double* H, long long* prof) {
-  constexpr int ROWS = KINDSEL == 0 ? 2 : 3;
-  int l0 = 0;
-  while (l0 < count) {
-    const int ks0 = __shfl(s_so3, l0, 64), kb0 = __shfl(s_b, l0, 64), kr0 = __shfl(s_r3, l0, 64), key0 = __shfl(key, l0, 64);
-    const bool brk = valid && lane > l0 && (KINDSEL == 0 ? key != key0 : (s_r3 != kr0 || s_b != kb0 || s_so3 < ks0 || s_so3 > ks0 + f.ks_extra));
-    const unsigned long long bm = __ballot(brk);
-    const int l1 = bm != 0ull ? __builtin_ctzll(bm) : count;
-    const int ks1 = __shfl(s_so3, l1 - 1, 64);                                   // (windows do not decrease inside a cell)
-    cell_column_info(cgr[lane], tl, T, KINDSEL, l_tl_so3, l_tl_r3, ks0, kr0, kb0, ks1 - ks0 + 6, colinfo + 3 * lane);
-    const auto write_row = [&](int r) { if (lane >= l0 && lane < l1) rs_write_row<KINDSEL>(f, rb + lane * f.item_stride, H + (r - 1) * kRsHeld); };
-    if (f.ncols <= 16) gram_cell_rs<1, DIRECT, KINDSEL != 0, ROWS>(f, cba, cfa, cgr, rb, l_zero, l0, l1, ks0, colinfo, T, lane, write_row, prof);
-    else if (f.ncols <= 32) gram_cell_rs<2, DIRECT, KINDSEL != 0, ROWS>(f, cba, cfa, cgr, rb, l_zero, l0, l1, ks0, colinfo, T, lane, write_row, prof);
-    else if (f.ncols <= 48) gram_cell_rs<3, DIRECT, KINDSEL != 0, ROWS>(f, cba, cfa, cgr, rb, l_zero, l0, l1, ks0, colinfo, T, lane, write_row, prof);
-    else gram_cell_rs<4, DIRECT, KINDSEL != 0, ROWS>(f, cba, cfa, cgr, rb, l_zero, l0, l1, ks0, colinfo, T, lane, write_row, prof);
-    wave_sync();
-    l0 = l1;
-  }
-}
-
 // One tile of a chain: P0 staging, P1 units, P2 stores (see the header of this file).  Returns the cost of the items this thread
 // evaluated.  (As a real function call -- OICC_TILE_BODY_ATTR = __noinline__ -- the pass is 7 % slower at C5 and 5 % at C2: measured
 // on one box against the inlined build, scripts/ab_pass.sh.)
 #ifndef OICC_TILE_BODY_ATTR
 #define OICC_TILE_BODY_ATTR __forceinline__
 #endif
-template <bool JAC, bool DIRECT, int MAXW, bool RS>
+template <bool JAC, bool DIRECT, int MAXW>
 __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S, const TileDyn& dyn, const int tile, const int tile0, const int tile1, long long* prof) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const EvalCtx& ctx = S->ctx; const ViewData& vd = S->vd; const ImuData& ia = S->ia; const ImuData& ig = S->ig;
@@ -692,79 +434,8 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
     const bool valid = lane < ud.count;
     const int64_t it = (int64_t)ud.first + lane;
     int s_so3 = 0x3fffffff, s_r3 = 0, s_b = 0;      // knot windows of the lane's item (relative to the staged knots)
-    if (RS && JAC) {
-      // ---- row-split build: row 0 of every item into the wave's records, rows 1.. in registers until their Gram pass ----
-      double H[2 * kRsHeld];
-      const int* cba = l_ct + 64 * ud.kind; const int* cfa = l_ct + 192 + 64 * ud.kind; const int* cgr = l_ct + 384 + 64 * ud.kind;
-      if (ud.kind == 0) {
-        // a unit of views is a run of corners: of one view (ud.view), or of several consecutive ones (ud.view < 0: the lane looks its view up)
-        const int v = ud.view >= 0 ? ud.view : vd.corner_view[valid ? it : (int64_t)ud.first];
-        s_so3 = vd.view_s_so3[v] - td.ks0; s_r3 = vd.view_s_r3[v] - td.kr0;
-        if (valid) {
-          ViewConst vc;
-          view_const_init(vc, xg + ctx.pl.tic);
-          vc.ld = xg[ctx.pl.ld];
-          vc.sh_s = ctx.rs_time_in_seconds ? ctx.inv_so3_dt : 1.0; vc.sh_r = ctx.rs_time_in_seconds ? ctx.inv_r3_dt : 1.0;
-          vc.inv_so3_dt = ctx.inv_so3_dt; vc.inv_r3_dt = ctx.inv_r3_dt; vc.cam_model = ctx.cam_model; vc.intr = ctx.intr; vc.gs_unit_loss = ctx.gs_unit_loss != 0;
-          vc.spline_active = fv.c_s >= 0; vc.tic_active = fv.c_t >= 0; vc.ld_active = fv.c_l >= 0;
-          const double* q0 = l_so3 + 4 * s_so3;
-          const Quat R0{q0[0], q0[1], q0[2], q0[3]};
-          const LdsSeg seg{l_seg + s_so3 * kSegStride};
-          const LdsR3 kr{l_r3 + 3 * s_r3};
-          double* dres = dyn.dbg_res ? dyn.dbg_res + 2 * it : nullptr;
-          double* djac = dyn.dbg_jac ? dyn.dbg_jac + 2 * it * 43 : nullptr;
-          if (djac) for (int k = 0; k < 2 * 43; ++k) djac[k] = 0.0;
-          const RowSink<0> sink(fv, rb + lane * fv.item_stride, H, s_so3, dres, djac);
-          cost_local += view_item<true>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], dyn.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
-                                        vd.corner_isx[it], vd.corner_isy[it], ctx.pts + 4 * (int64_t)vd.corner_pt[it], sink);
-        }
-        const long long tq1 = prof ? clock64() : 0;
-        rs_cells<0, DIRECT>(fv, cba, cfa, cgr, rb, l_zero, ud.count, valid, lane, s_so3, s_r3, 0, v, ctx.tl, T, l_tl_so3, l_tl_r3, colinfo, H, prof);
-        if (prof && lane == 0) { prof[0] += tq1 - tq0; prof[1] += clock64() - tq1; }
-      } else {
-        const bool accel = ud.kind == 1;
-        const ImuData& id = accel ? ia : ig;
-        if (valid) { s_so3 = id.s_so3[it] - td.ks0; s_r3 = accel ? id.s_r3[it] - td.kr0 : 0; s_b = id.s_b[it]; }
-        double m[3] = {0, 0, 0}, u_so3 = 0, u_r3 = 0, u_b = 0, w = 0;
-        if (valid) { m[0] = id.mx[it]; m[1] = id.my[it]; m[2] = id.mz[it]; u_so3 = id.u_so3[it]; u_r3 = accel ? id.u_r3[it] : 0.0; u_b = id.u_b[it]; w = id.w[it]; }
-        const double* q0 = l_so3 + 4 * (valid ? s_so3 : 0);
-        const Quat R0{q0[0], q0[1], q0[2], q0[3]};
-        const LdsSeg seg{l_seg + (valid ? s_so3 : 0) * kSegStride};
-        const LdsR3 kr{l_r3 + 3 * s_r3};
-        const double* bk = xg + (accel ? ctx.pl.ab : ctx.pl.gb) + 3 * (int64_t)s_b;
-        double* dres = dyn.dbg_res ? dyn.dbg_res + 3 * it : nullptr;
-        ImuConst ic;
-        ic.inv_so3_dt = ctx.inv_so3_dt; ic.inv_r3_dt = ctx.inv_r3_dt;
-        if (accel) {
-          if (valid) {
-            imu_const_init<0>(ic, xg + ctx.pl.ai, xg + ctx.pl.g);
-            ic.spline_active = fa_.c_s >= 0; ic.g_active = fa_.c_g >= 0; ic.bias_active = fa_.c_b >= 0; ic.intr_active = fa_.c_i >= 0;
-            double* djac = dyn.dbg_jac ? dyn.dbg_jac + 3 * it * 54 : nullptr;
-            if (djac) for (int k = 0; k < 3 * 54; ++k) djac[k] = 0.0;
-            const RowSink<1> sink(fa_, rb + lane * fa_.item_stride, H, s_so3, dres, djac);
-            cost_local += imu_item<0, true>(ic, R0, seg, kr, u_so3, u_r3, u_b, bk, m, w, sink);
-          }
-          const long long tq1 = prof ? clock64() : 0;
-          rs_cells<1, DIRECT>(fa_, cba, cfa, cgr, rb, l_zero, ud.count, valid, lane, s_so3, s_r3, s_b, 0, ctx.tl, T, l_tl_so3, l_tl_r3, colinfo, H, prof);
-          if (prof && lane == 0) { prof[0] += tq1 - tq0; prof[1] += clock64() - tq1; }
-        } else {
-          if (valid) {
-            imu_const_init<1>(ic, xg + ctx.pl.gi, xg + ctx.pl.g);
-            ic.spline_active = fg.c_s >= 0; ic.g_active = false; ic.bias_active = fg.c_b >= 0; ic.intr_active = fg.c_i >= 0;
-            double* djac = dyn.dbg_jac ? dyn.dbg_jac + 3 * it * 36 : nullptr;
-            if (djac) for (int k = 0; k < 3 * 36; ++k) djac[k] = 0.0;
-            const RowSink<2> sink(fg, rb + lane * fg.item_stride, H, s_so3, dres, djac);
-            cost_local += imu_item<1, true>(ic, R0, seg, kr, u_so3, 0.0, u_b, bk, m, w, sink);
-          }
-          const long long tq1 = prof ? clock64() : 0;
-          rs_cells<2, DIRECT>(fg, cba, cfa, cgr, rb, l_zero, ud.count, valid, lane, s_so3, s_r3, s_b, 0, ctx.tl, T, l_tl_so3, l_tl_r3, colinfo, H, prof);
-          if (prof && lane == 0) { prof[0] += tq1 - tq0; prof[1] += clock64() - tq1; }
-        }
-      }
-      continue;
-    }
     if (ud.kind == 0) {
-      const int v = ud.view >= 0 ? ud.view : vd.corner_view[valid ? it : (int64_t)ud.first];   // (runs of corners over several views: row-split units)
+      const int v = ud.view;
       s_so3 = vd.view_s_so3[v] - td.ks0; s_r3 = vd.view_s_r3[v] - td.kr0;
       if (valid) {
         ViewConst vc;
@@ -888,7 +559,7 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
 
 // CHAINED = false: every chain is one tile (one-round problems); the tile loop and its loop-carried state compile away
 // (inside the loop the kernel spills twice as many SGPRs: +2 us per C2 pass, measured with scripts/ab_kstats.sh).
-template <bool JAC, bool DIRECT, int MAXW, bool CHAINED, bool RS>
+template <bool JAC, bool DIRECT, int MAXW, bool CHAINED>
 __global__ void __launch_bounds__(64 * MAXW) tile_kernel(const TileStatic* __restrict__ S, TileDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TileParams& tp = S->tp;
@@ -914,7 +585,7 @@ __global__ void __launch_bounds__(64 * MAXW) tile_kernel(const TileStatic* __res
   }
   if (JAC && dyn.gmax != nullptr && blockIdx.x == 0 && tid == 0) *dyn.gmax = 0.0;   // the merge kernel (next launch) takes the maximum
   double cost_local = 0.0;
-  for (int tile = tile0; tile < tile1; ++tile) cost_local += tile_body<JAC, DIRECT, MAXW, RS>(S, dyn, tile, tile0, tile1, prof);
+  for (int tile = tile0; tile < tile1; ++tile) cost_local += tile_body<JAC, DIRECT, MAXW>(S, dyn, tile, tile0, tile1, prof);
 
 
   if (!JAC) {   // cost pass: one atomic per chain (the cost slot is a single address: thousands of atomics on it serialise)
@@ -1039,16 +710,16 @@ void launch_lds_poison(hipStream_t st) {
 }
 
 // ---- launchers ----
-template <bool JAC, bool DIRECT, int MAXW, bool CHAINED, bool RS>
+template <bool JAC, bool DIRECT, int MAXW, bool CHAINED>
 static void launch_tile_kernel_c(const TileStatic* dS, const TileDyn& dyn, int n_chains, int n_waves, size_t lds, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
-  allow_full_lds(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT, MAXW, CHAINED, RS>), done);
-  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT, MAXW, CHAINED, RS>), dim3(n_chains), dim3(64 * n_waves), lds, st, dS, dyn);
+  allow_full_lds(reinterpret_cast<const void*>(tile_kernel<JAC, DIRECT, MAXW, CHAINED>), done);
+  hipLaunchKernelGGL((tile_kernel<JAC, DIRECT, MAXW, CHAINED>), dim3(n_chains), dim3(64 * n_waves), lds, st, dS, dyn);
 }
-template <bool JAC, bool DIRECT, int MAXW, bool RS>
+template <bool JAC, bool DIRECT, int MAXW>
 static void launch_tile_kernel(const TileStatic* dS, const TileDyn& dyn, int n_chains, int n_waves, size_t lds, hipStream_t st, bool chained) {
-  if (chained) launch_tile_kernel_c<JAC, DIRECT, MAXW, true, RS>(dS, dyn, n_chains, n_waves, lds, st);
-  else launch_tile_kernel_c<JAC, DIRECT, MAXW, false, RS>(dS, dyn, n_chains, n_waves, lds, st);
+  if (chained) launch_tile_kernel_c<JAC, DIRECT, MAXW, true>(dS, dyn, n_chains, n_waves, lds, st);
+  else launch_tile_kernel_c<JAC, DIRECT, MAXW, false>(dS, dyn, n_chains, n_waves, lds, st);
 }
 // hS: the host copy of *dS (already uploaded on this stream)
 int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st) {
@@ -1058,11 +729,9 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
   const bool chained = tp.chain_len > 1;
   if (nw < 1 || nw > kTileMaxWaves) return -1;
   if (jac) {
-    // builds: the four-wave kernel with whole records (rounds 2-3) and the row-split kernel for up to eight waves (round 4)
-    if (tp.direct) { if (tp.rowsplit) launch_tile_kernel<true, true, 8, true>(dS, dyn, tp.n_chains, nw, tp.lds_bytes, st, chained); else launch_tile_kernel<true, true, 4, false>(dS, dyn, tp.n_chains, std::min(nw, 4), tp.lds_bytes, st, chained); }
+    if (tp.direct) launch_tile_kernel<true, true, 4>(dS, dyn, tp.n_chains, std::min(nw, 4), tp.lds_bytes, st, chained);
     else {
-      if (tp.rowsplit) launch_tile_kernel<true, false, 8, true>(dS, dyn, tp.n_chains, nw, tp.lds_bytes, st, chained);
-      else launch_tile_kernel<true, false, 4, false>(dS, dyn, tp.n_chains, std::min(nw, 4), tp.lds_bytes, st, chained);
+      launch_tile_kernel<true, false, 4>(dS, dyn, tp.n_chains, nw, tp.lds_bytes, st, chained);
       const int64_t entries = (int64_t)tp.n_merge_rows * (hS.ctx.tl.W + hS.ctx.tl.a);
       const int U = entries > (int64_t)256 * 2048 * 4 ? 4 : 1;           // several entries per thread only when there are enough workgroups to fill the chip anyway
       const int nb_rows = int((entries + 256 * U - 1) / (256 * U));
@@ -1075,8 +744,7 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
       else hipLaunchKernelGGL(slab_merge_kernel<1>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
     }
   } else {
-    if (nw > 4) launch_tile_kernel<false, false, 8, false>(dS, dyn, tp.n_chains, nw, (size_t)tp.o_acc * sizeof(double), st, chained);   // knots, tables and the queue only
-    else launch_tile_kernel<false, false, 4, false>(dS, dyn, tp.n_chains, nw, (size_t)tp.o_acc * sizeof(double), st, chained);
+    launch_tile_kernel<false, false, 4>(dS, dyn, tp.n_chains, std::min(nw, 4), (size_t)tp.o_acc * sizeof(double), st, chained);   // knots, tables and the queue only
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

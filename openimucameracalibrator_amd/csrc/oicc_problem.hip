@@ -184,8 +184,6 @@ struct oicc_problem {
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active
     opt["assembly"] = 0;        // 0: time tiles (LDS accumulators + slab merge), 2: tiles in direct mode (fp64 atomics on the packed buffer: the independent accumulation path of the tests)
     opt["tile_windows"] = 0;    // knot windows per tile; 0: automatic
-    opt["tile_rowsplit"] = -1;  // row-split records in the waves' row buffers (kernels_tiles.hip RowSink): -1 automatic (with more than four waves), 0 / 1
-    opt["tile_waves"] = 4;      // waves per workgroup of the Jacobian pass (4 = one per SIMD; up to 8)
     opt["chain_tiles"] = 0;     // consecutive tiles one workgroup walks with its ring accumulator (tiles.h); 0: automatic = ceil(tiles / compute units)
     opt["accumulation"] = 0;    // 1 = deterministic: one wave per chain, every sum of the Jacobian pass in a fixed order (bit-identical runs; slower)
     opt["view_unit_items"] = 0; opt["accel_unit_items"] = 0; opt["gyro_unit_items"] = 0;   // items per unit of the tile pass (0: as many as fit the wave's row buffer); smaller units = more waves per tile busy on one-round problems
@@ -409,18 +407,12 @@ int make_layout(oicc_problem* p, int flags) {
 // ---- time tiles of the Jacobian pass (tiles.h) ---------------------------------
 // Row formats: Gram column layout (the reference's parameter-block order of each residual family, active groups only)
 // and the compact row storage the kernels use.
-RowFmt row_fmt_finish(RowFmt f, int rows_per_item, bool rowsplit) {
-  f.cap = 0;
-  if (rowsplit) {   // one Jacobian row of an item at a time (kernels_tiles.hip RowSink): values, factors, the constant 1, a zero slot, (IMU) the window index
-    f.rows_per_item = 1;
-    f.item_stride = (f.nbase + f.nfac + 2 + (rows_per_item == 3 ? 1 : 0)) | 1;
-    return f;
-  }
-  f.rows_per_item = rows_per_item;
+RowFmt row_fmt_finish(RowFmt f, int rows_per_item) {
+  f.rows_per_item = rows_per_item; f.cap = 0;
   f.item_stride = (f.nbase * rows_per_item + f.nfac + 1 + rows_per_item + (rows_per_item == 3 ? 1 : 0)) | 1;   // values, factors, the constant 1, a zero slot, (IMU) the window index; odd: the lanes' records start in different banks
   return f;
 }
-RowFmt view_row_fmt(const TangentLayout& tl, bool spline, bool rowsplit) {
+RowFmt view_row_fmt(const TangentLayout& tl, bool spline) {
   RowFmt f{}; int n = 0, b = 0;
   f.c_g = f.c_b = f.c_i = -1; f.n_i = 0; f.b_m = f.b_i = -1; f.f_cb = -1; f.ks_extra = 0;
   f.c_s = spline ? n : -1; if (spline) n += 18;
@@ -434,9 +426,9 @@ RowFmt view_row_fmt(const TangentLayout& tl, bool spline, bool rowsplit) {
   f.b_l = tl.ld >= 0 ? b : -1; if (tl.ld >= 0) b += 1;
   f.b_res = b; f.nbase = b + 1;
   f.f_cf = spline ? 0 : -1; f.nfac = spline ? 6 : 0;
-  return row_fmt_finish(f, 2, rowsplit);
+  return row_fmt_finish(f, 2);
 }
-RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, int wide_max, bool rowsplit) {
+RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, int wide_max) {
   RowFmt f{}; int n = 0, b = 0, k = 0;
   f.c_t = f.c_l = -1; f.b_t = f.b_l = -1;
   const bool g = accel && tl.g >= 0, intr = (accel ? tl.ai : tl.gi) >= 0;
@@ -459,7 +451,7 @@ RowFmt imu_row_fmt(const TangentLayout& tl, bool accel, bool spline, bool bias, 
   f.f_cf = (spline && accel) ? k : -1; if (spline && accel) k += 6;
   f.f_cb = bias ? k : -1; if (bias) k += 3;
   f.nfac = k;
-  return row_fmt_finish(f, 3, rowsplit);
+  return row_fmt_finish(f, 3);
 }
 // largest item count whose records fit `rb` doubles
 void row_fmt_capacity(RowFmt& f, int rb, int max_items) { f.cap = std::max(0, std::min({max_items, 64, rb / f.item_stride})); }
@@ -474,33 +466,10 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
   auto tile_of = [&](int32_t s_so3) { return int32_t((int64_t(s_so3) * p->dt_so3) / (int64_t(T) * dt_fine)); };
   std::vector<UnitDesc>& U = out->units; std::vector<int32_t>& UT = out->unit_tile;
   U.clear(); UT.clear(); out->tiles.clear(); out->knot_rows.clear(); out->row_of.clear(); out->row_of_off.assign(1, 0);
-  if (!p->tp.rowsplit) for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) {
+  for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) {
     const int32_t t = tile_of(p->view_s_so3[v]);
     for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; c += p->fv.cap) {
       U.push_back(UnitDesc{0, int32_t(c), int32_t(std::min<int64_t>(p->fv.cap, p->view_c0[v + 1] - c)), int32_t(v)}); UT.push_back(t); }
-  } else {
-    // row-split build: a unit is a RUN of corners (<= cap) of consecutive views of one tile; the views inside are its cells.  A view
-    // that fits the rest of the open unit joins it whole; one that would fit an empty unit starts a new one; a view larger than a
-    // unit fills units to the brim (C5: 50-corner views, 47 records per buffer).  UnitDesc::view = -1: several views.
-    const int cap = p->fv.cap;
-    bool open = false; int32_t ot = -1;
-    for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) {
-      const int32_t t = tile_of(p->view_s_so3[v]);
-      int64_t pos = p->view_c0[v]; const int64_t end = p->view_c0[v + 1];
-      while (pos < end) {
-        const bool can_join = open && ot == t && U.back().count < cap;
-        const int64_t room = can_join ? cap - U.back().count : 0;
-        if (can_join && (end - pos <= room || end - pos > cap)) {
-          const int64_t take = std::min<int64_t>(room, end - pos);
-          U.back().count += int32_t(take); if (U.back().view != int32_t(v)) U.back().view = -1;
-          pos += take;
-        } else {
-          const int64_t take = std::min<int64_t>(cap, end - pos);
-          U.push_back(UnitDesc{0, int32_t(pos), int32_t(take), int32_t(v)}); UT.push_back(t); open = true; ot = t;
-          pos += take;
-        }
-      }
-    }
   }
   auto imu_units = [&](const ImuHost& h, int kind, int cap) {
     const int64_t n = int64_t(h.size());
@@ -548,7 +517,7 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
     };
     for (; j < U.size() && UT[j] == UT[i]; ++j) {
       const UnitDesc& u = U[j];
-      if (u.kind == 0) { int32_t pv = -1; for (int32_t c = u.first; c < u.first + u.count; ++c) { const int32_t v = p->corner_view[c]; if (v != pv) { touch(p->view_s_so3[v], p->view_s_r3[v]); pv = v; } } }   // (a run of corners may span several views)
+      if (u.kind == 0) touch(p->view_s_so3[u.view], p->view_s_r3[u.view]);
       else {
         const ImuHost& h = u.kind == 1 ? p->acc : p->gyr;
         int32_t ps = -1, pr = -1;
@@ -593,13 +562,11 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
 
 int build_tiles(oicc_problem* p) {
   const TangentLayout& tl = p->tl; const Active& a = p->act;
-  TileParams& tp = p->tp; tp = TileParams{};
-  const int nw_opt = p->opt["accumulation"] != 0.0 ? 1 : std::min(kTileMaxWaves, std::max(1, int(p->opt["tile_waves"])));
-  tp.rowsplit = p->opt["tile_rowsplit"] < 0.0 ? (nw_opt > 4 ? 1 : 0) : (p->opt["tile_rowsplit"] != 0.0 ? 1 : 0);
-  p->fv = view_row_fmt(tl, a.spline, tp.rowsplit != 0);
+  p->fv = view_row_fmt(tl, a.spline);
   const int wide_max = p->opt["wide_cells"] != 0.0 ? 8 : 0;
-  p->fa = imu_row_fmt(tl, true, a.spline, a.ab, wide_max, tp.rowsplit != 0);
-  p->fg = imu_row_fmt(tl, false, a.spline, a.gb, wide_max, tp.rowsplit != 0);
+  p->fa = imu_row_fmt(tl, true, a.spline, a.ab, wide_max);
+  p->fg = imu_row_fmt(tl, false, a.spline, a.gb, wide_max);
+  TileParams& tp = p->tp; tp = TileParams{};
   tp.Wl = (tl.W + tl.a + 1) | 1;   // [band W | arrow a | gradient 1], padded to an odd length: the four row groups of an MFMA result tile hit different LDS banks
   tp.corner = (tl.a + 1) * (tl.a + 1);
   // LDS budget (doubles) and the row buffer of a wave: the largest view in one piece if it fits 26 KB, never less than ~32 IMU samples
@@ -608,7 +575,7 @@ int build_tiles(oicc_problem* p) {
   for (size_t v = 0; v + 1 < p->view_c0.size(); ++v) max_nc = std::max<int>(max_nc, int(std::min<int64_t>(64, p->view_c0[v + 1] - p->view_c0[v])));
   auto need = [](const RowFmt& f, int items) { return f.item_stride * items; };
   int rb = std::max(need(p->fv, max_nc), std::max(need(p->fa, 32), need(p->fg, 32)));
-  rb = std::min(rb, nw_opt > 4 ? 3456 * 4 / nw_opt : 3456);   // 27 KB per wave: a 50-corner view in one piece (more than four waves share the same LDS)
+  rb = std::min(rb, 3456);   // 27 KB per wave: a 50-corner view in one piece
   rb = std::max(rb, 512);
   auto unit_cap = [&](const char* name) { const int v = int(p->opt[name]); return v > 0 ? std::min(v, 64) : 64; };
   row_fmt_capacity(p->fv, rb, unit_cap("view_unit_items")); row_fmt_capacity(p->fa, rb, unit_cap("accel_unit_items")); row_fmt_capacity(p->fg, rb, unit_cap("gyro_unit_items"));
@@ -634,7 +601,7 @@ int build_tiles(oicc_problem* p) {
   // waves per workgroup: one per SIMD; option accumulation = 1 ("deterministic"): ONE wave per chain takes the units in their fixed
   // order, so the LDS additions (and with the fixed chain order of the merge every sum of the pass) happen in one order: two runs
   // give the same bits (for bisecting a parity failure; slower)
-  tp.n_waves = p->opt["accumulation"] != 0.0 ? 1 : std::min(kTileMaxWaves, std::max(1, int(p->opt["tile_waves"])));
+  tp.n_waves = p->opt["accumulation"] != 0.0 ? 1 : 4;
   auto try_T = [&](int t) {   // builds the tiles for t windows; true if they fit
     make_tiles(p, t, &tb);
     if (tb.max_nks > kMaxTileKnots || tb.max_nkr > kMaxTileKnots) return false;

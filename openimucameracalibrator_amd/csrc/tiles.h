@@ -19,7 +19,9 @@
 
 namespace oicc {
 
-constexpr int kTileMaxWaves = 8;      // waves of a workgroup: TileParams::n_waves (4 = one per SIMD ... 8 = two per SIMD; 1: option accumulation = deterministic)
+constexpr int kTileMaxWaves = 4;      // waves of a workgroup: TileParams::n_waves (4 = one per SIMD; 1: option accumulation = deterministic).  A second wave per SIMD
+                                      // needs the item functions AND the Gram loop under 256 VGPRs and 8 row buffers in LDS: built and measured in round 4
+                                      // (commit abc7bac: row-split records, correct, 20 % slower through ~500 spilled registers), not kept
 constexpr int kSegDoubles = 17;       // = kSegStride of spline_seg.cuh (checked in kernels_tiles.hip): doubles of one knot pair's segment table
 constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 / r3)
 
@@ -70,7 +72,6 @@ struct TileParams {
   int32_t n_chains, chain_len;   // workgroup c walks tiles [c * chain_len, min((c + 1) * chain_len, n_tiles))
   int32_t n_waves;         // waves per workgroup (blockDim.x / 64)
   int32_t direct;          // 1: no LDS accumulator, fp64 atomics on the packed normal equations
-  int32_t rowsplit;        // 1: the wave's row buffer holds one Jacobian row of every item at a time (RowFmt::rows_per_item = 1; kernels_tiles.hip RowSink)
   int32_t Wl;              // accumulator row length = W + a + 1   [band | arrow columns | gradient]
   int32_t acc_rows;        // accumulator rows = ring slots (max over tiles of the rows a tile touches)
   int32_t slab_rows;       // rows of a chain's slab (max over chains)
