@@ -102,6 +102,8 @@ typedef struct oicc_summary {
   int32_t line_search_steps;      /* trial step sizes beyond the first                   */
   int64_t inner_lm_iterations;    /* LM iterations of the per-block solves, all sweeps   */
   double seconds_inner;           /* wall clock of the sweeps (part of seconds_residual) */
+  double seconds_setup;           /* host-side set-up inside this call (part of seconds_total): measurement upload, tangent
+                                   * layout + buffers, tiles, inner-iteration plan; ~0 when all of them are still current  */
 } oicc_summary;
 
 /* Per-iteration trace (optional, for parity tests): cost, cost change,

@@ -27,6 +27,7 @@ class Summary(C.Structure):
         ("message", C.c_char * 128),
         ("inner_sweeps", C.c_int32), ("line_search_steps", C.c_int32), ("inner_lm_iterations", C.c_int64),
         ("seconds_inner", C.c_double),
+        ("seconds_setup", C.c_double),
     ]
 
     def as_dict(self):

@@ -179,7 +179,7 @@ class SplineTrajectoryEstimator {
               << s.initial_cost << " -> " << s.final_cost << "  time " << s.seconds_total << " s (jacobian " << s.seconds_jacobian
               << ", residual " << s.seconds_residual << ", linear solver " << s.seconds_linear_solver << ")";
     if (s.inner_sweeps > 0 || s.line_search_steps > 0)   // Ceres FullReport: "Inner iterations", "Line search steps"
-      std::cout << "  inner sweeps " << s.inner_sweeps << " (" << s.inner_lm_iterations << " block LM iterations, " << s.seconds_inner << " s)  line search steps " << s.line_search_steps;
+      std::cout << "  inner sweeps " << s.inner_sweeps << " (" << s.inner_lm_iterations << " block LM iterations, " << s.seconds_inner << " s)  line search steps " << s.line_search_steps << "  set-up " << s.seconds_setup << " s";
     std::cout << "\n";
     return s;
   }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <vector>
+#include <cstring>
 #include "oicc_device.h"
 
 namespace oicc {
@@ -34,11 +35,12 @@ static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, c
 template <class T>
 struct DevBuf {
   T* p = nullptr; size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool owned = true;   // false: a piece of a DevArena block
+  ~DevBuf() { if (p && owned) (void)hipFree(p); }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
   bool resize(size_t count) {
     if (count <= n && p) return true;
-    if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
+    release();
     if (count == 0) return true;
     if (hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
     n = count; return true;
@@ -47,6 +49,59 @@ struct DevBuf {
     if (!resize(std::max<size_t>(h.size(), 1))) return false;
     if (h.empty()) return true;
     return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st) == hipSuccess;
+  }
+  void attach(T* ptr, size_t count) { release(); p = ptr; n = count; owned = false; }
+};
+
+// Many host arrays -> ONE device block with ONE copy (a hipMalloc + hipMemcpy per array costs 10-20 us each: 0.3 ms for the ~30
+// measurement arrays of the GoPro9 configuration).  add() registers an array, commit() packs them into a host staging block
+// (256-byte aligned pieces), grows the device block if needed, copies once and points every DevBuf at its piece.
+struct DevArena {
+  struct Item { const void* src; size_t bytes, off; void (*attach)(void* buf, void* dev, size_t count); void* buf; size_t count; size_t rbytes = 0; };   // rbytes: size of a piece without host data
+  std::vector<Item> items; std::vector<unsigned char> stage; unsigned char* dev = nullptr; size_t cap = 0;
+  ~DevArena() { if (dev) (void)hipFree(dev); }
+  template <class T>
+  void add(DevBuf<T>& b, const std::vector<T>& h) {
+    items.push_back(Item{h.data(), h.size() * sizeof(T), 0, [](void* buf, void* d, size_t c) { static_cast<DevBuf<T>*>(buf)->attach(static_cast<T*>(d), c); }, &b, std::max<size_t>(h.size(), 1)});
+  }
+  template <class T>
+  void reserve(DevBuf<T>& b, size_t count) {   // a piece without host data (workspace)
+    items.push_back(Item{nullptr, 0, 0, [](void* buf, void* d, size_t c) { static_cast<DevBuf<T>*>(buf)->attach(static_cast<T*>(d), c); }, &b, std::max<size_t>(count, 1)});
+    items.back().rbytes = std::max<size_t>(count, 1) * sizeof(T);
+  }
+  bool commit(hipStream_t st) {   // (the staging block outlives the asynchronous copy: it belongs to the arena)
+    size_t total = 0;
+    size_t copy_bytes = 0;   // the pieces with host data come first: one copy covers them
+    for (Item& it : items) if (!it.rbytes) { it.off = total; total += (std::max<size_t>(it.bytes, 8) + 255) & ~size_t(255); }
+    copy_bytes = total;
+    for (Item& it : items) if (it.rbytes) { it.off = total; total += (it.rbytes + 255) & ~size_t(255); }
+    if (total > cap) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr; cap = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&dev), total) != hipSuccess) { dev = nullptr; return false; }
+      cap = total;
+    }
+    // small arrays travel together through the staging block; a large one goes straight from where it lies (no second host copy)
+    constexpr size_t kDirect = size_t(1) << 20;
+    stage.resize(copy_bytes);
+    size_t staged_end = 0;
+    for (const Item& it : items) if (it.bytes && it.bytes < kDirect) { std::memcpy(stage.data() + it.off, it.src, it.bytes); staged_end = std::max(staged_end, it.off + it.bytes); }
+    for (const Item& it : items) if (it.bytes >= kDirect && hipMemcpyAsync(dev + it.off, it.src, it.bytes, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    // (the staged pieces may be interleaved with direct ones: copy the runs of staged pieces)
+    {
+      size_t run0 = 0; bool open = false; size_t run1 = 0;
+      for (const Item& it : items) {
+        if (it.rbytes) continue;
+        const bool staged = it.bytes < kDirect;
+        if (staged) { if (!open) { run0 = it.off; open = true; } run1 = it.off + ((std::max<size_t>(it.bytes, 8) + 255) & ~size_t(255)); }
+        else if (open) { if (hipMemcpyAsync(dev + run0, stage.data() + run0, run1 - run0, hipMemcpyHostToDevice, st) != hipSuccess) return false; open = false; }
+      }
+      if (open && hipMemcpyAsync(dev + run0, stage.data() + run0, run1 - run0, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    }
+    (void)staged_end;
+    for (const Item& it : items) it.attach(it.buf, dev + it.off, it.count);
+    items.clear();
+    return true;
   }
 };
 }  // namespace oicc
