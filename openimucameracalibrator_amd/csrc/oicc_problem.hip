@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <memory>
 #include <type_traits>
 #include <string>
@@ -88,6 +89,8 @@ bool calc_times(int64_t sensor_time, int64_t start_ns, int64_t dt_ns, size_t nr_
 
 }  // namespace
 
+struct InnerPlanOptions { int flags; bool gs_unit; bool general_kernel; int resident_wgs; double shared_share; int64_t layout_gen; };   // what the host part of the inner-iteration plan is built from (build_inner_plan_host)
+
 struct oicc_problem {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -113,7 +116,10 @@ struct oicc_problem {
   // knot windows of measurements held by OTHER ranks (multi-GPU): only for layout/bandwidth
   std::vector<int32_t> remote_so3, remote_r3;   // pairs; r3 = -1 for gyro
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
-  bool meas_dirty = true;
+  bool meas_dirty = true, groups_dirty = true;
+  std::thread plan_thread; InnerPlanOptions plan_job{}; bool plan_job_valid = false; double plan_ms[3] = {0, 0, 0};   // the plan's host part on a second thread (start_inner_plan)
+  void wait_plan() { if (plan_thread.joinable()) plan_thread.join(); }
+  int plan_wanted_flags = -2;   // oicc_optimize -> prepare: build the inner-iteration plan for these flags under the set-up
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
   oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
@@ -285,9 +291,13 @@ int sync_measurements(oicc_problem* p) {
     A.add(d.u_b, h.u_b); A.add(d.mx, h.mx); A.add(d.my, h.my); A.add(d.mz, h.mz); A.add(d.w, h.w);
   }
   if (!A.commit(st)) { p->err = "device upload of measurements failed"; return OICC_ERR_HIP; }
-  build_imu_groups(p->acc, true, p->acc_groups); build_imu_groups(p->gyr, false, p->gyr_groups);
   p->meas_dirty = false;
   return OICC_OK;
+}
+void sync_groups(oicc_problem* p) {   // host only: before anything that walks the IMU samples by runs
+  if (!p->groups_dirty) return;
+  build_imu_groups(p->acc, true, p->acc_groups); build_imu_groups(p->gyr, false, p->gyr_groups);
+  p->groups_dirty = false;
 }
 
 // SetFixedParams, impl.h:93-252 -> which parameter blocks are variable.
@@ -309,9 +319,11 @@ Active active_set(const oicc_problem* p, int flags) {
 }
 
 int build_tiles(oicc_problem* p);
+void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen);
 
-// Tangent layout: the ordering contract of include/oicc_hip.h.
-int make_layout(oicc_problem* p, int flags) {
+// Tangent layout: the ordering contract of include/oicc_hip.h.  Host part (no device work: the inner-iteration plan can be built
+// from it on a second host thread while the measurements travel and the tiles are made) ...
+void make_layout_host(oicc_problem* p, int flags) {
   const Active a = active_set(p, flags);
   // the layout also depends on whether line delay is currently zero (active_set) -> recompute when it might differ
   HostLayout& L = p->L;
@@ -356,6 +368,10 @@ int make_layout(oicc_problem* p, int flags) {
   }
   L.hb = hb;
   p->act = a;
+}
+// ... and device part: offsets, buffers of the normal equations and the solve, tiles
+int make_layout_device(oicc_problem* p, int flags) {
+  HostLayout& L = p->L;
   const bool timing = p->opt["verbose"] >= 2.0; const double tl0 = now_s();
   // device copies
   hipStream_t st = p->stream;
@@ -709,14 +725,23 @@ int prepare(oicc_problem* p, int flags) {
   ARG(p, !(flags & OICC_POINTS), "OICC_POINTS (board point refinement) is not supported on this path");
   HIPCK(p, hipSetDevice(p->device));
   const bool timing = p->opt["verbose"] >= 2.0;
+  const double t00 = now_s();
+  if (p->plan_wanted_flags != flags) p->wait_plan();   // (a plan job of an earlier call reads what this call may rebuild)
+  sync_groups(p);
+  const bool current = p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen;   // layout, buffers and tiles are current
+  if (!current) make_layout_host(p, flags);
+  // The inner-iteration plan of the solve that called (oicc_optimize announces it) only needs the host layout: its host part runs
+  // on a second thread under the uploads and the tiles below (build_inner_plan joins it).
+  if (p->plan_wanted_flags == flags) start_inner_plan(p, flags, current ? p->layout_gen : p->layout_gen + 1);
+  p->plan_wanted_flags = -2;
   const double t0 = now_s();
   int rc = sync_measurements(p); if (rc) return rc;
   const double t1 = now_s();
   rc = sync_params_to_device(p); if (rc) return rc;
   const double t2 = now_s();
-  if (p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen) return OICC_OK;   // layout, buffers and tiles are current
-  rc = make_layout(p, flags);
-  if (timing) std::printf("[oicc] prepare: measurements %.3f ms, parameters %.3f ms, layout + buffers + tiles %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
+  if (current) return OICC_OK;
+  rc = make_layout_device(p, flags);
+  if (timing) std::printf("[oicc] prepare: runs of samples + host layout %.3f ms, measurements %.3f ms, parameters %.3f ms, buffers + tiles %.3f ms\n", 1e3 * (t0 - t00), 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
   return rc;
 }
 
@@ -750,10 +775,11 @@ ImuData imu_data(const ImuHost& h, const ImuDev& d) {
 // ---- inner iterations: plan (host) and sweep (device), see inner_iterations.hip / oracle/ceres_inner.hpp ----------------
 // Parameter blocks of the reduced program in the order the reference's AddResidualBlock calls create them, the Hessian
 // graph, and Ceres' recursive independent-set ordering (reversed).
-int build_inner_plan(oicc_problem* p, int flags) {
+// Host part: everything up to the device copies, from host data only (problem measurements, host layout) and the options handed in
+// -- it may run on a second thread next to the set-up of the solve (start_inner_plan).
+void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_ms[3]) {
   oicc_problem::InnerPlan& ip = p->inner;
-  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
-  if (ip.flags == flags && ip.layout_gen == p->layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return OICC_OK;
+  const bool gs_unit = o.gs_unit;
   const double t_plan0 = now_s(); double t_plan1 = 0, t_plan2 = 0, t_plan3 = 0;
   const HostLayout& L = p->L; const ParamLayout& pl = p->pl;
   // Parameter blocks in the order the reference's AddResidualBlock calls create them (views in time order, then accelerometer /
@@ -958,7 +984,7 @@ int build_inner_plan(oicc_problem* p, int flags) {
   // must be resident, so a set's shared blocks split the CUs and come first in the launch).
   ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.n_ctls = 0;
   constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
-  const int resident_wgs = inner_set_resident_capacity(p->n_cu); const double shared_share = std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"]));
+  const int resident_wgs = o.resident_wgs; const double shared_share = o.shared_share;
   for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
     const int b0 = int(ip.blocks.size());
     int n_shared = 0;
@@ -986,11 +1012,41 @@ int build_inner_plan(oicc_problem* p, int flags) {
         if (nparts > 1) blk.ctl = ip.n_ctls++;
         for (int q = 0; q < nparts; ++q) ip.wgs.push_back(InnerWg{b, q, nparts, 0});
       }
-    char r3only = p->opt["debug_inner_general_kernel"] == 0.0;
+    char r3only = !o.general_kernel;
     for (int b = b0; b < b1; ++b) r3only = r3only && ip.blocks[b].kind == IK_R3 && ip.blocks[b].n_slots <= 1024;
     ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only);
   }
   t_plan3 = now_s();
+  t_ms[0] = 1e3 * (t_plan1 - t_plan0); t_ms[1] = 1e3 * (t_plan2 - t_plan1); t_ms[2] = 1e3 * (t_plan3 - t_plan2);
+}
+InnerPlanOptions inner_plan_options(oicc_problem* p, int flags, int64_t layout_gen) {   // (main thread: reads the option map, asks the runtime)
+  InnerPlanOptions o;
+  o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = p->opt["debug_inner_general_kernel"] != 0.0;
+  o.resident_wgs = inner_set_resident_capacity(p->n_cu); o.shared_share = std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"])); o.layout_gen = layout_gen;
+  return o;
+}
+void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  if (p->plan_thread.joinable()) p->plan_thread.join();
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  if (ip.flags == flags && ip.layout_gen == layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return;   // current
+  p->plan_job = inner_plan_options(p, flags, layout_gen);
+  p->plan_job_valid = true;
+  p->plan_thread = std::thread([p]() { build_inner_plan_host(p, p->plan_job, p->plan_ms); });
+}
+int build_inner_plan(oicc_problem* p, int flags) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  const double t0 = now_s();
+  if (p->plan_thread.joinable()) p->plan_thread.join();
+  const bool prebuilt = p->plan_job_valid && p->plan_job.flags == flags && p->plan_job.layout_gen == p->layout_gen && p->plan_job.gs_unit == gs_unit;
+  p->plan_job_valid = false;
+  if (!prebuilt) {
+    if (ip.flags == flags && ip.layout_gen == p->layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return OICC_OK;
+    build_inner_plan_host(p, inner_plan_options(p, flags, p->layout_gen), p->plan_ms);
+  }
+  const double t1 = now_s();
+  const ParamLayout& pl = p->pl;
   hipStream_t st = p->stream;
   DevArena& PA = p->plan_arena;
   PA.add(ip.d_blocks, ip.blocks); PA.add(ip.d_runs, ip.runs); PA.add(ip.d_wgs, ip.wgs);
@@ -998,8 +1054,8 @@ int build_inner_plan(oicc_problem* p, int flags) {
   if (!PA.commit(st)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
   HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
   ip.lm_iterations = 0;                 // host mirror of the device counter that was just cleared (oicc_optimize reports the difference)
-  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + cliques %.3f, adjacency + independent sets %.3f, runs + workgroups %.3f, device buffers %.3f\n",
-                                           ip.blocks.size(), ip.group_first.size() - 1, ip.wgs.size(), 1e3 * (t_plan1 - t_plan0), 1e3 * (t_plan2 - t_plan1), 1e3 * (t_plan3 - t_plan2), 1e3 * (now_s() - t_plan3));
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + neighbourhoods %.3f, independent sets %.3f, runs + workgroups %.3f (%s: waited %.3f), device buffers %.3f\n",
+                                           ip.blocks.size(), ip.group_first.size() - 1, ip.wgs.size(), p->plan_ms[0], p->plan_ms[1], p->plan_ms[2], prebuilt ? "second thread under the set-up" : "inline", 1e3 * (t1 - t0), 1e3 * (now_s() - t1));
   ip.flags = flags; ip.layout_gen = p->layout_gen; ip.gs_unit = gs_unit;
   return OICC_OK;
 }
@@ -1182,6 +1238,7 @@ int oicc_create(oicc_problem** out, int device_ordinal) {
 }
 void oicc_destroy(oicc_problem* p) {
   if (!p) return;
+  p->wait_plan();
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -1199,7 +1256,6 @@ int oicc_set_option(oicc_problem* p, const char* name, double value) {
   auto it = p->opt.find(name); ARG(p, it != p->opt.end(), std::string("unknown option ") + name);
   if (it->second != value) ++p->opt_gen;   // layout / tiles / inner plan are rebuilt at the next pass
   it->second = value;
-  if (std::string(name) == "imu_chunk_cells") p->meas_dirty = true;   // the work lists are rebuilt at the next pass
   return OICC_OK;
 }
 int oicc_set_allreduce(oicc_problem* p, oicc_allreduce_fn fn, void* user) { p->reduce = fn; p->reduce_user = user; return OICC_OK; }
@@ -1299,7 +1355,7 @@ static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, 
     for (int i = 0; i < kN; ++i) { p->so3_in[s_so3 + i] = 1; p->r3_in[s_r3 + i] = 1; }
     p->has_tic_block = true; if (rs) p->has_ld_block = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+  p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 int oicc_add_rs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* t, const int64_t* co, const double* uv, const double* cov,
@@ -1324,7 +1380,7 @@ int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_
     for (int k = 0; k < kNb; ++k) p->ab_in[s_b + k] = 1;
     p->has_acc = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+  p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
@@ -1343,7 +1399,7 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t
     for (int k = 0; k < kNb; ++k) p->gb_in[s_b + k] = 1;
     p->has_gyr = true;
   }
-  p->meas_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+  p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
   return OICC_OK;
 }
 
@@ -1429,6 +1485,8 @@ int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind, double* r
 // sequences kernels and reads one small struct per iteration.
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summary* sum) {
   const double t_start = now_s();
+  struct PlanJoin { oicc_problem* q; ~PlanJoin() { q->wait_plan(); } } plan_join{p};   // (no exit of this call leaves the second thread running)
+  if (p->opt["inner_iterations"] != 0.0 && p->inner_src == nullptr && p->reduce == nullptr) p->plan_wanted_flags = flags;   // the plan's host part runs under the set-up (prepare)
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
