@@ -205,7 +205,8 @@ def main():
                             inner_sweeps=s1["inner_sweeps"] + s2["inner_sweeps"], inner_lm_iterations=s1["inner_lm_iterations"] + s2["inner_lm_iterations"],
                             seconds_inner=s1["seconds_inner"] + s2["seconds_inner"], line_search_steps=s1["line_search_steps"] + s2["line_search_steps"],
                             seconds_jacobian=s1["seconds_jacobian"] + s2["seconds_jacobian"], seconds_residual=s1["seconds_residual"] + s2["seconds_residual"],
-                            seconds_linear_solver=s1["seconds_linear_solver"] + s2["seconds_linear_solver"]), s1, c
+                            seconds_linear_solver=s1["seconds_linear_solver"] + s2["seconds_linear_solver"],
+                            seconds_setup=s1["seconds_setup"] + s2["seconds_setup"]), s1, c   # seconds_setup: uploads, layout + buffers, tiles, inner-iteration plan (part of seconds)
             make_gpu = lambda: E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds)
             full_calibration(make_gpu, True)                                   # warm-up: code objects of the inner-iteration kernels
             full_ref, summ, _ = full_calibration(make_gpu, True)
@@ -226,8 +227,8 @@ def main():
         # three residual families timed as stand-alone launches; "solve" is the 13-launch block cyclic
         # reduction through the pivot inverses (bcri_build_invert / invert / schur / backward), a dependent-latency chain, reported as a group.
         times = dict(blocks=pass_ms, view=kern_ms[0], accel=kern_ms[1], gyro=kern_ms[2], solve=solve_ms)
-        names = dict(blocks="tile_kernel<true, false> + slab_merge_kernel", view="tile_kernel<true, false> (views only) + slab_merge_kernel",
-                     accel="tile_kernel<true, false> (accelerometer only) + slab_merge_kernel", gyro="tile_kernel<true, false> (gyroscope only) + slab_merge_kernel",
+        names = dict(blocks="tile_kernel<true, false, 4, *> + slab_merge_kernel", view="tile_kernel<true, false, 4, *> (views only) + slab_merge_kernel",
+                     accel="tile_kernel<true, false, 4, *> (accelerometer only) + slab_merge_kernel", gyro="tile_kernel<true, false, 4, *> (gyroscope only) + slab_merge_kernel",
                      solve="bcri_build_invert_kernel + bcri_invert_kernel + bcri_schur_kernel + bcri_backward_kernel")
         kernels = {k: dict(kernel=names[k], ms=times[k], alg_bytes=b_alg[k], alg_flops=f_alg[k],
                            hbm_GBps=b_alg[k] / (times[k] * 1e-3) / 1e9 if times[k] > 0 else 0.0,
@@ -353,7 +354,16 @@ def main():
                 c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
                 p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
                 s5 = c5.trajectory_.TimeLinearSolve(flags, repeats=5)
-                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false> + slab_merge_kernel",
+                # one full LM iteration and one inner sweep at C5 size (the reference's solver options: every sweep visits all 30 011 parameter blocks)
+                c5.trajectory_.RunLmIterations(flags, 2)
+                torch.cuda.synchronize(); t1 = time.perf_counter(); c5.trajectory_.RunLmIterations(flags, 5); torch.cuda.synchronize()
+                lm5 = 1e3 * (time.perf_counter() - t1) / 5
+                c5r = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                c5r.trajectory_.UseReferenceSolverOptions()
+                s5r = c5r.trajectory_.Optimize(3, flags)
+                out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false, 4, true> (chains of 8 tiles) + slab_merge_kernel",
+                                                  lm_step_ms=lm5, inner_sweep_ms=1e3 * s5r["seconds_inner"] / max(s5r["inner_sweeps"], 1), inner_sweeps_timed=s5r["inner_sweeps"],
+                                                  setup_ms_reference_options=1e3 * s5r["seconds_setup"],
                                                   fp64_frac_of_78p6=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 78.6e12,
                                                   kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
                                                   blocks_per_s_jacobian_pass=c5.num_blocks / (p5 * 1e-3),

@@ -8,31 +8,16 @@
 // biases, intrinsics) and the right-hand side ride along as dense border rows.
 //
 //   level l (stride s = 2^l): the active blocks are 0, s, 2s, ...; every block at an ODD
-//   position is a pivot and is eliminated by ONE workgroup, all pivots of a level
-//   concurrently:
-//        W = [ D_i ; S(left neighbour) ; S(right neighbour) ; F_i ]     (192 + a + 1) x 64
-//     dense right-looking Cholesky in 8-column panels (lane = row, v_readlane broadcasts,
-//     v_rsq_f64 + 2 Newton steps); the trailing matrix lives in REGISTERS as 16x16
-//     MFMA tiles (v_mfma_f64_16x16x4_f64) owned statically by the 16 waves, only the next
-//     panel's columns go back to LDS;
-//     Schur complement L_B L_B^T (K = 64) of the border onto the two neighbours, their
-//     new coupling, the arrow rows and the corner, again on MFMA: fp64 atomics for the
-//     shared targets, plain stores for the coupling.
+//   position is a pivot, all pivots of a level are eliminated concurrently, THROUGH THE EXPLICIT INVERSE of the pivot's 64 x 64
+//   diagonal block (round 3): only that block is factored in one workgroup, the pivot's border rows become matrix products on
+//   other CUs and the back substitution a matrix-vector product (bcri_* kernels below).
 //   After ceil(log2 n) levels block 0 is alone: its workgroup also factors the arrow
-//   corner, solves it and starts the back substitution, which then runs level by level
-//   in reverse, again one workgroup per pivot.
+//   corner, solves it and starts the back substitution, which then runs two levels per launch in reverse.
 //
-// The DEFAULT since round 3 is the same reduction through the explicit INVERSES of the pivot blocks (bcri_* kernels in the second
-// half of this file, solver_algorithm 4 = automatic): only the 64 x 64 diagonal block of a pivot is factored in one workgroup, its
-// border rows become matrix products on other CUs and the back substitution a matrix-vector product.  What follows first is the
-// factor-based formulation of rounds 1-2 (solver_algorithm 2), kept as an independent solver for the tests.
-//
-// PARALLEL cyclic reduction (round 3) for systems of at most one block per CU (n <= 256: BASELINE configs 2-4): every
-// level eliminates EVERY block against its neighbours at distance s (same kernels, all n blocks as pivots), which
-// decouples the blocks after ceil(log2 n) levels and needs no back substitution through the levels: the arrow columns
-// and the right-hand side ride along as a1 right-hand sides, a final launch solves D_i X_i = R_i per block, sums
-// E^T B^-1 [E | g] into the corner, and the last workgroup to finish solves the corner and writes the step.
-// 11 dependent launches instead of 17 for C2 (no bcr_backward launches), the idle CUs pay for the extra eliminations.
+// History: rounds 1-2 factored each pivot WITH its 138 + a border rows in one workgroup (solver_algorithm 2) and round 3 added a
+// parallel form of that (algorithm 3: every block a pivot at every level); both stayed in the library as independent solvers
+// until round 4 removed them (three kernels, ten instantiations: git history) -- the band sweep (kernels_cholesky.hip, algorithm 1)
+// is the independent solver the tests compare with.
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <unordered_map>
@@ -40,8 +25,6 @@
 
 namespace oicc {
 
-constexpr int kBcrThreads = 1024;
-constexpr int kBcrSlots = 4;   // register-resident trailing tiles per wave
 
 struct BcrArgs {
   double* D;    // [n][64*64]   diagonal blocks, column major (c*64 + r), lower part used
@@ -53,18 +36,10 @@ struct BcrArgs {
   int32_t* fail;
   long long* prof;   // optional cycle counters of block 0 / wave 0 (debug)
   int n, a, Pb, rtf, LD;
-  int no_diag_copy;            // debug: panel waves read the diagonal block in place (the hazard described in the panel factorisation)
   int delay;                   // debug: panel waves > 0 sleep this many x ~1000 cycles before they read a panel (makes that hazard deterministic)
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
   int top;                     // bcri_invert_kernel<LAST>: the one pivot of the top level (> 0), whose back substitution block 0's workgroup does as well
-  // parallel cyclic reduction: every block is a pivot at every level; the coupling of the pair (k, k + s) is stored twice,
-  // slot 2k with k's variables as the column index ("k major") and slot 2k + 1 with those of k + s
-  int pcr;
-  const double* F0;            // [n][64*a1] border rows as built (arrow columns E_i and rhs before the levels changed them)
-  double* X;                   // [n][a1][64] solutions of D_i X_i = R_i after the last level
-  double* Cacc;                // [a1*a1] sum_i E_i^T X_i
-  unsigned int* counter;       // workgroups of the final launch that have finished
 };
 
 __device__ __forceinline__ void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -169,433 +144,6 @@ __device__ __forceinline__ void bcr_corner_solve(double* C, double* da, int* fai
   __syncthreads();
 }
 
-// MODE 0: a pivot of a level;  1: block 0 after the last level of the cyclic reduction (+ corner + its back substitution);
-// 2: final launch of the parallel cyclic reduction (a decoupled block with its a1 right-hand sides; the last workgroup
-//    to finish also solves the corner and writes the step)
-template <int LD, int MODE, bool PROF>
-__global__ __launch_bounds__(kBcrThreads) void bcr_eliminate_kernel(BcrArgs A) {
-  constexpr bool LAST = MODE == 1;
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lq = lane >> 4;
-  const int a = A.a, a1 = a + 1, rtf = A.rtf;
-  const int Ru = 192 + a1;
-  double* const W = lds;                 // [64][LD] column major: rows 0..63 pivot, 64.. left, 128.. right, 192.. border
-  double* const dinvs = W + 64 * LD;     // [64]
-  double* const da = dinvs + 64;         // [64] arrow solution (LAST)
-  int* const failp = reinterpret_cast<int*>(da + 64);
-  double* const dg = da + 64 + 8;        // [8][8] copy of the current panel's diagonal block (column major), see the panel factorisation
-
-  const int s = A.s;
-  const int i = LAST ? 0 : ((A.pcr || MODE == 2) ? (int)blockIdx.x : s * (2 * (int)blockIdx.x + 1));
-  const int il = i - s, ir = i + s;
-  const bool hasL = MODE == 0 && il >= 0, hasR = MODE == 0 && ir < A.n;
-  const double* Dg = A.D + (int64_t)i * 4096;
-  const double* Fg = A.F + (int64_t)i * 64 * a1;
-  const double* SL = hasL ? A.S + (A.offS_in + (A.pcr ? 2 * il + 1 : il / s)) * 4096 : nullptr;   // (pcr: the pair (il, i) with i's variables as columns)
-  const double* SR = hasR ? A.S + (A.offS_in + (A.pcr ? 2 * i : i / s)) * 4096 : nullptr;         // (pcr: the pair (i, ir), again i major)
-
-  const bool prof = PROF && A.prof != nullptr && blockIdx.x == 0 && wave == 0;
-  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = prof ? clock64() : 0;
-#define BCR_MARK(k) do { if (PROF && prof) { const long long tn_ = clock64(); pc[k] += tn_ - tprev; tprev = tn_; } } while (0)
-  if (tid == 0) *failp = 0;
-  {
-    // all global loads are issued before the first LDS write (one round trip instead of four)
-    const int fr = 16 * rtf;
-    double gd[4], gl[4], gr[4], gf[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = tid + k * kBcrThreads;
-      gd[k] = Dg[e];
-      gl[k] = hasL ? SL[e] : 0.0;
-      gr[k] = hasR ? SR[e] : 0.0;
-      const int c = e / fr, q = e - c * fr;
-      gf[k] = (e < 64 * fr && q < a1) ? Fg[c * a1 + q] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = tid + k * kBcrThreads;
-      const int c = e >> 6, r = e & 63;
-      W[c * LD + r] = r >= c ? gd[k] : 0.0;
-      if (c < 8 && r < 8) dg[c * 8 + r] = r >= c ? gd[k] : 0.0;
-      W[c * LD + 64 + r] = gl[k];
-      W[c * LD + 128 + r] = gr[k];
-      const int cf = e / fr, q = e - cf * fr;
-      if (e < 64 * fr) W[cf * LD + 192 + q] = gf[k];
-    }
-  }
-  __syncthreads();
-
-  // ---- static tile ownership: tile (rt, ct), rt >= ct, of the (12+rtf) x 4 tile grid
-  const int nrt = 12 + rtf;
-  int t_rt[kBcrSlots], t_ct[kBcrSlots]; bool t_ok[kBcrSlots];
-  bcr_v4d acc[kBcrSlots];
-#pragma unroll
-  for (int k = 0; k < kBcrSlots; ++k) {
-    int rem = wave + 16 * k, ct = 0;
-    while (ct < 4 && rem >= nrt - ct) { rem -= nrt - ct; ++ct; }
-    t_ok[k] = ct < 4; t_ct[k] = t_ok[k] ? ct : 0; t_rt[k] = t_ok[k] ? ct + rem : 0;
-    if (MODE == 2 && t_rt[k] >= 4 && t_rt[k] < 12) t_ok[k] = false;   // no neighbours: the left / right rows are zero
-    const double* src = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
-    acc[k][0] = src[0]; acc[k][1] = src[4 * LD]; acc[k][2] = src[8 * LD]; acc[k][3] = src[12 * LD];
-  }
-  BCR_MARK(0);
-  const int NAW = (Ru - 8 + 55) / 56;   // waves of the panel factorisation (lanes 0..7: diagonal rows, 8..63: one row each)
-
-  for (int j0 = 0; j0 < 64; j0 += 8) {
-    // ---- panel factorisation, in place in W
-    if (wave < NAW) {
-      const int rho = lane < 8 ? j0 + lane : 8 + wave * 56 + (lane - 8);
-      const bool act = lane < 8 || (rho >= j0 + 8 && rho < Ru && !(MODE == 2 && rho >= 64 && rho < 192));
-      // eight reads off one base address (LD is a compile-time constant: immediate offsets); inactive lanes
-      // read row 0 and are masked afterwards
-      // The 8x8 diagonal block is read by lanes 0..7 of EVERY panel wave and rewritten in place by wave 0 at the end of its
-      // panel: a wave that starts late (two panel waves share a SIMD once the border has three 16-row tiles, a + 1 > 32) could
-      // read factored entries.  The waves therefore read the block from a copy the previous trailing update left in `dg`.
-      if (A.delay > 0 && wave > 0) for (int k = 0; k < A.delay; ++k) __builtin_amdgcn_s_sleep(16);   // (tests: a panel wave that starts late)
-      const bool from_copy = lane < 8 && !A.no_diag_copy;
-      const double* colp = from_copy ? dg + lane : W + j0 * LD + (act ? rho : 0);
-      const int cstride = from_copy ? 8 : LD;
-      double av[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { const double v = colp[c * cstride]; av[c] = (act && (lane >= 8 || lane >= c)) ? v : 0.0; }
-      if (PROF && prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-      BCR_MARK(6);
-      double rsd = 1.0;
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double piv = bcr_readlane(av[c], c);
-        bad |= !(piv > 0.0);      // off the dependent chain: a non-positive pivot poisons the factor (NaN) and is reported below
-        // 1/sqrt(piv) by two coupled (Goldschmidt) steps on the v_rsq_f64 seed (2^-24): the same
-        // 2^-52 as two Newton steps, but the dependent chain piv -> l is 6 fp64 ops deep instead of 8
-        const double y0 = __builtin_amdgcn_rsq(piv);
-        const double g0 = piv * y0, h0 = 0.5 * y0;
-        const double r0 = fma(-g0, h0, 0.5);
-        const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
-        const double r1 = fma(-g1, h1, 0.5);
-        const double u = (av[c] + av[c]) * h1;
-        const double l = fma(u, r1, u);
-        av[c] = l;
-        if (lane == c) { const double y1 = h1 + h1; rsd = fma(y1, r1, y1); }
-#pragma unroll
-        for (int c2 = c + 1; c2 < 8; ++c2) {
-          const double lc2 = bcr_readlane(l, c2);
-          av[c2] = fma(-l, lc2, av[c2]);
-        }
-      }
-      if (PROF && prof) { asm volatile("s_nop 0" :: "v"(av[7])); }
-      BCR_MARK(7);
-      // the strictly upper part of the 8x8 diagonal block is written too (finite garbage, never read as data)
-      if (act && (lane >= 8 || wave == 0)) {
-        double* cp = W + j0 * LD + rho;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) cp[c * LD] = av[c];
-      }
-      if (wave == 0 && lane < 8) dinvs[j0 + lane] = rsd;
-      if (bad && lane == 0) *failp = 1;
-    }
-    BCR_MARK(1);
-    bcr_lds_barrier();
-    BCR_MARK(2);
-    // ---- trailing update in registers; the next panel's columns go back to LDS
-    const int jn = j0 + 8;
-    if (jn < 64) {
-#pragma unroll
-      for (int k = 0; k < kBcrSlots; ++k) {
-        if (t_ok[k] && 16 * t_ct[k] + 15 >= jn) {
-          const double* pa = W + (j0 + lq) * LD + 16 * t_ct[k] + li;
-          const double* pb = W + (j0 + lq) * LD + 16 * t_rt[k] + li;
-          const double a0 = pa[0], a1v = pa[4 * LD];
-          const double b0 = -pb[0], b1 = -pb[4 * LD];
-          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1, acc[k], 0, 0, 0);
-          if (16 * t_ct[k] == (jn & ~15)) {
-            double* dst = W + (16 * t_ct[k] + lq) * LD + 16 * t_rt[k] + li;
-            if (jn & 8) { dst[8 * LD] = acc[k][2]; dst[12 * LD] = acc[k][3]; }
-            else { dst[0] = acc[k][0]; dst[4 * LD] = acc[k][1]; }
-            // the next panel's diagonal block once more, for the panel waves (rows jn..jn+7 of the diagonal tile)
-            const int rr = li - (jn & 8);
-            if (t_rt[k] == t_ct[k] && rr >= 0 && rr < 8) {
-              if (jn & 8) { dg[lq * 8 + rr] = acc[k][2]; dg[(lq + 4) * 8 + rr] = acc[k][3]; }
-              else { dg[lq * 8 + rr] = acc[k][0]; dg[(lq + 4) * 8 + rr] = acc[k][1]; }
-            }
-          }
-        }
-      }
-    }
-    BCR_MARK(3);
-    bcr_lds_barrier();
-    BCR_MARK(4);
-  }
-
-  // ---- factor rows to global memory (row major; diagonal slot = 1/L_ii, upper part zero)
-  if (MODE == 0) {
-    double* Lg = A.Lf + (int64_t)i * Ru * 64;
-    for (int e = tid; e < Ru * 64; e += kBcrThreads) {
-      const int r = e >> 6, c = e & 63;
-      double v = W[c * LD + r];
-      if (r < 64) v = r > c ? v : (r == c ? dinvs[c] : 0.0);
-      Lg[e] = v;
-    }
-  }
-  BCR_MARK(5);
-
-  if (MODE == 0) {
-    // the Schur complement of the border rows is formed by bcr_schur_kernel from the factor rows just written
-    __syncthreads();
-    if (tid == 0 && *failp) atomicOr(A.fail, 1);
-    if (PROF && prof && lane == 0) for (int k = 0; k < 8; ++k) A.prof[k] = pc[k];
-    return;
-  }
-
-  if (MODE == 2) {
-    // ---------------- final launch of the parallel cyclic reduction: X_i = D_i^-1 R_i for the a1 right-hand sides
-    // (the factorisation left Y = L^-1 R in the border rows; back substitution per column, one wave each)
-    __syncthreads();
-    for (int q = wave; q < a1; q += kBcrThreads / 64) {
-      double z = W[lane * LD + 192 + q];
-      double xv = 0.0;
-      const double dv = dinvs[lane];
-      for (int jb = 56; jb >= 0; jb -= 8) {
-        double l8[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) l8[t] = lane < jb + t ? -W[lane * LD + jb + t] : 0.0;   // L(jb+t, lane)
-#pragma unroll
-        for (int t = 7; t >= 0; --t) {
-          const double xj = bcr_readlane(z * dv, jb + t);
-          if (lane == jb + t) xv = xj;
-          z = fma(l8[t], xj, z);
-        }
-      }
-      W[q * LD + 64 + lane] = xv;          // X(lane, q) in the unused left rows
-    }
-    __syncthreads();
-    for (int e = tid; e < a1 * 64; e += kBcrThreads) { const int q = e >> 6, r = e & 63; A.X[((int64_t)i * a1 + q) * 64 + r] = W[q * LD + 64 + r]; }
-    // E_i^T X_i (arrow columns of the block as built) into the shared corner sum: E_i staged in the unused right rows
-    // (W[q*LD + 128 + r] = E_i(r, q)), coalesced, before the 64-term sums
-    const double* F0 = A.F0 + (int64_t)i * 64 * a1;
-    for (int e = tid; e < 64 * a1; e += kBcrThreads) { const int r = e / a1, q = e - r * a1; W[q * LD + 128 + r] = F0[e]; }
-    __syncthreads();
-    for (int e = tid; e < a * a1; e += kBcrThreads) {
-      const int q1 = e / a1, q2 = e - q1 * a1;
-      double v0 = 0.0, v1 = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < 64; r += 2) { v0 = fma(W[q1 * LD + 128 + r], W[q2 * LD + 64 + r], v0); v1 = fma(W[q1 * LD + 128 + r + 1], W[q2 * LD + 64 + r + 1], v1); }
-      const double v = v0 + v1;
-      if (v != 0.0) unsafeAtomicAdd(A.Cacc + q1 * a1 + q2, v);
-    }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      if (*failp) atomicOr(A.fail, 1);
-      const unsigned ticket = __hip_atomic_fetch_add(A.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      failp[1] = ticket == (unsigned)A.n - 1u;
-    }
-    __syncthreads();
-    if (!failp[1]) return;
-    // ---- last workgroup: reduced corner C - E^T B^-1 E with the rhs as row / column a, its solution, then the band part
-    __threadfence();
-    if (tid == 0) *failp = 0;
-    for (int e = tid; e < a1 * a1; e += kBcrThreads) {
-      const int c = e / a1, r = e - c * a1;
-      double v = A.Mc[r * a1 + c];
-      const int q1 = r < a ? r : c, q2 = r < a ? c : a;                  // row a (the rhs): by symmetry of B^-1 the sum stored at (c, a)
-      if (q1 < a) v -= __hip_atomic_load(A.Cacc + q1 * a1 + q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      W[c * LD + 64 + r] = v;
-    }
-    __syncthreads();
-    bcr_corner_solve<LD>(W + 64, da, failp, a, tid, wave, lane);
-    for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
-    for (int e = tid; e < A.n * 64; e += kBcrThreads) {
-      if (e >= A.Pb) break;
-      const int blk = e >> 6, r = e & 63;
-      const double* Xb = A.X + (int64_t)blk * a1 * 64 + r;
-      double v = Xb[a * 64];
-      int q = 0;
-      for (; q + 8 <= a; q += 8) {          // eight loads in flight before the dependent sum
-        double t8[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t8[k] = Xb[(q + k) * 64];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v = fma(-t8[k], da[q + k], v);
-      }
-      for (; q < a; ++q) v = fma(-Xb[q * 64], da[q], v);
-      A.x[e] = v;
-    }
-    __syncthreads();
-    if (tid == 0 && *failp) atomicOr(A.fail, 1);
-    return;
-  }
-
-  // ---------------- LAST: arrow corner, back substitution of block 0
-  __syncthreads();
-  // Cq(r, c) = W[c*LD + 64 + r]   (rows 64.. are unused without neighbours)
-  for (int e = tid; e < a1 * a1; e += kBcrThreads) {
-    const int c = e / a1, r = e - c * a1;
-    double v0 = A.Mc[r * a1 + c], v1 = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < 64; k += 2) {
-      v0 = fma(-W[k * LD + 192 + r], W[k * LD + 192 + c], v0);
-      v1 = fma(-W[(k + 1) * LD + 192 + r], W[(k + 1) * LD + 192 + c], v1);
-    }
-    W[c * LD + 64 + r] = v0 + v1;
-  }
-  __syncthreads();
-  bcr_corner_solve<LD>(W + 64, da, failp, a, tid, wave, lane);
-  for (int q = tid; q < a; q += kBcrThreads) A.x[A.Pb + q] = da[q];
-  if (wave == 0) {
-    double z = W[lane * LD + 192 + a];
-    for (int q = 0; q < a; ++q) z = fma(-W[lane * LD + 192 + q], da[q], z);
-    double xv = 0.0;
-    const double dv = dinvs[lane];
-    for (int jb = 56; jb >= 0; jb -= 8) {
-      double l8[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) l8[t] = lane < jb + t ? -W[lane * LD + jb + t] : 0.0;   // L(jb+t, lane)
-#pragma unroll
-      for (int t = 7; t >= 0; --t) {
-        const double xj = bcr_readlane(z * dv, jb + t);
-        if (lane == jb + t) xv = xj;
-        z = fma(l8[t], xj, z);
-      }
-    }
-    if (lane < A.Pb) A.x[lane] = xv;
-  }
-  __syncthreads();
-  if (tid == 0 && *failp) atomicOr(A.fail, 1);
-#undef BCR_MARK
-}
-
-// ---- Schur complement of the border rows of the pivots of one level: -L_B L_B^T onto the two
-// neighbours, their new coupling, the arrow rows and the corner.  ONE WAVE PER 16x16 TILE
-// (grid.x = tile groups of 4 waves, grid.y = pivots): the fp64 MFMA pipe of one CU
-// (128 FLOP/clk) would need ~11k cycles for the 45 tiles, spread over the chip it is one
-// dependent chain of 16 MFMAs.  Operands come straight from the factor rows in global memory,
-// 16 consecutive doubles per lane (the K index is permuted identically for both operands).
-__global__ __launch_bounds__(256) void bcr_schur_kernel(BcrArgs A) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lq = lane >> 4;
-  const int a1 = A.a + 1, rtf = A.rtf, Ru = 192 + a1, s = A.s;
-  const int i = A.pcr ? (int)blockIdx.y : s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
-  const bool hasL = il >= 0, hasR = ir < A.n;                       // (cyclic reduction: a pivot always has its left neighbour)
-  const int nRL = (hasL && hasR) ? 16 : 0, nLL = hasL ? 10 : 0, nRR = hasR ? 10 : 0;
-  const int nFL = hasL ? 4 * rtf : 0, nFR = hasR ? 4 * rtf : 0, nFF = A.pcr ? 0 : (rtf * (rtf + 1)) / 2;   // (pcr: the corner is formed once, by the final launch)
-  const int ntot = nRL + nLL + nRR + nFL + nFR + nFF;
-  const int t = (int)blockIdx.x * 4 + wave;
-  if (t >= ntot) return;
-  // orientation of the new coupling (il, ir): the pivot of the next level is the one at an odd position
-  const bool il_is_pivot = A.pcr || ((il / (2 * s)) & 1) != 0;
-  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)ir * 4096;
-  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)ir * 64 * a1;
-  double* So = A.S + (A.offS_out + (A.pcr ? 2 * il : il / (2 * s))) * 4096;
-  const double* Lg = A.Lf + (int64_t)i * Ru * 64;
-  int kind, xt, yt, u = t;
-  if (u < nRL) { kind = 0; xt = u >> 2; yt = u & 3; }
-  else if ((u -= nRL) < nLL) { kind = 1; tri10(u, xt, yt); }
-  else if ((u -= nLL) < nRR) { kind = 2; tri10(u, xt, yt); }
-  else if ((u -= nRR) < nFL) { kind = 3; xt = u >> 2; yt = u & 3; }
-  else if ((u -= nFL) < nFR) { kind = 4; xt = u >> 2; yt = u & 3; }
-  else { u -= nFR; kind = 5; xt = 0; while (u >= xt + 1) { u -= xt + 1; ++xt; } yt = u; }
-  // factor rows that form the tile: x = "row" operand, y = "column" operand
-  const int xr0 = kind == 0 ? 128 + 16 * xt : kind == 1 ? 64 + 16 * xt : kind == 2 ? 128 + 16 * xt : 192 + 16 * xt;
-  const int yr0 = kind == 0 ? 64 + 16 * yt : kind == 1 ? 64 + 16 * yt : kind == 2 ? 128 + 16 * yt : kind == 3 ? 64 + 16 * yt : kind == 4 ? 128 + 16 * yt : 192 + 16 * yt;
-  const bool swap = kind == 0 && !il_is_pivot;   // store with the y index contiguous
-  const int ar0 = swap ? xr0 : yr0, br0 = swap ? yr0 : xr0;
-  int ra = ar0 + li, rb = br0 + li;
-  ra = ra < Ru ? ra : Ru - 1; rb = rb < Ru ? rb : Ru - 1;      // padding rows of the last border tile (masked below)
-  const double* pa = Lg + (int64_t)ra * 64 + 16 * lq;
-  const double* pb = Lg + (int64_t)rb * 64 + 16 * lq;
-  double va[16], vb[16];
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) { va[kk] = pa[kk]; vb[kk] = pb[kk]; }
-  bcr_v4d g = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) g = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], g, 0, 0, 0);
-  // g[r] <-> (b-operand row br0 + li, a-operand row ar0 + lq + 4r)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double v = -g[r];
-    if (kind == 0) {
-      if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; if (A.pcr) So[4096 + x * 64 + y] = v; }   // Q[c = il var][r = ir var] (pcr: and the ir-major copy in the next slot)
-      else       { const int y = 16 * yt + li, x = 16 * xt + lq + 4 * r; So[x * 64 + y] = v; }       // Q[c = ir var][r = il var]
-    } else if (kind == 1 || kind == 2) {
-      const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
-      if (x >= y && v != 0.0) unsafeAtomicAdd((kind == 1 ? Dl : Dr) + y * 64 + x, v);
-    } else if (kind == 3 || kind == 4) {
-      const int q = 16 * xt + li, y = 16 * yt + lq + 4 * r;
-      if (q < a1 && v != 0.0) unsafeAtomicAdd((kind == 3 ? Fl : Fr) + y * a1 + q, v);
-    } else {
-      const int q1 = 16 * xt + li, q2 = 16 * yt + lq + 4 * r;
-      if (q1 < a1 && q2 <= q1 && v != 0.0) {
-        unsafeAtomicAdd(A.Mc + q1 * a1 + q2, v);
-        if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
-      }
-    }
-  }
-}
-
-// ---- back substitution of the pivots of one level (one workgroup of 4 waves per pivot):
-//   x_i = L_ii^-T ( y_i - L_left^T x_il - L_right^T x_ir - L_F^T x_arrow )
-// lane = column.  Every global load is issued before the first use; wave 0 keeps its column of
-// L_ii in registers so that the 64 dependent steps of the triangular solve are
-// mul -> v_readlane -> fma with nothing else on the chain.
-constexpr int kBackWaves = 8;    // (wave 0 keeps a 64-double column of L_ii in registers: at most 2 waves per SIMD) the kernel is a 100 KB load (the pivot's factor rows) followed by a 64-step dependent chain: more waves, more loads in flight
-__global__ __launch_bounds__(64 * kBackWaves) void bcr_backward_kernel(BcrArgs A) {
-  __shared__ double xs[192];
-  __shared__ double part[kBackWaves][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int a = A.a, a1 = a + 1, Ru = 192 + a1, s = A.s;
-  const int i = s * (2 * (int)blockIdx.x + 1), il = i - s, ir = i + s;
-  const bool hasR = ir < A.n;
-  const double* Lg = A.Lf + (int64_t)i * Ru * 64;
-  constexpr int RW = 192 / kBackWaves;         // border rows per wave: 192 >= 128 + a
-  double lv[RW];
-#pragma unroll
-  for (int k = 0; k < RW; ++k) {
-    const int r = wave + kBackWaves * k;
-    const int row = r < 128 ? 64 + r : 192 + (r - 128);
-    lv[k] = r < 128 + a ? Lg[row * 64 + lane] : 0.0;
-  }
-  double Lc[64], dv = 0.0, yv = 0.0;
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < 64; ++j) Lc[j] = Lg[j * 64 + lane];       // L(j, lane); diagonal slot = 1/L_jj; upper part zero
-    dv = Lg[lane * 64 + lane];
-    yv = Lg[(192 + a) * 64 + lane];
-  }
-  double xin = 0.0;
-  if (tid < 64) { const int gi = il * 64 + tid; xin = gi < A.Pb ? A.x[gi] : 0.0; }
-  else if (tid < 128) { const int gi = ir * 64 + (tid - 64); xin = (hasR && gi < A.Pb) ? A.x[gi] : 0.0; }
-  else if (tid < 128 + a) xin = A.x[A.Pb + (tid - 128)];
-  if (tid < 192) xs[tid] = xin;
-  __syncthreads();
-  double sum = 0.0;
-#pragma unroll
-  for (int k = 0; k < RW; ++k) { const int r = wave + kBackWaves * k; sum = fma(lv[k], r < 128 + a ? xs[r] : 0.0, sum); }
-  part[wave][lane] = sum;
-  __syncthreads();
-  if (wave == 0) {
-    double acc = 0.0;
-#pragma unroll
-    for (int w = 0; w < kBackWaves; ++w) acc += part[w][lane];
-    double z = yv - acc;
-    double xv = 0.0;
-#pragma unroll
-    for (int j = 63; j >= 0; --j) {
-      const double xj = bcr_readlane(z * dv, j);
-      if (lane == j) xv = xj;
-      z = fma(lane < j ? -Lc[j] : 0.0, xj, z);
-    }
-    const int gi = i * 64 + lane;
-    if (gi < A.Pb) A.x[gi] = xv;
-  }
-}
-
 // =====================================================================================================================
 // Cyclic reduction through the INVERSE of the pivot blocks (round 3, solver_algorithm 4).
 //
@@ -613,6 +161,7 @@ __global__ __launch_bounds__(64 * kBackWaves) void bcr_backward_kernel(BcrArgs A
 // Error: forward errors of B D^-1 B^T through the explicit inverse and through the Cholesky factor are both
 // O(cond(D_i) eps); the LM tests hold both to the oracle's steps.
 // =====================================================================================================================
+constexpr int kBackWaves = 8;   // waves of a back-substitution workgroup (one level alone: bcri_backward_kernel)
 constexpr int kInvWaves = 16;   // (measured: 13.3 us per pivot against 14.5 with 8 waves, 17 with 4)
 constexpr int kInvLD = 145;   // 128 rows, + 16 (two panels' rows of one wave land in different banks), + 1
 
@@ -1127,10 +676,6 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
                                                double max_diag, const BcrArgs& A, const int64_t tid, const int64_t nthreads) {
   const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
   const double radius = sb.radius;
-  if (A.pcr) {
-    for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) A.Cacc[e] = 0.0;
-    if (tid == 0) *A.counter = 0u;
-  }
   if (tid == 0) {   // results of the step that starts here
     sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
   }
@@ -1161,7 +706,7 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
       }
       A.D[e] = v;
     }
-    if (blk < n - 1 && !A.pcr) {
+    if (blk < n - 1) {
       // coupling (blk, blk+1): the pivot of level 0 is the odd one
       const bool right = (blk & 1) != 0;     // pivot = blk, neighbour = blk+1 (its right)
       const int64_t gr = (int64_t)(blk + 1) * 64 + (right ? r : c);
@@ -1171,16 +716,6 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
       if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
       A.S[e] = v;
     }
-    if (blk < n - 1 && A.pcr) {
-      // coupling (blk, blk+1) in both orientations: slot 2 blk with blk's variables as the column index c, slot 2 blk + 1 with those of blk + 1
-      for (int o = 0; o < 2; ++o) {
-        const int64_t gc = (int64_t)blk * 64 + (o == 0 ? c : r), gr = (int64_t)(blk + 1) * 64 + (o == 0 ? r : c);
-        const int64_t k = gr - gc;
-        double v = 0.0;
-        if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
-        A.S[(A.offS_in + 2 * blk + o) * 4096 + (e & 4095)] = v;
-      }
-    }
   }
   // border rows: arrow + rhs
   for (int64_t e = tid; e < (int64_t)n * 64 * a1; e += nthreads) {
@@ -1188,7 +723,6 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
     double v = 0.0;
     if (gi < Pb) v = q < a ? ne.Et()[(int64_t)q * Pb + gi] * sb.scale[gi] * sb.scale[Pb + q] : -ne.g()[gi] * sb.scale[gi];
     A.F[e] = v;
-    if (A.pcr) const_cast<double*>(A.F0)[e] = v;
   }
   // corner (same format as lm_build_kernel's Mc)
   for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) {
@@ -1260,12 +794,10 @@ static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
 // `dg` copy the limit is the kernels' own.
 // (the limit travels with the problem: SolveBuffers::bcr_max_border, option bcr_max_border; the workspace is sized for the kernels' own limit)
 bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 && tl.a + 1 <= 64; }
-constexpr int kPcrMaxBlocks = 256;   // parallel cyclic reduction while every block has its own CU (one round per level)
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
-  const int64_t pcr = n <= kPcrMaxBlocks ? 2 * n * 4096 + n * 64 * a1 + n * a1 * 64 + a1 * a1 + 8 : 0;   // second coupling buffer (two orientations, ping-pong), F0, X, Cacc, counter
-  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64 + pcr;
+  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64;
 }
 
 // build + factor + solve; the solution lands in sb.step_s.  Returns 0, or -1 if not applicable.
@@ -1278,28 +810,14 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.D = w; w += (int64_t)n * 4096;
   A.F = w; w += (int64_t)n * 64 * a1;
   A.S = w; w += (int64_t)2 * n * 4096;
-  // algorithm 0 / 2: cyclic reduction, 3: parallel cyclic reduction (measured on C2-C4: the same or more time -- every level costs more
-  // with all blocks as pivots and the final launch is a level of its own --, kept as an independent solver for the tests)
-  A.pcr = sb.algo == 3 && n <= kPcrMaxBlocks ? 1 : 0;
-  if (sb.algo == 3 && !A.pcr) return -1;
-  if (A.pcr) w += (int64_t)2 * n * 4096;     // second coupling buffer right behind the first (the levels ping-pong between them)
+  if (sb.algo != 0 && sb.algo != 4) return -1;   // (algorithms 2 and 3 -- the factor-based levels of rounds 1-2 and their parallel form -- left the library in round 4)
   A.Lf = w; w += (int64_t)n * (192 + a1) * 64 + 64;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
-  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.no_diag_copy = sb.bcr_no_diag_copy; A.delay = sb.bcr_delay;
+  A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.delay = sb.bcr_delay;
   A.rtf = (a1 + 15) / 16;
-  if (A.pcr) {
-    A.F0 = w; w += (int64_t)n * 64 * a1;
-    A.X = w; w += (int64_t)n * a1 * 64;
-    A.Cacc = w; w += (int64_t)a1 * a1;
-    A.counter = reinterpret_cast<unsigned int*>(w);
-  }
-  const int Rp = 192 + 16 * A.rtf;
-  A.LD = ((Rp % 32 == 16) ? Rp : Rp + 16) + 1;
-  const size_t lds = ((size_t)64 * A.LD + 64 + 64 + 8 + 64) * sizeof(double);
-  if (lds > 160 * 1024 - 64) return -1;
-  const bool inv = !A.pcr && (sb.algo == 0 || sb.algo == 4);   // (2: the factor-based levels, kept as an independent solver)
+  const bool inv = true;
   const size_t lds_inv = ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double), lds_inv_last = lds_inv + (size_t)64 * 65 * sizeof(double);
-  const bool fused_build = inv && n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
+  const bool fused_build = n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
   {
     int64_t work = (int64_t)n * 4096;
     A.s = 1; A.offS_in = 0; A.offS_out = 0;
@@ -1313,32 +831,6 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     }
   }
   using KernelFn = void (*)(BcrArgs);
-  KernelFn k_level = nullptr, k_last = nullptr, k_prof = nullptr, k_final = nullptr;
-  switch (A.LD) {
-    case 209: k_level = bcr_eliminate_kernel<209, 0, false>; k_last = bcr_eliminate_kernel<209, 1, false>; k_prof = bcr_eliminate_kernel<209, 0, true>; k_final = bcr_eliminate_kernel<209, 2, false>; break;
-    case 241: k_level = bcr_eliminate_kernel<241, 0, false>; k_last = bcr_eliminate_kernel<241, 1, false>; k_prof = k_level; k_final = bcr_eliminate_kernel<241, 2, false>; break;
-    case 273: k_level = bcr_eliminate_kernel<273, 0, false>; k_last = bcr_eliminate_kernel<273, 1, false>; k_prof = k_level; k_final = bcr_eliminate_kernel<273, 2, false>; break;
-    default: return -1;
-  }
-  bcr_allow_lds(reinterpret_cast<const void*>(k_level), lds);
-  bcr_allow_lds(reinterpret_cast<const void*>(k_last), lds);
-  bcr_allow_lds(reinterpret_cast<const void*>(k_prof), lds);
-  bcr_allow_lds(reinterpret_cast<const void*>(k_final), lds);
-  const int schur_groups = (36 + 8 * A.rtf + (A.rtf * (A.rtf + 1)) / 2 + 3) / 4;
-  if (A.pcr) {
-    // every level: all n blocks against their neighbours at distance s; the couplings ping-pong between the two buffers
-    // (offsets in 4096-double blocks from A.S)
-    int64_t in = 0, out = (int64_t)2 * n;
-    for (int s = 1; s < n; s *= 2) {
-      A.s = s; A.offS_in = in; A.offS_out = out;
-      hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(n), dim3(kBcrThreads), lds, st, A);
-      hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, n), dim3(256), 0, st, A);
-      std::swap(in, out);
-    }
-    A.s = 0;
-    hipLaunchKernelGGL(k_final, dim3(n), dim3(kBcrThreads), lds, st, A);
-    return 0;
-  }
   // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel)
   KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>, k_inv_last = bcri_invert_kernel<true, false>;
   if (inv) {
@@ -1353,22 +845,18 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
     const int m = (n + s - 1) / s;          // active blocks
     const int npiv = m / 2;
     A.s = s; A.offS_in = off; A.offS_out = off + (m - 1);
-    if (inv) {
+    {
       BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
       if (!(fused_build && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(inv_threads), lds_inv, st, Ai);
       hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv), dim3(256), 0, st, A);
-    } else {
-      hipLaunchKernelGGL((A.prof && s == 1) ? k_prof : k_level, dim3(npiv), dim3(kBcrThreads), lds, st, A);
-      hipLaunchKernelGGL(bcr_schur_kernel, dim3(schur_groups, npiv), dim3(256), 0, st, A);
     }
     strides[nlev] = s; npivs[nlev] = npiv; ++nlev;
     off += m - 1;
   }
   A.s = 0; A.offS_in = 0; A.offS_out = 0;
-  A.top = (inv && nlev >= 1) ? strides[nlev - 1] : 0;     // (the top level has one pivot, block `stride`)
-  if (inv) hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(inv_threads), lds_inv_last, st, A);
-  else hipLaunchKernelGGL(k_last, dim3(1), dim3(kBcrThreads), lds, st, A);
-  if (inv) {
+  A.top = nlev >= 1 ? strides[nlev - 1] : 0;     // (the top level has one pivot, block `stride`)
+  hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(inv_threads), lds_inv_last, st, A);
+  {
     // back substitution below the top level: two levels per launch from the bottom up (an odd count: the uppermost alone, first)
     int l = nlev - 2;        // (the top level went with block 0)
     if (l >= 0 && !(l & 1)) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); --l; }
@@ -1380,10 +868,6 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
       hipLaunchKernelGGL(bcri_backward2_kernel, dim3(npivs[l] + (orphan >= 0 ? 1 : 0)), dim3(1024), 0, st, A, npivs[l], orphan);
     }
     return 0;
-  }
-  for (int l = nlev - 1; l >= 0; --l) {
-    A.s = strides[l];
-    hipLaunchKernelGGL(bcr_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A);
   }
   return 0;
 }

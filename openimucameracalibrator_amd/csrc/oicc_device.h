@@ -105,10 +105,9 @@ struct SolveBuffers {
   double* ws;      // workspace of the time-partitioned solve (separator rows, reduced system)
   int64_t ws_doubles;
   int force_p;     // > 0: force this many partitions (tests); 0: heuristic
-  int algo;        // 0: auto (= 4 where it applies), 1: time-partitioned band sweep, 2: block cyclic reduction (factors), 3: parallel block cyclic reduction (at most 256 blocks), 4: block cyclic reduction through the inverses of the pivot blocks
+  int algo;        // 0: auto (= 4 where it applies), 1: time-partitioned band sweep, 4: block cyclic reduction through the inverses of the pivot blocks (2, 3: the factor-based formulations of rounds 1-3, removed in round 4)
   double radius;   // trust-region radius of this step (kernel argument, no host->device copy)
   int bcr_max_border = 64;      // arrow + rhs rows the block cyclic reduction accepts (per problem: option bcr_max_border)
-  int bcr_no_diag_copy = 0;     // debug: panel waves read the diagonal block in place (option debug_bcr_no_diag_copy)
   int bcr_delay = 0;            // debug: panel waves other than wave 0 start every panel this many ~1000-cycle sleeps late (option debug_bcr_delay)
 };
 

@@ -197,7 +197,6 @@ struct oicc_problem {
     opt["debug_unit_order"] = 0;  // 1: units of a tile ordered views, accelerometer, gyroscope instead of by expected duration
     opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
     opt["debug_seg_precompute"] = 0;   // 1 / 2: segment tables always / never precomputed per parameter vector (default: by problem size)
-    opt["debug_bcr_no_diag_copy"] = 0;
     opt["debug_bcr_delay"] = 0;        // panel waves other than wave 0 of the BCR elimination start every panel this many ~1000-cycle sleeps late (tests)
     opt["bcr_max_border"] = 64;        // arrow + rhs rows the block cyclic reduction accepts (kernels_bcr.hip: up to 64 by construction; round 2 held it at 32 until the panel hazard was settled, test_bcr_wide_borders_and_the_panel_hazard)
     opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
@@ -1145,7 +1144,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
 
 SolveBuffers solve_buffers(oicc_problem* p, long long* prof = nullptr) {
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, prof, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
-  sb.radius = 0.0; sb.bcr_max_border = int(p->opt["bcr_max_border"]); sb.bcr_no_diag_copy = int(p->opt["debug_bcr_no_diag_copy"]); sb.bcr_delay = int(p->opt["debug_bcr_delay"]);
+  sb.radius = 0.0; sb.bcr_max_border = int(p->opt["bcr_max_border"]); sb.bcr_delay = int(p->opt["debug_bcr_delay"]);
   return sb;
 }
 

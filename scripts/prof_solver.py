@@ -2,7 +2,7 @@ import sys, ctypes as C
 sys.path.insert(0,'/root/repo')
 import numpy as np
 from openimucameracalibrator_amd import synthetic, estimator as E
-algo = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+algo = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ds = synthetic.make_config("C2")
 cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
 tr = cal.trajectory_

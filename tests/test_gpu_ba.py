@@ -114,7 +114,7 @@ def test_intrinsics_only_stage_and_solver_variants():
     assert np.abs(gpu.GetCamera() - cpu.GetCamera()).max() < 1e-7
     assert np.abs(gpu.GetCamera()[3:5] - ds["intrinsics"][3:5]).max() < 0.5
     res = []
-    for algo in (1, 2):
+    for algo in (1, 4):
         g, _ = pair(ds, solver_algorithm=algo)
         s = g.Optimize(100, POSE, CC.intrinsics_mask(ds["model"], CC.FOCAL_LENGTH))
         res.append((s["num_iterations"], g.GetCamera(), g.GetPoses()))

@@ -183,11 +183,11 @@ def test_c2_reestimate_biases_mode_matches_the_jet_oracle():
     assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-6
 
 
-@pytest.mark.parametrize("algo,parts", [(1, 2), (1, 3), (1, 5), (2, 0), (3, 0), (4, 0), (0, 0)])
+@pytest.mark.parametrize("algo,parts", [(1, 2), (1, 3), (1, 5), (4, 0), (0, 0)])
 def test_parallel_solvers_match_sequential(algo, parts):
     """The time-partitioned band+arrow Cholesky (algorithm 1: p interior sweeps + reduced
-    separator system), the block cyclic reduction (algorithm 2: log-depth nested
-    dissection in time), its parallel form (algorithm 3: every block a pivot at every level,
+    separator system), the block cyclic reduction through the pivot inverses (algorithm 4 = the automatic choice 0: log-depth nested
+    dissection in time; the factor-based formulations 2 and 3 of rounds 1-3 left the library in round 4:
     no back substitution levels) and the automatic choice must reproduce the single-workgroup
     sequential sweep: same LM iterates on C2."""
     ds = synthetic.make_config("C2")
@@ -208,7 +208,7 @@ def test_parallel_solvers_match_sequential(algo, parts):
     assert np.abs(k1[0] - k2[0]).max() < 1e-9 and (np.abs(k1[1] - k2[1]) / (1 + np.abs(k1[1]))).max() < 1e-9
 
 
-@pytest.mark.parametrize("algo,intrinsics", [(1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1), (0, 1)])
+@pytest.mark.parametrize("algo,intrinsics", [(1, 1), (4, 0), (4, 1), (0, 1)])
 def test_bias_and_intrinsics_active_lm_matches_oracle(algo, intrinsics):
     """IMU_BIASES | IMU_INTRINSICS: 27+15 arrow columns, box-bounded bias knots, through the band sweep (1), the block cyclic
     reduction (2: three border tiles; IMU_BIASES alone: two) and the automatic choice (0 = BCR)."""
@@ -232,12 +232,11 @@ def test_bias_and_intrinsics_active_lm_matches_oracle(algo, intrinsics):
 
 @pytest.mark.parametrize("cfg", ["tiny", "C1"])
 def test_bcr_wide_borders_and_the_panel_hazard(cfg):
-    """Block cyclic reduction with three and four 16-row border tiles (biases + IMU intrinsics: > 31 arrow columns, a fifth panel
-    wave), LDS poisoned before every pass and solve, over accepted and rejected steps: the iterates of the band sweep.  And the
-    hazard behind round 2's sporadic NaN pivots, made deterministic: panel waves that start a panel late (debug_bcr_delay) read
-    the 8 x 8 diagonal block AFTER wave 0 has overwritten it with its factor when they read it in place
-    (debug_bcr_no_diag_copy = 1: the round-2 code) -- wrong factors; with the copy the trailing update leaves for them (`dg`,
-    kernels_bcr.hip) the same delay changes nothing."""
+    """Block cyclic reduction with three and four 16-row border tiles (biases + IMU intrinsics: > 31 arrow columns), LDS poisoned
+    before every pass and solve, over accepted and rejected steps: the iterates of the band sweep, also when the panel waves other
+    than wave 0 start every panel late (debug_bcr_delay: they read the panel's diagonal block from the copy `dg` the trailing update
+    leaves for them, kernels_bcr.hip -- the in-place read of round 2's kernel, the cause of its sporadic NaN pivots, left the library
+    with that kernel in round 4)."""
     ds = synthetic.make_config(cfg)
     flags = FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS
 
@@ -254,11 +253,9 @@ def test_bcr_wide_borders_and_the_panel_hazard(cfg):
 
     def same(it):
         return len(it) == len(it_ref) and all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(it, it_ref))
-    for opts in ({}, {"debug_bcr_delay": 3}, {"debug_bcr_delay": 9}, {"solver_algorithm": 3}, {"solver_algorithm": 3, "debug_bcr_delay": 5}, {"solver_algorithm": 4}, {"solver_algorithm": 4, "debug_bcr_delay": 5}):
-        s_, it = run(2, **opts)
+    for opts in ({}, {"debug_bcr_delay": 3}, {"debug_bcr_delay": 9}):
+        s_, it = run(4, **opts)
         assert s_["termination"] == s_ref["termination"] and same(it), (opts, [i["cost"] for i in it], [i["cost"] for i in it_ref])
-    s_bad, it_bad = run(2, debug_bcr_delay=3, debug_bcr_no_diag_copy=1)
-    assert not same(it_bad)                      # the in-place read of a late wave sees wave 0's factor
 
 
 @pytest.mark.parametrize("unit_loss", [0, 1])
@@ -323,14 +320,14 @@ def test_block_cyclic_reduction_deep_tree_c4():
     iterations with the block cyclic reduction equal those of the partitioned band sweep."""
     ds = synthetic.make_config("C4")
     costs = []
-    for algo in (1, 2, 0, 4):     # (0: more than 256 blocks -> the cyclic reduction as well; 4: through the inverses of the pivots)
+    for algo in (1, 0, 4):     # (0 = 4: the cyclic reduction through the inverses of the pivots)
         cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
         cal.trajectory_.SetOption("solver_algorithm", algo)
         cal.trajectory_.Optimize(3, FLAGS1)
         costs.append([i["cost"] for i in cal.trajectory_.GetIterations()])
         steps = [i["step_norm"] for i in cal.trajectory_.GetIterations()]
         assert all(np.isfinite(steps))
-    assert len(costs[0]) == len(costs[1]) == len(costs[2]) == len(costs[3]) >= 3
+    assert len(costs[0]) == len(costs[1]) == len(costs[2]) >= 3
     assert all(np.allclose(costs[0], c, rtol=1e-9, atol=0) for c in costs[1:])
 
 
@@ -342,7 +339,7 @@ def test_linear_solvers_leave_a_small_residual_at_full_size(cfg):
     reduction through the explicit inverses of the pivot blocks (the automatic choice) and the parallel cyclic reduction pay a
     factor of 10-150, still 1e-14 -- five orders below the tolerance of the LM iterate comparisons."""
     ds = synthetic.make_config(cfg)
-    for algo, bound in ((1, 2e-14), (2, 2e-14), (0, 1e-12), (4, 1e-12)) + (((3, 1e-12),) if cfg == "C2" else ()):
+    for algo, bound in ((1, 2e-14), (0, 1e-12), (4, 1e-12)):
         cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
         cal.trajectory_.SetOption("solver_algorithm", algo)
         for radius in (1e4, 1e16):       # Ceres' initial radius; (almost) no damping: the normal equations as they are
@@ -350,23 +347,23 @@ def test_linear_solvers_leave_a_small_residual_at_full_size(cfg):
             assert not failed and rhs_norm > 0 and res < bound, (cfg, algo, radius, res)
 
 
-def test_parallel_cyclic_reduction_on_c3():
-    """C3 (606 + 306 knots: 43 blocks, 6 levels of the parallel cyclic reduction) against the partitioned band sweep, with LDS
-    poisoned before every solve and through rejected steps (a start far from the valley)."""
+def test_cyclic_reduction_on_c3_through_rejected_steps():
+    """C3 (606 + 306 knots: 43 blocks, 6 levels of the cyclic reduction through the pivot inverses) against the partitioned band sweep,
+    with LDS poisoned before every solve and through rejected steps (a start far from the valley)."""
     ds = synthetic.make_config("C3")
     costs = []
-    for algo in (1, 3, 4):
+    for algo in (1, 4):
         cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
         cal.trajectory_.SetOption("solver_algorithm", algo); cal.trajectory_.SetOption("debug_poison_lds", 1)
         cal.trajectory_.SetOption("initial_trust_region_radius", 1e9)      # the first steps overshoot: rejected steps, reused diagonals
         s_ = cal.trajectory_.Optimize(8, FLAGS1)
         costs.append([(i["cost"], i["step_is_successful"]) for i in cal.trajectory_.GetIterations()])
-    assert len(costs[0]) == len(costs[1]) == len(costs[2]) >= 4
+    assert len(costs[0]) == len(costs[1]) >= 4
     for other in costs[1:]:
         assert all(a[1] == b[1] and abs(a[0] - b[0]) <= 1e-9 * b[0] for a, b in zip(costs[0], other))
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [1, 4])
 @pytest.mark.parametrize("duration,views", [(0.3, 3), (0.75, 8)])
 def test_very_short_trajectories_single_and_two_block_band(algo, duration, views):
     """Band of <= 64 columns (one block: only the last elimination runs) and of two blocks."""
