@@ -93,7 +93,7 @@ def main():
     native = use_dist and os.environ.get("OICC_BENCH_TORCH_ALLREDUCE") != "1"
     if use_dist and not native:   # torch staging path: share torch's stream so that the all-reduce is ordered with the kernels
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
-    cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None)
+    cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None, owner_computes=world > 1)   # owner-computes exchange (round 4) where the native RCCL path is up; else the all-reduce of the whole buffer
 
     if native:
         # native path: the library calls ncclAllReduce (RCCL over xGMI) in place on its own stream; torch.distributed only
@@ -170,11 +170,27 @@ def main():
 
     # N > 1: the all-reduce of the packed system, timed by HIP events on the library's stream (a collective: every rank runs it)
     allreduce_ms, allreduce_bytes = None, None
+    exchange_ms, exchange_bytes = None, None
     if use_dist:
         try:
             allreduce_ms, allreduce_bytes = tr.TimeAllReduce(flags, repeats=10)
         except Exception as e:
             sys.stderr.write("rank %d: all-reduce timing failed (%s)\n" % (rank, e))
+        barrier()
+        # the owner-computes exchange the steps above used, where it is set up (world > 1, native RCCL with send / recv): a collective,
+        # so every rank first agrees on whether it can run it
+        can = 0
+        if world > 1 and reduce_path == "rccl-native":
+            try:
+                tr.TimeExchange(flags, repeats=-1); can = 1      # (a local question, nothing is sent)
+            except Exception:
+                can = 0
+        f = torch.tensor([can], dtype=torch.int32, device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        if int(f[0]) == 1:
+            try:
+                exchange_ms, exchange_bytes = tr.TimeExchange(flags, repeats=10)
+            except Exception as e:
+                sys.stderr.write("rank %d: exchange timing failed (%s)\n" % (rank, e))
         barrier()
 
     out = None
@@ -279,6 +295,9 @@ def main():
         if use_dist:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
             out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
                                    allreduce_ms=allreduce_ms, allreduce_bytes=allreduce_bytes, allreduce_timing="HIP events around 10 all-reduces of the packed normal equations on the library's stream (%s)" % reduce_path,
+                                   exchange_ms=exchange_ms, exchange_bytes=exchange_bytes,
+                                   exchange="owner-computes (what the timed steps ran): halo rows to their owners (ncclSend / ncclRecv), gather of the owned band ranges (ncclBroadcast per owner), all-reduce of the arrow corner" if exchange_ms is not None else "all-reduce of the whole packed buffer (owner-computes exchange not available on this path)",
+                                   roofline_per_rank=dict(fp64_frac=kernels["blocks"]["fp64_TFLOPs"] / 78.6, hbm_frac=kernels["blocks"]["hbm_GBps"] / 8000.0, note="this rank's shard: algorithmic FLOPs / bytes of its Jacobian pass over the pass time by HIP events"),
                                    rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms - (allreduce_ms or 0.0)))
         if summ is not None:
             out["full_calibration"] = dict(full_ref, solver_options="reference: inner iterations + bounds line search + projected gradient norm (impl.h:255-276)",

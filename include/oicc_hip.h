@@ -263,6 +263,33 @@ int oicc_set_inner_iteration_source(oicc_problem* p, oicc_problem* whole);
  * timed with HIP events on the library's stream (every rank must call it with the same arguments: it is a collective).
  * ms_per_call: average; bytes: size of the reduced buffer.  OICC_ERR_STATE without a reduction path. */
 int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes);
+/* ---- multi-GPU, owner-computes assembly (SURVEY 8e "v2", round 4).  With time shards every band row (knot) is touched by one rank
+ * or by two neighbours.  Instead of summing the whole packed buffer over all ranks (52 MB at BASELINE config 5), the band rows are
+ * cut into one contiguous OWNED range per rank;  after its local pass a rank (1) sends the partial rows it holds of ranges it does not
+ * own to their owners and adds what it receives (~50 rows per neighbour), (2) the owners' ranges are gathered by every rank (each
+ * piece broadcast from its owner: the solve stays replicated), (3) only the arrow corner, the arrow gradient and the cost are
+ * all-reduced (oicc_set_allreduce / the native RCCL communicator).  Half the bytes of the all-reduce, no reduction arithmetic on them.
+ * The spline estimator of the reference has no counterpart (one process, Ceres threads: impl.h:260); the local support that makes
+ * the band rows rank-local is impl.h:384-397,455-460,505-516.
+ *   oicc_set_shard        this problem holds shard `rank` of `nranks` time-contiguous shards (ascending in time with the rank)
+ *   oicc_declare_remote_measurements_from   as oicc_declare_remote_measurements, with the rank that holds them: every rank then
+ *                         derives the same owned ranges and send / receive row lists
+ *   oicc_set_exchange     transport twin of the native path (ncclSend / ncclRecv / ncclBroadcast of oicc_rccl_init) for callers with
+ *                         their own transport (the tests: gloo through host memory).  op OICC_XCHG_SENDRECV: send `send_count` doubles
+ *                         to rank `peer` and receive `recv_count` doubles from it (either may be 0); op OICC_XCHG_BROADCAST: `send`
+ *                         (= `recv`) holds `send_count` doubles on rank `peer`, which every rank receives in place.  Ordered on the
+ *                         given stream, like the all-reduce hook.
+ * Without oicc_set_shard the all-reduce of the whole buffer ("v1") is what runs. */
+enum { OICC_XCHG_SENDRECV = 0, OICC_XCHG_BROADCAST = 1 };
+typedef int (*oicc_exchange_fn)(void* user, int32_t op, void* send, int64_t send_count, void* recv, int64_t recv_count,
+                                int32_t peer, void* hip_stream);
+int oicc_set_shard(oicc_problem* p, int32_t nranks, int32_t rank);
+int oicc_set_exchange(oicc_problem* p, oicc_exchange_fn fn, void* user);
+int oicc_declare_remote_measurements_from(oicc_problem* p, int32_t owner_rank, int32_t kind, int64_t n, const int64_t* t_ns);
+/* Measurement: `repeats` owner-computes exchanges of the packed normal equations (halo rows + gather + corner all-reduce), timed
+ * with HIP events on the library's stream; bytes_moved: what this rank sent + received per exchange.  A collective -- except with
+ * repeats < 0, which only answers (OICC_OK / OICC_ERR_STATE) whether the exchange is set up on this rank. */
+int oicc_time_exchange(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes_moved);
 /* Tell this rank about measurements held by OTHER ranks (timestamps only), so
  * that every rank derives the same tangent layout (which knots are in the
  * problem, bandwidth, which parameter blocks exist).

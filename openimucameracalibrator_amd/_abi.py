@@ -50,6 +50,7 @@ class Iteration(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)   # oicc_exchange_fn
 
 H = C.c_void_p  # oicc_problem*
 
@@ -112,6 +113,10 @@ DEVICE_ONLY = {
     "rccl_init": (C.c_int, [H, C.c_int32, C.c_int32, c_u8p]),
     "set_inner_iteration_source": (C.c_int, [H, H]),
     "time_allreduce": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_i64p]),
+    "time_exchange": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_i64p]),
+    "set_shard": (C.c_int, [H, C.c_int32, C.c_int32]),
+    "set_exchange": (C.c_int, [H, EXCHANGE_FN, C.c_void_p]),
+    "declare_remote_measurements_from": (C.c_int, [H, C.c_int32, C.c_int32, C.c_int64, c_i64p]),
     "sew_knot_spacing_and_variance": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, c_dp, c_dp, C.c_double, C.c_double, C.c_double,
                                                 c_dp, c_dp, c_i32p]),
 }

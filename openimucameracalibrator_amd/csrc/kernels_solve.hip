@@ -358,6 +358,34 @@ __global__ void rank_unpack_kernel(double* x, int64_t n, LmState* s, const doubl
     }
   }
 }
+// Owner-computes exchange (multi-GPU, oicc_set_shard): rows of the packed normal equations <-> a dense message.
+// Row r of the band travels as [band W | arrow columns a | gradient entry]: W + a + 1 doubles.
+__global__ void ne_pack_rows_kernel(NormalEq ne, TangentLayout tl, const int32_t* rows, int n_rows, double* buf) {
+  const int L = tl.W + tl.a + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_rows * L; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = int(i / L), e = int(i - (int64_t)k * L); const int64_t r = rows[k];
+    buf[i] = e < tl.W ? ne.band()[r * tl.W + e] : (e < tl.W + tl.a ? ne.Et()[(int64_t)(e - tl.W) * tl.Pb + r] : ne.g()[r]);
+  }
+}
+__global__ void ne_add_rows_kernel(NormalEq ne, TangentLayout tl, const int32_t* rows, int n_rows, const double* buf) {
+  const int L = tl.W + tl.a + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_rows * L; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = int(i / L), e = int(i - (int64_t)k * L); const int64_t r = rows[k];
+    double* dst = e < tl.W ? ne.band() + r * tl.W + e : (e < tl.W + tl.a ? ne.Et() + (int64_t)(e - tl.W) * tl.Pb + r : ne.g() + r);
+    *dst += buf[i];     // (each entry belongs to one thread: the rows of a message are distinct)
+  }
+}
+void launch_ne_pack_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, double* buf, hipStream_t st) {
+  if (n_rows <= 0) return;
+  const int64_t work = (int64_t)n_rows * (tl.W + tl.a + 1);
+  hipLaunchKernelGGL(ne_pack_rows_kernel, dim3(int(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st, ne, tl, rows, n_rows, buf);
+}
+void launch_ne_add_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, const double* buf, hipStream_t st) {
+  if (n_rows <= 0) return;
+  const int64_t work = (int64_t)n_rows * (tl.W + tl.a + 1);
+  hipLaunchKernelGGL(ne_add_rows_kernel, dim3(int(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st, ne, tl, rows, n_rows, buf);
+}
+
 void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st) {
   hipLaunchKernelGGL(rank_pack_kernel, dim3(int(std::min<int64_t>(1024, (n + 5 + 255) / 256))), dim3(256), 0, st, x, n, s, pack);
 }

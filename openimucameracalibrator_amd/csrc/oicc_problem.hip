@@ -44,6 +44,8 @@ void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t s
 int inner_set_resident_capacity(int n_cu);
 void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st);
 void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hipStream_t st);
+void launch_ne_pack_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, double* buf, hipStream_t st);
+void launch_ne_add_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, const double* buf, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
@@ -115,6 +117,12 @@ struct oicc_problem {
   ImuGroups acc_groups, gyr_groups;   // (sync_measurements)
   // knot windows of measurements held by OTHER ranks (multi-GPU): only for layout/bandwidth
   std::vector<int32_t> remote_so3, remote_r3;   // pairs; r3 = -1 for gyro
+  std::vector<int32_t> remote_owner;            // the rank that holds the remote measurement (-1: not told; owner-computes exchange needs it)
+  // owner-computes exchange (oicc_set_shard): owned band-row ranges of all ranks, the rows this rank sends to / receives from every other rank
+  int shard_n = 1, shard_rank = 0;
+  oicc_exchange_fn exchange = nullptr; void* exchange_user = nullptr;
+  struct OwnerPlan { bool valid = false; std::vector<int32_t> cut; std::vector<std::vector<int32_t>> send_rows, recv_rows; std::vector<int32_t> flat, send_off, recv_off; int max_rows = 0; } owner;
+  DevBuf<int32_t> d_xrows; DevBuf<double> d_xsend, d_xrecv;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
   bool meas_dirty = true, groups_dirty = true;
   std::thread plan_thread; InnerPlanOptions plan_job{}; bool plan_job_valid = false; double plan_ms[3] = {0, 0, 0};   // the plan's host part on a second thread (start_inner_plan)
@@ -320,6 +328,52 @@ Active active_set(const oicc_problem* p, int flags) {
 int build_tiles(oicc_problem* p);
 void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen);
 
+// Owner-computes exchange of time-sharded ranks (include/oicc_hip.h, oicc_set_shard): which band rows each rank touches (its own
+// measurements; the other ranks' from the remote measurements declared with their owner), one contiguous OWNED range of band rows per
+// rank (the cut between two neighbours in the middle of the rows both touch, on a knot boundary), and per other rank the rows this
+// rank sends to it (rows it touches inside that rank's range) and receives from it.  Every rank derives the same tables.
+void build_owner_plan(oicc_problem* p) {
+  oicc_problem::OwnerPlan& op = p->owner;
+  op.valid = false;
+  const int n = p->shard_n, me = p->shard_rank;
+  const HostLayout& L = p->L;
+  if (n <= 1 || !p->act.spline || L.Pb <= 0) return;
+  for (int32_t o : p->remote_owner) if (o < 0 || o >= n || o == me) return;   // (owners not declared: the whole-buffer all-reduce runs)
+  const int nk = L.Pb / 3;                                                  // knots in layout order (row = 3 knot)
+  std::vector<std::vector<uint8_t>> touch(size_t(n), std::vector<uint8_t>(size_t(nk), 0));
+  auto mark = [&](int k, int s_so3, int s_r3) {
+    for (int i = 0; i < kN; ++i) { const int o = L.so3[s_so3 + i]; if (o >= 0) touch[k][o / 3] = 1; }
+    if (s_r3 >= 0) for (int i = 0; i < kN; ++i) { const int o = L.r3[s_r3 + i]; if (o >= 0) touch[k][o / 3] = 1; }
+  };
+  for (size_t v = 0; v < p->view_s_so3.size(); ++v) mark(me, p->view_s_so3[v], p->view_s_r3[v]);
+  for (size_t g = 0; g < p->acc_groups.size(); ++g) { const int32_t i = p->acc_groups.first[g]; mark(me, p->acc.s_so3[i], p->acc.s_r3[i]); }
+  for (size_t g = 0; g < p->gyr_groups.size(); ++g) { const int32_t i = p->gyr_groups.first[g]; mark(me, p->gyr.s_so3[i], -1); }
+  for (size_t i = 0; i < p->remote_so3.size(); ++i) mark(p->remote_owner[i], p->remote_so3[i], p->remote_r3[i]);
+  std::vector<int> lo(n, nk), hi(n, 0);
+  for (int k = 0; k < n; ++k) for (int q = 0; q < nk; ++q) if (touch[k][q]) { lo[k] = std::min(lo[k], q); hi[k] = std::max(hi[k], q + 1); }
+  op.cut.assign(size_t(n) + 1, 0);
+  int prev_hi = 0;
+  for (int k = 1; k < n; ++k) {
+    prev_hi = std::max(prev_hi, hi[k - 1]);
+    int c = lo[k] < nk ? (std::min(lo[k], prev_hi) + std::max(lo[k], prev_hi)) / 2 : prev_hi;   // middle of the overlap (or of the gap)
+    c = std::min(std::max(c, op.cut[k - 1] / 3), nk);
+    op.cut[k] = 3 * c;
+  }
+  op.cut[n] = L.Pb;
+  op.send_rows.assign(size_t(n), {}); op.recv_rows.assign(size_t(n), {});
+  for (int q = 0; q < n; ++q) {
+    if (q == me) continue;
+    for (int k = op.cut[q] / 3; k < op.cut[q + 1] / 3; ++k) if (touch[me][k]) for (int r = 0; r < 3; ++r) op.send_rows[q].push_back(3 * k + r);
+    for (int k = op.cut[me] / 3; k < op.cut[me + 1] / 3; ++k) if (touch[q][k]) for (int r = 0; r < 3; ++r) op.recv_rows[q].push_back(3 * k + r);
+  }
+  op.flat.clear(); op.send_off.assign(size_t(n) + 1, 0); op.recv_off.assign(size_t(n) + 1, 0); op.max_rows = 0;
+  for (int q = 0; q < n; ++q) { op.send_off[q] = int32_t(op.flat.size()); op.flat.insert(op.flat.end(), op.send_rows[q].begin(), op.send_rows[q].end()); op.max_rows = std::max(op.max_rows, int(op.send_rows[q].size())); }
+  op.send_off[n] = int32_t(op.flat.size());
+  for (int q = 0; q < n; ++q) { op.recv_off[q] = int32_t(op.flat.size()); op.flat.insert(op.flat.end(), op.recv_rows[q].begin(), op.recv_rows[q].end()); op.max_rows = std::max(op.max_rows, int(op.recv_rows[q].size())); }
+  op.recv_off[n] = int32_t(op.flat.size());
+  op.valid = true;
+}
+
 // Tangent layout: the ordering contract of include/oicc_hip.h.  Host part (no device work: the inner-iteration plan can be built
 // from it on a second host thread while the measurements travel and the tiles are made) ...
 void make_layout_host(oicc_problem* p, int flags) {
@@ -367,6 +421,7 @@ void make_layout_host(oicc_problem* p, int flags) {
   }
   L.hb = hb;
   p->act = a;
+  build_owner_plan(p);
 }
 // ... and device part: offsets, buffers of the normal equations and the solve, tiles
 int make_layout_device(oicc_problem* p, int flags) {
@@ -392,6 +447,10 @@ int make_layout_device(oicc_problem* p, int flags) {
   tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
+  if (p->owner.valid) {   // row lists and message buffers of the owner-computes exchange
+    const size_t msg = size_t(std::max(p->owner.max_rows, 1)) * size_t(tl.W + tl.a + 1);
+    if (!p->d_xrows.upload(p->owner.flat, st) || !p->d_xsend.resize(msg) || !p->d_xrecv.resize(msg)) { p->err = "hipMalloc exchange buffers"; return OICC_ERR_HIP; }
+  }
   p->layout_flags = -1;   // (stays invalid if the tiles cannot be built)
   const double tl1 = now_s();
   const int rc = build_tiles(p);
@@ -1089,6 +1148,8 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the probl
   return OICC_OK;
 }
 
+bool owner_exchange_ready(const oicc_problem* p);
+int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved = nullptr);
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
               bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false,
@@ -1136,7 +1197,9 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   if (p->opt["debug_sync"] != 0.0) HIPCK(p, hipStreamSynchronize(st));
   if (p->reduce) {
     double* cdst = (!jac && cost_out) ? cost_out : ne.cost();
-    int rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, cdst, 1, st);
+    int rc;
+    if (jac && owner_exchange_ready(p)) return owner_exchange(p, ne, st);       // owner-computes: halo rows, gather of the owned ranges, all-reduce of the corner
+    rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, cdst, 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   }
   return OICC_OK;
@@ -1164,7 +1227,11 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  bool ok = false;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false, p2p = false;
 };
 RcclApi& rccl_api() {
   static RcclApi api;
@@ -1180,7 +1247,10 @@ RcclApi& rccl_api() {
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend")); api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart")); api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.Broadcast;
+    api.p2p = api.ok && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
   }
   return api;
 }
@@ -1209,6 +1279,64 @@ int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream
   launch_rank_pack(xv, n, with_state ? p->d_state.p : nullptr, p->d_rank_pack.p, st);
   if (p->reduce(p->reduce_user, p->d_rank_pack.p, n + 5, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   launch_rank_unpack(xv, n, with_state ? p->d_state.p : nullptr, p->d_rank_pack.p, st);
+  return OICC_OK;
+}
+// ---- owner-computes exchange of the packed normal equations (include/oicc_hip.h: oicc_set_shard) ----
+bool owner_exchange_ready(const oicc_problem* p) {
+  if (!p->owner.valid || p->shard_n <= 1 || p->reduce == nullptr) return false;
+  if (p->rccl_comm != nullptr) return rccl_api().p2p && p->rccl_nranks == p->shard_n;
+  return p->exchange != nullptr;
+}
+int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved) {
+  const oicc_problem::OwnerPlan& op = p->owner;
+  const TangentLayout& tl = p->tl;
+  const int n = p->shard_n, me = p->shard_rank, L = tl.W + tl.a + 1;
+  const bool native = p->rccl_comm != nullptr;
+  ncclComm_t comm = static_cast<ncclComm_t>(p->rccl_comm);
+  RcclApi& api = rccl_api();
+  int64_t moved = 0;
+  // (1) halo: partial rows of ranges this rank does not own go to their owners; what the others hold of this rank's range comes in
+  //     and is added.  Peers in ascending rank order on every rank, the lower rank of a pair sends first: no cyclic wait with a
+  //     blocking transport.
+  for (int q = 0; q < n; ++q) {
+    if (q == me) continue;
+    const int ns = op.send_off[q + 1] - op.send_off[q], nr = op.recv_off[q + 1] - op.recv_off[q];
+    if (ns == 0 && nr == 0) continue;
+    launch_ne_pack_rows(ne, tl, p->d_xrows.p + op.send_off[q], ns, p->d_xsend.p, st);
+    if (native) {
+      bool ok = api.GroupStart() == ncclSuccess;
+      if (ns) ok = ok && api.Send(p->d_xsend.p, size_t(ns) * L, ncclDouble, q, comm, st) == ncclSuccess;
+      if (nr) ok = ok && api.Recv(p->d_xrecv.p, size_t(nr) * L, ncclDouble, q, comm, st) == ncclSuccess;
+      ok = (api.GroupEnd() == ncclSuccess) && ok;
+      if (!ok) { p->err = "ncclSend / ncclRecv of the halo rows failed"; return OICC_ERR_STATE; }
+    } else if (p->exchange(p->exchange_user, OICC_XCHG_SENDRECV, p->d_xsend.p, int64_t(ns) * L, p->d_xrecv.p, int64_t(nr) * L, q, st) != 0) {
+      p->err = "exchange callback (send / receive) failed"; return OICC_ERR_STATE; }
+    launch_ne_add_rows(ne, tl, p->d_xrows.p + op.recv_off[q], nr, p->d_xrecv.p, st);
+    moved += int64_t(ns + nr) * L * int64_t(sizeof(double));
+  }
+  // (2) gather: every rank's owned range -- its band rows (one contiguous piece), its entries of every arrow row and of the gradient --
+  //     broadcast from the owner, in place
+  auto bcast = [&](double* ptr, int64_t count, int root) -> bool {
+    if (count <= 0) return true;
+    if (root != me) moved += count * int64_t(sizeof(double));
+    if (native) return api.Broadcast(ptr, ptr, size_t(count), ncclDouble, root, comm, st) == ncclSuccess;
+    return p->exchange(p->exchange_user, OICC_XCHG_BROADCAST, ptr, count, ptr, count, root, st) == 0;
+  };
+  bool ok = true;
+  if (native) ok = api.GroupStart() == ncclSuccess;
+  for (int k = 0; k < n && ok; ++k) {
+    const int64_t r0 = op.cut[k], nr = op.cut[k + 1] - op.cut[k];
+    ok = ok && bcast(ne.band() + r0 * tl.W, nr * tl.W, k);
+    for (int c = 0; c < tl.a && ok; ++c) ok = bcast(ne.Et() + int64_t(c) * tl.Pb + r0, nr, k);
+    ok = ok && bcast(ne.g() + r0, nr, k);
+  }
+  if (native) ok = (api.GroupEnd() == ncclSuccess) && ok;
+  if (!ok) { p->err = "gather of the owned band ranges failed"; return OICC_ERR_STATE; }
+  // (3) what every rank contributes to: the arrow corner, the arrow part of the gradient and the cost
+  if (tl.a > 0 && p->reduce(p->reduce_user, ne.C(), int64_t(tl.a) * tl.a, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+  if (p->reduce(p->reduce_user, ne.g() + tl.Pb, int64_t(tl.a) + 1, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }   // (the cost follows the gradient in the packed buffer)
+  moved += 2 * (int64_t(tl.a) * tl.a + tl.a + 1) * int64_t(sizeof(double));
+  if (bytes_moved) *bytes_moved = moved;
   return OICC_OK;
 }
 }  // namespace
@@ -1404,7 +1532,7 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t
 
 // Multi-GPU: measurements held by other ranks only shape the layout (which knots
 // are in the problem, bandwidth, which parameter blocks exist).
-int oicc_declare_remote_measurements(oicc_problem* p, int32_t kind, int64_t n, const int64_t* t_ns) {
+int oicc_declare_remote_measurements_from(oicc_problem* p, int32_t owner_rank, int32_t kind, int64_t n, const int64_t* t_ns) {
   ARG(p, p->pl.n_so3 > 0, "set_times first");
   for (int64_t i = 0; i < n; ++i) {
     double u; int64_t s_so3 = 0, s_r3 = -1, s_b = 0;
@@ -1420,11 +1548,18 @@ int oicc_declare_remote_measurements(oicc_problem* p, int32_t kind, int64_t n, c
     if (kind == 3) { p->has_tic_block = true; }
     if (kind == 1) p->has_acc = true;
     if (kind == 2) p->has_gyr = true;
-    p->remote_so3.push_back(int32_t(s_so3)); p->remote_r3.push_back(kind == 2 ? -1 : int32_t(s_r3));
+    p->remote_so3.push_back(int32_t(s_so3)); p->remote_r3.push_back(kind == 2 ? -1 : int32_t(s_r3)); p->remote_owner.push_back(owner_rank);
   }
   p->layout_flags = -1;
   return OICC_OK;
 }
+int oicc_declare_remote_measurements(oicc_problem* p, int32_t kind, int64_t n, const int64_t* t_ns) { return oicc_declare_remote_measurements_from(p, -1, kind, n, t_ns); }
+int oicc_set_shard(oicc_problem* p, int32_t nranks, int32_t rank) {
+  ARG(p, nranks >= 1 && rank >= 0 && rank < nranks, "shard rank");
+  p->shard_n = nranks; p->shard_rank = rank; p->layout_flags = -1;
+  return OICC_OK;
+}
+int oicc_set_exchange(oicc_problem* p, oicc_exchange_fn fn, void* user) { p->exchange = fn; p->exchange_user = user; return OICC_OK; }
 
 int oicc_get_tangent_layout(oicc_problem* p, int32_t flags, int32_t* nt, int32_t* so3, int32_t* r3, int32_t* ab, int32_t* gb, int32_t other[5]) {
   int rc = prepare(p, flags); if (rc) return rc;
@@ -1911,6 +2046,25 @@ int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double*
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   if (ms_per_call) *ms_per_call = double(ms) / std::max(repeats, 1);
   if (bytes) *bytes = int64_t(p->ne.total) * int64_t(sizeof(double));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return OICC_OK;
+}
+
+int oicc_time_exchange(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes_moved) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  if (!owner_exchange_ready(p)) { p->err = "owner-computes exchange not set up (oicc_set_shard, remote measurements with their owners, a transport)"; return OICC_ERR_STATE; }
+  if (repeats < 0) return OICC_OK;                                               // (a local question: is the exchange set up? nothing is sent)
+  hipStream_t st = p->stream;
+  HIPCK(p, hipMemsetAsync(p->d_ne2.p, 0, p->ne.total * sizeof(double), st));   // (the second buffer: the current system stays intact)
+  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  int64_t moved = 0;
+  rc = owner_exchange(p, p->ne2, st, &moved); if (rc) return rc;                  // warm-up (connection set-up)
+  HIPCK(p, hipEventRecord(e0, st));
+  for (int i = 0; i < repeats; ++i) { rc = owner_exchange(p, p->ne2, st, &moved); if (rc) return rc; }
+  HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_per_call) *ms_per_call = double(ms) / std::max(repeats, 1);
+  if (bytes_moved) *bytes_moved = moved;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return OICC_OK;
 }

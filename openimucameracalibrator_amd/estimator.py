@@ -313,9 +313,37 @@ class SplineTrajectoryEstimator:
     def RunLmIterations(self, flags, steps):
         self._ck(self._b.run_lm_iterations(self._h, int(flags), int(steps)))
 
-    def DeclareRemoteMeasurements(self, kind, t_ns):
+    def DeclareRemoteMeasurements(self, kind, t_ns, owner=None):
+        """Timestamps of measurements another rank holds (layout only); owner: that rank (needed by the owner-computes exchange)."""
         t_ns = np.ascontiguousarray(t_ns, dtype=np.int64)
-        self._ck(self._b.declare_remote_measurements(self._h, int(kind), len(t_ns), t_ns.ctypes.data_as(_abi.c_i64p)))
+        if owner is None:
+            self._ck(self._b.declare_remote_measurements(self._h, int(kind), len(t_ns), t_ns.ctypes.data_as(_abi.c_i64p)))
+        else:
+            self._ck(self._b.declare_remote_measurements_from(self._h, int(owner), int(kind), len(t_ns), t_ns.ctypes.data_as(_abi.c_i64p)))
+
+    def SetShard(self, nranks, rank):
+        """This problem holds time shard `rank` of `nranks` (owner-computes exchange of the normal equations, include/oicc_hip.h)."""
+        self._ck(self._b.set_shard(self._h, int(nranks), int(rank)))
+
+    def SetExchange(self, fn):
+        """fn(op:int, send_ptr:int, send_count:int, recv_ptr:int, recv_count:int, peer:int, stream:int) -> None: transport twin of
+        ncclSend / ncclRecv (op 0, both directions with rank `peer`) and ncclBroadcast (op 1, root `peer`, in place)."""
+        def tramp(user, op, sp, sc, rp, rc_, peer, stream):
+            try:
+                fn(int(op), int(sp or 0), int(sc), int(rp or 0), int(rc_), int(peer), int(stream or 0))
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("exchange callback failed:", e)
+                return -1
+        cb = _abi.EXCHANGE_FN(tramp)
+        self._keep.append(cb)
+        self._ck(self._b.set_exchange(self._h, cb, None))
+
+    def TimeExchange(self, flags, repeats=10):
+        """(ms per owner-computes exchange of the packed normal equations, bytes this rank moved); a collective: every rank calls it."""
+        ms = C.c_double(0.0); nb = C.c_int64(0)
+        self._ck(self._b.time_exchange(self._h, int(flags), int(repeats), C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
 
     def TimeLinearSolve(self, flags, repeats=10):
         ms = C.c_double(0)
@@ -483,7 +511,7 @@ class ImuCameraCalibrator:
         self.trajectory_ = SplineTrajectoryEstimator(backend=backend, device=device)
         self.inital_cam_line_delay_s_ = 0.0
 
-    def BatchInitSpline(self, ds, shard=None, known_gravity=None):
+    def BatchInitSpline(self, ds, shard=None, known_gravity=None, owner_computes=False):
         """imu_camera_calibrator.cc:21-124 for a synthetic.Dataset.  ``shard``
         (rank, world) adds only that rank's time window of measurements; knots and
         calibration are initialised from the whole dataset on every rank."""
@@ -522,7 +550,18 @@ class ImuCameraCalibrator:
         self.cam_timestamps_ = [float(x) for x in vt]
         self.gyro_measurements_ = {float(x): g for x, g in zip(t[keep], ds.gyro[keep])}
         self.accl_measurements_ = {float(x): a for x, a in zip(t[keep], ds.accel[keep])}
-        if shard is not None and shard[1] > 1:
+        if shard is not None and shard[1] > 1 and owner_computes:
+            # owner-computes exchange: every other rank's measurements declared with their owner (timestamps only)
+            tr.SetShard(shard[1], shard[0])
+            for q in range(shard[1]):
+                if q == shard[0]:
+                    continue
+                dq = ds.shard(q, shard[1])
+                tr.DeclareRemoteMeasurements(0 if ds.line_delay_init != 0.0 else 3, (dq.shard_view_t_s * S_TO_NS).astype(np.int64), owner=q)
+                oq = (t >= self.t0_s_) & (t < self.tend_s_) & dq.shard_imu
+                tq = (t[oq] * S_TO_NS).astype(np.int64)
+                tr.DeclareRemoteMeasurements(1, tq, owner=q); tr.DeclareRemoteMeasurements(2, tq, owner=q)
+        elif shard is not None and shard[1] > 1:
             # other ranks' measurements: timestamps only, so that every rank derives the same tangent layout
             mine = np.zeros(ds.num_views, bool); mine[d.shard_view_index] = True
             tr.DeclareRemoteMeasurements(0 if ds.line_delay_init != 0.0 else 3, (ds.view_t_s[~mine] * S_TO_NS).astype(np.int64))

@@ -798,13 +798,18 @@ def test_projected_gradient_norm_of_the_bounded_problem_matches_the_oracle():
 
 
 # ---- two processes, one GPU: the product's all-reduce hook inside oicc_optimize ---------------------------------------------
-@pytest.mark.parametrize("cfg,flags,ls,inner", [("C1", FLAGS1, 0, 0), ("tiny", FLAGS1 | E.ACC_BIAS, 1, 0), ("C1", FLAGS1, 0, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1)])
-def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner, tmp_path):
+@pytest.mark.parametrize("cfg,flags,ls,inner,owner", [("C1", FLAGS1, 0, 0, 0), ("tiny", FLAGS1 | E.ACC_BIAS, 1, 0, 0), ("C1", FLAGS1, 0, 1, 0), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1, 0),
+                                                     ("C1", FLAGS1, 0, 0, 1), ("C2", FLAGS1, 0, 0, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1, 1), ("C1", FLAGS1, 0, 1, 1)])   # (C1 with the line delay free is chaotic from run to run within ONE process: not a test case)
+def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner, owner, tmp_path):
     """Rank r of two PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
     all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
     LmState) after every cost pass, slopes of the bounds line search.  RCCL refuses two ranks on one device, so the hook stages
     through host memory and gloo -- the product side of the hook is what is tested.  Both ranks must take the same steps as ONE
-    process holding the whole problem."""
+    process holding the whole problem.
+    owner = 1 (round 4): the owner-computes exchange instead of the all-reduce of the whole buffer -- every band row has one owning
+    rank; the ranks send the partial rows they hold of the other's range (oicc_set_exchange: send / receive), gather the owned
+    ranges (broadcast per owner) and all-reduce only the arrow corner, the arrow gradient and the cost: the whole buffer is never
+    summed, the steps are those of ONE process."""
     import os, subprocess, sys as _sys, json as _json, socket
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_shard_worker.py")
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -814,7 +819,7 @@ def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner,
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), LOCAL_RANK="0")
             out = str(tmp_path / ("w%d_r%d.json" % (world, r))); outs.append(out)
-            procs.append(subprocess.Popen([_sys.executable, worker, cfg, str(int(flags)), "6", str(ls), out, str(inner)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+            procs.append(subprocess.Popen([_sys.executable, worker, cfg, str(int(flags)), "6", str(ls), out, str(inner), str(owner)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         for p_ in procs:
             o, _ = p_.communicate(timeout=240)
             assert p_.returncode == 0, o.decode()[-2000:]
@@ -823,6 +828,11 @@ def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner,
     whole = run(1)[0]
     parts = run(2)
     assert sum(p_["blocks"] for p_ in parts) == whole["blocks"] and all(p_["hook_calls"] >= 2 * (len(whole["iterations"]) - 1) for p_ in parts)
+    if owner:   # halo rows travelled, owned ranges were gathered, and no all-reduce was larger than the arrow corner + a rank-consistency pack
+        assert all(p_["exchange"]["sendrecv"] >= len(whole["iterations"]) and p_["exchange"]["broadcast"] >= 2 * len(whole["iterations"]) for p_ in parts)
+        assert all(p_["hook_max_doubles"] < 10 * p_["P"] for p_ in parts)       # (the packed buffer is ~50 P doubles: it was never all-reduced)
+    else:
+        assert all(p_["hook_max_doubles"] > 10 * p_["P"] for p_ in parts)
     if inner:   # the reference's solver configuration on time-sharded ranks: the sweeps run (replicated) over the whole problem's measurements
         assert whole["inner_sweeps"] >= 1 and all(p_["inner_sweeps"] == whole["inner_sweeps"] for p_ in parts)
     for p_ in parts:
