@@ -9,6 +9,8 @@ flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
 for r in range(reps):
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cal.trajectory_.UseReferenceSolverOptions()
+    for a in sys.argv[3:]:
+        if "=" in a: cal.trajectory_.SetOption(a.split("=")[0], float(a.split("=")[1]))
     t = time.perf_counter(); cal.trajectory_.EvaluateCost(flags); t_prep = time.perf_counter() - t     # uploads, layout, tiles + one cost pass
     t = time.perf_counter(); s = cal.trajectory_.Optimize(50, flags); dt = time.perf_counter() - t
     print("   first cost evaluation (uploads, layout, tiles) %.3f ms; solver %.3f ms (jacobian %.3f, residual incl. sweeps %.3f, linear solver %.3f)" % (
