@@ -56,7 +56,10 @@ typedef enum oicc_camera_model {
 
 /* SplineOptimFlags, spline_trajectory_estimator.h:17-27 (same bit values). */
 typedef enum oicc_optim_flags {
-  OICC_POINTS = 1 << 0, /* not supported (never set by the reference CLI) */
+  OICC_POINTS = 1 << 0, /* impl.h:136-153: the board points the views observe become variables (homogeneous 4-vectors under
+                         * ceres::HomogeneousVectorParameterization(4): 3 tangent dimensions each, the LAST arrow columns, in
+                         * point order).  Never set by the reference CLI; here: complete, not tuned (csrc/kernels_points.hip),
+                         * not combinable with the inner_iterations option (OICC_ERR_UNSUPPORTED). */
   OICC_T_I_C = 1 << 1,
   OICC_IMU_BIASES = 1 << 2,
   OICC_IMU_INTRINSICS = 1 << 3,
@@ -163,8 +166,11 @@ int oicc_set_imu_intrinsics(oicc_problem* p, const double accl[6],
  * ceres_calib_split_residuals.h:218-221,333-336 (constant on this path). */
 int oicc_set_camera(oicc_problem* p, int32_t camera_model,
                     const double* intrinsics, int32_t num_intrinsics);
-/* Board points = tracks of the reconstruction, homogeneous (x,y,z,w). */
+/* Board points = tracks of the reconstruction, homogeneous (x,y,z,w), w != 0.  They are the tail of the parameter vector:
+ * oicc_optimize with OICC_POINTS refines them in place (as the reference refines image_data_'s tracks), oicc_get_scene_points
+ * reads them back. */
 int oicc_set_scene_points(oicc_problem* p, const double* xyzw, int64_t n);
+int oicc_get_scene_points(const oicc_problem* p, double* xyzw, int64_t n);
 
 /* ---- problem construction: mirrors Add*Measurement --------------------- */
 /* AddRSCameraMeasurement (impl.h:539-613) / AddGSCameraMeasurement
@@ -308,6 +314,10 @@ int oicc_get_tangent_layout(oicc_problem* p, int32_t flags, int32_t* num_tangent
                             int32_t* accl_bias_offsets,
                             int32_t* gyro_bias_offsets,
                             int32_t other_offsets[5] /* T_i_c,g,ld,acc_intr,gyr_intr */);
+/* Tangent offset of every board point for `flags`: -1 unless OICC_POINTS is set and a corner of some view refers to the
+ * point (impl.h:136-153: tracks_in_problem_); the point columns follow the arrow blocks listed above, 3 per point, in
+ * point order.  offsets: one entry per point of oicc_set_scene_points. */
+int oicc_get_scene_point_offsets(oicc_problem* p, int32_t flags, int32_t* offsets);
 /* One residual + Jacobian + normal-equation pass at the current parameters.
  * cost = 0.5*sum r^2.  H_dense (P*P row-major, symmetric) and g (P) optional. */
 int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H_dense,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "set_imu_intrinsics": (C.c_int, [H, c_dp, c_dp]),
     "set_camera": (C.c_int, [H, C.c_int32, c_dp, C.c_int32]),
     "set_scene_points": (C.c_int, [H, c_dp, C.c_int64]),
+    "get_scene_points": (C.c_int, [H, c_dp, C.c_int64]),
+    "get_scene_point_offsets": (C.c_int, [H, C.c_int32, c_i32p]),
     "add_rs_camera_measurements": (C.c_int, [H, C.c_int64, c_i64p, c_i64p, c_dp, c_dp, c_i32p, c_u8p]),
     "add_gs_camera_measurements": (C.c_int, [H, C.c_int64, c_i64p, c_i64p, c_dp, c_dp, c_i32p, c_u8p]),
     "add_accelerometer_measurements": (C.c_int, [H, C.c_int64, c_i64p, c_dp, C.c_double, c_u8p]),

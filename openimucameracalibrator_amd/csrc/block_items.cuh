@@ -41,6 +41,12 @@ OICC_DEV void view_const_init(ViewConst& C, const double* T_i_c) {
   so3_matrix(C.q_ic, C.Ric);
 }
 
+// A sink that declares `static constexpr bool kWantsPoint = true` also receives the Jacobian with respect to the corner's board
+// point (pt: 2 x 4 over the homogeneous vector) -- SplineOptimFlags::POINTS, kernels_points.hip.  For every other sink that code
+// does not exist.
+template <class S, class = void> struct sink_wants_point { static constexpr bool value = false; };
+template <class S> struct sink_wants_point<S, decltype(void(S::kWantsPoint))> { static constexpr bool value = S::kWantsPoint; };
+
 // KR(j) -> pointer to R^3 knot j of the window (3 doubles); SEG(i) -> segment table entry i of the window.
 // Returns the item's cost 1/2 |r|^2.
 template <bool JAC, class SegAcc, class R3Acc, class Sink>
@@ -83,6 +89,21 @@ OICC_DEV double view_item(const ViewConst& C, const Quat& R0, const SegAcc& SEG,
       for (int cc = 0; cc < 3; ++cc) {
         M1[cc] = isx * (Jpi[0] * C.Ric[cc * 3] + Jpi[1] * C.Ric[cc * 3 + 1] + Jpi[2] * C.Ric[cc * 3 + 2]);
         M1[3 + cc] = isy * (Jpi[3] * C.Ric[cc * 3] + Jpi[4] * C.Ric[cc * 3 + 1] + Jpi[5] * C.Ric[cc * 3 + 2]);
+      }
+      if constexpr (sink_wants_point<Sink>::value) {
+        // p_c = R_ic^T (R_wi^T (X.xyz / X.w - t_wi) - t_ic): d r / d X = [M1 R_wi^T / w | -M1 R_wi^T X.xyz / w^2]
+        double jx[8];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          double s = 0.0;
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const double m = M1[rr * 3] * Rwi[cc * 3] + M1[rr * 3 + 1] * Rwi[cc * 3 + 1] + M1[rr * 3 + 2] * Rwi[cc * 3 + 2];
+            jx[rr * 4 + cc] = m * iw; s += m * X[cc];
+          }
+          jx[rr * 4 + 3] = -s * iw * iw;
+        }
+        out.pt(jx);
       }
       if (C.spline_active) {
         double MQ[6], nB[6];

@@ -23,6 +23,7 @@
 #include "oicc_device.h"
 #include "spline_math.cuh"
 #include "spline_seg.cuh"
+#include "ba_math.cuh"   // homogeneous_plus4: the board points under SplineOptimFlags::POINTS
 
 namespace oicc {
 
@@ -181,6 +182,15 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
       const double v1 = fmin(fmax(v0 + alpha * (sb.step_s[o + c] * sb.scale[o + c]), -max_gb), max_gb);
       xc[pl.gb + 3 * k + c] = v1; step_sq += (v1 - v0) * (v1 - v0); x_sq += v0 * v0; }
   }
+  for (int64_t k = tid; k < tl.n_pts; k += nthreads) {   // SplineOptimFlags::POINTS: ceres::HomogeneousVectorParameterization(4)::Plus
+    const int o = tl.pts[k];
+    if (o >= 0) {
+      const double d3[3] = {alpha * (sb.step_s[o] * sb.scale[o]), alpha * (sb.step_s[o + 1] * sb.scale[o + 1]), alpha * (sb.step_s[o + 2] * sb.scale[o + 2])};
+      const double* X0 = x + pl.pts + 4 * k;
+      double X1[4]; homogeneous_plus4(X0, d3, X1);
+      for (int c = 0; c < 4; ++c) { xc[pl.pts + 4 * k + c] = X1[c]; const double dd = X1[c] - X0[c]; step_sq += dd * dd; x_sq += X0[c] * X0[c]; }
+    }
+  }
   // the extrinsics (coupled SE(3) exponential) and the small Euclidean blocks are each one thread's work: threads that have no
   // knot of their own, in different waves, so that their chains run beside the SO(3) retractions instead of behind thread 0's
   const int64_t busy = pl.n_so3 > pl.n_r3 ? pl.n_so3 : pl.n_r3;
@@ -251,6 +261,15 @@ __global__ void lm_projected_gradient_kernel(const double* x, ParamLayout pl, Ta
   for (int64_t k = tid; k < pl.n_gb; k += nthreads) {
     const int o = tl.gb[k];
     if (o >= 0) for (int c = 0; c < 3; ++c) { const double v0 = x[pl.gb + 3 * k + c]; m = fmax(m, fabs(fmin(fmax(v0 - g[o + c], -max_gb), max_gb) - v0)); }
+  }
+  for (int64_t k = tid; k < tl.n_pts; k += nthreads) {
+    const int o = tl.pts[k];
+    if (o >= 0) {
+      const double d3[3] = {-g[o], -g[o + 1], -g[o + 2]};
+      const double* X0 = x + pl.pts + 4 * k;
+      double X1[4]; homogeneous_plus4(X0, d3, X1);
+      for (int c = 0; c < 4; ++c) m = fmax(m, fabs(X1[c] - X0[c]));
+    }
   }
   if (tid == 0) {
     if (tl.tic >= 0) {

@@ -164,14 +164,14 @@ __device__ __forceinline__ void column_table_entry(const RowFmt& f, int col, int
 // residual column Pb + a (so (i, Pb + a) is a gradient entry and (Pb + a, Pb + a) twice the cost).
 struct Target {
   double* acc;          // LDS accumulator of the tile: rows [lo, lo + nrows) x [band W | arrow a | gradient], then the (a + 1)^2 corner
-  int Wl, W, Pb, a, corner0;
+  int Wl, W, Pb, a, corner0, ldc;   // ldc: row stride of the packed corner (TileParams::ldc)
   NormalEq ne;          // DIRECT mode: fp64 atomics on the packed normal equations
 };
 __device__ __forceinline__ void target_add_direct(const Target& T, int i, int j, double v) {
   const int P = T.Pb + T.a;
   if (j < T.Pb) unsafeAtomicAdd(T.ne.band() + (int64_t)i * T.W + (j - i), v);
   else if (i < T.Pb) { if (j < P) unsafeAtomicAdd(T.ne.Et() + (int64_t)(j - T.Pb) * T.Pb + i, v); else unsafeAtomicAdd(T.ne.g() + i, v); }
-  else if (j < P) { unsafeAtomicAdd(T.ne.C() + (int64_t)(i - T.Pb) * T.a + (j - T.Pb), v); if (i != j) unsafeAtomicAdd(T.ne.C() + (int64_t)(j - T.Pb) * T.a + (i - T.Pb), v); }
+  else if (j < P) { unsafeAtomicAdd(T.ne.C() + (int64_t)(i - T.Pb) * T.ldc + (j - T.Pb), v); if (i != j) unsafeAtomicAdd(T.ne.C() + (int64_t)(j - T.Pb) * T.ldc + (i - T.Pb), v); }
   else if (i < P) unsafeAtomicAdd(T.ne.g() + i, v);
   else unsafeAtomicAdd(T.ne.cost(), 0.5 * v);
 }
@@ -345,7 +345,7 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
   int* const l_todo_so3 = l_tl_so3 + 4 * kMaxTileKnots; int* const l_todo_r3 = l_tl_r3 + 4 * kMaxTileKnots;   // TileDesc::rows_off, table `todo`
   int* const l_tdb = reinterpret_cast<int*>(lds + tp.o_misc + 12);   // descriptors of the chain's later tiles, [tile & 1][12 ints]
   Target T;
-  T.acc = acc; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
+  T.acc = acc; T.Wl = tp.Wl; T.W = ctx.tl.W; T.Pb = ctx.tl.Pb; T.a = ctx.tl.a; T.corner0 = tp.acc_rows * tp.Wl; T.ldc = tp.ldc; T.ne = ctx.ne; T.ne.base = dyn.ne_base;
   double cost_local = 0.0;
   const long long tp0 = prof ? clock64() : 0;
   // the tile's descriptor: the chain's first one straight from memory (issued here, first needed after the staging below), the
@@ -453,7 +453,7 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
         if (djac) for (int k = 0; k < 2 * 43; ++k) djac[k] = 0.0;
         const TileSink<0, JAC> sink(fv, rb + lane * fv.item_stride, s_so3, dres, djac);
         cost_local += view_item<JAC>(vc, R0, seg, kr, vd.view_u_so3[v], vd.view_u_r3[v], dyn.view_rs[v] != 0, vd.corner_u[it], vd.corner_v[it],
-                                     vd.corner_isx[it], vd.corner_isy[it], ctx.pts + 4 * (int64_t)vd.corner_pt[it], sink);
+                                     vd.corner_isx[it], vd.corner_isy[it], xg + ctx.pl.pts + 4 * (int64_t)vd.corner_pt[it], sink);
       }
     } else {
       const bool accel = ud.kind == 1;
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) {
     const double v = red[0];
-    if (q < tl.a) { ne.C()[(int64_t)p * tl.a + q] = v; ne.C()[(int64_t)q * tl.a + p] = v; }
+    if (q < tl.a) { ne.C()[(int64_t)p * tp.ldc + q] = v; ne.C()[(int64_t)q * tp.ldc + p] = v; }
     else if (p < tl.a) { ne.g()[tl.Pb + p] = v; if (tp.gmax != nullptr) atomicMax(reinterpret_cast<unsigned long long*>(tp.gmax), (unsigned long long)__double_as_longlong(fabs(v))); }
     else ne.cost()[0] = 0.5 * v;
   }

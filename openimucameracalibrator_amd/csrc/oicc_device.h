@@ -9,6 +9,7 @@ namespace oicc {
 struct ParamLayout {
   int64_t so3, r3, ab, gb, tic, g, ld, ai, gi, total;
   int32_t n_so3, n_r3, n_ab, n_gb;
+  int64_t pts; int32_t n_pts, pad_;   // the board points (homogeneous 4-vectors) behind everything else: variables under SplineOptimFlags::POINTS
 };
 
 // Tangent layout of the active set (the ordering contract of include/oicc_hip.h).
@@ -19,6 +20,10 @@ struct TangentLayout {
   const int32_t* gb;   // [n_gb]
   int32_t tic, g, ld, ai, gi;  // arrow offsets or -1
   int32_t P, Pb, a, hb, W;     // W = hb + 1 (band row length)
+  // SplineOptimFlags::POINTS: the LAST a_pts arrow columns are the tangents of the board points (3 each, in point order); the tile
+  // pass works on the layout without them (kernels_points.hip adds their rows and columns)
+  const int32_t* pts;          // [n_pts] offset or -1
+  int32_t n_pts, a_pts;
 };
 
 // Normal equations in band + arrow storage, ONE contiguous fp64 buffer so that a

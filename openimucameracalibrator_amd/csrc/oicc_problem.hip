@@ -39,6 +39,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
                        hipStream_t st);
 int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& dyn, bool jac, hipStream_t st);
 void launch_lds_poison(hipStream_t st);
+void launch_point_columns(const EvalCtx& ctx, const ViewData& vd, const uint8_t* view_rs, bool spline_active, hipStream_t st);   // kernels_points.hip
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
 void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st);
 int inner_set_resident_capacity(int n_cu);
@@ -68,12 +69,13 @@ struct ImuHost {
 struct ImuDev { DevBuf<int32_t> s_so3, s_r3, s_b; DevBuf<double> u_so3, u_r3, u_b, mx, my, mz, w; };
 struct ImuGroups { std::vector<int32_t> first, count; size_t size() const { return first.size(); } };   // runs of samples with identical knot windows
 
-struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g; };
+struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g, pts; };
 
 struct HostLayout {
   std::vector<int32_t> so3, r3, ab, gb;
   int32_t other[5];
   int32_t P, Pb, a, hb;
+  std::vector<int32_t> pts; int32_t a_pts = 0;   // SplineOptimFlags::POINTS: the last a_pts arrow columns (3 per observed board point, in point order)
 };
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -106,10 +108,12 @@ struct oicc_problem {
   ParamLayout pl{};
   std::vector<double> x;
   bool x_host_dirty = true;       // host mirror newer than device
+  bool x_host_dirty_pts = false;  // oicc_set_scene_points since the parameter vector was laid out: `pts` is newer than x's copy
   std::vector<char> so3_in, r3_in, ab_in, gb_in;   // *_knot_in_problem_, impl.h:282-283
   int cam_model = 0, n_intr = 0; double intr[10] = {0};
   std::vector<double> pts;
   // measurements (host SoA)
+  int32_t max_corner_pt = -1;
   std::vector<int32_t> corner_view, corner_pt; std::vector<double> cu, cv, cisx, cisy;
   std::vector<int64_t> view_c0{0}; std::vector<int32_t> view_s_so3, view_s_r3; std::vector<double> view_u_so3, view_u_r3;
   std::vector<uint8_t> view_rs;
@@ -135,7 +139,7 @@ struct oicc_problem {
   int rccl_nranks = 1;
   oicc_problem* inner_src = nullptr;   // time-sharded ranks: the problem whose measurements (all ranks') the inner-iteration sweeps run over
   // device
-  DevBuf<double> d_x, d_xc, d_pts;
+  DevBuf<double> d_x, d_xc;
   // segment tables (spline_seg.cuh) of the SO(3) knot pairs of the two parameter buffers, keyed by the buffer's address (d_x.p and
   // d_xc.p trade places when a step is accepted); valid = computed for the buffer's current contents
   struct SegTable { DevBuf<double> buf; const double* of = nullptr; bool valid = false; } seg_tab[2];
@@ -150,7 +154,7 @@ struct oicc_problem {
   DevBuf<int64_t> d_view_c0; DevBuf<uint8_t> d_view_rs, d_view_rs_all; std::vector<uint8_t> h_view_rs_all;
   DevArena meas_arena, layout_arena, tile_arena, plan_arena;   // one device block + one copy per group of arrays
   ImuDev d_acc, d_gyr;
-  DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb;
+  DevBuf<int32_t> d_tl_so3, d_tl_r3, d_tl_ab, d_tl_gb, d_tl_pts;
   DevBuf<double> d_ws;
   DevBuf<double> d_rank_pack;   // all-reduce hook path: [candidate | step scalars | rank count] (make_rank_consistent)
   DevBuf<double> d_ne2;   // second normal-equation buffer: the Jacobian pass at the candidate runs while the host decides
@@ -178,7 +182,7 @@ struct oicc_problem {
   // layout_flags = -1 invalidates (measurements, knot counts, line delay set by the caller); otherwise the layout and the tiles are
   // rebuilt only when the flags, the zero-ness of the line delay (active_set) or an option changed since they were built
   int layout_flags = -1; bool layout_ld_zero = false; int64_t opt_gen = 0, layout_opt_gen = -1, layout_gen = 0;
-  HostLayout L; TangentLayout tl{}; NormalEq ne{}; NormalEq ne2{};
+  HostLayout L; TangentLayout tl{}; TangentLayout tl_tiles{}; NormalEq ne{}; NormalEq ne2{};   // tl_tiles: tl without the point columns (SplineOptimFlags::POINTS), what the tile pass sees
   Active act{};
 
   oicc_problem() {
@@ -231,6 +235,7 @@ void rebuild_param_layout(oicc_problem* p, int64_t n_so3, int64_t n_r3, int64_t 
   // keep calibration scalars when the knot counts change
   double T_i_c[7] = {0, 0, 0, 1, 0, 0, 0}, g[3] = {0, 0, 9.81}, ld = 0, ai[6] = {0, 0, 0, 1, 1, 1}, gi[9] = {0, 0, 0, 0, 0, 0, 1, 1, 1};
   std::vector<double> so3, r3, ab, gb;
+  if (!p->x.empty() && p->pl.n_pts > 0 && !p->x_host_dirty_pts) p->pts.assign(xs(p, p->pl.pts), xs(p, p->pl.pts) + 4 * p->pl.n_pts);   // (refined points live in x)
   if (!p->x.empty()) {
     std::memcpy(T_i_c, xs(p, p->pl.tic), sizeof(T_i_c)); std::memcpy(g, xs(p, p->pl.g), sizeof(g)); ld = p->x[p->pl.ld];
     std::memcpy(ai, xs(p, p->pl.ai), sizeof(ai)); std::memcpy(gi, xs(p, p->pl.gi), sizeof(gi));
@@ -241,8 +246,10 @@ void rebuild_param_layout(oicc_problem* p, int64_t n_so3, int64_t n_r3, int64_t 
   pl.n_so3 = int32_t(n_so3); pl.n_r3 = int32_t(n_r3); pl.n_ab = int32_t(n_ab); pl.n_gb = int32_t(n_gb);
   int64_t o = 0;
   pl.so3 = o; o += 4 * n_so3; pl.r3 = o; o += 3 * n_r3; pl.ab = o; o += 3 * n_ab; pl.gb = o; o += 3 * n_gb;
-  pl.tic = o; o += 7; pl.g = o; o += 3; pl.ld = o; o += 1; pl.ai = o; o += 6; pl.gi = o; o += 9; pl.total = o;
+  pl.tic = o; o += 7; pl.g = o; o += 3; pl.ld = o; o += 1; pl.ai = o; o += 6; pl.gi = o; o += 9;
+  pl.pts = o; pl.n_pts = int32_t(p->pts.size() / 4); o += 4 * int64_t(pl.n_pts); pl.total = o;
   p->x.assign(o, 0.0);
+  std::copy(p->pts.begin(), p->pts.end(), p->x.begin() + pl.pts); p->x_host_dirty_pts = false;
   for (int64_t i = 0; i < n_so3; ++i) p->x[pl.so3 + 4 * i + 3] = 1.0;
   auto keep = [&](const std::vector<double>& v, int64_t off, size_t cnt) { if (v.size() == cnt && cnt) std::copy(v.begin(), v.end(), p->x.begin() + off); };
   keep(so3, pl.so3, 4 * n_so3); keep(r3, pl.r3, 3 * n_r3); keep(ab, pl.ab, 3 * n_ab); keep(gb, pl.gb, 3 * n_gb);
@@ -289,7 +296,7 @@ int sync_measurements(oicc_problem* p) {
   A.add(p->d_corner_view, p->corner_view); A.add(p->d_corner_pt, p->corner_pt); A.add(p->d_cu, p->cu); A.add(p->d_cv, p->cv);
   A.add(p->d_cisx, p->cisx); A.add(p->d_cisy, p->cisy); A.add(p->d_view_c0, p->view_c0); A.add(p->d_view_s_so3, p->view_s_so3);
   A.add(p->d_view_s_r3, p->view_s_r3); A.add(p->d_view_u_so3, p->view_u_so3); A.add(p->d_view_u_r3, p->view_u_r3);
-  A.add(p->d_view_rs, p->view_rs); A.add(p->d_pts, p->pts);
+  A.add(p->d_view_rs, p->view_rs);
   p->h_view_rs_all.assign(p->view_rs.size(), 1);
   A.add(p->d_view_rs_all, p->h_view_rs_all);
   for (int k = 0; k < 2; ++k) {
@@ -322,6 +329,7 @@ Active active_set(const oicc_problem* p, int flags) {
   a.spline = (flags & OICC_SPLINE) != 0;                               // impl.h:180-204
   a.ab = (flags & (OICC_ACC_BIAS | OICC_IMU_BIASES)) != 0;             // impl.h:208-229
   a.gb = (flags & (OICC_GYR_BIAS | OICC_IMU_BIASES)) != 0;             // impl.h:230-251
+  a.pts = (flags & OICC_POINTS) != 0;                                  // impl.h:136-153
   return a;
 }
 
@@ -405,6 +413,13 @@ void make_layout_host(oicc_problem* p, int flags) {
   if (a.gb) for (int i = 0; i < pl.n_gb; ++i) if (p->gb_in[i]) { L.gb[i] = off; off += 3; }
   if (a.intr_a && p->has_acc) { L.other[3] = off; off += 6; }
   if (a.intr_g && p->has_gyr) { L.other[4] = off; off += 9; }
+  // impl.h:136-153: the tracks of the views in the problem become variable (HomogeneousVectorParameterization(4): 3 tangent
+  // dimensions); a point no corner refers to has no parameter block.  Behind every other block, in point order.
+  L.pts.assign(size_t(pl.n_pts), -1); L.a_pts = 0;
+  if (a.pts) {
+    for (int32_t id : p->corner_pt) L.pts[id] = 0;
+    for (int32_t& o : L.pts) if (o == 0) { o = off; off += 3; L.a_pts += 3; }
+  }
   L.P = off; L.a = off - L.Pb;
   int hb = 0;
   auto span = [&](int s_so3, int s_r3) {
@@ -431,10 +446,12 @@ int make_layout_device(oicc_problem* p, int flags) {
   hipStream_t st = p->stream;
   DevArena& LA = p->layout_arena;   // tangent offsets + every buffer of the normal equations and the solve: one block, one copy
   LA.add(p->d_tl_so3, L.so3); LA.add(p->d_tl_r3, L.r3); LA.add(p->d_tl_ab, L.ab); LA.add(p->d_tl_gb, L.gb);
+  if (L.a_pts > 0) LA.add(p->d_tl_pts, L.pts);
   TangentLayout& tl = p->tl;
   tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
   tl.tic = L.other[0]; tl.g = L.other[1]; tl.ld = L.other[2]; tl.ai = L.other[3]; tl.gi = L.other[4];
   tl.P = L.P; tl.Pb = L.Pb; tl.a = L.a; tl.hb = L.hb; tl.W = L.hb + 1;
+  tl.pts = nullptr; tl.n_pts = L.a_pts > 0 ? int32_t(L.pts.size()) : 0; tl.a_pts = L.a_pts;
   NormalEq& ne = p->ne;
   const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
   ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
@@ -445,6 +462,9 @@ int make_layout_device(oicc_problem* p, int flags) {
   LA.reserve(p->d_ws, size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))));
   if (!LA.commit(st)) { p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
+  tl.pts = L.a_pts > 0 ? p->d_tl_pts.p : nullptr;
+  // the tile pass assembles everything but the point columns: the same layout without the last a_pts arrow columns (kernels_points.hip)
+  p->tl_tiles = tl; p->tl_tiles.a = tl.a - tl.a_pts; p->tl_tiles.P = tl.P - tl.a_pts; p->tl_tiles.a_pts = 0; p->tl_tiles.n_pts = 0; p->tl_tiles.pts = nullptr;
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   if (p->owner.valid) {   // row lists and message buffers of the owner-computes exchange
@@ -592,7 +612,7 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
 }
 
 int build_tiles(oicc_problem* p) {
-  const TangentLayout& tl = p->tl; const Active& a = p->act;
+  const TangentLayout& tl = p->tl_tiles; const Active& a = p->act;   // (without the board-point columns: kernels_points.hip adds those)
   p->fv = view_row_fmt(tl, a.spline);
   const int wide_max = p->opt["wide_cells"] != 0.0 ? 8 : 0;
   p->fa = imu_row_fmt(tl, true, a.spline, a.ab, wide_max);
@@ -600,6 +620,7 @@ int build_tiles(oicc_problem* p) {
   TileParams& tp = p->tp; tp = TileParams{};
   tp.Wl = (tl.W + tl.a + 1) | 1;   // [band W | arrow a | gradient 1], padded to an odd length: the four row groups of an MFMA result tile hit different LDS banks
   tp.corner = (tl.a + 1) * (tl.a + 1);
+  tp.ldc = p->tl.a;
   // LDS budget (doubles) and the row buffer of a wave: the largest view in one piece if it fits 26 KB, never less than ~32 IMU samples
   const int budget = 160 * 1024 / 8 - 64;
   int max_nc = 1;
@@ -780,7 +801,7 @@ int build_tiles(oicc_problem* p) {
 
 int prepare(oicc_problem* p, int flags) {
   ARG(p, p->pl.n_so3 > 0, "oicc_set_times has not been called");
-  ARG(p, !(flags & OICC_POINTS), "OICC_POINTS (board point refinement) is not supported on this path");
+  ARG(p, p->max_corner_pt < p->pl.n_pts, "a corner refers to a board point beyond those of oicc_set_scene_points");
   HIPCK(p, hipSetDevice(p->device));
   const bool timing = p->opt["verbose"] >= 2.0;
   const double t00 = now_s();
@@ -805,7 +826,7 @@ int prepare(oicc_problem* p, int flags) {
 
 EvalCtx make_ctx(oicc_problem* p, const double* x) {
   EvalCtx c{};
-  c.x = x; c.pl = p->pl; c.tl = p->tl; c.ne = p->ne; c.pts = p->d_pts.p;
+  c.x = x; c.pl = p->pl; c.tl = p->tl; c.ne = p->ne; c.pts = x + p->pl.pts;   // (the board points are part of the parameter vector)
   c.inv_so3_dt = p->inv_so3_dt; c.inv_r3_dt = p->inv_r3_dt;
   std::memcpy(c.intr, p->intr, sizeof(c.intr)); c.cam_model = p->cam_model;
   c.gs_unit_loss = p->opt["gs_unit_loss"] != 0.0; c.rs_time_in_seconds = p->opt["rs_time_in_seconds"] != 0.0;
@@ -1159,16 +1180,22 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
   const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
   if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
   {                                     // time tiles (kernels_tiles.hip): the slab merge writes every entry of the packed buffer
+    const bool with_points = jac && p->tl.a_pts > 0 && (only_kind < 0 || only_kind == 0);   // SplineOptimFlags::POINTS
     if (jac && (p->tp.direct || p->tp.n_tiles == 0)) HIPCK(p, hipMemsetAsync(ne.base, 0, ne.total * sizeof(double), st));
+    else if (jac && p->tl.a_pts > 0) {   // the parts only the point kernel adds to (the merge writes the rest): arrow rows of the points + the corner, their gradient entries
+      const int a_np = p->tl.a - p->tl.a_pts;
+      HIPCK(p, hipMemsetAsync(ne.base + ne.off_E + int64_t(a_np) * p->tl.Pb, 0, size_t(ne.off_g - ne.off_E - int64_t(a_np) * p->tl.Pb) * sizeof(double), st));
+      HIPCK(p, hipMemsetAsync(ne.g() + p->tl.Pb + a_np, 0, size_t(p->tl.a_pts) * sizeof(double), st));
+    }
     else if (!jac && !cost_already_zero) HIPCK(p, hipMemsetAsync(ne.cost(), 0, sizeof(double), st));
     const TileParams& tp = p->tp;
-    p->gmax_folded = jac && want_gmax && !tp.direct && tp.n_tiles > 0 && !p->reduce;   // (with an all-reduce the gradient is only final afterwards)
+    p->gmax_folded = jac && want_gmax && !tp.direct && tp.n_tiles > 0 && !p->reduce && p->tl.a_pts == 0;   // (with an all-reduce, or with point columns, the gradient is only final afterwards)
     // the problem-constant arguments live in device memory (tiles.h: TileStatic); uploaded when they differ from the last upload
     if (!p->h_tstatic) { p->h_tstatic.reset(new TileStatic); std::memset(p->h_tstatic.get(), 0, sizeof(TileStatic)); p->tstatic_valid = false; }
     {
       static_assert(std::is_trivially_copyable<TileStatic>::value, "TileStatic is copied bytewise");
       TileStatic S; std::memset(&S, 0, sizeof(S));
-      S.ctx = make_ctx(p, nullptr); S.ctx.ne = p->ne; S.ctx.ne.base = nullptr;
+      S.ctx = make_ctx(p, nullptr); S.ctx.ne = p->ne; S.ctx.ne.base = nullptr; S.ctx.pts = nullptr; S.ctx.tl = p->tl_tiles;
       S.vd = view_data(p, false); S.vd.view_rs = nullptr;
       S.ia = imu_data(p->acc, p->d_acc); S.ig = imu_data(p->gyr, p->d_gyr);
       S.fmt[0] = p->fv; S.fmt[1] = p->fa; S.fmt[2] = p->fg; S.tp = tp; S.tp.gmax = nullptr;
@@ -1192,6 +1219,10 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = null
     dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
     if (launch_tile_pass(*p->h_tstatic, p->d_tstatic.p, dyn, jac, st) != 0) {
       p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
+    if (with_points) {   // rows, columns and gradient entries of the board points, behind the merge
+      EvalCtx c = make_ctx(p, x); c.ne = ne;
+      launch_point_columns(c, view_data(p, false), dyn.view_rs, p->act.spline, st);
+    }
   }
   HIPCK(p, hipGetLastError());
   if (p->opt["debug_sync"] != 0.0) HIPCK(p, hipStreamSynchronize(st));
@@ -1458,7 +1489,17 @@ int oicc_set_camera(oicc_problem* p, int32_t model, const double* intr, int32_t 
   ARG(p, model == OICC_CAM_PINHOLE || model == OICC_CAM_PINHOLE_RADIAL_TANGENTIAL || model == OICC_CAM_FISHEYE ||
              model == OICC_CAM_DIVISION_UNDISTORTION || model == OICC_CAM_DOUBLE_SPHERE || model == OICC_CAM_EXTENDED_UNIFIED, "camera model");
   p->cam_model = model; p->n_intr = n; std::fill(p->intr, p->intr + 10, 0.0); std::copy(intr, intr + n, p->intr); return OICC_OK; }
-int oicc_set_scene_points(oicc_problem* p, const double* xyzw, int64_t n) { p->pts.assign(xyzw, xyzw + 4 * n); p->meas_dirty = true; return OICC_OK; }
+int oicc_set_scene_points(oicc_problem* p, const double* xyzw, int64_t n) {
+  ARG(p, n >= 0 && (xyzw != nullptr || n == 0), "scene points");
+  for (int64_t i = 0; i < n; ++i) ARG(p, xyzw[4 * i + 3] != 0.0, "a board point at infinity (w = 0): the reprojection divides by w");
+  p->pts.assign(xyzw, xyzw + 4 * n); p->x_host_dirty_pts = true;
+  rebuild_param_layout(p, p->pl.n_so3, p->pl.n_r3, p->pl.n_ab, p->pl.n_gb);   // the points are the tail of the parameter vector
+  return OICC_OK;
+}
+int oicc_get_scene_points(const oicc_problem* p, double* xyzw, int64_t n) {
+  if (n < 0 || n > p->pl.n_pts) return OICC_ERR_INVALID_ARG;
+  std::copy(p->x.begin() + p->pl.pts, p->x.begin() + p->pl.pts + 4 * n, xyzw); return OICC_OK;
+}
 
 static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, const int64_t* coff, const double* uv, const double* cov,
                      const int32_t* pidx, uint8_t* accepted) {
@@ -1472,7 +1513,7 @@ static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, 
     const int32_t vid = int32_t(p->view_rs.size());
     for (int64_t c = coff[v]; c < coff[v + 1]; ++c) {
       ARG(p, pidx[c] >= 0 && size_t(pidx[c]) < p->pts.size() / 4, "point index out of range (set_scene_points first)");
-      p->corner_view.push_back(vid); p->corner_pt.push_back(pidx[c]);
+      p->corner_view.push_back(vid); p->corner_pt.push_back(pidx[c]); p->max_corner_pt = std::max(p->max_corner_pt, pidx[c]);
       p->cu.push_back(uv[2 * c]); p->cv.push_back(uv[2 * c + 1]);
       p->cisx.push_back(1.0 / std::sqrt(cov ? cov[2 * c] : 1.0)); p->cisy.push_back(1.0 / std::sqrt(cov ? cov[2 * c + 1] : 1.0));
     }
@@ -1573,6 +1614,12 @@ int oicc_get_tangent_layout(oicc_problem* p, int32_t flags, int32_t* nt, int32_t
   return OICC_OK;
 }
 
+int oicc_get_scene_point_offsets(oicc_problem* p, int32_t flags, int32_t* offsets) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  std::copy(p->L.pts.begin(), p->L.pts.end(), offsets);
+  return OICC_OK;
+}
+
 int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H, double* g, int32_t Pcap) {
   int rc = prepare(p, flags); if (rc) return rc;
   rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
@@ -1620,6 +1667,7 @@ int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind, double* r
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summary* sum) {
   const double t_start = now_s();
   struct PlanJoin { oicc_problem* q; ~PlanJoin() { q->wait_plan(); } } plan_join{p};   // (no exit of this call leaves the second thread running)
+  if ((flags & OICC_POINTS) && p->opt["inner_iterations"] != 0.0) { p->err = "OICC_POINTS with inner iterations is not supported (the reference's application never sets POINTS)"; return OICC_ERR_UNSUPPORTED; }
   if (p->opt["inner_iterations"] != 0.0 && p->inner_src == nullptr && p->reduce == nullptr) p->plan_wanted_flags = flags;   // the plan's host part runs under the set-up (prepare)
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;
@@ -1746,7 +1794,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (p->opt["debug_sync"] == 2.0) HIPCK(p, hipStreamSynchronize(st));
     if (p->opt["debug_sync"] >= 4.0) {   // D2H copy of one buffer before the solve: 4 scene points (unrelated), 5 normal equations, 6 scale + diag, 7 solver workspace
       static std::vector<double> sink; const int w = int(p->opt["debug_sync"]);
-      const double* src = w == 4 ? p->d_pts.p : (w == 5 ? p->ne.base : (w == 6 || w == 8 ? sb.scale : (w == 9 ? sb.diag : (w == 10 ? sb.D2 : (w == 11 ? reinterpret_cast<const double*>(p->d_state.p) : p->d_ws.p)))));
+      const double* src = w == 4 ? p->d_x.p + p->pl.pts : (w == 5 ? p->ne.base : (w == 6 || w == 8 ? sb.scale : (w == 9 ? sb.diag : (w == 10 ? sb.D2 : (w == 11 ? reinterpret_cast<const double*>(p->d_state.p) : p->d_ws.p)))));
       const size_t cnt = w == 4 ? p->pts.size() : (w == 5 ? size_t(p->ne.total) : (w == 6 || w == 8 || w == 9 || w == 10 ? size_t(P) : (w == 11 ? size_t(7) : p->d_ws.n)));
       sink.resize(cnt);
       HIPCK(p, hipMemcpyAsync(sink.data(), src, cnt * sizeof(double), hipMemcpyDeviceToHost, st));

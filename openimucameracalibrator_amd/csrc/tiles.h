@@ -76,6 +76,7 @@ struct TileParams {
   int32_t acc_rows;        // accumulator rows = ring slots (max over tiles of the rows a tile touches)
   int32_t slab_rows;       // rows of a chain's slab (max over chains)
   int32_t corner;          // (a + 1)^2: [C | g_arrow ; . | 2 cost]
+  int32_t ldc;             // row stride of the packed arrow corner C: a, plus the board-point columns behind it under SplineOptimFlags::POINTS (kernels_points.hip)
   // LDS carve (in doubles from the start of dynamic LDS)
   int32_t o_so3, o_r3, o_seg, o_tl, o_misc, o_units, o_ct, o_zero, o_acc, o_wave, wave_doubles;   // [knots | segment tables | layout offsets and accumulator rows of the knots | queue | the tile's unit descriptors | column tables | zero record | accumulator | per wave: column info 192 ints, row buffer]
   int32_t rb_doubles;

@@ -386,6 +386,19 @@ class SplineTrajectoryEstimator:
         self._ck(self._b.get_T_i_c(self._h, _dp(x)))
         return x
 
+    def GetScenePoints(self):
+        """The board points (homogeneous x, y, z, w) as they stand -- refined in place by Optimize under SplineOptimFlags::POINTS
+        (impl.h:136-153: the tracks of image_data_ are the parameter blocks)."""
+        out = np.zeros((len(self._points), 4))
+        self._ck(self._b.get_scene_points(self._h, _dp(out), len(out)))
+        return out
+
+    def GetScenePointOffsets(self, flags):
+        """Tangent offset of every board point for `flags` (-1: constant, or observed by no view)."""
+        out = np.full(len(self._points), -1, np.int32)
+        self._ck(self._b.get_scene_point_offsets(self._h, int(flags), out.ctypes.data_as(_abi.c_i32p)))
+        return out
+
     def GetGravity(self):
         g = np.zeros(3)
         self._ck(self._b.get_gravity(self._h, _dp(g)))

@@ -177,34 +177,8 @@ bool solve_damped(const Dense& ne, const std::vector<double>& scale, const std::
   *d = rhs; return true;
 }
 
-// ---- ceres::HomogeneousVectorParameterization(4) [EXT, ceres/local_parameterization.cc + internal/householder_vector.h]
-void householder_vector(const double x[4], double v[4], double* beta) {
-  const double sigma = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
-  for (int i = 0; i < 3; ++i) v[i] = x[i];
-  v[3] = 1.0; *beta = 0.0;
-  const double x_pivot = x[3];
-  if (sigma <= std::numeric_limits<double>::epsilon()) { if (x_pivot < 0.0) *beta = 2.0; return; }
-  const double mu = std::sqrt(x_pivot * x_pivot + sigma);
-  double v_pivot = 1.0;
-  if (x_pivot <= 0.0) v_pivot = x_pivot - mu; else v_pivot = -sigma / (x_pivot + mu);
-  *beta = 2.0 * v_pivot * v_pivot / (sigma + v_pivot * v_pivot);
-  for (int i = 0; i < 3; ++i) v[i] /= v_pivot;
-}
-void homogeneous_plus(const double x[4], const double d[3], double out[4]) {
-  const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  if (nd == 0.0) { for (int i = 0; i < 4; ++i) out[i] = x[i]; return; }
-  const double h = 0.5 * nd, sbd = std::sin(h) / h;
-  const double y[4] = {0.5 * sbd * d[0], 0.5 * sbd * d[1], 0.5 * sbd * d[2], std::cos(h)};
-  double v[4], beta; householder_vector(x, v, &beta);
-  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-  const double vy = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
-  for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vy));
-}
-void homogeneous_plus_jacobian(const double x[4], double J[12] /*4x3 row major*/) {
-  double v[4], beta; householder_vector(x, v, &beta);
-  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-  for (int r = 0; r < 4; ++r) for (int c = 0; c < 3; ++c) J[r * 3 + c] = nx * (-0.5 * beta * v[c] * v[r] + (r == c ? 0.5 : 0.0));
-}
+// (ceres::HomogeneousVectorParameterization(4): householder_vector / homogeneous_plus / homogeneous_plus_jacobian live in oicc_oracle_math.hpp,
+// shared with the spline problem's SplineOptimFlags::POINTS)
 
 // Ceres 2.1 TrustRegionMinimizer [EXT] with the LM strategy over an abstract problem
 struct LmProblem {

@@ -36,6 +36,7 @@ struct Layout {
   int P = 0, P_band = 0, arrow = 0, hb = 0;
   std::vector<int> so3, r3, ab, gb;
   int other[5] = {-1, -1, -1, -1, -1};  // T_i_c, g, ld, acc_intr, gyr_intr
+  std::vector<int> pts;                 // SplineOptimFlags::POINTS: 3 tangent dimensions per board point that a view observes, behind everything else
 };
 
 struct Problem {
@@ -76,7 +77,7 @@ struct Problem {
 };
 
 // ---- which parameter blocks are variable: SetFixedParams, impl.h:93-252 ----
-struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g; };
+struct Active { bool tic, ld, g, spline, ab, gb, intr_a, intr_g, pts; };
 Active active_set(const Problem& p, int flags) {
   Active a;
   a.tic = (flags & OICC_T_I_C) != 0;                                  // impl.h:95-106
@@ -90,6 +91,7 @@ Active active_set(const Problem& p, int flags) {
   a.spline = (flags & OICC_SPLINE) != 0;                              // impl.h:180-204
   a.ab = (flags & (OICC_ACC_BIAS | OICC_IMU_BIASES)) != 0;            // impl.h:208-229
   a.gb = (flags & (OICC_GYR_BIAS | OICC_IMU_BIASES)) != 0;            // impl.h:230-251
+  a.pts = (flags & OICC_POINTS) != 0;                                 // impl.h:136-153
   return a;
 }
 
@@ -118,6 +120,14 @@ Layout make_layout(const Problem& p, int flags) {
   if (a.gb) for (size_t i = 0; i < L.gb.size(); ++i) if (p.gb_in[i]) { L.gb[i] = off; off += 3; }
   if (a.intr_a && (!p.acc.empty() || p.remote_acc)) { L.other[3] = off; off += 6; }
   if (a.intr_g && (!p.gyr.empty() || p.remote_gyr)) { L.other[4] = off; off += 9; }
+  // impl.h:136-153: the tracks of the views in the problem (tracks_in_problem_) become variable under
+  // ceres::HomogeneousVectorParameterization(4); a point no view observes has no parameter block
+  L.pts.assign(p.pts.size() / 4, -1);
+  if (a.pts) {
+    std::vector<char> seen(L.pts.size(), 0);
+    for (int32_t id : p.pidx) seen[id] = 1;
+    for (size_t i = 0; i < L.pts.size(); ++i) if (seen[i]) { L.pts[i] = off; off += 3; }
+  }
   L.P = off; L.arrow = off - L.P_band;
   // half bandwidth of the band part
   int hb = 0;
@@ -235,7 +245,7 @@ static void eval_gyro_analytic(const Problem& p, const Layout& L, const Active& 
 }
 
 void eval_view(const Problem& p, const Layout& L, const Active& a, const ViewBlk& v, bool want_jac, BlockEval* out) {
-  if (want_jac && p.opt.at("analytic_jacobians") != 0.0) { eval_view_analytic(p, L, a, v, out); return; }
+  if (want_jac && p.opt.at("analytic_jacobians") != 0.0 && !a.pts) { eval_view_analytic(p, L, a, v, out); return; }   // (point columns: Jets only)
   const int n = int(v.c1 - v.c0);
   ReprojFunctor f;
   f.rolling_shutter = v.rs; f.n = n; f.obs = &p.uv[2 * v.c0]; f.cov = &p.cov[2 * v.c0];
@@ -246,28 +256,38 @@ void eval_view(const Problem& p, const Layout& L, const Active& a, const ViewBlk
   for (int i = 0; i < kN; ++i) { par.push_back(&p.r3[3 * (v.s_r3 + i)]); sz.push_back(3); act.push_back(a.spline); }
   par.push_back(p.T_i_c); sz.push_back(7); act.push_back(a.tic);
   if (v.rs) { par.push_back(&p.ld); sz.push_back(1); act.push_back(a.ld); }
-  for (int i = 0; i < n; ++i) { par.push_back(&p.pts[4 * p.pidx[v.c0 + i]]); sz.push_back(4); act.push_back(0); }
-  out->nres = 2 * n; out->ncols = 43; out->r.assign(2 * n, 0.0);
+  const int pt0 = int(par.size());
+  for (int i = 0; i < n; ++i) { par.push_back(&p.pts[4 * p.pidx[v.c0 + i]]); sz.push_back(4); act.push_back(a.pts); }
+  // columns: the 43 of include/oicc_hip.h, then (POINTS) 3 per corner: the tangent of that corner's board point
+  const int nc = 43 + (a.pts ? 3 * n : 0);
+  out->nres = 2 * n; out->ncols = nc; out->r.assign(2 * n, 0.0);
   std::vector<std::vector<double>> jac;
   autodiff(f, par, sz, act, 2 * n, out->r.data(), want_jac ? &jac : nullptr);
   if (!want_jac) return;
-  out->J.assign(size_t(2 * n) * 43, 0.0); out->col_off.assign(43, -1);
+  out->J.assign(size_t(2 * n) * nc, 0.0); out->col_off.assign(nc, -1);
   for (int i = 0; i < kN; ++i) {
-    if (a.spline) { so3_cols(jac[i].data(), 2 * n, par[i], out->J.data(), 43, 3 * i);
+    if (a.spline) { so3_cols(jac[i].data(), 2 * n, par[i], out->J.data(), nc, 3 * i);
       for (int c = 0; c < 3; ++c) out->col_off[3 * i + c] = L.so3[v.s_so3 + i] + c; }
-    if (a.spline) { for (int r = 0; r < 2 * n; ++r) for (int c = 0; c < 3; ++c) out->J[r * 43 + 18 + 3 * i + c] = jac[kN + i][r * 3 + c];
+    if (a.spline) { for (int r = 0; r < 2 * n; ++r) for (int c = 0; c < 3; ++c) out->J[r * nc + 18 + 3 * i + c] = jac[kN + i][r * 3 + c];
       for (int c = 0; c < 3; ++c) out->col_off[18 + 3 * i + c] = L.r3[v.s_r3 + i] + c; }
   }
   if (a.tic) {
     double Jp[42]; se3_plus_jacobian(p.T_i_c, Jp);
     for (int r = 0; r < 2 * n; ++r) for (int c = 0; c < 6; ++c) {
       double s = 0; for (int k = 0; k < 7; ++k) s += jac[2 * kN][r * 7 + k] * Jp[k * 6 + c];
-      out->J[r * 43 + 36 + c] = s; }
+      out->J[r * nc + 36 + c] = s; }
     for (int c = 0; c < 6; ++c) out->col_off[36 + c] = L.other[0] + c;
   }
   if (v.rs && a.ld) {
-    for (int r = 0; r < 2 * n; ++r) out->J[r * 43 + 42] = jac[2 * kN + 1][r];
+    for (int r = 0; r < 2 * n; ++r) out->J[r * nc + 42] = jac[2 * kN + 1][r];
     out->col_off[42] = L.other[2];
+  }
+  if (a.pts) for (int i = 0; i < n; ++i) {   // HomogeneousVectorParameterization::ComputeJacobian (4 x 3) behind the ambient 4 columns
+    double Jp[12]; homogeneous_plus_jacobian(par[pt0 + i], Jp);
+    for (int r = 0; r < 2 * n; ++r) for (int c = 0; c < 3; ++c) {
+      double s = 0; for (int k = 0; k < 4; ++k) s += jac[pt0 + i][r * 4 + k] * Jp[k * 3 + c];
+      out->J[r * nc + 43 + 3 * i + c] = s; }
+    for (int c = 0; c < 3; ++c) out->col_off[43 + 3 * i + c] = L.pts[p.pidx[v.c0 + i]] + c;
   }
 }
 
@@ -533,15 +553,19 @@ void apply_step(Problem* p, const Layout& L, const std::vector<double>& d) {
     double v = p->gb[3 * i + c] + d[L.gb[i] + c]; v = std::min(std::max(v, -p->max_gb), p->max_gb); p->gb[3 * i + c] = v; }
   if (L.other[3] >= 0) for (int c = 0; c < 6; ++c) p->acc_intr[c] += d[L.other[3] + c];
   if (L.other[4] >= 0) for (int c = 0; c < 9; ++c) p->gyr_intr[c] += d[L.other[4] + c];
+  for (size_t i = 0; i < L.pts.size(); ++i) if (L.pts[i] >= 0) {   // HomogeneousVectorParameterization::Plus
+    double out[4]; homogeneous_plus(&p->pts[4 * i], &d[L.pts[i]], out);
+    for (int c = 0; c < 4; ++c) p->pts[4 * i + c] = out[c];
+  }
 }
 
-struct ParamSnapshot { std::vector<double> so3, r3, ab, gb; double T_i_c[7], g[3], ld, ai[6], gi[9]; };
+struct ParamSnapshot { std::vector<double> so3, r3, ab, gb, pts; double T_i_c[7], g[3], ld, ai[6], gi[9]; };
 void snapshot(const Problem& p, ParamSnapshot* s) {
-  s->so3 = p.so3; s->r3 = p.r3; s->ab = p.ab; s->gb = p.gb; std::memcpy(s->T_i_c, p.T_i_c, sizeof(p.T_i_c));
+  s->so3 = p.so3; s->r3 = p.r3; s->ab = p.ab; s->gb = p.gb; s->pts = p.pts; std::memcpy(s->T_i_c, p.T_i_c, sizeof(p.T_i_c));
   std::memcpy(s->g, p.g, sizeof(p.g)); s->ld = p.ld; std::memcpy(s->ai, p.acc_intr, sizeof(p.acc_intr)); std::memcpy(s->gi, p.gyr_intr, sizeof(p.gyr_intr));
 }
 void restore(Problem* p, const ParamSnapshot& s) {
-  p->so3 = s.so3; p->r3 = s.r3; p->ab = s.ab; p->gb = s.gb; std::memcpy(p->T_i_c, s.T_i_c, sizeof(p->T_i_c));
+  p->so3 = s.so3; p->r3 = s.r3; p->ab = s.ab; p->gb = s.gb; p->pts = s.pts; std::memcpy(p->T_i_c, s.T_i_c, sizeof(p->T_i_c));
   std::memcpy(p->g, s.g, sizeof(p->g)); p->ld = s.ld; std::memcpy(p->acc_intr, s.ai, sizeof(p->acc_intr)); std::memcpy(p->gyr_intr, s.gi, sizeof(p->gyr_intr));
 }
 // ambient norms over the ACTIVE parameter blocks (Ceres' reduced program).
@@ -557,6 +581,7 @@ double ambient_sq(const Problem& p, const Layout& L, const ParamSnapshot* other)
   for (size_t i = 0; i < L.gb.size(); ++i) if (L.gb[i] >= 0) acc(&p.gb[3 * i], other ? &other->gb[3 * i] : nullptr, 3);
   if (L.other[3] >= 0) acc(p.acc_intr, other ? other->ai : nullptr, 6);
   if (L.other[4] >= 0) acc(p.gyr_intr, other ? other->gi : nullptr, 9);
+  for (size_t i = 0; i < L.pts.size(); ++i) if (L.pts[i] >= 0) acc(&p.pts[4 * i], other ? &other->pts[4 * i] : nullptr, 4);
   return s;
 }
 
@@ -573,6 +598,7 @@ double ambient_max(const Problem& p, const Layout& L, const ParamSnapshot& other
   for (size_t i = 0; i < L.gb.size(); ++i) if (L.gb[i] >= 0) acc(&p.gb[3 * i], &other.gb[3 * i], 3);
   if (L.other[3] >= 0) acc(p.acc_intr, other.ai, 6);
   if (L.other[4] >= 0) acc(p.gyr_intr, other.gi, 9);
+  for (size_t i = 0; i < L.pts.size(); ++i) if (L.pts[i] >= 0) acc(&p.pts[4 * i], &other.pts[4 * i], 4);
   return m;
 }
 
@@ -734,6 +760,12 @@ int oicc_oracle_get_tangent_layout(oicc_problem* prob, int32_t flags, int32_t* n
   return OICC_OK;
 }
 
+// SplineOptimFlags::POINTS: tangent offset of every board point (-1: constant or observed by no view); the points themselves
+int oicc_oracle_get_scene_point_offsets(oicc_problem* prob, int32_t flags, int32_t* offsets) {
+  const Layout L = make_layout(P_, flags); std::copy(L.pts.begin(), L.pts.end(), offsets); return OICC_OK; }
+int oicc_oracle_get_scene_points(oicc_problem* prob, double* xyzw, int64_t n) {
+  CHECK_ARG(size_t(4 * n) <= prob->p.pts.size(), "more points than were set"); std::copy(prob->p.pts.begin(), prob->p.pts.begin() + 4 * n, xyzw); return OICC_OK; }
+
 int oicc_oracle_evaluate(oicc_problem* prob, int32_t flags, double* cost, double* H, double* g, int32_t Pcap) {
   const Layout L = make_layout(P_, flags); const Active a = active_set(P_, flags);
   NormalEq ne; build_normal_equations(P_, L, a, &ne);
@@ -752,7 +784,7 @@ int oicc_oracle_evaluate_blocks(oicc_problem* prob, int32_t flags, int32_t kind,
   if (kind == 0) {
     for (const auto& v : P_.views) { eval_view(P_, L, a, v, jac != nullptr, &be);
       std::copy(be.r.begin(), be.r.end(), residuals + 2 * v.c0);
-      if (jac) std::copy(be.J.begin(), be.J.end(), jac + size_t(2 * v.c0) * 43); }
+      if (jac) for (int r = 0; r < be.nres; ++r) std::copy(be.J.begin() + size_t(r) * be.ncols, be.J.begin() + size_t(r) * be.ncols + 43, jac + (size_t(2 * v.c0) + r) * 43); }   // (the 43 columns of the ABI; POINTS appends the point columns behind them)
   } else if (kind == 1) {
     for (size_t i = 0; i < P_.acc.size(); ++i) { eval_accel(P_, L, a, P_.acc[i], jac != nullptr, &be);
       std::copy(be.r.begin(), be.r.end(), residuals + 3 * i); if (jac) std::copy(be.J.begin(), be.J.end(), jac + i * 3 * 54); }
@@ -816,6 +848,7 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   int iter = 0, invalid = 0;
   // inner iterations (ceres_inner.hpp): set up when the reduced program has at least two parameter blocks
   inner::Ordering ord; bool inner_enabled = false;
+  if (p.opt["inner_iterations"] != 0 && a.pts) { p.err = "POINTS with inner iterations is not restated (the reference never sets POINTS)"; return OICC_ERR_UNSUPPORTED; }
   if (p.opt["inner_iterations"] != 0) { inner::build_ordering(p, L, a, &ord); inner_enabled = ord.blocks.size() >= 2; }
   const double inner_tol = p.opt["inner_iteration_tolerance"];
   const bool line_search = p.opt["bounds_line_search"] != 0 && (a.ab || a.gb);   // is_constrained

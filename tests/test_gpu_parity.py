@@ -842,3 +842,73 @@ def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner,
         assert np.abs(np.array(p_["T_i_c"]) - np.array(whole["T_i_c"])).max() < (1e-6 if inner else 1e-7)
     assert np.abs(np.array(parts[0]["T_i_c"]) - np.array(parts[1]["T_i_c"])).max() < 1e-9
 
+
+
+# ---- SplineOptimFlags::POINTS (impl.h:136-153): the board points as variables ------------------------------------------
+POINT_CASES = [("tiny", FLAGS1 | E.POINTS), ("tiny", E.T_I_C | E.POINTS), ("tiny", FLAGS1 | E.CAM_LINE_DELAY | E.IMU_BIASES | E.POINTS),
+               ("C1", FLAGS1 | E.POINTS)]
+
+
+@pytest.mark.parametrize("cfg,flags", POINT_CASES)
+def test_points_flag_layout_and_normal_equations(cfg, flags):
+    """Tangent layout (the point columns behind every other block, 3 per observed point), cost, gradient and J^T J with the
+    board points variable, against the Jet oracle (HomogeneousVectorParameterization::ComputeJacobian behind the ambient
+    4-vector columns); the time tiles and the direct-atomics route of the tile pass give the same system."""
+    _, gpu, cpu = build_pair(cfg)
+    tg, tc = gpu.trajectory_, cpu.trajectory_
+    lg, lc = tg.GetTangentLayout(flags), tc.GetTangentLayout(flags)
+    assert lg["P"] == lc["P"]
+    for k in ("so3", "r3", "accl_bias", "gyro_bias", "other"):
+        assert np.array_equal(lg[k], lc[k]), k
+    og, oc = tg.GetScenePointOffsets(flags), tc.GetScenePointOffsets(flags)
+    assert np.array_equal(og, oc) and (og >= 0).any()
+    assert (tg.GetScenePointOffsets(flags & ~E.POINTS) == -1).all()
+    cc, Hc, gc = tc.Evaluate(flags)
+    for assembly in (0, 2):
+        tg.SetOption("assembly", assembly)
+        cg, Hg, gg = tg.Evaluate(flags)
+        assert abs(cg - cc) <= 1e-11 * cc
+        assert rel_err(gg, gc) < 1e-9, (assembly, rel_err(gg, gc))
+        assert rel_err(Hg, Hc) < 1e-9, (assembly, rel_err(Hg, Hc))
+        p0 = og[og >= 0].min()
+        assert rel_err(Hg[p0:, :], Hc[p0:, :]) < 1e-9 and rel_err(gg[p0:], gc[p0:]) < 1e-9      # the point rows on their own scale
+        assert np.abs(Hg - Hg.T).max() <= 1e-13 * np.abs(Hg).max()
+    tg.SetOption("assembly", 0)
+    # the flag off again: the system of the other blocks is what it was (the layout cache keys on the flags)
+    c0, H0, g0 = tg.Evaluate(flags & ~E.POINTS)
+    c1, H1, g1 = tc.Evaluate(flags & ~E.POINTS)
+    assert H0.shape == H1.shape and rel_err(H0, H1) < 1e-9 and rel_err(g0, g1) < 1e-9
+
+
+@pytest.mark.parametrize("cfg,flags", [POINT_CASES[0], POINT_CASES[3]])
+def test_points_flag_lm_iterates_and_refined_points(cfg, flags):
+    """oicc_optimize with POINTS: the iterates of the oracle's trust-region loop (same accept / reject sequence, costs),
+    the refined points (HomogeneousVectorParameterization::Plus keeps |x|), T_i_c and the knots; inner iterations with
+    POINTS are refused."""
+    _, gpu, cpu = build_pair(cfg)
+    tg, tc = gpu.trajectory_, cpu.trajectory_
+    p0 = tg.GetScenePoints()
+    assert np.array_equal(p0, tc.GetScenePoints())
+    sg, sc = tg.Optimize(30, flags), tc.Optimize(30, flags)
+    ig, ic = tg.GetIterations(), tc.GetIterations()
+    assert sg["termination"] == sc["termination"] and sg["num_iterations"] == sc["num_iterations"], (sg, sc)
+    assert sg["arrow_dim"] == sc["arrow_dim"] and sg["num_parameters_tangent"] == sc["num_parameters_tangent"]
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-6 * max(b["step_norm"], 1e-12)
+    pg, pc = tg.GetScenePoints(), tc.GetScenePoints()
+    seen = tg.GetScenePointOffsets(flags) >= 0
+    assert np.abs(pg - pc).max() < 1e-7 and np.abs(pg[seen] - p0[seen]).max() > 1e-6
+    assert np.allclose(np.linalg.norm(pg, axis=1), np.linalg.norm(p0, axis=1), rtol=1e-12)
+    assert np.abs(tg.GetT_i_c() - tc.GetT_i_c()).max() < 1e-7
+    kg, kc = tg.GetKnots(), tc.GetKnots()
+    assert np.abs(kg[0] - kc[0]).max() < 1e-7 and np.abs(kg[1] - kc[1]).max() < 1e-7
+    assert abs(tg.GetMeanReprojectionError() - tc.GetMeanReprojectionError()) < 1e-7
+    # a second solve without the flag starts from the refined points on both sides
+    s2g, s2c = tg.Optimize(5, flags & ~E.POINTS), tc.Optimize(5, flags & ~E.POINTS)
+    assert abs(s2g["initial_cost"] - s2c["initial_cost"]) <= 1e-8 * s2c["initial_cost"]
+    assert abs(s2g["initial_cost"] - sg["final_cost"]) <= 1e-8 * sg["final_cost"]
+    tg.SetOption("inner_iterations", 1)
+    with pytest.raises(Exception):
+        tg.Optimize(3, flags)

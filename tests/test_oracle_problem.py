@@ -111,3 +111,106 @@ def test_analytic_cpu_path_equals_forward_mode_jets(flags, camera):
         assert (np.abs(Ja - Jj) / scale).max() < 1e-8
     sj = jets.trajectory_.Optimize(10, flags); sa = ana.trajectory_.Optimize(10, flags)
     assert sj["num_iterations"] == sa["num_iterations"] and abs(sj["final_cost"] - sa["final_cost"]) <= 1e-8 * sj["final_cost"]
+
+
+def homogeneous_plus(x, d):
+    """ceres::HomogeneousVectorParameterization(4)::Plus written out independently in numpy (Householder reflection of
+    the unit-sphere update, internal/householder_vector.h)."""
+    nd = np.linalg.norm(d)
+    if nd == 0.0:
+        return x.copy()
+    y = np.concatenate([0.5 * np.sin(0.5 * nd) / (0.5 * nd) * d, [np.cos(0.5 * nd)]])
+    sigma = x[:3] @ x[:3]
+    v = x.copy(); v[3] = 1.0; beta = 0.0
+    if sigma <= np.finfo(float).eps:
+        beta = 2.0 if x[3] < 0 else 0.0
+    else:
+        mu = np.sqrt(x[3] ** 2 + sigma)
+        vp = x[3] - mu if x[3] <= 0 else -sigma / (x[3] + mu)
+        beta = 2.0 * vp * vp / (sigma + vp * vp)
+        v[:3] /= vp
+    return np.linalg.norm(x) * (y - v * (beta * (v @ y)))
+
+
+def test_points_flag_gradient_matches_finite_differences():
+    """SplineOptimFlags::POINTS (impl.h:136-153): the board points a view observes become variables with three tangent
+    dimensions each, behind every other block.  The gradient of the oracle (Jets + HomogeneousVectorParameterization::
+    ComputeJacobian) against central differences of the cost along Plus(x, h d)."""
+    ds = synthetic.make_config("tiny")
+    flags = E.SPLINE | E.T_I_C | E.POINTS
+    cal = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    tr = cal.trajectory_
+    lay = tr.GetTangentLayout(flags)
+    off = tr.GetScenePointOffsets(flags)
+    lay0 = tr.GetTangentLayout(flags & ~E.POINTS)
+    seen = off >= 0
+    assert seen.any() and lay["P"] == lay0["P"] + 3 * int(seen.sum())
+    assert np.array_equal(np.sort(off[seen]), lay0["P"] + 3 * np.arange(int(seen.sum())))       # behind everything else, in point order
+    assert (tr.GetScenePointOffsets(flags & ~E.POINTS) == -1).all()
+    cost, H, g = tr.Evaluate(flags)
+    assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
+    # the point block of H is block diagonal: a corner sees one point
+    Hp = H[lay0["P"]:, lay0["P"]:]
+    mask = np.kron(np.eye(int(seen.sum())), np.ones((3, 3))) > 0
+    assert np.abs(Hp[~mask]).max() == 0.0 and np.abs(Hp[mask]).max() > 0.0
+    pts0 = tr.GetScenePoints()
+
+    def cost_at(delta):
+        c2 = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+        t2 = c2.trajectory_
+        pts = pts0.copy()
+        for i, o in enumerate(off):
+            if o >= 0:
+                pts[i] = homogeneous_plus(pts0[i], delta[o:o + 3])
+        t2.SetImageData(t2._views, pts)
+        return perturbed_cost_of(t2, delta, lay, flags)
+
+    rng = np.random.RandomState(1)
+    for only_points in (True, False):
+        d = rng.normal(0, 1, lay["P"])
+        if only_points:
+            d[:lay0["P"]] = 0.0
+        d /= np.linalg.norm(d)
+        h = 1e-6
+        fd = (cost_at(h * d) - cost_at(-h * d)) / (2 * h)
+        assert abs(fd - g @ d) <= 2e-5 * max(1.0, abs(g @ d)), (only_points, fd, g @ d)
+
+
+def perturbed_cost_of(tr, delta, lay, flags):
+    so3, r3 = tr.GetKnots()
+    for i, o in enumerate(lay["so3"]):
+        if o >= 0:
+            so3[i] = quat_mul(so3[i], quat_exp(delta[o:o + 3]))
+    for i, o in enumerate(lay["r3"]):
+        if o >= 0:
+            r3[i] += delta[o:o + 3]
+    tr.SetKnots(so3, r3)
+    T = tr.GetT_i_c()
+    o = lay["other"][0]
+    if o >= 0:
+        from openimucameracalibrator_amd.synthetic import mat_from_quat
+        tr.SetT_i_c(quat_mul(T[:4], quat_exp(delta[o + 3:o + 6])), T[4:] + mat_from_quat(T[:4]) @ delta[o:o + 3])
+    return tr.EvaluateCost(flags)
+
+
+def test_points_flag_lm_moves_the_points_and_reduces_the_cost():
+    ds = synthetic.make_config("tiny")
+    flags = E.SPLINE | E.T_I_C | E.GRAVITY_DIR | E.POINTS
+    cal = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    tr = cal.trajectory_
+    p0 = tr.GetScenePoints()
+    s = tr.Optimize(30, flags)
+    it = tr.GetIterations()
+    costs = [i["cost"] for i in it if i["step_is_successful"]]
+    assert s["termination"] == 0 and all(b <= a for a, b in zip(costs, costs[1:]))
+    p1 = tr.GetScenePoints()
+    seen = tr.GetScenePointOffsets(flags) >= 0
+    assert np.abs(p1[seen] - p0[seen]).max() > 0 and np.array_equal(p1[~seen], p0[~seen])
+    assert np.allclose(np.linalg.norm(p1, axis=1), np.linalg.norm(p0, axis=1), rtol=1e-12)   # Plus keeps |x|
+    # the same problem with the points held: a higher (or equal) final cost
+    cal2 = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    s2 = cal2.trajectory_.Optimize(30, flags & ~E.POINTS)
+    assert s["final_cost"] <= s2["final_cost"] * (1 + 1e-9)
+    tr.SetOption("inner_iterations", 1)
+    with pytest.raises(Exception):
+        tr.Optimize(3, flags)
