@@ -181,6 +181,11 @@ class SplineTrajectoryEstimator {
     if (s.inner_sweeps > 0 || s.line_search_steps > 0)   // Ceres FullReport: "Inner iterations", "Line search steps"
       std::cout << "  inner sweeps " << s.inner_sweeps << " (" << s.inner_lm_iterations << " block LM iterations, " << s.seconds_inner << " s)  line search steps " << s.line_search_steps << "  set-up " << s.seconds_setup << " s";
     std::cout << "\n";
+    if (flags & POINTS) {   // impl.h:136-153: the tracks of image_data_ are the parameter blocks, Optimize leaves them refined
+      std::vector<double> pts(4 * track_index_.size());
+      ck(oicc_get_scene_points(h_, pts.data(), int64_t(track_index_.size())));
+      for (const auto& kv : track_index_) for (int c = 0; c < 4; ++c) image_data_.tracks[kv.first][c] = pts[4 * kv.second + c];
+    }
     return s;
   }
 

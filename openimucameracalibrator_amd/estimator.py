@@ -236,6 +236,8 @@ class SplineTrajectoryEstimator:
     def Optimize(self, max_iters, flags):
         s = _abi.Summary()
         self._ck(self._b.optimize(self._h, int(max_iters), int(flags), C.byref(s)))
+        if int(flags) & POINTS and getattr(self, "_points", None) is not None:   # impl.h:136-153: the tracks of image_data_ are left refined
+            self._points = self.GetScenePoints()
         return s.as_dict()
 
     def GetIterations(self, capacity=256):
