@@ -189,8 +189,11 @@ __device__ __forceinline__ bool inner_cholesky_solve(const double* M, const doub
 // `xl` (may be null), return the next command.  Mirrors oracle/ceres_inner.hpp solve_block (= TrustRegionMinimizer +
 // LevenbergMarquardtStrategy, default options).  The segment-table entries of an SO(3) knot are updated by the caller (S.seg_action).
 // (a real function call, one per dimension: the unrolled d x d algebra stays out of the register allocation of the evaluation loops)
+#ifndef OICC_INNER_ADVANCE_ATTR
+#define OICC_INNER_ADVANCE_ATTR __noinline__
+#endif
 template <int D, int NX>
-__device__ __noinline__ int inner_lm_advance(InnerLm& S, int kind, int cmd, const double* tot, double* x, double* xl, double max_ab, double max_gb) {
+__device__ OICC_INNER_ADVANCE_ATTR int inner_lm_advance(InnerLm& S, int kind, int cmd, const double* tot, double* x, double* xl, double max_ab, double max_gb) {
   constexpr double ftol = 1e-6, ptol = 1e-8, gtol = 1e-10, min_rel_dec = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
   constexpr int NV = D * (D + 1) / 2 + D + 1;
   const bool so3 = D == 3 && kind == IK_SO3;
@@ -528,7 +531,9 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
       __threadfence(); __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&ctl->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (master) {
+        INNER_MARK();
         if (tid == 0) { const unsigned want = (unsigned)wg.nparts * (round + 1); while (__hip_atomic_load(&ctl->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1); }
+        INNER_MARK();
         __syncthreads(); __threadfence();
         if (tid < nv) s_tot[tid] = __hip_atomic_exchange(&ctl->acc[tid], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read and clear for the next round
       }

@@ -1162,7 +1162,7 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the probl
   if (prof_set >= 0 && d_prof.p) {
     long long h[64];
     HIPCK(p, hipMemcpyAsync(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
-    std::printf("[oicc] inner profile, set %d (%d workgroups), workgroup 0 / thread 0, cycles between marks [eval | barrier | advance | publish]:", prof_set, ip.group_wg0[prof_set + 1] - ip.group_wg0[prof_set]);
+    std::printf("[oicc] inner profile, set %d (%d workgroups), workgroup 0 / thread 0, cycles between marks [eval | barrier | (shared blocks: sums + arrival | wait for the parts |) advance | publish]:", prof_set, ip.group_wg0[prof_set + 1] - ip.group_wg0[prof_set]);
     for (int k = 1; k < int(h[0]); ++k) std::printf(" %lld", h[1 + k] - h[k]);
     std::printf("\n");
   }
