@@ -128,6 +128,7 @@ struct oicc_problem {
   struct OwnerPlan { bool valid = false; std::vector<int32_t> cut; std::vector<std::vector<int32_t>> send_rows, recv_rows; std::vector<int32_t> flat, send_off, recv_off; int max_rows = 0; } owner;
   DevBuf<int32_t> d_xrows; DevBuf<double> d_xsend, d_xrecv;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
+  bool has_remote_views = false;   // other ranks hold views too: under SplineOptimFlags::POINTS every board point is a variable on every rank (which points they see is not declared)
   bool meas_dirty = true, groups_dirty = true;
   std::thread plan_thread; InnerPlanOptions plan_job{}; bool plan_job_valid = false; double plan_ms[3] = {0, 0, 0};   // the plan's host part on a second thread (start_inner_plan)
   void wait_plan() { if (plan_thread.joinable()) plan_thread.join(); }
@@ -417,6 +418,9 @@ void make_layout_host(oicc_problem* p, int flags) {
   // dimensions); a point no corner refers to has no parameter block.  Behind every other block, in point order.
   L.pts.assign(size_t(pl.n_pts), -1); L.a_pts = 0;
   if (a.pts) {
+    // (time shards: the ranks must agree on the layout, and a rank does not know which points the other ranks' views see -- all
+    // points then; one that no view sees anywhere keeps a zero gradient and never moves)
+    if (p->has_remote_views) std::fill(L.pts.begin(), L.pts.end(), 0);
     for (int32_t id : p->corner_pt) L.pts[id] = 0;
     for (int32_t& o : L.pts) if (o == 0) { o = off; off += 3; L.a_pts += 3; }
   }
@@ -1585,8 +1589,8 @@ int oicc_declare_remote_measurements_from(oicc_problem* p, int32_t owner_rank, i
     for (int k = 0; k < kN; ++k) { p->so3_in[s_so3 + k] = 1; if (kind != 2) p->r3_in[s_r3 + k] = 1; }
     if (kind == 1) for (int k = 0; k < kNb; ++k) p->ab_in[s_b + k] = 1;
     if (kind == 2) for (int k = 0; k < kNb; ++k) p->gb_in[s_b + k] = 1;
-    if (kind == 0) { p->has_tic_block = true; p->has_ld_block = true; }
-    if (kind == 3) { p->has_tic_block = true; }
+    if (kind == 0) { p->has_tic_block = true; p->has_ld_block = true; p->has_remote_views = true; }
+    if (kind == 3) { p->has_tic_block = true; p->has_remote_views = true; }
     if (kind == 1) p->has_acc = true;
     if (kind == 2) p->has_gyr = true;
     p->remote_so3.push_back(int32_t(s_so3)); p->remote_r3.push_back(kind == 2 ? -1 : int32_t(s_r3)); p->remote_owner.push_back(owner_rank);

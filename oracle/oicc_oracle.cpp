@@ -57,7 +57,7 @@ struct Problem {
   std::vector<double> pts;               // n*4
   std::vector<ViewBlk> views; std::vector<double> uv, cov; std::vector<int32_t> pidx;
   std::vector<ImuBlk> acc, gyr;
-  bool has_ld_block = false, has_tic_block = false, remote_acc = false, remote_gyr = false;
+  bool has_ld_block = false, has_tic_block = false, remote_acc = false, remote_gyr = false, remote_views = false;
   std::vector<int> remote_so3, remote_r3;
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
@@ -124,7 +124,7 @@ Layout make_layout(const Problem& p, int flags) {
   // ceres::HomogeneousVectorParameterization(4); a point no view observes has no parameter block
   L.pts.assign(p.pts.size() / 4, -1);
   if (a.pts) {
-    std::vector<char> seen(L.pts.size(), 0);
+    std::vector<char> seen(L.pts.size(), p.remote_views ? 1 : 0);   // time shards: which points the other ranks' views see is not declared -- all of them, on every rank
     for (int32_t id : p.pidx) seen[id] = 1;
     for (size_t i = 0; i < L.pts.size(); ++i) if (seen[i]) { L.pts[i] = off; off += 3; }
   }
@@ -740,8 +740,8 @@ int oicc_oracle_declare_remote_measurements(oicc_problem* prob, int32_t kind, in
     for (int k = 0; k < kN; ++k) { P_.so3_in[s_so3 + k] = 1; if (kind != 2) P_.r3_in[s_r3 + k] = 1; }
     if (kind == 1) for (int k = 0; k < kNb; ++k) P_.ab_in[s_b + k] = 1;
     if (kind == 2) for (int k = 0; k < kNb; ++k) P_.gb_in[s_b + k] = 1;
-    if (kind == 0) { P_.has_tic_block = true; P_.has_ld_block = true; }
-    if (kind == 3) P_.has_tic_block = true;
+    if (kind == 0) { P_.has_tic_block = true; P_.has_ld_block = true; P_.remote_views = true; }
+    if (kind == 3) { P_.has_tic_block = true; P_.remote_views = true; }
     if (kind == 1) P_.remote_acc = true;
     if (kind == 2) P_.remote_gyr = true;
     P_.remote_so3.push_back(int(s_so3)); P_.remote_r3.push_back(kind == 2 ? -1 : int(s_r3));

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = 64 | 2 | 16   # SPLINE | T_I_C | GRAVITY_DIR
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, FLAGS=FLAGS):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,10 +44,11 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_normal_equations_sum_to_whole(tmp_path):
+@pytest.mark.parametrize("flags", [FLAGS, FLAGS | 1])   # | SplineOptimFlags::POINTS: every board point a variable on every rank (the ranks agree on the layout)
+def test_two_rank_sharded_normal_equations_sum_to_whole(tmp_path, flags):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, flags), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 

@@ -799,7 +799,8 @@ def test_projected_gradient_norm_of_the_bounded_problem_matches_the_oracle():
 
 # ---- two processes, one GPU: the product's all-reduce hook inside oicc_optimize ---------------------------------------------
 @pytest.mark.parametrize("cfg,flags,ls,inner,owner", [("C1", FLAGS1, 0, 0, 0), ("tiny", FLAGS1 | E.ACC_BIAS, 1, 0, 0), ("C1", FLAGS1, 0, 1, 0), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1, 0),
-                                                     ("C1", FLAGS1, 0, 0, 1), ("C2", FLAGS1, 0, 0, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1, 1), ("C1", FLAGS1, 0, 1, 1)])   # (C1 with the line delay free is chaotic from run to run within ONE process: not a test case)
+                                                     ("C1", FLAGS1, 0, 0, 1), ("C2", FLAGS1, 0, 0, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1, 1, 1), ("C1", FLAGS1, 0, 1, 1),
+                                                     ("C1", FLAGS1 | E.POINTS, 0, 0, 0), ("C1", FLAGS1 | E.POINTS, 0, 0, 1)])   # (C1 with the line delay free is chaotic from run to run within ONE process: not a test case)
 def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner, owner, tmp_path):
     """Rank r of two PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
     all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
@@ -830,7 +831,8 @@ def test_two_processes_on_one_gpu_reduce_through_the_hook(cfg, flags, ls, inner,
     assert sum(p_["blocks"] for p_ in parts) == whole["blocks"] and all(p_["hook_calls"] >= 2 * (len(whole["iterations"]) - 1) for p_ in parts)
     if owner:   # halo rows travelled, owned ranges were gathered, and no all-reduce was larger than the arrow corner + a rank-consistency pack
         assert all(p_["exchange"]["sendrecv"] >= len(whole["iterations"]) and p_["exchange"]["broadcast"] >= 2 * len(whole["iterations"]) for p_ in parts)
-        assert all(p_["hook_max_doubles"] < 10 * p_["P"] for p_ in parts)       # (the packed buffer is ~50 P doubles: it was never all-reduced)
+        if not flags & E.POINTS:   # (with the board points in the arrow the corner alone, 150 x 150, is as large as the packed buffer of C1)
+            assert all(p_["hook_max_doubles"] < 10 * p_["P"] for p_ in parts)       # (the packed buffer is ~50 P doubles: it was never all-reduced)
     else:
         assert all(p_["hook_max_doubles"] > 10 * p_["P"] for p_ in parts)
     if inner:   # the reference's solver configuration on time-sharded ranks: the sweeps run (replicated) over the whole problem's measurements
