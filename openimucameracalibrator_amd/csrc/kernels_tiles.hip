@@ -523,9 +523,11 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
 
   // ---- P2: the rows of the knots that leave the chain with this tile ----
   const long long tp3 = prof ? clock64() : 0;
-  if (JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0 && tile + 1 == tile1) { dyn.prof[8 + (wave & 3)] = clock64(); if (wave == 0) dyn.prof[12] = tp0; }   // when each wave ran out of units (last tile of the chain)
+  const bool prof_idle = JAC && dyn.prof != nullptr && blockIdx.x == gridDim.x / 2 && lane == 0;   // every wave of the profiled chain: cycles between running out of units and the other waves doing so, summed over the tiles
+  const long long t_idle0 = prof_idle ? clock64() : 0;
   if (JAC && !DIRECT) {
     __syncthreads();
+    if (prof_idle) dyn.prof[8 + (wave & 3)] += clock64() - t_idle0;
     // A knot no later tile of the chain touches is complete as far as this chain goes.  If no other chain touches it either its
     // three rows are final: band rows (one contiguous piece of the packed band), arrow columns and gradient entries go straight
     // into the packed normal equations; else they go to the chain's slab for the merge.

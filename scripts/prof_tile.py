@@ -17,4 +17,4 @@ for kind in kinds:
         if k == 0: continue
         print(cfg, "kind", kind, rc, "eval %d gram %d (mfma %d scatter %d) | staging %d segments %d units %d wait+flush %d | total %d" % (
             out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[4] + out[5] + out[6] + out[7]),
-            "| waves out of units at", [out[8 + w] - out[12] for w in range(4)])
+            "| cycles each wave waited for the others at the tile barriers (sum over the chain)", [out[8 + w] for w in range(4)])
