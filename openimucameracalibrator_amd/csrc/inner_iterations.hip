@@ -3,7 +3,7 @@
 // descent over all parameter blocks [EXT Ceres 2.1.0: coordinate_descent_minimizer.cc, parameter_block_ordering.cc,
 // trust_region_minimizer.cc DoInnerIterationsIfNeeded; restated for the checker in oracle/ceres_inner.hpp].
 //
-// The blocks are grouped on the host (build_inner_plan, oicc_problem.hip) into independent sets of the Hessian graph: no
+// The blocks are grouped on the host (build_inner_plan, oicc_inner.hip) into independent sets of the Hessian graph: no
 // residual block depends on two blocks of a set, so all blocks of a set are minimised at the same time, each by its own
 // Levenberg-Marquardt loop with Ceres' default minimiser options.  ONE LAUNCH PER SET (round 3; round 2 ran the blocks of a
 // set in lock step, ~25 launches and a host read-back per set):
@@ -609,7 +609,7 @@ __global__ void inner_diff_norm_kernel(const double* x, const double* xc, const 
   if (threadIdx.x == 0 && red[0] != 0.0) unsafeAtomicAdd(step_norm_sq, red[0]);
 }
 
-// ---- launchers (the plan and the loop over the sets live in oicc_problem.hip) ----
+// ---- launchers (the plan and the loop over the sets live in oicc_inner.hip) ----
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st) {
   if (n_pairs > 0) hipLaunchKernelGGL(inner_seg_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, so3, n_pairs, seg);
 }

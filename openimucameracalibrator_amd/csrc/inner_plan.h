@@ -1,5 +1,5 @@
 // Inner iterations (inner_iterations.hip): parameter blocks of the reduced program, grouped into independent sets, the
-// measurements each block depends on and the workgroups that minimise it.  Internal, shared by oicc_problem.hip (plan) and
+// measurements each block depends on and the workgroups that minimise it.  Internal, shared by oicc_inner.hip (plan) and
 // inner_iterations.hip (kernels).
 #pragma once
 #include <cstdint>

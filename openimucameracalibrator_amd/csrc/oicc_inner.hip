@@ -1,0 +1,326 @@
+// liboicc_hip, host side: plan (host) and sweep (device launches) of the inner iterations -- Ceres' use_inner_iterations, reference
+// impl.h:266 (inner_plan.h, inner_iterations.hip; see oicc_problem.h).
+#include "oicc_problem.h"
+
+namespace oicc {
+
+// ---- inner iterations: plan (host) and sweep (device), see inner_iterations.hip / oracle/ceres_inner.hpp ----------------
+// Parameter blocks of the reduced program in the order the reference's AddResidualBlock calls create them, the Hessian
+// graph, and Ceres' recursive independent-set ordering (reversed).
+// Host part: everything up to the device copies, from host data only (problem measurements, host layout) and the options handed in
+// -- it may run on a second thread next to the set-up of the solve (start_inner_plan).
+void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_ms[3]) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  const bool gs_unit = o.gs_unit;
+  const double t_plan0 = now_s(); double t_plan1 = 0, t_plan2 = 0, t_plan3 = 0;
+  const HostLayout& L = p->L; const ParamLayout& pl = p->pl;
+  // Parameter blocks in the order the reference's AddResidualBlock calls create them (views in time order, then accelerometer /
+  // gyroscope samples in turn, imu_camera_calibrator.cc:90-120), each with the RUNS of consecutive items that depend on it and the
+  // knot ranges those items read.  Round 4: everything is derived from the three time-ordered lists of GROUPS (a view; a run of
+  // samples with identical knot windows) by monotone pointers -- the neighbours of a knot in the Hessian graph are INTERVALS of
+  // knots (the union of the windows of the consecutive groups that contain it), so neither cliques nor adjacency lists are built:
+  // O(knots + groups) instead of O(groups x window^2) (C5: 22 ms -> ~2 ms).
+  struct HB { InnerBlock b; int order; int run0 = 0, nruns = 0; int s0 = 1 << 30, s1 = -1, r0 = 1 << 30, r1 = -1, a0 = 1 << 30, a1 = -1, g0 = 1 << 30, g1 = -1; };
+  std::vector<HB> B; B.reserve(size_t(pl.n_so3 + pl.n_r3 + pl.n_ab + pl.n_gb) + 5);
+  struct TaggedRun { int v; InnerRun r; }; std::vector<TaggedRun> trun;        // generated family by family, gathered per block below
+  std::vector<InnerRun> hruns;                                                   // ... per block (HB::run0, nruns)
+  enum { CS = 0, CR = 1, CA = 2, CG = 3 };                                   // knot classes: SO(3), R^3, accelerometer bias, gyroscope bias
+  const int wcls[4] = {kN, kN, kNb, kNb};
+  const std::vector<int32_t>* Lc[4] = {&L.so3, &L.r3, &L.ab, &L.gb};
+  std::vector<int> id[4] = {std::vector<int>(pl.n_so3, -1), std::vector<int>(pl.n_r3, -1), std::vector<int>(pl.n_ab, -1), std::vector<int>(pl.n_gb, -1)};
+  int id_o[5] = {-1, -1, -1, -1, -1};                                          // T_i_c, gravity, line delay, accelerometer / gyroscope intrinsics
+  struct Fam { std::vector<int32_t> lo[4], first, count; std::vector<uint8_t> ld; int cls[3], ncls, scal[3], nscal; size_t size() const { return first.size(); } };
+  Fam F[3];
+  F[0].ncls = 2; F[0].cls[0] = CS; F[0].cls[1] = CR; F[0].nscal = 2; F[0].scal[0] = 0; F[0].scal[1] = 2;                       // views: T_i_c, line delay (rolling shutter views)
+  F[1].ncls = 3; F[1].cls[0] = CS; F[1].cls[1] = CR; F[1].cls[2] = CA; F[1].nscal = 2; F[1].scal[0] = 1; F[1].scal[1] = 3;     // accelerometer: gravity, intrinsics
+  F[2].ncls = 2; F[2].cls[0] = CS; F[2].cls[1] = CG; F[2].nscal = 1; F[2].scal[0] = 4;                                          // gyroscope: intrinsics
+  const size_t nv = p->view_rs.size();
+  for (size_t v = 0; v < nv; ++v) {
+    if (!p->view_rs[v] && !gs_unit) continue;                     // quirk Q2: no weight, numerically no block
+    F[0].lo[CS].push_back(p->view_s_so3[v]); F[0].lo[CR].push_back(p->view_s_r3[v]);
+    F[0].first.push_back(int32_t(p->view_c0[v])); F[0].count.push_back(int32_t(p->view_c0[v + 1] - p->view_c0[v])); F[0].ld.push_back(p->view_rs[v] ? 1 : 0);
+  }
+  for (size_t g = 0; g < p->acc_groups.size(); ++g) { const int32_t i = p->acc_groups.first[g];
+    F[1].lo[CS].push_back(p->acc.s_so3[i]); F[1].lo[CR].push_back(p->acc.s_r3[i]); F[1].lo[CA].push_back(p->acc.s_b[i]); F[1].first.push_back(i); F[1].count.push_back(p->acc_groups.count[g]); }
+  for (size_t g = 0; g < p->gyr_groups.size(); ++g) { const int32_t i = p->gyr_groups.first[g];
+    F[2].lo[CS].push_back(p->gyr.s_so3[i]); F[2].lo[CG].push_back(p->gyr.s_b[i]); F[2].first.push_back(i); F[2].count.push_back(p->gyr_groups.count[g]); }
+  const int sc_kind[5] = {IK_TIC, IK_G, IK_LD, IK_AI, IK_GI}, sc_dim[5] = {6, 3, 1, 6, 9}, sc_amb[5] = {7, 3, 1, 6, 9};
+  const int64_t sc_xoff[5] = {pl.tic, pl.g, pl.ld, pl.ai, pl.gi};
+  const int cl_kind[4] = {IK_SO3, IK_R3, IK_AB, IK_GB}, cl_amb[4] = {4, 3, 3, 3};
+  const int64_t cl_xoff[4] = {pl.so3, pl.r3, pl.ab, pl.gb};
+  auto create = [&](int kind, int idx, int dim, int amb, int64_t xoff) {
+    HB h; h.b = InnerBlock{}; h.b.kind = kind; h.b.idx = idx; h.b.dim = dim; h.b.ambient = amb; h.b.xoff = xoff; h.b.ctl = -1; h.order = int(B.size());
+    B.push_back(h); return int(B.size()) - 1; };
+  {   // creation order: a family's windows only move forwards, so each group adds the knots behind the family's last window
+    int32_t next[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto visit = [&](int f, size_t g) {
+      for (int q = 0; q < F[f].ncls; ++q) {
+        const int c = F[f].cls[q]; const int32_t lo = F[f].lo[c][g], hi = lo + wcls[c];
+        for (int32_t k = std::max(lo, next[f][c]); k < hi; ++k)
+          if (id[c][k] < 0 && (*Lc[c])[k] >= 0) id[c][k] = create(cl_kind[c], k, 3, cl_amb[c], cl_xoff[c] + int64_t(cl_amb[c]) * k);
+        next[f][c] = std::max(next[f][c], hi);
+      }
+      for (int q = 0; q < F[f].nscal; ++q) {
+        const int o = F[f].scal[q];
+        if (o == 2 && !F[f].ld[g]) continue;
+        if (id_o[o] < 0 && L.other[o] >= 0) id_o[o] = create(sc_kind[o], 0, sc_dim[o], sc_amb[o], sc_xoff[o]);
+      }
+    };
+    for (size_t g = 0; g < F[0].size(); ++g) visit(0, g);
+    size_t ga = 0, gg = 0;
+    while (ga < F[1].size() || gg < F[2].size()) {                 // samples in turn: accelerometer i, gyroscope i
+      if (gg >= F[2].size() || (ga < F[1].size() && F[1].first[ga] <= F[2].first[gg])) visit(1, ga++); else visit(2, gg++);
+    }
+  }
+  const int n = int(B.size());
+  // Neighbour intervals.  For knot (c, i) and family f: the groups that contain it are consecutive ([gl, gh], two pointers: the
+  // windows ascend); their windows of class c' ascend too, so the union is one interval unless two consecutive windows leave a hole
+  // (a pause in the data with dt_c' much shorter than dt_c), in which case the pieces are listed.
+  struct Iv { int32_t c, lo, hi; };
+  std::vector<Iv> iv; std::vector<int32_t> iv_off(size_t(n) + 1, 0); std::vector<uint8_t> scal_nb(n, 0);
+  struct TaggedIv { int v; Iv x; }; std::vector<TaggedIv> tiv; tiv.reserve(size_t(n) * 6);   // (generated family by family, gathered per vertex below)
+  trun.reserve(size_t(n) * 3);
+  auto add_union = [&](int v, int f, int c2, size_t gl, size_t gh) {   // union of the class-c2 windows of groups gl..gh of family f
+    const std::vector<int32_t>& lo = F[f].lo[c2];
+    int32_t a0 = lo[gl], a1 = lo[gl] + wcls[c2];
+    for (size_t g = gl + 1; g <= gh; ++g) { if (lo[g] > a1) { tiv.push_back(TaggedIv{v, Iv{c2, a0, a1}}); a0 = lo[g]; } a1 = lo[g] + wcls[c2]; }
+    tiv.push_back(TaggedIv{v, Iv{c2, a0, a1}});
+  };
+  auto hull = [](HB& h, int c, int32_t lo, int32_t hi) {
+    if (c == CS) { h.s0 = std::min(h.s0, int(lo)); h.s1 = std::max(h.s1, int(hi)); } else if (c == CR) { h.r0 = std::min(h.r0, int(lo)); h.r1 = std::max(h.r1, int(hi)); }
+    else if (c == CA) { h.a0 = std::min(h.a0, int(lo)); h.a1 = std::max(h.a1, int(hi)); } else { h.g0 = std::min(h.g0, int(lo)); h.g1 = std::max(h.g1, int(hi)); } };
+  for (int f = 0; f < 3; ++f) {
+    const size_t ng = F[f].size();
+    if (ng == 0) continue;
+    // prefix counts: holes between consecutive windows of each class, rolling-shutter views
+    std::vector<int32_t> hole[4], ldc(ng + 1, 0);
+    for (int q = 0; q < F[f].ncls; ++q) { const int c2 = F[f].cls[q]; hole[c2].assign(ng, 0); for (size_t g = 1; g < ng; ++g) hole[c2][g] = hole[c2][g - 1] + (F[f].lo[c2][g] > F[f].lo[c2][g - 1] + wcls[c2] ? 1 : 0); }
+    if (f == 0) for (size_t g = 0; g < ng; ++g) ldc[g + 1] = ldc[g] + F[f].ld[g];
+    for (int q = 0; q < F[f].ncls; ++q) {
+      const int c = F[f].cls[q]; const std::vector<int32_t>& lo = F[f].lo[c];
+      size_t gl = 0, gh = 0;                                                   // groups with lo in (i - w, i]
+      const int32_t i_end = lo[ng - 1] + wcls[c];
+      for (int32_t i = lo[0]; i < i_end; ++i) {
+        while (gl < ng && lo[gl] + wcls[c] <= i) ++gl;
+        if (gh < gl) gh = gl;
+        while (gh < ng && lo[gh] <= i) ++gh;                                    // gh: one past the last group that contains i
+        if (gl >= gh) continue;                                                 // a hole in this family's own windows
+        const int v = id[c][i];
+        if (v < 0) continue;
+        HB& h = B[v];
+        for (int q2 = 0; q2 < F[f].ncls; ++q2) {
+          const int c2 = F[f].cls[q2];
+          hull(h, c2, F[f].lo[c2][gl], F[f].lo[c2][gh - 1] + wcls[c2]);         // what the block's items read (whether or not those knots are variables)
+          if ((*Lc[c2])[F[f].lo[c2][gl]] < 0) continue;                         // class not among the variables
+          if (hole[c2][gh - 1] == hole[c2][gl]) tiv.push_back(TaggedIv{v, Iv{c2, F[f].lo[c2][gl], F[f].lo[c2][gh - 1] + wcls[c2]}});
+          else add_union(v, f, c2, gl, gh - 1);
+        }
+        for (int q2 = 0; q2 < F[f].nscal; ++q2) { const int o = F[f].scal[q2]; if (id_o[o] >= 0 && (o != 2 || ldc[gh] > ldc[gl])) scal_nb[v] |= uint8_t(1u << o); }
+        // the block's items of this family: consecutive unless a view in between carries no weight
+        int32_t r0 = F[f].first[gl], r1 = r0 + F[f].count[gl];
+        for (size_t g = gl + 1; g < gh; ++g) { if (F[f].first[g] != r1) { trun.push_back(TaggedRun{v, InnerRun{f, r0, r1 - r0, 0}}); r0 = F[f].first[g]; } r1 = F[f].first[g] + F[f].count[g]; }
+        trun.push_back(TaggedRun{v, InnerRun{f, r0, r1 - r0, 0}});
+      }
+    }
+    // the blocks every group of the family depends on
+    for (int q = 0; q < F[f].nscal; ++q) {
+      const int o = F[f].scal[q], v = id_o[o];
+      if (v < 0) continue;
+      HB& h = B[v];
+      for (int q2 = 0; q2 < F[f].ncls; ++q2) {
+        const int c2 = F[f].cls[q2]; const std::vector<int32_t>& lo = F[f].lo[c2];
+        const bool variable = (*Lc[c2])[lo[0]] >= 0;
+        bool open = false; int32_t a0 = 0, a1 = 0;
+        for (size_t g = 0; g < ng; ++g) {
+          if (o == 2 && !F[f].ld[g]) continue;
+          hull(h, c2, lo[g], lo[g] + wcls[c2]);
+          if (!variable) continue;
+          if (open && lo[g] > a1) { tiv.push_back(TaggedIv{v, Iv{c2, a0, a1}}); open = false; }
+          if (!open) { a0 = lo[g]; open = true; }
+          a1 = lo[g] + wcls[c2];
+        }
+        if (open) tiv.push_back(TaggedIv{v, Iv{c2, a0, a1}});
+      }
+      for (int q2 = 0; q2 < F[f].nscal; ++q2) { const int o2 = F[f].scal[q2]; if (o2 != o && id_o[o2] >= 0 && (f != 0 || ldc[ng] > 0)) scal_nb[v] |= uint8_t(1u << o2); }
+      bool open = false; int32_t r0 = 0, r1 = 0;
+      for (size_t g = 0; g < ng; ++g) {
+        if (o == 2 && !F[f].ld[g]) continue;
+        if (open && F[f].first[g] != r1) { trun.push_back(TaggedRun{v, InnerRun{f, r0, r1 - r0, 0}}); open = false; }
+        if (!open) { r0 = F[f].first[g]; open = true; }
+        r1 = F[f].first[g] + F[f].count[g];
+      }
+      if (open) trun.push_back(TaggedRun{v, InnerRun{f, r0, r1 - r0, 0}});
+    }
+  }
+  // per vertex: the families' intervals of one class merged (the families overlap), the knot ranges its items read, its degree
+  std::vector<int> deg(n, 0);
+  {   // gather the tagged runs and intervals per vertex (counting sort: generation order kept inside a vertex)
+    std::vector<int32_t> cnt(size_t(n) + 1, 0);
+    for (const TaggedRun& t : trun) ++cnt[t.v + 1];
+    for (int v = 0; v < n; ++v) { cnt[v + 1] += cnt[v]; B[v].run0 = cnt[v]; B[v].nruns = cnt[v + 1] - cnt[v]; }
+    hruns.resize(trun.size());
+    for (const TaggedRun& t : trun) hruns[size_t(cnt[t.v]++)] = t.r;
+  }
+  std::vector<Iv> giv(tiv.size()); std::vector<int32_t> goff(size_t(n) + 1, 0);
+  {
+    for (const TaggedIv& t : tiv) ++goff[t.v + 1];
+    for (int v = 0; v < n; ++v) goff[v + 1] += goff[v];
+    std::vector<int32_t> pos(goff.begin(), goff.end() - 1);
+    for (const TaggedIv& t : tiv) giv[size_t(pos[t.v]++)] = t.x;
+  }
+  for (int v = 0; v < n; ++v) {
+    Iv* t = giv.data() + goff[v]; const size_t nt = size_t(goff[v + 1] - goff[v]);
+    std::sort(t, t + nt, [](const Iv& x, const Iv& y) { return x.c != y.c ? x.c < y.c : x.lo < y.lo; });   // (a handful)
+    iv_off[v] = int32_t(iv.size());
+    for (size_t k = 0; k < nt; ++k) {
+      if (iv.size() > size_t(iv_off[v]) && iv.back().c == t[k].c && t[k].lo <= iv.back().hi) iv.back().hi = std::max(iv.back().hi, t[k].hi);
+      else iv.push_back(t[k]);
+    }
+    int d = 0;
+    for (size_t k = size_t(iv_off[v]); k < iv.size(); ++k) { const Iv& x = iv[k]; const std::vector<int>& ids = id[x.c]; for (int32_t j = x.lo; j < x.hi; ++j) d += ids[j] >= 0 && ids[j] != v; }
+    for (int o = 0; o < 5; ++o) if (scal_nb[v] & (1u << o)) ++d;
+    deg[v] = d;
+  }
+  iv_off[n] = int32_t(iv.size());
+  t_plan1 = now_s();
+  auto for_neighbours = [&](int v, auto&& fn) {
+    for (int32_t k = iv_off[v]; k < iv_off[v + 1]; ++k) { const Iv& x = iv[k]; const std::vector<int>& ids = id[x.c]; for (int32_t j = x.lo; j < x.hi; ++j) { const int w = ids[j]; if (w >= 0 && w != v) fn(w); } }
+    for (int o = 0; o < 5; ++o) if (scal_nb[v] & (1u << o)) fn(id_o[o]);
+  };
+  // Ceres' recursive independent-set ordering: round after round the greedy maximal independent set of what is left, vertices in
+  // order of increasing degree (ties: creation order); degrees are kept up to date as vertices leave.  (Bucket sort by degree:
+  // creation order inside a bucket comes for free; the few vertices of huge degree -- T_i_c, gravity ... -- are sorted.)
+  std::vector<char> removed(n, 0);
+  std::vector<std::vector<int>> rounds;
+  std::vector<int> queue; queue.reserve(n);
+  std::vector<char> color(n, 0);
+  constexpr int kBuckets = 512;
+  std::vector<int> bucket_n(kBuckets + 1), big;
+  for (int covered = 0; covered < n;) {
+    std::fill(bucket_n.begin(), bucket_n.end(), 0); big.clear();
+    for (int v = 0; v < n; ++v) if (!removed[v]) { color[v] = 0; if (deg[v] < kBuckets) ++bucket_n[deg[v] + 1]; else big.push_back(v); }
+    for (int d = 0; d < kBuckets; ++d) bucket_n[d + 1] += bucket_n[d];
+    queue.assign(size_t(bucket_n[kBuckets]), 0);
+    for (int v = 0; v < n; ++v) if (!removed[v] && deg[v] < kBuckets) queue[size_t(bucket_n[deg[v]]++)] = v;   // (creation order = index order)
+    std::sort(big.begin(), big.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
+    queue.insert(queue.end(), big.begin(), big.end());
+    std::vector<int> set;
+    for (int v : queue) { if (color[v]) continue; set.push_back(v); color[v] = 2; for_neighbours(v, [&](int w) { if (!removed[w]) color[w] = 1; }); }
+    for (int v : set) { removed[v] = 1; for_neighbours(v, [&](int w) { if (!removed[w]) --deg[w]; }); }
+    covered += int(set.size());
+    rounds.push_back(std::move(set));
+  }
+  t_plan2 = now_s();
+  // processing order: last set first; blocks of a set contiguous.  Per block its runs and its workgroups -- one for a knot block;
+  // the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on each other: all of them
+  // must be resident, so a set's shared blocks split the CUs and come first in the launch).
+  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.n_ctls = 0;
+  constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
+  const int resident_wgs = o.resident_wgs; const double shared_share = o.shared_share;
+  for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
+    const int b0 = int(ip.blocks.size());
+    int n_shared = 0;
+    for (int v : *it) {
+      const HB& h = B[v];
+      InnerBlock b = h.b;
+      b.run0 = int32_t(ip.runs.size()); b.nruns = int32_t(h.nruns); b.n_items = 0; b.n_slots = 0; b.ctl = -1;
+      for (int k = 0; k < h.nruns; ++k) { const InnerRun& r = hruns[size_t(h.run0 + k)]; ip.runs.push_back(r); b.n_items += r.count; b.n_slots += (r.count + 63) & ~63; }
+      b.ks0 = h.s1 >= 0 ? h.s0 : 0; b.nks = h.s1 >= 0 ? h.s1 - h.s0 : 0; b.kr0 = h.r1 >= 0 ? h.r0 : 0; b.nkr = h.r1 >= 0 ? h.r1 - h.r0 : 0;
+      b.kab0 = h.a1 >= 0 ? h.a0 : 0; b.nkab = h.a1 >= 0 ? h.a1 - h.a0 : 0; b.kgb0 = h.g1 >= 0 ? h.g0 : 0; b.nkgb = h.g1 >= 0 ? h.g1 - h.g0 : 0;
+      if (b.n_slots > kSharedAbove) ++n_shared;
+      ip.blocks.push_back(b);
+    }
+    const int b1 = int(ip.blocks.size());
+    // (all parts of a set's shared blocks together take at most `inner_shared_residency` (default one half) of the workgroups the
+    // occupancy query says are resident at once: a second problem on the same device -- another rank, another stream -- that runs
+    // the same kind of set at the same time still fits next to it, so neither can strand the other's spinning parts)
+    const int cap = std::max(1, int(double(resident_wgs) * shared_share) / std::max(n_shared, 1));
+    for (int pass = 0; pass < 2; ++pass)        // shared blocks first
+      for (int b = b0; b < b1; ++b) {
+        InnerBlock& blk = ip.blocks[b];
+        const bool shared = blk.n_slots > kSharedAbove;
+        if (shared != (pass == 0)) continue;
+        const int nparts = shared ? std::min(cap, (blk.n_slots + kThreads - 1) / kThreads) : 1;
+        if (nparts > 1) blk.ctl = ip.n_ctls++;
+        for (int q = 0; q < nparts; ++q) ip.wgs.push_back(InnerWg{b, q, nparts, 0});
+      }
+    char r3only = !o.general_kernel;
+    for (int b = b0; b < b1; ++b) r3only = r3only && ip.blocks[b].kind == IK_R3 && ip.blocks[b].n_slots <= 1024;
+    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only);
+  }
+  t_plan3 = now_s();
+  t_ms[0] = 1e3 * (t_plan1 - t_plan0); t_ms[1] = 1e3 * (t_plan2 - t_plan1); t_ms[2] = 1e3 * (t_plan3 - t_plan2);
+}
+InnerPlanOptions inner_plan_options(oicc_problem* p, int flags, int64_t layout_gen) {   // (main thread: reads the option map, asks the runtime)
+  InnerPlanOptions o;
+  o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = p->opt["debug_inner_general_kernel"] != 0.0;
+  o.resident_wgs = inner_set_resident_capacity(p->n_cu); o.shared_share = std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"])); o.layout_gen = layout_gen;
+  return o;
+}
+void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  if (p->plan_thread.joinable()) p->plan_thread.join();
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  if (ip.flags == flags && ip.layout_gen == layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return;   // current
+  p->plan_job = inner_plan_options(p, flags, layout_gen);
+  p->plan_job_valid = true;
+  p->plan_thread = std::thread([p]() { build_inner_plan_host(p, p->plan_job, p->plan_ms); });
+}
+int build_inner_plan(oicc_problem* p, int flags) {
+  oicc_problem::InnerPlan& ip = p->inner;
+  const bool gs_unit = p->opt["gs_unit_loss"] != 0.0;
+  const double t0 = now_s();
+  if (p->plan_thread.joinable()) p->plan_thread.join();
+  const bool prebuilt = p->plan_job_valid && p->plan_job.flags == flags && p->plan_job.layout_gen == p->layout_gen && p->plan_job.gs_unit == gs_unit;
+  p->plan_job_valid = false;
+  if (!prebuilt) {
+    if (ip.flags == flags && ip.layout_gen == p->layout_gen && ip.gs_unit == gs_unit && !ip.blocks.empty()) return OICC_OK;
+    build_inner_plan_host(p, inner_plan_options(p, flags, p->layout_gen), p->plan_ms);
+  }
+  const double t1 = now_s();
+  const ParamLayout& pl = p->pl;
+  hipStream_t st = p->stream;
+  DevArena& PA = p->plan_arena;
+  PA.add(ip.d_blocks, ip.blocks); PA.add(ip.d_runs, ip.runs); PA.add(ip.d_wgs, ip.wgs);
+  PA.reserve(ip.d_ctls, size_t(std::max(ip.n_ctls, 1))); PA.reserve(ip.d_lm_iterations, 1); PA.reserve(ip.d_seg, size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles);
+  if (!PA.commit(st)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
+  HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
+  ip.lm_iterations = 0;                 // host mirror of the device counter that was just cleared (oicc_optimize reports the difference)
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + neighbourhoods %.3f, independent sets %.3f, runs + workgroups %.3f (%s: waited %.3f), device buffers %.3f\n",
+                                           ip.blocks.size(), ip.group_first.size() - 1, ip.wgs.size(), p->plan_ms[0], p->plan_ms[1], p->plan_ms[2], prebuilt ? "second thread under the set-up" : "inline", 1e3 * (t1 - t0), 1e3 * (now_s() - t1));
+  ip.flags = flags; ip.layout_gen = p->layout_gen; ip.gs_unit = gs_unit;
+  return OICC_OK;
+}
+
+// One sweep of coordinate descent on the parameter vector `xv` (device, modified in place): the segment tables of xv, then ONE
+// launch per independent set (inner_iterations.hip); nothing comes back to the host.
+int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the problem whose measurements and plan are used (xv may belong to another problem with the same spline)
+  oicc_problem::InnerPlan& ip = p->inner;
+  InnerArgs A{};
+  A.ctx = make_ctx(p, xv); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
+  A.xv = xv; A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.wgs = nullptr; A.ctls = ip.d_ctls.p;
+  A.lm_iterations = ip.d_lm_iterations.p; A.max_ab = p->max_ab; A.max_gb = p->max_gb;
+  ++ip.sweeps;
+  launch_inner_seg(xv + p->pl.so3, std::max(p->pl.n_so3 - 1, 0), ip.d_seg.p, st);
+  if (ip.n_ctls > 0) HIPCK(p, hipMemsetAsync(ip.d_ctls.p, 0, size_t(ip.n_ctls) * sizeof(InnerCtl), st));
+  const int prof_set = int(p->opt["debug_inner_profile"]) - 1;   // debug: phase clocks of workgroup 0 of this set
+  DevBuf<long long> d_prof;
+  for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
+    A.wgs = ip.d_wgs.p + ip.group_wg0[g];
+    A.prof = nullptr;
+    if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); A.prof = d_prof.p; }
+    launch_inner_set(A, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st);
+  }
+  HIPCK(p, hipGetLastError());
+  if (prof_set >= 0 && d_prof.p) {
+    long long h[64];
+    HIPCK(p, hipMemcpyAsync(h, d_prof.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
+    std::printf("[oicc] inner profile, set %d (%d workgroups), workgroup 0 / thread 0, cycles between marks [eval | barrier | (shared blocks: sums + arrival | wait for the parts |) advance | publish]:", prof_set, ip.group_wg0[prof_set + 1] - ip.group_wg0[prof_set]);
+    for (int k = 1; k < int(h[0]); ++k) std::printf(" %lld", h[1 + k] - h[k]);
+    std::printf("\n");
+  }
+  return OICC_OK;
+}
+
+
+}  // namespace oicc

@@ -1,4 +1,4 @@
-// Time tiles of the Jacobian / normal-equation pass (internal, shared by oicc_problem.hip and kernels_tiles.hip).
+// Time tiles of the Jacobian / normal-equation pass (internal, shared by oicc_tiles.hip / oicc_problem.hip and kernels_tiles.hip).
 //
 // The measurements are cut into TILES of consecutive knot windows, the tiles into CHAINS of consecutive tiles.  One workgroup
 // owns a chain and walks its tiles in time order: per tile it stages the tile's knots and per-knot-pair segment tables in LDS,
