@@ -882,6 +882,23 @@ def test_points_flag_layout_and_normal_equations(cfg, flags):
     assert H0.shape == H1.shape and rel_err(H0, H1) < 1e-9 and rel_err(g0, g1) < 1e-9
 
 
+def test_points_flag_with_the_bounds_line_search_and_the_projected_gradient_norm():
+    """POINTS next to box-bounded bias knots: Ceres' Armijo search along the projected path re-retracts the points with its step
+    sizes (HomogeneousVectorParameterization::Plus of alpha * delta) and reports the ambient max norm of Plus(x, -g) - x, points
+    included.  Same iterates and gradient norms as the oracle."""
+    flags = FLAGS1 | E.IMU_BIASES | E.POINTS
+    _, gpu, cpu = build_pair("tiny")
+    for c in (gpu, cpu):
+        c.trajectory_.SetOption("bounds_line_search", 1); c.trajectory_.SetOption("projected_gradient_norm", 1)
+    sg, sc = gpu.trajectory_.Optimize(8, flags), cpu.trajectory_.Optimize(8, flags)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert sg["num_iterations"] == sc["num_iterations"] and sg["line_search_steps"] == sc["line_search_steps"] >= 1, (sg, sc)
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-8 * b["cost"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * max(b["gradient_max_norm"], 1e-12), (a, b)
+    assert np.abs(gpu.trajectory_.GetScenePoints() - cpu.trajectory_.GetScenePoints()).max() < 1e-7
+
+
 @pytest.mark.parametrize("cfg,flags", [POINT_CASES[0], POINT_CASES[3]])
 def test_points_flag_lm_iterates_and_refined_points(cfg, flags):
     """oicc_optimize with POINTS: the iterates of the oracle's trust-region loop (same accept / reject sequence, costs),
