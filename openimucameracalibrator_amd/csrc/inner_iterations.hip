@@ -146,7 +146,9 @@ struct InnerLm {
 
 template <int D>
 __device__ __forceinline__ bool inner_cholesky_solve(const double* M, const double* rhs, double* x) {   // M (D x D, stride D) x = rhs, all in registers
-  double L[D * D], y[D];
+  // one reciprocal per pivot, products everywhere else: this runs on ONE lane between two evaluations, every fp64 division is
+  // ~10 dependent instructions of its chain (round 4: 45 divisions -> 6 for T_i_c)
+  double L[D * D], y[D], inv[D];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
@@ -156,12 +158,13 @@ __device__ __forceinline__ bool inner_cholesky_solve(const double* M, const doub
     ok = ok && s > 0.0 && isfinite(s);
     const double l = sqrt(s);
     L[j * D + j] = l;
+    inv[j] = 1.0 / l;
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double t = M[i * D + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= L[i * D + k] * L[j * D + k];
-      L[i * D + j] = t / l;
+      L[i * D + j] = t * inv[j];
     }
   }
   if (!ok) return false;
@@ -170,14 +173,14 @@ __device__ __forceinline__ bool inner_cholesky_solve(const double* M, const doub
     double t = rhs[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) t -= L[i * D + k] * y[k];
-    y[i] = t / L[i * D + i];
+    y[i] = t * inv[i];
   }
 #pragma unroll
   for (int i = D - 1; i >= 0; --i) {
     double t = y[i];
 #pragma unroll
     for (int k = i + 1; k < D; ++k) t -= L[k * D + i] * x[k];
-    x[i] = t / L[i * D + i];
+    x[i] = t * inv[i];
   }
 #pragma unroll
   for (int i = 0; i < D; ++i) ok = ok && isfinite(x[i]);
@@ -277,17 +280,18 @@ __device__ OICC_INNER_ADVANCE_ATTR int inner_lm_advance(InnerLm& S, int kind, in
     if (iter >= 50 || !(radius > min_radius)) break;
     ++iter;
     double M[D * D], rhs[D], step[D];
+    const double inv_radius = 1.0 / radius;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       rhs[i] = -g[i] * sc[i];
 #pragma unroll
-      for (int j = 0; j < D; ++j) M[i * D + j] = H[i * D + j] * sc[i] * sc[j] + (i == j ? dg[i] / radius : 0.0);
+      for (int j = 0; j < D; ++j) M[i * D + j] = H[i * D + j] * sc[i] * sc[j] + (i == j ? dg[i] * inv_radius : 0.0);
     }
     bool ok = inner_cholesky_solve<D>(M, rhs, step);
     double model = 0.0;
     if (ok) {
 #pragma unroll
-      for (int i = 0; i < D; ++i) model += 0.5 * step[i] * ((dg[i] / radius) * step[i] - g[i] * sc[i]);
+      for (int i = 0; i < D; ++i) model += 0.5 * step[i] * ((dg[i] * inv_radius) * step[i] - g[i] * sc[i]);
       ok = model > 0.0;
     }
     if (!ok) {
