@@ -95,15 +95,16 @@ def main():
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
     cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None, owner_computes=world > 1)   # owner-computes exchange (round 4) where the native RCCL path is up; else the all-reduce of the whole buffer
 
+    # Every step of the set-up is agreed on by all ranks (MIN all-reduce of a success flag), so that a rank that cannot bind RCCL,
+    # build the communicator or run the exchange takes every other rank to the fallback with it instead of leaving them in a collective.
+    def all_ok(ok):
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return int(f[0]) == 1
+
     if native:
         # native path: the library calls ncclAllReduce (RCCL over xGMI) in place on its own stream; torch.distributed only
         # carries the 128-byte ncclUniqueId from rank 0 to the other ranks
-        # Every step is agreed on by all ranks (MIN all-reduce of a success flag), so that a rank that cannot bind RCCL or
-        # build the communicator takes every other rank to the fallback with it instead of leaving them in a collective.
-        def all_ok(ok):
-            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            return int(f[0]) == 1
         my_id = None
         try:
             my_id = tr.RcclUniqueId()          # probes the binding on every rank; only rank 0's id is used
@@ -143,6 +144,32 @@ def main():
             assert hip.hipMemcpyAsync(ptr, t.data_ptr(), nbytes, 3, strm) == 0
         tr.SetAllReduce(allreduce)
 
+    # The owner-computes exchange (ncclSend / ncclRecv of halo rows, ncclBroadcast per owner) has only ever run through the transport
+    # hooks of the two-process tests: before the timed steps depend on it, one trial exchange that every rank must survive -- else all
+    # ranks go back to the all-reduce of the whole packed buffer (oicc_set_shard(1, 0) switches the exchange off).
+    assembly_path = "single"
+    if world > 1:
+        assembly_path = "allreduce"
+        ok = reduce_path == "rccl-native"
+        if ok:
+            try:
+                tr.TimeExchange(flags, repeats=-1)           # (a local question, nothing is sent)
+            except Exception as e:
+                ok = False
+                sys.stderr.write("rank %d: owner-computes exchange not set up (%s)\n" % (rank, e))
+        ok = all_ok(ok)
+        if ok:
+            try:
+                tr.TimeExchange(flags, repeats=1)            # a collective: every rank runs it
+            except Exception as e:
+                ok = False
+                sys.stderr.write("rank %d: trial exchange failed (%s)\n" % (rank, e))
+            ok = all_ok(ok)
+        if ok:
+            assembly_path = "owner-computes exchange"
+        else:
+            tr.SetShard(1, 0)
+
     n_blocks_local = cal.num_blocks
     blocks = torch.tensor([n_blocks_local, cal.num_corners], dtype=torch.int64, device="cuda")
     if use_dist:
@@ -179,14 +206,7 @@ def main():
         barrier()
         # the owner-computes exchange the steps above used, where it is set up (world > 1, native RCCL with send / recv): a collective,
         # so every rank first agrees on whether it can run it
-        can = 0
-        if world > 1 and reduce_path == "rccl-native":
-            try:
-                tr.TimeExchange(flags, repeats=-1); can = 1      # (a local question, nothing is sent)
-            except Exception:
-                can = 0
-        f = torch.tensor([can], dtype=torch.int32, device="cuda"); dist.all_reduce(f, op=dist.ReduceOp.MIN)
-        if int(f[0]) == 1:
+        if assembly_path == "owner-computes exchange":
             try:
                 exchange_ms, exchange_bytes = tr.TimeExchange(flags, repeats=10)
             except Exception as e:
@@ -286,7 +306,7 @@ def main():
             "config": {"workload": ("C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s" if world == 1 else
                                     "C5 synthetic, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s, " + "%d time shards (strong scaling), all-reduce of JtJ/Jtr" % world)
                                    % (ds.num_views, n_corners, n_blocks - ds.num_views),
-                       "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR", "allreduce": reduce_path,
+                       "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR", "allreduce": reduce_path, "assembly": assembly_path,
                        "step": "one LM iteration: Jacobian+assembly, block-cyclic-reduction solve, retraction, cost pass, one host read-back"},
             "corners_per_s": n_corners * args.steps / dt,
             "jacobian_pass_ms": pass_ms,
