@@ -931,3 +931,45 @@ def test_points_flag_lm_iterates_and_refined_points(cfg, flags):
     tg.SetOption("inner_iterations", 1)
     with pytest.raises(Exception):
         tg.Optimize(3, flags)
+
+
+# ---- a sweep over small problems of varied geometry (round 4): knot spacing ratios, IMU rates, view counts, shutters, cameras, flags ----
+def _random_cases():
+    rng = np.random.RandomState(424242)
+    cams = ["pinhole", "pinhole_radtan", "gopro9_division", "gopro6_fisheye", "gopro6_double_sphere", "gopro9_eucm"]
+    spacing = [(0.05, 0.1), (0.1, 0.1), (0.04, 0.12), (0.1, 0.05), (0.03, 0.09), (0.07, 0.11)]
+    flag_sets = [FLAGS1, FLAGS1 | E.CAM_LINE_DELAY, FLAGS1 | E.IMU_BIASES, FLAGS1 | E.IMU_INTRINSICS | E.ACC_BIAS, E.T_I_C | E.GRAVITY_DIR,
+                 FLAGS1 | E.POINTS, E.SPLINE, FLAGS1 | E.GYR_BIAS | E.CAM_LINE_DELAY | E.POINTS]
+    cases = []
+    for k in range(12):
+        dt_so3, dt_r3 = spacing[k % len(spacing)]
+        cases.append(dict(num_views=int(rng.randint(6, 40)), corners_per_view=int(rng.randint(4, 20)), duration=float(rng.uniform(0.9, 3.5)),
+                          camera=cams[k % len(cams)], imu_rate=float(rng.choice([100.0, 200.0, 400.0])), dt_so3=dt_so3, dt_r3=dt_r3,
+                          rolling_shutter=bool(k % 4 != 3), seed=1000 + k, flags=flag_sets[k % len(flag_sets)]))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(), ids=lambda c: "seed%d" % c["seed"])
+def test_small_problems_of_varied_geometry_match_the_oracle(case):
+    """Twelve seeded small problems -- knot spacing ratios from 1:3 to 2:1, IMU rates 100-400 Hz, 6-40 views of 4-20 corners, rolling and
+    global shutter, six camera models, eight flag sets (POINTS among them): tangent layout, cost, gradient and J^T J against the Jet
+    oracle through the time tiles and through the direct-atomics route, and the first LM iterates."""
+    kw = dict(case); flags = kw.pop("flags")
+    _, gpu, cpu = build_pair("tiny", board=(6, 5), **kw)
+    tg, tc = gpu.trajectory_, cpu.trajectory_
+    lg, lc = tg.GetTangentLayout(flags), tc.GetTangentLayout(flags)
+    assert lg["P"] == lc["P"]
+    for k in ("so3", "r3", "accl_bias", "gyro_bias", "other"):
+        assert np.array_equal(lg[k], lc[k]), k
+    cc, Hc, gc = tc.Evaluate(flags)
+    for assembly in (0, 2):
+        tg.SetOption("assembly", assembly)
+        cg, Hg, gg = tg.Evaluate(flags)
+        assert abs(cg - cc) <= 1e-11 * max(cc, 1e-300), (assembly, cg, cc)
+        assert rel_err(gg, gc) < 1e-9 and rel_err(Hg, Hc) < 1e-9, (assembly, rel_err(gg, gc), rel_err(Hg, Hc))
+    tg.SetOption("assembly", 0)
+    sg, sc = tg.Optimize(4, flags), tc.Optimize(4, flags)
+    ig, ic = tg.GetIterations(), tc.GetIterations()
+    assert len(ig) == len(ic)
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * max(b["cost"], 1e-300), (a, b)
