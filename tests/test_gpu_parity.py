@@ -973,3 +973,22 @@ def test_small_problems_of_varied_geometry_match_the_oracle(case):
     assert len(ig) == len(ic)
     for a, b in zip(ig, ic):
         assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * max(b["cost"], 1e-300), (a, b)
+
+
+@pytest.mark.parametrize("k,flags", [(3, FLAGS1), (5, FLAGS1 | E.CAM_LINE_DELAY), (9, FLAGS1 | E.IMU_BIASES), (10, FLAGS1)])
+def test_reference_solver_options_on_small_problems_of_varied_geometry(k, flags):
+    """The reference's solver configuration (inner iterations, bounds line search, projected gradient norm) on four of the seeded small
+    problems above -- knot spacings 2:1 and 1:3, 100-400 Hz -- against the Jet oracle: the inner-iteration plan (blocks, independent sets,
+    the items of every block) on geometries the BASELINE configurations do not have."""
+    kw = dict(_random_cases()[k]); kw.pop("flags")
+    ds = synthetic.make_config("tiny", board=(6, 5), **kw)
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.UseReferenceSolverOptions()
+    sg, sc = gpu.trajectory_.Optimize(6, flags), cpu.trajectory_.Optimize(6, flags)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert len(ig) == len(ic) and sg["inner_sweeps"] == sc["inner_sweeps"] >= 1, (sg, sc)
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * max(b["cost"], 1e-300), (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
