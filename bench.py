@@ -93,6 +93,8 @@ def main():
     native = use_dist and os.environ.get("OICC_BENCH_TORCH_ALLREDUCE") != "1"
     if use_dist and not native:   # torch staging path: share torch's stream so that the all-reduce is ordered with the kernels
         tr.SetStream(torch.cuda.current_stream().cuda_stream)
+    for kv in filter(None, os.environ.get("OICC_BENCH_OPTS", "").split(",")):   # developer A/B: library options for the timed steps, e.g. OICC_BENCH_OPTS=device_lm=0
+        tr.SetOption(kv.split("=")[0], float(kv.split("=")[1]))
     cal.BatchInitSpline(ds, shard=(rank, world) if world > 1 else None, owner_computes=world > 1)   # owner-computes exchange (round 4) where the native RCCL path is up; else the all-reduce of the whole buffer
 
     # Every step of the set-up is agreed on by all ranks (MIN all-reduce of a success flag), so that a rank that cannot bind RCCL,

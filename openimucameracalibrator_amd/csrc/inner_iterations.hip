@@ -156,9 +156,16 @@ __device__ __forceinline__ bool inner_cholesky_solve(const double* M, const doub
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * D + k] * L[j * D + k];
     ok = ok && s > 0.0 && isfinite(s);
-    const double l = sqrt(s);
+    // sqrt(s) and 1 / sqrt(s) together from v_rsq_f64 (2^-24) and two coupled Goldschmidt steps (2^-52; scripts/micro: the chain is
+    // 8 dependent operations against ~25 for an IEEE square root followed by a division -- this runs on ONE lane)
+    const double y0 = __builtin_amdgcn_rsq(s);
+    const double g0 = s * y0, h0 = 0.5 * y0;
+    const double r0 = fma(-g0, h0, 0.5);
+    const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+    const double r1 = fma(-g1, h1, 0.5);
+    const double l = fma(g1, r1, g1), h2 = fma(h1, r1, h1);
     L[j * D + j] = l;
-    inv[j] = 1.0 / l;
+    inv[j] = h2 + h2;
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double t = M[i * D + j];
@@ -324,7 +331,7 @@ struct ItemRec {
 };
 
 // slot i of the block: every run of items starts at a multiple of 64 slots, so that a wave evaluates items of one family only
-__device__ __forceinline__ void inner_load_item(const InnerArgs& A, const InnerBlock& blk, int i, ItemRec& R) {
+__device__ __forceinline__ void inner_load_item(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R) {
   R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
 #pragma unroll
   for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
@@ -340,7 +347,7 @@ __device__ __forceinline__ void inner_load_item(const InnerArgs& A, const InnerB
     const int v = vd.corner_view[idx];
     R.s_so3 = vd.view_s_so3[v]; R.s_r3 = vd.view_s_r3[v]; R.sx = vd.view_rs[v] != 0;
     R.d[0] = vd.view_u_so3[v]; R.d[1] = vd.view_u_r3[v]; R.d[2] = vd.corner_u[idx]; R.d[3] = vd.corner_v[idx]; R.d[4] = vd.corner_isx[idx]; R.d[5] = vd.corner_isy[idx];
-    const double* X = A.ctx.pts + 4 * (int64_t)vd.corner_pt[idx];
+    const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)vd.corner_pt[idx];   // (the board points are the tail of the parameter vector)
     R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
   } else if (R.kind > 0) {
     const ImuData& id = R.kind == 1 ? A.ia : A.ig;
@@ -402,7 +409,7 @@ __device__ __forceinline__ void item_fetch(ItemRec& R, const int* si, const doub
 
 // all items of the block that fall to this workgroup: sums into the wave's LDS row [H upper | g | cost]
 template <bool JAC, class CFG>
-__device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, int part, int nparts, bool staged, const int* si, const double* sd,
+__device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const double* xv, const InnerBlock& blk, const ParamView& P, int part, int nparts, bool staged, const int* si, const double* sd,
                                                  double* row /* this wave's [56] */, double* s_J /* [CFG::NJ][CFG::T] */) {
   constexpr int T = CFG::T, JS = CFG::JS;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -411,7 +418,7 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const Inner
   int slot = tid;
   for (int base = part * T; base < blk.n_slots; base += nparts * T, slot += T) {
     ItemRec R;
-    if (staged) item_fetch<CFG::SLOTS>(R, si, sd, slot); else inner_load_item(A, blk, base + tid, R);
+    if (staged) item_fetch<CFG::SLOTS>(R, si, sd, slot); else inner_load_item(A, xv, blk, base + tid, R);
     if (__ballot(R.kind >= 0) == 0ull) continue;   // (padding slots of the last wave of a run)
     if (JAC) for (int k = 0; k < 3 * JS; ++k) J[k] = 0.0;
     res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
@@ -444,9 +451,11 @@ __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
 }
 
 // workgroup = (block of the set, part): the block's whole Levenberg-Marquardt loop
+// prof: debug (option debug_inner_profile): shader clock of workgroup 0 / thread 0 at every phase boundary, [0] = count
 template <bool R3ONLY>
-__global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArgs A) {
+__global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const InnerArgs* __restrict__ Sp, double* xv, const InnerWg* __restrict__ wgs, long long* prof_buf) {
   using CFG = InnerCfg<R3ONLY>;
+  const InnerArgs& A = *Sp;
   constexpr int kInnerThreads = CFG::T, kInnerSlots = CFG::SLOTS;
   __shared__ double s_J[CFG::NJ * kInnerThreads];  // per lane: Jacobian columns of the block (3 x JS) and the residuals
   __shared__ double s_item_d[10 * kInnerSlots];    // per lane and round: the item's measurement (ItemRec)
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
   __shared__ double s_tot[56];
   __shared__ InnerLm S;
   __shared__ int s_cmd;
-  const InnerWg wg = A.wgs[blockIdx.x];
+  const InnerWg wg = wgs[blockIdx.x];
   const InnerBlock blk = A.blocks[wg.block];
   const ParamLayout& pl = A.ctx.pl;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6; constexpr int nwaves = kInnerThreads / 64;
@@ -470,15 +479,15 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
   const bool local = ctl == nullptr && blk.nks <= kCapS && blk.nkr <= kCapR && blk.nkab <= kCapB && blk.nkgb <= kCapB;
   ParamView P;
   if (local) {
-    for (int e = tid; e < 4 * blk.nks; e += kInnerThreads) s_so3[e] = A.xv[pl.so3 + 4 * (int64_t)blk.ks0 + e];
+    for (int e = tid; e < 4 * blk.nks; e += kInnerThreads) s_so3[e] = xv[pl.so3 + 4 * (int64_t)blk.ks0 + e];
     for (int e = tid; e < kSegStride * (blk.nks - 1); e += kInnerThreads) s_seg[e] = A.seg[(size_t)blk.ks0 * kSegStride + e];
-    for (int e = tid; e < 3 * blk.nkr; e += kInnerThreads) s_r3[e] = A.xv[pl.r3 + 3 * (int64_t)blk.kr0 + e];
-    for (int e = tid; e < 3 * blk.nkab; e += kInnerThreads) s_ab[e] = A.xv[pl.ab + 3 * (int64_t)blk.kab0 + e];
-    for (int e = tid; e < 3 * blk.nkgb; e += kInnerThreads) s_gb[e] = A.xv[pl.gb + 3 * (int64_t)blk.kgb0 + e];
-    if (tid < 26) s_scal[tid] = A.xv[pl.tic + tid];
+    for (int e = tid; e < 3 * blk.nkr; e += kInnerThreads) s_r3[e] = xv[pl.r3 + 3 * (int64_t)blk.kr0 + e];
+    for (int e = tid; e < 3 * blk.nkab; e += kInnerThreads) s_ab[e] = xv[pl.ab + 3 * (int64_t)blk.kab0 + e];
+    for (int e = tid; e < 3 * blk.nkgb; e += kInnerThreads) s_gb[e] = xv[pl.gb + 3 * (int64_t)blk.kgb0 + e];
+    if (tid < 26) s_scal[tid] = xv[pl.tic + tid];
     P = ParamView{s_so3, s_seg, s_r3, s_ab, s_gb, s_scal, blk.ks0, blk.kr0, blk.kab0, blk.kgb0};
   } else {
-    P = ParamView{A.xv + pl.so3, A.seg, A.xv + pl.r3, A.xv + pl.ab, A.xv + pl.gb, A.xv + pl.tic, 0, 0, 0, 0};
+    P = ParamView{xv + pl.so3, A.seg, xv + pl.r3, xv + pl.ab, xv + pl.gb, xv + pl.tic, 0, 0, 0, 0};
   }
   // the block's value inside the LDS copy (the master writes candidates to both)
   double* xl = nullptr;
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
   if (staged) {
     int slot = tid;
     for (int base = wg.part * kInnerThreads; base < blk.n_slots; base += wg.nparts * kInnerThreads, slot += kInnerThreads) {
-      ItemRec R; inner_load_item(A, blk, base + tid, R); item_store<kInnerSlots>(R, s_item_i, s_item_d, slot);
+      ItemRec R; inner_load_item(A, xv, blk, base + tid, R); item_store<kInnerSlots>(R, s_item_i, s_item_d, slot);
     }
   }
   if (master) {
@@ -504,9 +513,9 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
       S.radius = 1e4; S.decrease_factor = 2.0; S.cost = 0.0; S.x_norm = 0.0; S.model = 0.0;
       S.iter = 0; S.invalid = 0; S.reuse_diagonal = 0; S.first = 1; S.seg_action = 0;
     }
-    if (tid < blk.ambient) S.xcur[tid] = A.xv[blk.xoff + tid];
+    if (tid < blk.ambient) S.xcur[tid] = xv[blk.xoff + tid];
     if (so3) {
-      const double* q = A.xv + pl.so3;
+      const double* q = xv + pl.so3;
       if (tid >= 16 && tid < 20) S.qprev[tid - 16] = blk.idx > 0 ? q[4 * (int64_t)(blk.idx - 1) + (tid - 16)] : 0.0;
       if (tid >= 20 && tid < 24) S.qnext[tid - 20] = blk.idx + 1 < pl.n_so3 ? q[4 * (int64_t)(blk.idx + 1) + (tid - 20)] : 0.0;
       if (tid >= 64 && tid < 64 + 2 * kSegStride) { const int e = tid - 64; S.segcur[e] = s_lo * kSegStride + e < n_pairs * kSegStride ? A.seg[(size_t)s_lo * kSegStride + e] : 0.0; }
@@ -515,14 +524,14 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
   __syncthreads();
   int cmd = INNER_CMD_JAC;
   unsigned round = 0;
-  const bool prof = A.prof != nullptr && blockIdx.x == 0 && tid == 0;
+  const bool prof = prof_buf != nullptr && blockIdx.x == 0 && tid == 0;
   int nprof = 0;
-#define INNER_MARK() do { if (prof && nprof < 62) A.prof[1 + nprof++] = clock64(); } while (0)
+#define INNER_MARK() do { if (prof && nprof < 62) prof_buf[1 + nprof++] = clock64(); } while (0)
   INNER_MARK();
   while (true) {
     if (lane < 56) s_part[wave][lane] = 0.0;
-    if (cmd == INNER_CMD_JAC) inner_eval_items<true, CFG>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
-    else inner_eval_items<false, CFG>(A, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    if (cmd == INNER_CMD_JAC) inner_eval_items<true, CFG>(A, xv, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
+    else inner_eval_items<false, CFG>(A, xv, blk, P, wg.part, wg.nparts, staged, s_item_i, s_item_d, s_part[wave], s_J);
     INNER_MARK();
     __syncthreads();
     INNER_MARK();
@@ -545,7 +554,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
     __syncthreads();
     if (master) {
       if (tid == 0) {
-        double* x = A.xv + blk.xoff;
+        double* x = xv + blk.xoff;
         int nc = INNER_CMD_DONE;
         if (R3ONLY) nc = inner_lm_advance<3, 3>(S, IK_R3, cmd, s_tot, x, xl, A.max_ab, A.max_gb);
         else switch (blk.kind) {
@@ -598,7 +607,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(InnerArg
     if (cmd == INNER_CMD_DONE) break;
   }
   if (master && tid == 0 && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
-  if (prof) A.prof[0] = nprof;
+  if (prof) prof_buf[0] = nprof;
 #undef INNER_MARK
 }
 
@@ -617,10 +626,10 @@ __global__ void inner_diff_norm_kernel(const double* x, const double* xc, const 
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st) {
   if (n_pairs > 0) hipLaunchKernelGGL(inner_seg_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, so3, n_pairs, seg);
 }
-void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 1024 item slots
+void launch_inner_set(const InnerArgs* dA, double* xv, const InnerWg* wgs, long long* prof, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 1024 item slots
   if (n_wgs <= 0) return;
-  if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, A);
-  else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, A);
+  if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, dA, xv, wgs, prof);
+  else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, dA, xv, wgs, prof);
 }
 // Workgroups of the general build that are resident at the same time on `n_cu` compute units (occupancy query, not an assumption: the
 // workgroups that share a block spin on each other, so a set's shared parts must all fit next to whatever else runs on the device)

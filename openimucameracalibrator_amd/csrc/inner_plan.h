@@ -38,15 +38,17 @@ struct InnerCtl {
   unsigned int pad[2];
 };
 
-// kernel arguments of one set's launch (inner_set_kernel)
+// Arguments of inner_set_kernel that only change with the problem / the plan (~0.9 KB): they live in DEVICE memory and are read
+// where they are needed (round 5; by value the kernel's prologue loaded and spilled them lane by lane -- 326 spilled SGPRs, the
+// round-2 finding of the tile kernel).  What changes from launch to launch travels by value: the parameter vector the sweep works
+// on (`xv`: the kernels of a sweep change it in place), the set's workgroup table and the debug clock buffer.
 struct InnerArgs {
-  EvalCtx ctx;              // ctx.x == xv (the kernels of a sweep change the vector in place)
+  EvalCtx ctx;              // ctx.x is not used
   ViewData vd; ImuData ia, ig;
-  double* xv; double* seg;
-  const InnerBlock* blocks; const InnerRun* runs; const InnerWg* wgs; InnerCtl* ctls;
+  double* seg;
+  const InnerBlock* blocks; const InnerRun* runs; InnerCtl* ctls;
   unsigned long long* lm_iterations;
   double max_ab, max_gb;
-  long long* prof;          // debug (option debug_inner_profile): shader clock of workgroup 0 / thread 0 at every phase boundary, [0] = count
 };
 
 }  // namespace oicc

@@ -40,7 +40,9 @@ struct BcrArgs {
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
   int top;                     // bcri_invert_kernel<LAST>: the one pivot of the top level (> 0), whose back substitution block 0's workgroup does as well
+  const LmCtl* ctl;            // device-side LM control (oicc_device.h): every kernel returns at once when the loop is done
 };
+#define BCR_RETURN_IF_DONE(A) do { if ((A).ctl != nullptr && (A).ctl->done != 0) return; } while (0)
 
 __device__ __forceinline__ void bcr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ double bcr_readlane(double v, int lane) {
@@ -434,6 +436,7 @@ __device__ __forceinline__ void bcri_invert_body(const BcrArgs& A, const int i, 
 
 template <bool LAST, bool PROF>
 __global__ __launch_bounds__(64 * kInvWaves) void bcri_invert_kernel(BcrArgs A) {
+  BCR_RETURN_IF_DONE(A);
   const int i = LAST ? 0 : A.s * (2 * (int)blockIdx.x + 1);
   const double* Dg = A.D + (int64_t)i * 4096;
   bcri_invert_body<LAST, PROF>(A, i, [Dg](int e) { return Dg[e]; });
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void bcri_invert_kernel(BcrArgs A) 
 
 // one workgroup (4 waves) per (pivot, 16-row tile x of the border rows, group of up to four column tiles y)
 __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
+  BCR_RETURN_IF_DONE(A);
   __shared__ double Ts[16][68];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
 
 // back substitution of the pivots of one level: lane = column of T, the 128 + a rows spread over the waves
 __global__ __launch_bounds__(64 * kBackWaves) void bcri_backward_kernel(BcrArgs A) {
+  BCR_RETURN_IF_DONE(A);
   __shared__ double xs[192];
   __shared__ double part[kBackWaves][64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(64 * kBackWaves) void bcri_backward_kernel(BcrArgs 
 // Every row of T the three products read is in flight before the first barrier.  A lower pivot whose upper neighbour lies beyond
 // the last block (at most one) gets a workgroup of its own behind the others.
 __global__ __launch_bounds__(1024) void bcri_backward2_kernel(BcrArgs A, int npiv_upper, int orphan) {
+  BCR_RETURN_IF_DONE(A);
   constexpr int NW = 16, RW1 = 192 / NW, RW2 = 192 / (NW / 2);
   __shared__ double xs[4][64];            // x of j - 2 s, j, j + 2 s, the arrow part
   __shared__ double part[NW][64];
@@ -678,6 +684,7 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
   const double radius = sb.radius;
   if (tid == 0) {   // results of the step that starts here
     sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
+    if (sb.ctl != nullptr && sb.ctl->stamps != nullptr && sb.ctl->seq < sb.ctl->trace_cap) sb.ctl->stamps[3 * sb.ctl->seq] = wall_clock64();
   }
   auto damp = [&](int64_t i, double hii) -> double {
     const double sc = sb.scale[i];
@@ -737,8 +744,17 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
   }
 }
 
+// device-side LM control: the system to build, its radius and the reuse-diagonal flag come from the control block
+__device__ __forceinline__ bool lm_ctl_build_inputs(NormalEq& ne, SolveBuffers& sb, int& reuse_diagonal) {
+  if (sb.ctl == nullptr) return true;
+  if (sb.ctl->done != 0) return false;
+  ne.base = sb.ctl->nep[0]; sb.radius = sb.ctl->radius; reuse_diagonal = sb.ctl->reuse_diagonal;
+  return true;
+}
+
 __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal, double min_diag,
                                  double max_diag, BcrArgs A) {
+  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal)) return;
   bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
@@ -747,6 +763,7 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
 // the build, which still writes every block for the later levels -- while the other workgroups build the system.
 __global__ __launch_bounds__(64 * kInvWaves) void bcri_build_invert_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                                                            double min_diag, double max_diag, BcrArgs A) {
+  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal)) return;
   const int npiv = A.n / 2;
   if ((int)blockIdx.x >= npiv) {
     bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)((int)blockIdx.x - npiv) * blockDim.x + threadIdx.x, (int64_t)((int)gridDim.x - npiv) * blockDim.x);
@@ -814,7 +831,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   A.Lf = w; w += (int64_t)n * (192 + a1) * 64 + 64;
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
   A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.delay = sb.bcr_delay;
-  A.rtf = (a1 + 15) / 16;
+  A.rtf = (a1 + 15) / 16; A.ctl = sb.ctl;
   const bool inv = true;
   const size_t lds_inv = ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double), lds_inv_last = lds_inv + (size_t)64 * 65 * sizeof(double);
   const bool fused_build = n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)

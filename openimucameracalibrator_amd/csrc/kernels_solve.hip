@@ -30,12 +30,17 @@ namespace oicc {
 // ---- build the damped system  M = S H S + diag(D2),  rhs = -S g ----------------
 __global__ void lm_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                 double min_diag, double max_diag) {
+  if (sb.ctl != nullptr) {   // device-side LM control (oicc_device.h)
+    if (sb.ctl->done != 0) return;
+    ne.base = sb.ctl->nep[0]; sb.radius = sb.ctl->radius; reuse_diagonal = sb.ctl->reuse_diagonal;
+  }
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   const int Pb = tl.Pb, a = tl.a, W = tl.W, ar = a + 1;
   const double radius = sb.radius;
   if (tid == 0) {   // results of the step that starts here
     sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
+    if (sb.ctl != nullptr && sb.ctl->stamps != nullptr && sb.ctl->seq < sb.ctl->trace_cap) sb.ctl->stamps[3 * sb.ctl->seq] = wall_clock64();
   }
   // diagonal / damping
   for (int64_t i = tid; i < tl.P; i += nthreads) {
@@ -128,14 +133,23 @@ __device__ __forceinline__ void se3_exp_dev(const double a6[6], Quat* q, double 
 
 // alpha scales the step (1 for the trust-region candidate; the bounds line search of oicc_optimize re-retracts with its
 // step sizes, and then the model cost change of the FULL step is kept: with_model = 0).
+// SEG: also the candidate's segment tables (multi-round problems); without it that code -- a second retraction per knot -- does not exist
+// (round 5: the one-round build is the one inside the benchmark step).  ctl (device-side LM control, oicc_device.h): current and
+// candidate buffers come from the control block.
+template <bool SEG>
 __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, TangentLayout tl, SolveBuffers sb,
-                                  NormalEq ne, double max_ab, double max_gb, double alpha, int with_model, double* seg_out) {
+                                  NormalEq ne, double max_ab, double max_gb, double alpha, int with_model, double* seg_out, const LmCtl* ctl) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
   double step_sq = 0.0, x_sq = 0.0, model = 0.0;
+  if (ctl != nullptr) {
+    if (ctl->done != 0) return;
+    x = ctl->xp[0]; xc = ctl->xp[1]; ne.base = ctl->nep[0]; if (SEG) seg_out = ctl->segp[1];
+    if (tid == 0 && ctl->stamps != nullptr && ctl->seq < ctl->trace_cap) ctl->stamps[3 * ctl->seq + 1] = wall_clock64();   // (the solve has finished: this kernel depends on it)
+  }
   // xc equals x on every inactive entry (copied once per Optimize call; inactive entries never change);
   // all active blocks are rewritten here.  The cost slot is cleared for the candidate cost pass.
-  if (tid == 0) *ne.cost() = 0.0;
+  else if (tid == 0) *ne.cost() = 0.0;
   // model cost change = 0.5 * d.(D2 d - g_s)  (from (H_s + D2) d = -g_s)
   if (with_model) for (int64_t i = tid; i < tl.P; i += nthreads) {
     const double d = sb.step_s[i];
@@ -160,7 +174,7 @@ __global__ void lm_retract_kernel(const double* x, double* xc, ParamLayout pl, T
     }
     // segment table of the candidate's knot pair (k, k+1) for the residual passes at xc (tiles.h: TileDyn::seg); the neighbour's
     // retraction is repeated here with the same operations, hence the same bits as its own thread stores
-    if (seg_out != nullptr && k + 1 < pl.n_so3) so3_segment_prepare(r, moved(k + 1), seg_out + k * kSegStride);
+    if (SEG && seg_out != nullptr && k + 1 < pl.n_so3) so3_segment_prepare(r, moved(k + 1), seg_out + k * kSegStride);
   }
   for (int64_t k = tid; k < pl.n_r3; k += nthreads) {
     const int o = tl.r3[k];
@@ -437,7 +451,79 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha, int with_model, double* seg_out) {
   int64_t work = pl.total;
   int grid = int((work + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(lm_retract_kernel, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model, seg_out);
+  if (seg_out != nullptr) hipLaunchKernelGGL(lm_retract_kernel<true>, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model, seg_out, sb.ctl);
+  else hipLaunchKernelGGL(lm_retract_kernel<false>, dim3(grid), dim3(256), 0, st, x, xc, pl, tl, sb, ne, max_ab, max_gb, alpha, with_model, seg_out, sb.ctl);
+}
+
+// ---- the trust-region decision on the device (LmCtl, oicc_device.h) -----------------------------------------------------------
+// One thread, behind the Jacobian pass at the candidate (whose merge left the candidate's cost in its cost slot and max |g| in
+// LmState).  Mirrors the host loop of oicc_optimize = TrustRegionMinimizer::Minimize [EXT Ceres 2.1.0] with the reference's
+// options: invalid step -> shrink; parameter / function tolerance; IsStepSuccessful -> swap the buffers, StepAccepted(rho);
+// else StepRejected; then the tests Ceres makes before the next iteration (iterations, gradient tolerance, radius).
+__global__ void lm_decide_kernel(LmCtl* ctl, const LmState* st, int64_t off_cost) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (ctl->done != 0) return;
+  const long long seq = ctl->seq;
+  const LmState hs = *st;
+  const double cand_cost = ctl->nep[1][off_cost];
+  const double cost = ctl->cost;
+  double radius = ctl->radius;
+  int done = LM_RUNNING;
+  bool push = true;
+  LmIterRec rec;
+  const int iter = ctl->iter + 1;
+  ctl->iter = iter;
+  const double model_cost_change = hs.model_cost_change;
+  const bool ok = hs.chol_failed == 0 && isfinite(model_cost_change) && isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
+  if (ctl->hold) {          // benchmark: the full decision arithmetic, no state change
+    const double rel = (cost - cand_cost) / model_cost_change;
+    rec = LmIterRec{iter, ok && rel > ctl->min_rel_dec ? 1 : 0, cand_cost, cost - cand_cost, hs.gradient_max_norm, sqrt(hs.step_norm_sq), rel, radius};
+    if (!ok) done = LM_DONE_INVALID_STEPS;   // (the benchmark's system must stay solvable)
+  } else if (!ok) {         // invalid step: LINEAR_SOLVER_FAILURE or a non-positive model decrease
+    const int invalid = ctl->invalid + 1;
+    ctl->invalid = invalid;
+    if (invalid >= ctl->max_invalid) { done = LM_DONE_INVALID_STEPS; rec = LmIterRec{iter, 0, cost, 0.0, ctl->gmax, 0.0, 0.0, radius}; push = false; }
+    else {
+      radius /= ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diagonal = 1; ctl->num_unsuccessful += 1;
+      rec = LmIterRec{iter, 0, cost, 0.0, ctl->gmax, 0.0, 0.0, radius};
+    }
+  } else {
+    ctl->invalid = 0;
+    const double x_norm = sqrt(hs.x_norm_sq), step_norm = sqrt(hs.step_norm_sq);
+    const double cost_change = cost - cand_cost, rel_dec = cost_change / model_cost_change;
+    if (step_norm <= ctl->ptol * (x_norm + ctl->ptol)) { done = LM_DONE_PARAMETER_TOL; rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius}; }
+    else if (fabs(cost_change) <= ctl->ftol * cost) { done = LM_DONE_FUNCTION_TOL; rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius}; }
+    else if (rel_dec > ctl->min_rel_dec) {   // IsStepSuccessful: the candidate and its normal equations become current
+      double* t = ctl->xp[0]; ctl->xp[0] = ctl->xp[1]; ctl->xp[1] = t;
+      t = ctl->nep[0]; ctl->nep[0] = ctl->nep[1]; ctl->nep[1] = t;
+      t = ctl->segp[0]; ctl->segp[0] = ctl->segp[1]; ctl->segp[1] = t;
+      ctl->cost = cand_cost; ctl->gmax = hs.gradient_max_norm; ctl->num_successful += 1;
+      const double q = 2.0 * rel_dec - 1.0;
+      radius = fmin(ctl->max_radius, radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+      ctl->decrease_factor = 2.0; ctl->reuse_diagonal = 0;
+      rec = LmIterRec{iter, 1, cand_cost, cost_change, hs.gradient_max_norm, step_norm, rel_dec, radius};
+    } else {
+      radius /= ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diagonal = 1; ctl->num_unsuccessful += 1;
+      rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius};
+    }
+  }
+  ctl->radius = radius;
+  if (push && ctl->trace != nullptr && ctl->trace_n < ctl->trace_cap) ctl->trace[ctl->trace_n++] = rec;
+  if (done == LM_RUNNING && !ctl->hold) {   // what the host loop tests before it starts the next iteration, in its order
+    if (iter >= ctl->max_iters) done = LM_DONE_MAX_ITERATIONS;
+    else if (radius <= ctl->min_radius) done = LM_DONE_MIN_RADIUS;
+    else if (rec.step_is_successful && ctl->gmax <= ctl->gtol) done = LM_DONE_GRADIENT_TOL;
+  }
+  if (ctl->stamps != nullptr && seq < ctl->trace_cap) ctl->stamps[3 * seq + 2] = wall_clock64();
+  ctl->done = done;
+  ctl->seq = seq + 1;
+  if (ctl->host != nullptr) {   // the host polls this one iteration behind
+    if (done != 0) __hip_atomic_store(&ctl->host->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&ctl->host->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream) {
+  hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(64), 0, stream, ctl, st, off_cost);
 }
 
 }  // namespace oicc

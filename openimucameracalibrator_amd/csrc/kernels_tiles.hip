@@ -564,6 +564,12 @@ __device__ OICC_TILE_BODY_ATTR double tile_body(const TileStatic* __restrict__ S
 template <bool JAC, bool DIRECT, int MAXW, bool CHAINED>
 __global__ void __launch_bounds__(64 * MAXW) tile_kernel(const TileStatic* __restrict__ S, TileDyn dyn) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (dyn.ctl != nullptr) {   // device-side LM control (oicc_device.h): the pass runs at the control block's CANDIDATE into its second buffer
+    const LmCtl* const c = dyn.ctl;
+    if (c->done != 0) return;
+    dyn.x = c->xp[1]; dyn.ne_base = c->nep[1];
+    if (dyn.seg != nullptr) dyn.seg = c->segp[1];
+  }
   const TileParams& tp = S->tp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kTileThreads = blockDim.x, kTileWaves = kTileThreads >> 6;   // (run-time: TileParams::n_waves)
@@ -613,7 +619,8 @@ __global__ void __launch_bounds__(64 * MAXW) tile_kernel(const TileStatic* __res
 // max |g| (LmState::gradient_max_norm, tp.gmax) is reduced per block first: one atomic per block, and only few blocks carry
 // gradient entries -- thousands of atomicMax on one address cost more than the whole merge (15 us at C2, round-2 profile).
 template <int kMergeU>
-__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows, int nb_gm, int nb_gd) {
+__global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq ne, TangentLayout tl, int nb_rows, int nb_gm, int nb_gd, const LmCtl* ctl) {
+  if (ctl != nullptr) { if (ctl->done != 0) return; ne.base = ctl->nep[1]; }   // device-side LM control: the candidate's buffer
   const int b = blockIdx.x;
   if (b < nb_rows) {
     // kMergeU entries per thread, a quarter of the index space apart: the three dependent loads of an entry (row tables ->
@@ -742,8 +749,8 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
       TileParams tpm = tp; tpm.gmax = dyn.gmax;
       NormalEq ne = hS.ctx.ne; ne.base = dyn.ne_base;
       const dim3 grid(nb_rows + nb_gm + nb_gd + tp.corner);
-      if (U == 4) hipLaunchKernelGGL(slab_merge_kernel<4>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
-      else hipLaunchKernelGGL(slab_merge_kernel<1>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd);
+      if (U == 4) hipLaunchKernelGGL(slab_merge_kernel<4>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd, dyn.ctl);
+      else hipLaunchKernelGGL(slab_merge_kernel<1>, grid, dim3(256), 0, st, tpm, ne, hS.ctx.tl, nb_rows, nb_gm, nb_gd, dyn.ctl);
     }
   } else {
     launch_tile_kernel<false, false, 4>(dS, dyn, tp.n_chains, std::min(nw, 4), (size_t)tp.o_acc * sizeof(double), st, chained);   // knots, tables and the queue only

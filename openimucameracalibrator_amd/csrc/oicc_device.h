@@ -97,6 +97,36 @@ struct LmState {
 };
 constexpr size_t kLmStepResultsOffset = 2 * sizeof(double);
 
+// ---- Levenberg-Marquardt control ON THE DEVICE (round 5; north star: "the LM trust-region step runs on-device") ----------
+// Plain LM (no inner iterations / line search / collective): the trust-region logic of TrustRegionMinimizer [EXT Ceres 2.1.0:
+// IsStepSuccessful, HandleSuccessfulStep / HandleUnsuccessfulStep, LevenbergMarquardtStrategy::StepAccepted / StepRejected, the
+// tolerance tests] runs in a one-thread epilogue behind the Jacobian pass at the candidate (lm_decide_kernel, kernels_solve.hip).
+// The two parameter buffers and the two normal-equation buffers are addressed THROUGH this block ([0] current, [1] candidate):
+// an accepted step swaps the entries, so the host enqueues iteration k + 1 without knowing the outcome of iteration k and only
+// polls a pinned word (LmHostMsg) one iteration behind.  Every kernel of the loop returns at once when `done` is set.
+struct LmIterRec {            // = oicc_iteration (include/oicc_hip.h), checked by a static_assert on the host side
+  int32_t iteration, step_is_successful;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+};
+struct LmHostMsg { long long seq; int done; int pad; };   // pinned host memory, written by the device (system scope)
+struct LmCtl {
+  double* xp[2];              // parameter vectors: [0] current, [1] candidate
+  double* nep[2];             // packed normal equations: [0] at the current point, [1] the Jacobian pass at the candidate fills this one
+  double* segp[2];            // segment tables of xp[0] / xp[1] (multi-round problems; else null)
+  double radius, decrease_factor, cost, gmax;
+  double ftol, ptol, gtol, min_radius, max_radius, min_rel_dec;
+  int32_t reuse_diagonal, done, iter, invalid, num_successful, num_unsuccessful, max_iters, max_invalid;
+  int32_t hold;               // benchmark mode: decide, record, but never accept / shrink / terminate (every step re-runs the same system)
+  int32_t trace_cap, trace_n, pad;
+  long long seq;              // decisions taken since the loop started
+  LmIterRec* trace;           // [trace_cap]
+  long long* stamps;          // [3 * trace_cap] wall_clock64 of every iteration: the build kernel, the retraction (= the solve is done), the decision (seconds_* of the summary)
+  LmHostMsg* host;
+};
+// LmCtl::done: 0 = running, else why the loop ended (the host turns it into oicc_termination + Ceres' message)
+enum { LM_RUNNING = 0, LM_DONE_PARAMETER_TOL = 1, LM_DONE_FUNCTION_TOL = 2, LM_DONE_GRADIENT_TOL = 3, LM_DONE_MIN_RADIUS = 4,
+       LM_DONE_MAX_ITERATIONS = 5, LM_DONE_INVALID_STEPS = 6 };
+
 struct SolveBuffers {
   double* Mb;      // [Pb][W]   damped scaled band; overwritten by the factor (diagonal slot = 1/L_ii)
   double* Mt;      // [a+1][Pb] arrow rows + rhs row (-g_s); overwritten by Y = L^-1 E
@@ -114,6 +144,8 @@ struct SolveBuffers {
   double radius;   // trust-region radius of this step (kernel argument, no host->device copy)
   int bcr_max_border = 64;      // arrow + rhs rows the block cyclic reduction accepts (per problem: option bcr_max_border)
   int bcr_delay = 0;            // debug: panel waves other than wave 0 start every panel this many ~1000-cycle sleeps late (option debug_bcr_delay)
+  const LmCtl* ctl = nullptr;   // device-side LM control (round 5): the build kernels take the current normal equations, the radius and the
+                                // reuse-diagonal flag from it, every kernel of the solve returns at once when it says done
 };
 
 }  // namespace oicc

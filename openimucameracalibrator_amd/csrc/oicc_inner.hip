@@ -296,20 +296,28 @@ int build_inner_plan(oicc_problem* p, int flags) {
 // launch per independent set (inner_iterations.hip); nothing comes back to the host.
 int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the problem whose measurements and plan are used (xv may belong to another problem with the same spline)
   oicc_problem::InnerPlan& ip = p->inner;
-  InnerArgs A{};
-  A.ctx = make_ctx(p, xv); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
-  A.xv = xv; A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.wgs = nullptr; A.ctls = ip.d_ctls.p;
+  static_assert(std::is_trivially_copyable<InnerArgs>::value, "InnerArgs is copied bytewise");
+  InnerArgs A; std::memset(&A, 0, sizeof(A));
+  A.ctx = make_ctx(p, nullptr); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
+  A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.ctls = ip.d_ctls.p;
   A.lm_iterations = ip.d_lm_iterations.p; A.max_ab = p->max_ab; A.max_gb = p->max_gb;
+  if (!ip.h_args) { ip.h_args.reset(new InnerArgs); std::memset(ip.h_args.get(), 0, sizeof(InnerArgs)); ip.args_valid = false; }
+  if (!ip.args_valid || std::memcmp(&A, ip.h_args.get(), sizeof(A)) != 0) {   // (rare: plan, layout or measurement changes)
+    if (!ip.d_args.resize(1)) { p->err = "hipMalloc inner-iteration arguments"; return OICC_ERR_HIP; }
+    *ip.h_args = A;
+    HIPCK(p, hipMemcpyAsync(ip.d_args.p, ip.h_args.get(), sizeof(InnerArgs), hipMemcpyHostToDevice, st));
+    HIPCK(p, hipStreamSynchronize(st));   // the host copy may be rewritten right away
+    ip.args_valid = true;
+  }
   ++ip.sweeps;
   launch_inner_seg(xv + p->pl.so3, std::max(p->pl.n_so3 - 1, 0), ip.d_seg.p, st);
   if (ip.n_ctls > 0) HIPCK(p, hipMemsetAsync(ip.d_ctls.p, 0, size_t(ip.n_ctls) * sizeof(InnerCtl), st));
   const int prof_set = int(p->opt["debug_inner_profile"]) - 1;   // debug: phase clocks of workgroup 0 of this set
   DevBuf<long long> d_prof;
   for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
-    A.wgs = ip.d_wgs.p + ip.group_wg0[g];
-    A.prof = nullptr;
-    if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); A.prof = d_prof.p; }
-    launch_inner_set(A, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st);
+    long long* prof = nullptr;
+    if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); prof = d_prof.p; }
+    launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st);
   }
   HIPCK(p, hipGetLastError());
   if (prof_set >= 0 && d_prof.p) {
@@ -324,3 +332,40 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the probl
 
 
 }  // namespace oicc
+
+// ---- host-only debug entry points (outside include/oicc_hip.h; tests/test_inner_plan_host.py) ---------------------------------
+// The plan of the inner iterations is pure host logic (blocks, Hessian graph as neighbour intervals, Ceres' independent-set
+// ordering, runs of items, workgroups): these two calls build it WITHOUT a device, so that the CPU test suite can check it
+// against the oracle's restatement of Ceres' ordering and against the definition of an independent set.
+extern "C" {
+int oicc_debug_create_host_only(oicc_problem** out) {   // a problem object without stream / device buffers: only the setters, add_* and the call below work on it
+  if (!out) return OICC_ERR_INVALID_ARG;
+  oicc_problem* p = new oicc_problem();
+  p->device = -1;
+  rebuild_param_layout(p, 0, 0, 0, 0);
+  *out = p; return OICC_OK;
+}
+void oicc_debug_destroy_host_only(oicc_problem* p) { if (p) { p->wait_plan(); delete p; } }
+// per block, in processing order: [set, kind, idx, n_items, n_slots, first run's kind, first run's first item, nruns]; returns the number of blocks (or -needed)
+int oicc_debug_host_inner_plan(oicc_problem* p, int32_t flags, int32_t* out8, int32_t cap_blocks, int32_t* n_sets, int32_t* n_wgs) {
+  sync_groups(p);
+  make_layout_host(p, flags);
+  InnerPlanOptions o; o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = false; o.resident_wgs = 256; o.shared_share = 0.5; o.layout_gen = 0;
+  double ms[3];
+  build_inner_plan_host(p, o, ms);
+  const oicc_problem::InnerPlan& ip = p->inner;
+  if (n_sets) *n_sets = int32_t(ip.group_first.size()) - 1;
+  if (n_wgs) *n_wgs = int32_t(ip.wgs.size());
+  const int nb = int(ip.blocks.size());
+  if (nb > cap_blocks) return -nb;
+  for (size_t g = 0; g + 1 < ip.group_first.size(); ++g)
+    for (int b = ip.group_first[g]; b < ip.group_first[g + 1]; ++b) {
+      const InnerBlock& k = ip.blocks[size_t(b)];
+      int32_t* o8 = out8 + 8 * size_t(b);
+      o8[0] = int32_t(g); o8[1] = k.kind; o8[2] = k.idx; o8[3] = k.n_items; o8[4] = k.n_slots;
+      o8[5] = k.nruns > 0 ? ip.runs[size_t(k.run0)].kind : -1; o8[6] = k.nruns > 0 ? ip.runs[size_t(k.run0)].first : -1; o8[7] = k.nruns;
+    }
+  return nb;
+}
+}  // extern "C"
+

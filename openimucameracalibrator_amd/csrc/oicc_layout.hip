@@ -271,19 +271,19 @@ int make_layout_device(oicc_problem* p, int flags) {
 
 
 int prepare(oicc_problem* p, int flags) {
+  const int plan_wanted = p->plan_wanted_flags; p->plan_wanted_flags = -2;   // (consumed on EVERY exit: an early error return must not leave the request for a later call from another entry point)
   ARG(p, p->pl.n_so3 > 0, "oicc_set_times has not been called");
   ARG(p, p->max_corner_pt < p->pl.n_pts, "a corner refers to a board point beyond those of oicc_set_scene_points");
   HIPCK(p, hipSetDevice(p->device));
   const bool timing = p->opt["verbose"] >= 2.0;
   const double t00 = now_s();
-  if (p->plan_wanted_flags != flags) p->wait_plan();   // (a plan job of an earlier call reads what this call may rebuild)
+  if (plan_wanted != flags) p->wait_plan();   // (a plan job of an earlier call reads what this call may rebuild)
   sync_groups(p);
   const bool current = p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen;   // layout, buffers and tiles are current
   if (!current) make_layout_host(p, flags);
   // The inner-iteration plan of the solve that called (oicc_optimize announces it) only needs the host layout: its host part runs
   // on a second thread under the uploads and the tiles below (build_inner_plan joins it).
-  if (p->plan_wanted_flags == flags) start_inner_plan(p, flags, current ? p->layout_gen : p->layout_gen + 1);
-  p->plan_wanted_flags = -2;
+  if (plan_wanted == flags) start_inner_plan(p, flags, current ? p->layout_gen : p->layout_gen + 1);
   const double t0 = now_s();
   int rc = sync_measurements(p); if (rc) return rc;
   const double t1 = now_s();

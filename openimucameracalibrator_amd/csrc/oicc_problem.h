@@ -40,7 +40,7 @@ int launch_tile_pass(const TileStatic& hS, const TileStatic* dS, const TileDyn& 
 void launch_lds_poison(hipStream_t st);
 void launch_point_columns(const EvalCtx& ctx, const ViewData& vd, const uint8_t* view_rs, bool spline_active, hipStream_t st);   // kernels_points.hip
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
-void launch_inner_set(const InnerArgs& A, int n_wgs, bool r3_only, hipStream_t st);
+void launch_inner_set(const InnerArgs* dA, double* xv, const InnerWg* wgs, long long* prof, int n_wgs, bool r3_only, hipStream_t st);
 int inner_set_resident_capacity(int n_cu);
 void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st);
 void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hipStream_t st);
@@ -51,6 +51,7 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st);
 void launch_lm_projected_gradient(const double* x, const ParamLayout& pl, const TangentLayout& tl, const NormalEq& ne, double max_ab, double max_gb, LmState* s, hipStream_t st);
+void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream);   // the trust-region decision on the device (kernels_solve.hip)
 }  // namespace oicc
 
 
@@ -150,6 +151,9 @@ struct oicc_problem {
   DevBuf<double> d_ne, d_Mb, d_Mt, d_Mc, d_scale, d_diag, d_D2, d_step, d_dbg_res, d_dbg_jac, d_traj;
   DevBuf<int32_t> d_traj_i;
   DevBuf<LmState> d_state; DevBuf<double> d_ls; int64_t line_search_steps = 0;   // d_ls: slope and max norm of the step (bounds line search)
+  // device-side LM control (oicc_device.h: LmCtl): the control block, the iteration records and kernel time stamps it fills, and the
+  // pinned word the decision kernel writes for the host (polled one iteration behind; no copy, no event in the loop)
+  DevBuf<LmCtl> d_ctl; DevBuf<LmIterRec> d_trace; DevBuf<long long> d_stamps; LmHostMsg* hmsg = nullptr; LmHostMsg* hmsg_dev = nullptr; double wall_clock_hz = 1e8;
   struct HostPin { LmState st; double cost; double radius; double ls[2]; };
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -164,6 +168,7 @@ struct oicc_problem {
   struct InnerPlan {
     std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0; std::vector<char> group_r3only;   // set g holds nothing but R^3 knots of at most 1024 item slots: the 8-wave build of the kernel   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
     DevBuf<InnerBlock> d_blocks; DevBuf<InnerRun> d_runs; DevBuf<InnerWg> d_wgs; DevBuf<InnerCtl> d_ctls; DevBuf<unsigned long long> d_lm_iterations; DevBuf<double> d_seg; int n_ctls = 0;
+    DevBuf<InnerArgs> d_args; std::unique_ptr<InnerArgs> h_args; bool args_valid = false;   // problem-constant kernel arguments in device memory (inner_plan.h)
     int flags = -2; int64_t layout_gen = -1; bool gs_unit = false;   // what the plan was built from: the tangent layout (make_layout generation) and the GS weighting
     size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
   } inner;
@@ -184,6 +189,8 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["device_lm"] = 1;   // 1: plain Levenberg-Marquardt (no inner iterations / line search / collective) takes its trust-region decisions on the device
+                            //    (LmCtl, lm_decide_kernel): the host enqueues iterations and polls a pinned word one iteration behind.  0: the host-driven loop
     opt["inner_shared_residency"] = 0.5;     // share of the device's resident workgroups the parts of a set's shared blocks (T_i_c, gravity, line delay, IMU intrinsics) may take together
     opt["debug_inner_general_kernel"] = 0;   // 1: sets of R^3 knots run on the general 4-wave build of the inner kernel too (tests: both builds give the same sweep)
     opt["debug_inner_profile"] = 0;   // g + 1: print the phase clocks of workgroup 0 of independent set g after every sweep
@@ -244,7 +251,7 @@ int build_inner_plan(oicc_problem* p, int flags);
 int inner_sweep(oicc_problem* p, double* xv, hipStream_t st);
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
               bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false,
-              double* cost_out = nullptr);
+              double* cost_out = nullptr, const LmCtl* ctl = nullptr);
 SolveBuffers solve_buffers(oicc_problem* p, long long* prof = nullptr);
 int read_cost(oicc_problem* p, double* cost);
 void rccl_release(oicc_problem* p);   // destroys the problem's communicator, if any

@@ -15,7 +15,8 @@ namespace oicc {
 // One residual(+Jacobian+normal equation) pass at parameter vector x (device).
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res, double* dbg_jac, int only_kind,
               bool cost_already_zero, const NormalEq* target, bool force_rs, long long* prof, bool want_gmax,
-              double* cost_out) {   // cost_out (tile assembly, cost passes): device address the cost is added to instead of the cost slot
+              double* cost_out, const LmCtl* ctl) {   // cost_out (tile assembly, cost passes): device address the cost is added to instead of the cost slot
+                                                      // ctl (device-side LM control): the pass runs at the control block's candidate into its second buffer
   p->gmax_folded = false;
   hipStream_t st = p->stream;
   const NormalEq ne = target ? *target : p->ne;   // where this pass accumulates
@@ -49,7 +50,9 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res, doubl
       }
     }
     TileDyn dyn{};
-    if (p->seg_precomputed()) {
+    dyn.ctl = ctl;
+    if (ctl != nullptr) { if (p->seg_precomputed()) dyn.seg = p->seg_tab[0].buf.p; }   // (non-null = "tables exist": the kernel takes the candidate's from the control block, the retraction wrote them)
+    else if (p->seg_precomputed()) {
       oicc_problem::SegTable* sgt = p->seg_of(x);
       if (sgt == nullptr) { p->err = "residual pass on an unknown parameter buffer"; return OICC_ERR_STATE; }
       if (!sgt->valid) { launch_inner_seg(x + p->pl.so3, int(p->pl.n_so3 - 1), sgt->buf.p, st); sgt->valid = true; }
@@ -90,6 +93,81 @@ int read_cost(oicc_problem* p, double* cost) {
 }
 
 
+// ---- device-side LM control (oicc_device.h: LmCtl; kernels: the build kernels, lm_retract_kernel, tile_kernel, slab_merge_kernel,
+// lm_decide_kernel) ---------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(LmIterRec) == sizeof(oicc_iteration) && offsetof(LmIterRec, trust_region_radius) == offsetof(oicc_iteration, trust_region_radius), "LmIterRec mirrors oicc_iteration");
+
+// Can this solve run under device-side control?  Plain LM on one rank with the tile assembly (the merge leaves max |g| in LmState).
+bool device_lm_applicable(oicc_problem* p, bool inner, bool line_search, bool projected_gmax) {
+  if (p->opt["device_lm"] == 0.0 || p->hmsg == nullptr || inner || line_search || projected_gmax || p->reduce != nullptr) return false;
+  if (p->tp.direct || p->tp.n_tiles == 0 || p->tl.a_pts != 0 || p->tl.P == 0) return false;
+  for (const char* name : {"debug_sync", "debug_check_ne", "debug_poison_lds"}) if (p->opt[name] != 0.0) return false;
+  return true;
+}
+// Upload the control block: current = d_x / ne, candidate = d_xc / ne2.
+int device_lm_begin(oicc_problem* p, LmCtl h, int trace_cap) {
+  hipStream_t st = p->stream;
+  if (!p->d_ctl.resize(1) || !p->d_trace.resize(size_t(std::max(trace_cap, 1))) || !p->d_stamps.resize(size_t(3) * std::max(trace_cap, 1))) { p->err = "hipMalloc LM control"; return OICC_ERR_HIP; }
+  h.xp[0] = p->d_x.p; h.xp[1] = p->d_xc.p; h.nep[0] = p->ne.base; h.nep[1] = p->ne2.base;
+  oicc_problem::SegTable* s0 = p->seg_of(p->d_x.p); oicc_problem::SegTable* s1 = p->seg_of(p->d_xc.p);
+  h.segp[0] = s0 ? s0->buf.p : nullptr; h.segp[1] = s1 ? s1->buf.p : nullptr;
+  h.done = 0; h.iter = 0; h.invalid = 0; h.num_successful = 0; h.num_unsuccessful = 0; h.seq = 0; h.trace_n = 0; h.trace_cap = trace_cap;
+  h.trace = p->d_trace.p; h.stamps = p->d_stamps.p; h.host = p->hmsg_dev;
+  __atomic_store_n(&p->hmsg->seq, 0ll, __ATOMIC_RELAXED); __atomic_store_n(&p->hmsg->done, 0, __ATOMIC_RELEASE);
+  HIPCK(p, hipMemcpyAsync(p->d_ctl.p, &h, sizeof(LmCtl), hipMemcpyHostToDevice, st));
+  HIPCK(p, hipStreamSynchronize(st));   // (h is a stack object; once per solve)
+  return OICC_OK;
+}
+// One iteration: damped solve -> retraction -> Jacobian pass at the candidate (its merge leaves the candidate's cost and max |g|) ->
+// the decision.  Nothing here waits for the device.
+int device_lm_enqueue(oicc_problem* p, SolveBuffers sb, double min_diag, double max_diag) {
+  hipStream_t st = p->stream;
+  sb.ctl = p->d_ctl.p;
+  if (launch_lm_solve(p->ne, p->tl, sb, 0.0, 0, min_diag, max_diag, st) != 0) {
+    p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)"; return OICC_ERR_UNSUPPORTED; }
+  launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, p->tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, p->seg_precomputed() ? p->seg_tab[0].buf.p : nullptr);
+  int rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true, nullptr, p->d_ctl.p); if (rc) return rc;
+  launch_lm_decide(p->d_ctl.p, p->d_state.p, p->ne.off_cost, st);
+  HIPCK(p, hipGetLastError());
+  return OICC_OK;
+}
+// Host side of the pinned word: wait until `want` decisions have been taken or the loop is done.  The stream is queried now and
+// then so that a device fault ends the wait instead of hanging it.
+int device_lm_wait(oicc_problem* p, long long want, int* done) {
+  unsigned spins = 0;
+  while (true) {
+    const int d = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE);
+    const long long s = __atomic_load_n(&p->hmsg->seq, __ATOMIC_ACQUIRE);
+    if (d != 0 || s >= want) { *done = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE); return OICC_OK; }
+    if ((++spins & 0xfff) == 0) {
+      const hipError_t e = hipStreamQuery(p->stream);
+      if (e == hipSuccess) {   // everything enqueued has run: the word is final
+        *done = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE);
+        if (*done != 0 || __atomic_load_n(&p->hmsg->seq, __ATOMIC_ACQUIRE) >= want) return OICC_OK;
+        p->err = "device-side LM control: the stream drained without the awaited decision"; return OICC_ERR_STATE;
+      }
+      if (e != hipErrorNotReady) { p->err = std::string("device-side LM control: ") + hipGetErrorString(e); return OICC_ERR_HIP; }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+// After the loop: the control block as the device left it; the problem's buffers take the roles it ended with.
+int device_lm_end(oicc_problem* p, LmCtl* out, std::vector<LmIterRec>* trace, std::vector<long long>* stamps) {
+  hipStream_t st = p->stream;
+  HIPCK(p, hipMemcpyAsync(out, p->d_ctl.p, sizeof(LmCtl), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipStreamSynchronize(st));
+  const int n = std::min(out->trace_n, out->trace_cap);
+  if (trace) { trace->resize(size_t(n)); if (n > 0) HIPCK(p, hipMemcpyAsync(trace->data(), p->d_trace.p, size_t(n) * sizeof(LmIterRec), hipMemcpyDeviceToHost, st)); }
+  const long long ns = std::min<long long>(out->seq, out->trace_cap);
+  if (stamps) { stamps->resize(size_t(3 * ns)); if (ns > 0) HIPCK(p, hipMemcpyAsync(stamps->data(), p->d_stamps.p, size_t(3 * ns) * sizeof(long long), hipMemcpyDeviceToHost, st)); }
+  HIPCK(p, hipStreamSynchronize(st));
+  if (out->xp[0] != p->d_x.p) { std::swap(p->d_x.p, p->d_xc.p); std::swap(p->ne.base, p->ne2.base); }   // (an odd number of accepted steps)
+  p->seg_invalidate(p->d_x.p); p->seg_invalidate(p->d_xc.p);
+  return OICC_OK;
+}
+
 }  // namespace oicc
 
 extern "C" {
@@ -110,6 +188,11 @@ int oicc_create(oicc_problem** out, int device_ordinal) {
   p->own_stream = true;
   if (hipHostMalloc(reinterpret_cast<void**>(&p->pin), sizeof(*p->pin), hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(p->stream); delete p; return OICC_ERR_HIP; }
   std::memset(p->pin, 0, sizeof(*p->pin));
+  // the word the device-side LM control writes for the host: mapped, fine-grained (coherent) host memory
+  if (hipHostMalloc(reinterpret_cast<void**>(&p->hmsg), sizeof(LmHostMsg), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hmsg_dev), p->hmsg, 0) != hipSuccess) { p->hmsg = nullptr; p->hmsg_dev = nullptr; (void)hipGetLastError(); }   // (without it the host-driven loop runs)
+  else std::memset(p->hmsg, 0, sizeof(LmHostMsg));
+  { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_ordinal) == hipSuccess && khz > 0) p->wall_clock_hz = 1e3 * double(khz); }
   for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { oicc_destroy(p); return OICC_ERR_HIP; }
   *out = p;
   return OICC_OK;
@@ -123,6 +206,7 @@ void oicc_destroy(oicc_problem* p) {
   rccl_release(p);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->pin) (void)hipHostFree(p->pin);
+  if (p->hmsg) (void)hipHostFree(p->hmsg);
   delete p;
 }
 const char* oicc_last_error(const oicc_problem* p) { return p ? p->err.c_str() : "null problem"; }
@@ -200,6 +284,7 @@ int oicc_get_scene_points(const oicc_problem* p, double* xyzw, int64_t n) {
 
 static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, const int64_t* coff, const double* uv, const double* cov,
                      const int32_t* pidx, uint8_t* accepted) {
+  p->wait_plan();   // (a plan job on the second thread reads the measurement vectors this call may reallocate)
   ARG(p, p->pl.n_so3 > 0, "set_times first");
   for (int64_t v = 0; v < nv; ++v) {
     double u_r3, u_so3; int64_t s_r3, s_so3;
@@ -229,6 +314,7 @@ int oicc_add_gs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* 
                                     const int32_t* pi, uint8_t* acc) { return add_views(p, false, nv, t, co, uv, cov, pi, acc); }
 
 int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
+  p->wait_plan();
   ARG(p, p->pl.n_ab > 0, "init_bias_splines first");
   for (int64_t i = 0; i < n; ++i) {
     double u_r3, u_so3, u_b; int64_t s_r3, s_so3, s_b;
@@ -249,6 +335,7 @@ int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_
   return OICC_OK;
 }
 int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t_ns, const double* m, double w, uint8_t* accepted) {
+  p->wait_plan();
   ARG(p, p->pl.n_gb > 0, "init_bias_splines first");
   for (int64_t i = 0; i < n; ++i) {
     double u_so3, u_b; int64_t s_so3, s_b;
@@ -456,6 +543,40 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
   }
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
+  // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide_kernel).  Per iteration the host enqueues
+  // solve -> retraction -> Jacobian pass at the candidate (cost, gradient, normal equations in one pass: no separate cost pass) ->
+  // decision, and looks at a pinned word the decision kernel wrote ONE ITERATION EARLIER: no copy, no event, no synchronisation
+  // inside the loop; the iteration enqueued past the end returns at its first instruction (LmCtl::done).
+  if (device_lm_applicable(p, inner_enabled || p->opt["inner_iterations"] != 0.0, line_search, projected_gmax)) {
+    LmCtl h; std::memset(&h, 0, sizeof(h));
+    h.radius = radius; h.decrease_factor = 2.0; h.cost = cost; h.gmax = gmax;
+    h.ftol = ftol; h.ptol = ptol; h.gtol = gtol; h.min_radius = min_radius; h.max_radius = max_radius; h.min_rel_dec = min_rel_dec;
+    h.reuse_diagonal = 0; h.max_iters = max_iters; h.max_invalid = max_invalid; h.hold = 0;
+    if (max_iters <= 0) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.");
+    if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
+    rc = device_lm_begin(p, h, max_iters); if (rc) return rc;
+    int done = 0;
+    for (int k = 0; k < max_iters && done == 0; ++k) {
+      rc = device_lm_enqueue(p, sb, min_diag, max_diag); if (rc) return rc;
+      if (k >= 1) { rc = device_lm_wait(p, k, &done); if (rc) return rc; }   // the decision of iteration k - 1
+    }
+    std::vector<LmIterRec> recs; std::vector<long long> stamps;
+    rc = device_lm_end(p, &h, &recs, &stamps); if (rc) return rc;
+    for (const LmIterRec& r : recs) { oicc_iteration it; std::memcpy(&it, &r, sizeof(it)); p->trace.push_back(it);
+      if (verbose) std::printf("[oicc] iter %d %s cost %.12e change %.3e rho %.3f |step| %.3e gmax %.3e radius %.3e (device-side control)\n", it.iteration, it.step_is_successful ? "ok " : "rej", it.cost, it.cost_change, it.relative_decrease, it.step_norm, it.gradient_max_norm, it.trust_region_radius); }
+    const double tick = 1.0 / p->wall_clock_hz;
+    for (size_t k = 0; 3 * k + 2 < stamps.size(); ++k) { S.seconds_linear_solver += tick * double(stamps[3 * k + 1] - stamps[3 * k]); S.seconds_jacobian += tick * double(stamps[3 * k + 2] - stamps[3 * k + 1]); }
+    S.num_iterations = h.iter; S.num_successful_steps = h.num_successful; S.num_unsuccessful_steps = h.num_unsuccessful;
+    cost = h.cost; radius = h.radius; gmax = h.gmax;
+    switch (h.done) {
+      case LM_DONE_PARAMETER_TOL: return finish(OICC_CONVERGENCE, "Parameter tolerance reached.");
+      case LM_DONE_FUNCTION_TOL: return finish(OICC_CONVERGENCE, "Function tolerance reached.");
+      case LM_DONE_GRADIENT_TOL: return finish(OICC_CONVERGENCE, "Gradient tolerance reached.");
+      case LM_DONE_MIN_RADIUS: return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
+      case LM_DONE_INVALID_STEPS: return finish(OICC_FAILURE, "Number of consecutive invalid steps more than max.");
+      default: return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.");
+    }
+  }
   bool gmax_pending = false;     // an accepted step's Jacobian pass is in flight; its gradient norm is not read yet
   auto settle_gmax = [&]() -> int {   // used on the exits that do not go through the per-iteration read-back
     if (!gmax_pending) return OICC_OK;
@@ -679,6 +800,25 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   rc = eval_pass(p, p->d_x.p, true, nullptr, nullptr, -1, false, nullptr, false, nullptr, true); if (rc) return rc;
   launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
   if (!p->gmax_folded) launch_lm_gradmax(p->ne, tl.P, p->d_state.p, st);
+  if (device_lm_applicable(p, p->opt["inner_iterations"] != 0.0, p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb), p->opt["projected_gradient_norm"] != 0.0 && (p->act.ab || p->act.gb))) {
+    // the loop of oicc_optimize under device-side control, in its benchmark mode: every iteration solves the system at x, retracts,
+    // runs the Jacobian pass at the candidate and takes the decision -- which is recorded but not applied (LmCtl::hold)
+    double c0 = 0.0; rc = read_cost(p, &c0); if (rc) return rc;
+    LmCtl h; std::memset(&h, 0, sizeof(h));
+    h.radius = p->opt["initial_trust_region_radius"]; h.decrease_factor = 2.0; h.cost = c0; h.gmax = 0.0;
+    h.ftol = p->opt["function_tolerance"]; h.ptol = p->opt["parameter_tolerance"]; h.gtol = p->opt["gradient_tolerance"];
+    h.min_radius = p->opt["min_trust_region_radius"]; h.max_radius = p->opt["max_trust_region_radius"]; h.min_rel_dec = p->opt["min_relative_decrease"];
+    h.max_iters = steps; h.max_invalid = int(p->opt["max_num_consecutive_invalid_steps"]); h.hold = 1;
+    rc = device_lm_begin(p, h, steps); if (rc) return rc;
+    int done = 0;
+    for (int it = 0; it < steps && done == 0; ++it) {
+      rc = device_lm_enqueue(p, sb, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"]); if (rc) return rc;
+      if (it >= 1) { rc = device_lm_wait(p, it, &done); if (rc) return rc; }
+    }
+    rc = device_lm_end(p, &h, nullptr, nullptr); if (rc) return rc;
+    if (h.done != 0 || h.seq != steps) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
+    return OICC_OK;
+  }
   for (int it = 0; it < steps; ++it) {
     if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
     {

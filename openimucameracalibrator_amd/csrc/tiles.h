@@ -108,6 +108,7 @@ struct TileDyn {
   double* ne_base; double* cost_out;   // cost_out: where a cost pass adds its cost (the normal equations' cost slot, or LmState::cand_cost)
   double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
   int32_t only_kind, pad;
+  const LmCtl* ctl;   // device-side LM control (round 5): x / seg / ne_base are LmCtl's CANDIDATE buffers, nothing runs once it says done
 };
 
 }  // namespace oicc

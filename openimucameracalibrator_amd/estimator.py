@@ -522,8 +522,8 @@ def _slerp(q0, q1, t):
 class ImuCameraCalibrator:
     """Mirror of OpenICC::core::ImuCameraCalibrator (src/core/imu_camera_calibrator.cc)."""
 
-    def __init__(self, backend=None, device=0):
-        self.trajectory_ = SplineTrajectoryEstimator(backend=backend, device=device)
+    def __init__(self, backend=None, device=0, trajectory=None):
+        self.trajectory_ = trajectory if trajectory is not None else SplineTrajectoryEstimator(backend=backend, device=device)
         self.inital_cam_line_delay_s_ = 0.0
 
     def BatchInitSpline(self, ds, shard=None, known_gravity=None, owner_computes=False):

@@ -795,6 +795,21 @@ int oicc_oracle_evaluate_blocks(oicc_problem* prob, int32_t flags, int32_t kind,
   return OICC_OK;
 }
 
+// Test hook: the ordering of the inner iterations (ceres_inner.hpp build_ordering: explicit cliques per residual block, Ceres'
+// recursive independent-set ordering, reversed) -- per block in processing order [set, kind, knot index, residual blocks that depend on it].
+// Returns the number of blocks (or -needed).
+int oicc_oracle_inner_ordering(oicc_problem* prob, int32_t flags, int32_t* out4, int32_t cap_blocks, int32_t* n_sets) {
+  const Layout L = make_layout(P_, flags); const Active a = active_set(P_, flags);
+  inner::Ordering ord; inner::build_ordering(P_, L, a, &ord);
+  if (n_sets) *n_sets = int32_t(ord.groups.size());
+  if (int(ord.blocks.size()) > cap_blocks) return -int(ord.blocks.size());
+  int k = 0;
+  for (size_t g = 0; g < ord.groups.size(); ++g)
+    for (int b : ord.groups[g]) { const inner::PBlock& q = ord.blocks[size_t(b)]; int32_t* o = out4 + 4 * size_t(k++);
+      o[0] = int32_t(g); o[1] = q.kind; o[2] = q.idx; o[3] = int32_t(q.views.size() + q.accs.size() + q.gyrs.size()); }
+  return k;
+}
+
 // Optimize, impl.h:255-276 -> ceres::Solve [EXT Ceres 2.1.0 TrustRegionMinimizer
 // + LevenbergMarquardtStrategy, restated; options impl.h:257-266].
 int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, oicc_summary* sum) {

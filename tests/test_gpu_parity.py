@@ -1005,3 +1005,39 @@ def test_reference_solver_options_on_small_problems_of_varied_geometry(k, flags)
     for a, b in zip(ig, ic):
         assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * max(b["cost"], 1e-300), (a, b)
     assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg,radius,iters", [("tiny", 1e4, 50), ("C2", 1e4, 50), ("C3", 1e9, 50), ("C2", 1e4, 2), ("tiny", 1e-30, 50)])
+def test_device_side_lm_control_takes_the_steps_of_the_host_loop(cfg, radius, iters):
+    """Round 5: plain LM takes its trust-region decisions on the device (LmCtl / lm_decide_kernel; option device_lm, default on) and
+    evaluates a candidate with ONE Jacobian pass (cost + gradient + normal equations) instead of a cost pass followed by a Jacobian
+    pass.  Same accept / reject sequence, termination, iteration records and final parameters as the host-driven loop (the
+    candidate's cost is summed in another order: 1e-12), stage 1 and stage 2, with rejected steps (C3 from a radius of 1e9), an
+    iteration limit inside the run, and a start radius below the minimum radius."""
+    ds = synthetic.make_config(cfg)
+    runs = []
+    for dev in (1, 0):
+        tr = E.ImuCameraCalibrator().BatchInitSpline(ds).trajectory_
+        tr.SetOption("device_lm", dev); tr.SetOption("initial_trust_region_radius", radius)
+        s1 = tr.Optimize(iters, FLAGS1); it1 = tr.GetIterations()
+        s2 = tr.Optimize(10, E.CAM_LINE_DELAY); it2 = tr.GetIterations()
+        runs.append((s1, it1, s2, it2, tr.GetT_i_c(), tr.GetKnots(), tr.GetRSLineDelay(), tr.GetGravity()))
+    d, h = runs
+    for k in (0, 2):
+        for key in ("termination", "num_iterations", "num_successful_steps", "num_unsuccessful_steps", "message"):
+            assert d[k][key] == h[k][key], (k, key, d[k], h[k])
+        assert abs(d[k]["final_cost"] - h[k]["final_cost"]) <= 1e-11 * h[k]["final_cost"]
+        assert abs(d[k]["final_radius"] - h[k]["final_radius"]) <= 1e-6 * h[k]["final_radius"]
+    for k in (1, 3):
+        assert len(d[k]) == len(h[k])
+        for a, b in zip(d[k], h[k]):
+            assert a["iteration"] == b["iteration"] and a["step_is_successful"] == b["step_is_successful"], (a, b)
+            assert abs(a["cost"] - b["cost"]) <= 1e-11 * b["cost"], (a, b)
+            assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(b["step_norm"], 1e-12), (a, b)
+            assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-7 * max(b["gradient_max_norm"], 1e-9), (a, b)
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"], (a, b)
+    assert np.abs(d[4] - h[4]).max() < 1e-9 and np.abs(d[7] - h[7]).max() < 1e-8
+    assert np.abs(d[5][0] - h[5][0]).max() < 1e-9 and np.abs(d[5][1] - h[5][1]).max() < 1e-9
+    assert abs(d[6] - h[6]) < 1e-12
+    if cfg == "C3":
+        assert d[0]["num_unsuccessful_steps"] >= 1

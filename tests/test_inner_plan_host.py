@@ -1,0 +1,102 @@
+"""The plan of the inner iterations (Ceres' use_inner_iterations, reference impl.h:266) is host logic of the product library:
+parameter blocks in the reference's creation order, the Hessian graph, Ceres' recursive independent-set ordering, the items of
+every block.  The library builds it from INTERVALS of neighbouring knots (no cliques, no adjacency lists: O(knots)); the oracle
+restates Ceres literally (a clique per residual block, sorted adjacency lists).  These tests build the library's plan WITHOUT a
+device (oicc_debug_create_host_only / oicc_debug_host_inner_plan, debug exports outside include/oicc_hip.h) and compare:
+same blocks, same sets, same order inside the sets -- and check the definition: no residual block depends on two blocks of a set.
+CPU only; the sweeps themselves are compared on the GPU (tests/test_gpu_parity.py::test_inner_iterations_match_the_oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_backend
+from openimucameracalibrator_amd import _abi, _lib, synthetic, estimator as E
+
+FLAGS1 = E.SPLINE | E.T_I_C | E.GRAVITY_DIR
+
+
+class _HostOnly(E.SplineTrajectoryEstimator):
+    """The mirror on a problem object that has no device behind it: only set-up and Add* calls are valid."""
+
+    def __init__(self):
+        b = _lib.load()
+        raw = b.lib
+        raw.oicc_debug_create_host_only.restype = C.c_int
+        raw.oicc_debug_create_host_only.argtypes = [C.POINTER(_abi.H)]
+        raw.oicc_debug_destroy_host_only.restype = None
+        raw.oicc_debug_destroy_host_only.argtypes = [_abi.H]
+        raw.oicc_debug_host_inner_plan.restype = C.c_int
+        raw.oicc_debug_host_inner_plan.argtypes = [_abi.H, C.c_int32, _abi.c_i32p, C.c_int32, _abi.c_i32p, _abi.c_i32p]
+        self._b = b
+        self._raw = raw
+        h = _abi.H()
+        assert raw.oicc_debug_create_host_only(C.byref(h)) == 0
+        self._h = h
+        self._views = []; self._points = None
+        self._T_i_c = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64)
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._raw.oicc_debug_destroy_host_only(self._h); self._h = None
+
+    def plan(self, flags):
+        cap = 1 << 17
+        out = np.zeros((cap, 8), dtype=np.int32); ns = C.c_int32(0); nw = C.c_int32(0)
+        n = self._raw.oicc_debug_host_inner_plan(self._h, int(flags), out.ctypes.data_as(_abi.c_i32p), cap, C.byref(ns), C.byref(nw))
+        assert n >= 0, n
+        return out[:n].copy(), ns.value, nw.value
+
+
+def _oracle_ordering(cal, flags):
+    raw = oracle_backend.load().raw
+    raw.oicc_oracle_inner_ordering.restype = C.c_int
+    raw.oicc_oracle_inner_ordering.argtypes = [_abi.H, C.c_int32, _abi.c_i32p, C.c_int32, _abi.c_i32p]
+    cap = 1 << 17
+    out = np.zeros((cap, 4), dtype=np.int32); ns = C.c_int32(0)
+    n = raw.oicc_oracle_inner_ordering(cal.trajectory_._h, int(flags), out.ctypes.data_as(_abi.c_i32p), cap, C.byref(ns))
+    assert n >= 0, n
+    return out[:n].copy(), ns.value
+
+
+def _pair(cfg, **kw):
+    ds = synthetic.make_config(cfg, **kw)
+    host = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    return ds, host, cpu
+
+
+@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES | E.CAM_LINE_DELAY | E.IMU_INTRINSICS), ("C1", FLAGS1 | E.CAM_LINE_DELAY),
+                                       ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES), ("C3", FLAGS1)])
+def test_library_plan_equals_the_oracles_ordering(cfg, flags):
+    ds, host, cpu = _pair(cfg)
+    blocks, n_sets, n_wgs = host.trajectory_.plan(flags)
+    ord_, n_sets_o = _oracle_ordering(cpu, flags)
+    assert n_sets == n_sets_o and len(blocks) == len(ord_)
+    assert np.array_equal(blocks[:, :3], ord_[:, :3])          # set, kind, knot index -- block by block, in processing order
+    assert n_wgs >= len(blocks)
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "C2"])
+def test_sets_are_independent(cfg):
+    """Definition check from the measurements themselves (CalcTimes arithmetic, impl.h:764-788): inside a set no two knots of one
+    spline share a window, and no view touches an SO(3) knot and an R^3 knot of the same set."""
+    ds, host, _ = _pair(cfg)
+    blocks, n_sets, _ = host.trajectory_.plan(FLAGS1)
+    S = 10 ** 9
+    start_ns = int(float(ds.view_t_s.min()) * S)
+    dts, dtr = int(ds.dt_so3 * S), int(ds.dt_r3 * S)
+    t_ns = (np.asarray(ds.view_t_s) * S).astype(np.int64)
+    s_so3 = (t_ns - start_ns) // dts; s_r3 = (t_ns - start_ns) // dtr
+    seen = set()
+    for g in range(n_sets):
+        blk = blocks[blocks[:, 0] == g]
+        so3 = np.sort(blk[blk[:, 1] == 0][:, 2]); r3 = np.sort(blk[blk[:, 1] == 1][:, 2])
+        assert np.all(np.diff(so3) >= 6) and np.all(np.diff(r3) >= 6), (g, so3, r3)
+        for v in range(len(t_ns)):
+            hit = np.sum((so3 >= s_so3[v]) & (so3 < s_so3[v] + 6)) + np.sum((r3 >= s_r3[v]) & (r3 < s_r3[v] + 6))
+            assert hit <= 1, (g, v)
+        for b in blk:
+            key = (int(b[1]), int(b[2])); assert key not in seen; seen.add(key)
+    assert len(seen) == len(blocks)
