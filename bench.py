@@ -6,8 +6,11 @@ metric : residual+Jacobian blocks/sec (whole job), with ms_per_step = wall-clock
 step   : the device work and host synchronisation of ONE successful Levenberg-
          Marquardt iteration over all residual blocks (one block per view, per
          accelerometer sample, per gyroscope sample): residual + analytic Jacobian
-         + J^T J / J^T r assembly, [RCCL all-reduce when N > 1], damped band+arrow
-         Cholesky solve, retraction, candidate cost pass, state read-back
+         + J^T J / J^T r assembly (at the candidate: cost, gradient and normal equations in
+         one pass), [exchange / all-reduce when N > 1], damped band+arrow solve (block
+         cyclic reduction), retraction, trust-region decision.  N = 1: the decision runs
+         on the device (LmCtl), the host polls a pinned word one iteration behind; N > 1:
+         host-driven with a separate candidate cost pass and one read-back
          (liboicc_hip: oicc_run_lm_iterations == loop body of oicc_optimize).
 N = 1  : BASELINE config[1] = C2 (GoPro9 Division-Undistortion 960x540, 200 views x
          40 corners, 4000 IMU samples, dt_r3/so3 = 0.1/0.05 s), synthetic, seeded.
@@ -19,6 +22,7 @@ N > 1  : BASELINE config[4] = C5 (10 000 views x 50 corners + 200 000 IMU sample
 Launch:  python bench.py                      (N=1)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
                 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+         python bench.py --gpus N             (spawns the line above itself)
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -64,6 +68,20 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the C5-size single-GPU Jacobian-pass measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher the driver would have used -- one process per GPU through
+        # torch.distributed.run on 127.0.0.1 (a free port), stdout (rank 0's JSON line) passed through
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        os.write(_REAL_STDOUT, r.stdout)
+        raise SystemExit(r.returncode)
+
     import torch
     import torch.distributed as dist
     from openimucameracalibrator_amd import synthetic, estimator as E
@@ -72,8 +90,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -215,6 +232,24 @@ def main():
                 sys.stderr.write("rank %d: exchange timing failed (%s)\n" % (rank, e))
         barrier()
 
+    # N > 1: the SAME workload on ONE GPU, measured in the same run -- rank 0 builds the whole (unsharded) C5 problem and times the
+    # same steps alone while the other ranks wait at the barrier below: the N = 1 point of this curve (the default N = 1 line is
+    # C2, another workload, and must not be compared with the N > 1 lines)
+    n1_same = None
+    if world > 1 and rank == 0:
+        try:
+            c1 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds)
+            c1.trajectory_.RunLmIterations(flags, max(args.warmup, 1))
+            torch.cuda.synchronize(); t1 = time.perf_counter(); c1.trajectory_.RunLmIterations(flags, args.steps); torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            n1_same = dict(n_gpus=1, ms_per_step=1e3 * d1 / args.steps, value=c1.num_blocks * args.steps / d1, unit="blocks/s", blocks=c1.num_blocks,
+                           speedup_of_this_run=(d1 / args.steps) / (dt / args.steps),
+                           note="the whole C5 problem on rank 0's GPU alone, same steps, timed after the sharded run while the other ranks wait")
+            del c1
+        except Exception as e:
+            n1_same = {"error": str(e)[:200]}
+    barrier()
+
     out = None
     if rank == 0:
         # ---- per-kernel HIP-event timings (library stream) and roofline ----------
@@ -306,14 +341,21 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seed 20241115)",
             "config": {"workload": ("C2 GoPro9 Division-Undistortion 960x540, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s" if world == 1 else
-                                    "C5 synthetic, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s, " + "%d time shards (strong scaling), all-reduce of JtJ/Jtr" % world)
+                                    "C5 synthetic, %d views, %d corners, %d IMU blocks, dt_r3/so3=0.1/0.05 s, " + "%d time shards (strong scaling), %s" % (
+                                        world, "owner-computes exchange of JtJ/Jtr (halo rows + gather per owner + corner all-reduce)" if assembly_path == "owner-computes exchange" else "all-reduce of JtJ/Jtr"))
                                    % (ds.num_views, n_corners, n_blocks - ds.num_views),
                        "blocks": n_blocks, "corners": n_corners, "tangent_dim": P, "flags": "SPLINE|T_I_C|GRAVITY_DIR", "allreduce": reduce_path, "assembly": assembly_path,
-                       "step": "one LM iteration: Jacobian+assembly, block-cyclic-reduction solve, retraction, cost pass, one host read-back"},
+                       "step": ("one LM iteration under device-side control (LmCtl): block-cyclic-reduction solve, retraction, ONE Jacobian+assembly pass at the candidate "
+                                "(its corner holds the candidate's cost, its merge the gradient norm), trust-region decision on the device; the host enqueues and polls a pinned word one iteration behind"
+                                if world == 1 and os.environ.get("OICC_BENCH_OPTS", "").find("device_lm=0") < 0 else
+                                "one LM iteration, host-driven: Jacobian+assembly, [reduction], block-cyclic-reduction solve, retraction, [broadcast], cost pass, one host read-back")},
             "corners_per_s": n_corners * args.steps / dt,
             "jacobian_pass_ms": pass_ms,
             "roofline": roofline,
         }
+        if n1_same is not None:
+            out["n1_same_workload"] = n1_same
+            out["scaling_note"] = "no multi-GPU node was available while this was built: the N > 1 path has run on hardware only through the driver; the curve is unmeasured until SCALE_rNN.json exists"
         if use_dist:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
             out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
                                    allreduce_ms=allreduce_ms, allreduce_bytes=allreduce_bytes, allreduce_timing="HIP events around 10 all-reduces of the packed normal equations on the library's stream (%s)" % reduce_path,
@@ -402,9 +444,19 @@ def main():
                 c5r = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
                 c5r.trajectory_.UseReferenceSolverOptions()
                 s5r = c5r.trajectory_.Optimize(3, flags)
+                c5p = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                s5p = c5p.trajectory_.Optimize(1, flags)                     # plain LM: set-up without the inner-iteration plan
+                # the FULL C5 calibration with the reference's solver options (stage 1 + stage 2, as full_calibration above)
+                c5f = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                c5f.trajectory_.UseReferenceSolverOptions()
+                t1 = time.perf_counter()
+                f1 = c5f.trajectory_.Optimize(50, flags); rp5 = c5f.trajectory_.GetMeanReprojectionError(); f2 = c5f.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
+                full5 = dict(seconds=time.perf_counter() - t1, stage1_iterations=f1["num_iterations"], stage2_iterations=f2["num_iterations"], inner_sweeps=f1["inner_sweeps"] + f2["inner_sweeps"],
+                             seconds_inner=f1["seconds_inner"] + f2["seconds_inner"], seconds_setup=f1["seconds_setup"] + f2["seconds_setup"], final_cost=f1["final_cost"], final_reproj_error_px=rp5)
                 out["extra_c5_single_gpu"] = dict(blocks=c5.num_blocks, corners=c5.num_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false, 4, true> (chains of 8 tiles) + slab_merge_kernel",
                                                   lm_step_ms=lm5, inner_sweep_ms=1e3 * s5r["seconds_inner"] / max(s5r["inner_sweeps"], 1), inner_sweeps_timed=s5r["inner_sweeps"],
-                                                  setup_ms_reference_options=1e3 * s5r["seconds_setup"],
+                                                  setup_ms_reference_options=1e3 * s5r["seconds_setup"], setup_ms_plain_lm=1e3 * s5p["seconds_setup"],
+                                                  full_calibration_reference_options=full5,
                                                   fp64_frac_of_78p6=(6.9e3 * c5.num_corners + 11.3e3 * int(c5.accl_accepted.sum())) / (p5 * 1e-3) / 78.6e12,
                                                   kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
                                                   blocks_per_s_jacobian_pass=c5.num_blocks / (p5 * 1e-3),

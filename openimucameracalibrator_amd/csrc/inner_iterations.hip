@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const In
     ++round;
     if (cmd == INNER_CMD_DONE) break;
   }
-  if (master && tid == 0 && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
+  if (master && tid == 0 && A.lm_iterations != nullptr && wg.pad == 0) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);   // (pad = 1: a replicated block on a rank other than 0 of an owner-computes sweep, counted there)
   if (prof) prof_buf[0] = nprof;
 #undef INNER_MARK
 }

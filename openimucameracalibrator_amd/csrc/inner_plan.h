@@ -27,7 +27,7 @@ struct InnerBlock {
 };
 
 // one workgroup of a set's launch: part `part` of `nparts` of block `block`
-struct InnerWg { int32_t block, part, nparts, pad; };
+struct InnerWg { int32_t block, part, nparts, pad; };   // pad = 1: the block's LM iterations are not added to the sweep's counter (oicc_inner.hip: build_rank_part)
 
 // device-resident rendezvous of the workgroups that share one block (all-singleton sets: T_i_c, gravity, line delay, IMU
 // intrinsics, whose items are all views / all samples): partial sums by fp64 atomics, an arrival counter, and the master's

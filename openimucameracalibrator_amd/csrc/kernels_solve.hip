@@ -408,6 +408,36 @@ __global__ void ne_add_rows_kernel(NormalEq ne, TangentLayout tl, const int32_t*
     *dst += buf[i];     // (each entry belongs to one thread: the rows of a message are distinct)
   }
 }
+// The gather of the owned ranges (round 5): rank k's range [cut[k], cut[k + 1]) travels as ONE contiguous message of packed rows
+// (slot k of the gather buffer, `piece` doubles apart) instead of a + 2 strided pieces.
+__global__ void ne_pack_range_kernel(NormalEq ne, TangentLayout tl, int row0, int n_rows, double* buf) {
+  const int L = tl.W + tl.a + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_rows * L; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = int(i / L), e = int(i - (int64_t)k * L); const int64_t r = row0 + k;
+    buf[i] = e < tl.W ? ne.band()[r * tl.W + e] : (e < tl.W + tl.a ? ne.Et()[(int64_t)(e - tl.W) * tl.Pb + r] : ne.g()[r]);
+  }
+}
+__global__ void ne_unpack_ranges_kernel(NormalEq ne, TangentLayout tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf) {
+  const int L = tl.W + tl.a + 1;
+  const int64_t total = (int64_t)tl.Pb * L;                  // one entry per (band row, packed column); the rows of rank `me` are skipped
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / L; const int e = int(i - r * L);
+    int k = 0; while (k + 1 < n && r >= cut[k + 1]) ++k;     // (n <= a few dozen ranks; cut is ascending)
+    if (k == me) continue;
+    const double v = buf[(int64_t)k * piece + (r - cut[k]) * L + e];
+    if (e < tl.W) ne.band()[r * tl.W + e] = v; else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + r] = v; else ne.g()[r] = v;
+  }
+}
+void launch_ne_pack_range(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st) {
+  if (n_rows <= 0) return;
+  const int64_t work = (int64_t)n_rows * (tl.W + tl.a + 1);
+  hipLaunchKernelGGL(ne_pack_range_kernel, dim3(int(std::min<int64_t>(2048, (work + 255) / 256))), dim3(256), 0, st, ne, tl, row0, n_rows, buf);
+}
+void launch_ne_unpack_ranges(const NormalEq& ne, const TangentLayout& tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf, hipStream_t st) {
+  const int64_t work = (int64_t)tl.Pb * (tl.W + tl.a + 1);
+  if (work <= 0) return;
+  hipLaunchKernelGGL(ne_unpack_ranges_kernel, dim3(int(std::min<int64_t>(4096, (work + 255) / 256))), dim3(256), 0, st, ne, tl, cut, n, me, piece, buf);
+}
 void launch_ne_pack_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, double* buf, hipStream_t st) {
   if (n_rows <= 0) return;
   const int64_t work = (int64_t)n_rows * (tl.W + tl.a + 1);
@@ -462,64 +492,67 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
 // else StepRejected; then the tests Ceres makes before the next iteration (iterations, gradient tolerance, radius).
 __global__ void lm_decide_kernel(LmCtl* ctl, const LmState* st, int64_t off_cost) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (ctl->done != 0) return;
-  const long long seq = ctl->seq;
+  // ONE wide load of the control block and of the step's scalars (field-by-field reads behind the stores below would each wait for
+  // their own round trip: 4.8 us for this kernel in the first round-5 profile), the decision on the copies, one store back
+  LmCtl c = *ctl;
   const LmState hs = *st;
-  const double cand_cost = ctl->nep[1][off_cost];
-  const double cost = ctl->cost;
-  double radius = ctl->radius;
+  if (c.done != 0) return;
+  const long long seq = c.seq;
+  const double cand_cost = c.nep[1][off_cost];
+  const double cost = c.cost;
+  double radius = c.radius;
   int done = LM_RUNNING;
   bool push = true;
   LmIterRec rec;
-  const int iter = ctl->iter + 1;
-  ctl->iter = iter;
+  const int iter = c.iter + 1;
+  c.iter = iter;
   const double model_cost_change = hs.model_cost_change;
   const bool ok = hs.chol_failed == 0 && isfinite(model_cost_change) && isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
-  if (ctl->hold) {          // benchmark: the full decision arithmetic, no state change
+  if (c.hold) {          // benchmark: the full decision arithmetic, no state change
     const double rel = (cost - cand_cost) / model_cost_change;
-    rec = LmIterRec{iter, ok && rel > ctl->min_rel_dec ? 1 : 0, cand_cost, cost - cand_cost, hs.gradient_max_norm, sqrt(hs.step_norm_sq), rel, radius};
+    rec = LmIterRec{iter, ok && rel > c.min_rel_dec ? 1 : 0, cand_cost, cost - cand_cost, hs.gradient_max_norm, sqrt(hs.step_norm_sq), rel, radius};
     if (!ok) done = LM_DONE_INVALID_STEPS;   // (the benchmark's system must stay solvable)
   } else if (!ok) {         // invalid step: LINEAR_SOLVER_FAILURE or a non-positive model decrease
-    const int invalid = ctl->invalid + 1;
-    ctl->invalid = invalid;
-    if (invalid >= ctl->max_invalid) { done = LM_DONE_INVALID_STEPS; rec = LmIterRec{iter, 0, cost, 0.0, ctl->gmax, 0.0, 0.0, radius}; push = false; }
+    c.invalid += 1;
+    if (c.invalid >= c.max_invalid) { done = LM_DONE_INVALID_STEPS; rec = LmIterRec{iter, 0, cost, 0.0, c.gmax, 0.0, 0.0, radius}; push = false; }
     else {
-      radius /= ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diagonal = 1; ctl->num_unsuccessful += 1;
-      rec = LmIterRec{iter, 0, cost, 0.0, ctl->gmax, 0.0, 0.0, radius};
+      radius /= c.decrease_factor; c.decrease_factor *= 2.0; c.reuse_diagonal = 1; c.num_unsuccessful += 1;
+      rec = LmIterRec{iter, 0, cost, 0.0, c.gmax, 0.0, 0.0, radius};
     }
   } else {
-    ctl->invalid = 0;
+    c.invalid = 0;
     const double x_norm = sqrt(hs.x_norm_sq), step_norm = sqrt(hs.step_norm_sq);
     const double cost_change = cost - cand_cost, rel_dec = cost_change / model_cost_change;
-    if (step_norm <= ctl->ptol * (x_norm + ctl->ptol)) { done = LM_DONE_PARAMETER_TOL; rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius}; }
-    else if (fabs(cost_change) <= ctl->ftol * cost) { done = LM_DONE_FUNCTION_TOL; rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius}; }
-    else if (rel_dec > ctl->min_rel_dec) {   // IsStepSuccessful: the candidate and its normal equations become current
-      double* t = ctl->xp[0]; ctl->xp[0] = ctl->xp[1]; ctl->xp[1] = t;
-      t = ctl->nep[0]; ctl->nep[0] = ctl->nep[1]; ctl->nep[1] = t;
-      t = ctl->segp[0]; ctl->segp[0] = ctl->segp[1]; ctl->segp[1] = t;
-      ctl->cost = cand_cost; ctl->gmax = hs.gradient_max_norm; ctl->num_successful += 1;
+    if (step_norm <= c.ptol * (x_norm + c.ptol)) { done = LM_DONE_PARAMETER_TOL; rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius}; }
+    else if (fabs(cost_change) <= c.ftol * cost) { done = LM_DONE_FUNCTION_TOL; rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius}; }
+    else if (rel_dec > c.min_rel_dec) {   // IsStepSuccessful: the candidate and its normal equations become current
+      double* t = c.xp[0]; c.xp[0] = c.xp[1]; c.xp[1] = t;
+      t = c.nep[0]; c.nep[0] = c.nep[1]; c.nep[1] = t;
+      t = c.segp[0]; c.segp[0] = c.segp[1]; c.segp[1] = t;
+      c.cost = cand_cost; c.gmax = hs.gradient_max_norm; c.num_successful += 1;
       const double q = 2.0 * rel_dec - 1.0;
-      radius = fmin(ctl->max_radius, radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
-      ctl->decrease_factor = 2.0; ctl->reuse_diagonal = 0;
+      radius = fmin(c.max_radius, radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+      c.decrease_factor = 2.0; c.reuse_diagonal = 0;
       rec = LmIterRec{iter, 1, cand_cost, cost_change, hs.gradient_max_norm, step_norm, rel_dec, radius};
     } else {
-      radius /= ctl->decrease_factor; ctl->decrease_factor *= 2.0; ctl->reuse_diagonal = 1; ctl->num_unsuccessful += 1;
-      rec = LmIterRec{iter, 0, cost, cost_change, ctl->gmax, step_norm, rel_dec, radius};
+      radius /= c.decrease_factor; c.decrease_factor *= 2.0; c.reuse_diagonal = 1; c.num_unsuccessful += 1;
+      rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius};
     }
   }
-  ctl->radius = radius;
-  if (push && ctl->trace != nullptr && ctl->trace_n < ctl->trace_cap) ctl->trace[ctl->trace_n++] = rec;
-  if (done == LM_RUNNING && !ctl->hold) {   // what the host loop tests before it starts the next iteration, in its order
-    if (iter >= ctl->max_iters) done = LM_DONE_MAX_ITERATIONS;
-    else if (radius <= ctl->min_radius) done = LM_DONE_MIN_RADIUS;
-    else if (rec.step_is_successful && ctl->gmax <= ctl->gtol) done = LM_DONE_GRADIENT_TOL;
+  c.radius = radius;
+  if (push && c.trace != nullptr && c.trace_n < c.trace_cap) c.trace[c.trace_n++] = rec;
+  if (done == LM_RUNNING && !c.hold) {   // what the host loop tests before it starts the next iteration, in its order
+    if (iter >= c.max_iters) done = LM_DONE_MAX_ITERATIONS;
+    else if (radius <= c.min_radius) done = LM_DONE_MIN_RADIUS;
+    else if (rec.step_is_successful && c.gmax <= c.gtol) done = LM_DONE_GRADIENT_TOL;
   }
-  if (ctl->stamps != nullptr && seq < ctl->trace_cap) ctl->stamps[3 * seq + 2] = wall_clock64();
-  ctl->done = done;
-  ctl->seq = seq + 1;
-  if (ctl->host != nullptr) {   // the host polls this one iteration behind
-    if (done != 0) __hip_atomic_store(&ctl->host->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&ctl->host->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (c.stamps != nullptr && seq < c.trace_cap) c.stamps[3 * seq + 2] = wall_clock64();
+  c.done = done;
+  c.seq = seq + 1;
+  *ctl = c;
+  if (c.host != nullptr) {   // the host polls this one iteration behind
+    if (done != 0) __hip_atomic_store(&c.host->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&c.host->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream) {

@@ -16,6 +16,7 @@ struct RcclApi {
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;   // optional (the gather falls back to one broadcast per owner)
   bool ok = false, p2p = false;
 };
 RcclApi& rccl_api() {
@@ -34,6 +35,7 @@ RcclApi& rccl_api() {
     api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
     api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend")); api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
     api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart")); api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy && api.Broadcast;
     api.p2p = api.ok && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
   }
@@ -68,10 +70,49 @@ int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream
   return OICC_OK;
 }
 // ---- owner-computes exchange of the packed normal equations (include/oicc_hip.h: oicc_set_shard) ----
-bool owner_exchange_ready(const oicc_problem* p) {
+bool owner_exchange_ready(const oicc_problem* p) {   // this rank alone: can it run the exchange?
   if (!p->owner.valid || p->shard_n <= 1 || p->reduce == nullptr) return false;
   if (p->rccl_comm != nullptr) return rccl_api().p2p && p->rccl_nranks == p->shard_n;
   return p->exchange != nullptr;
+}
+// ... and all ranks together (round 5, the advisor's finding: a rank that chose the whole-buffer all-reduce while its peers entered
+// send / receive would hang them).  Once per layout every rank of a sharded problem (oicc_set_shard with nranks > 1 is a
+// collective statement) sums [ready, 1, h, h^2] through the installed reduction, h = a hash of the cuts and of every pair's row
+// count as THIS rank derived them: the exchange is used only if every rank is ready and all hashes are equal (n sum h^2 == (sum h)^2,
+// exact in doubles for 20-bit hashes); otherwise every rank falls back to the all-reduce of the whole packed buffer.
+int owner_exchange_agree(oicc_problem* p, hipStream_t st, bool* use) {
+  *use = false;
+  if (p->shard_n <= 1 || p->reduce == nullptr) return OICC_OK;
+  oicc_problem::OwnerPlan& op = p->owner;
+  if (op.agreed_gen == p->layout_gen) { *use = op.agreed; return OICC_OK; }
+  const double h = double(op.valid ? (op.hash & 0xfffffu) : 0u);
+  double v[4] = {owner_exchange_ready(p) ? 1.0 : 0.0, 1.0, h, h * h};
+  if (!p->d_xagree.resize(4)) { p->err = "hipMalloc exchange agreement"; return OICC_ERR_HIP; }
+  HIPCK(p, hipMemcpyAsync(p->d_xagree.p, v, sizeof(v), hipMemcpyHostToDevice, st));
+  if (p->reduce(p->reduce_user, p->d_xagree.p, 4, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+  HIPCK(p, hipMemcpyAsync(v, p->d_xagree.p, sizeof(v), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipStreamSynchronize(st));
+  op.agreed = v[0] == v[1] && v[1] == double(p->shard_n) && v[1] * v[3] == v[2] * v[2];
+  op.agreed_gen = p->layout_gen;
+  if (!op.agreed && p->opt["verbose"] != 0.0) std::printf("[oicc] rank %d: owner-computes exchange not agreed on by all ranks (ready %g of %g, shard size %d): all-reduce of the packed buffer\n", p->shard_rank, v[0], v[1], p->shard_n);
+  *use = op.agreed;
+  return OICC_OK;
+}
+// Broadcasts of pieces of the parameter vector between the sets of an owner-computes sweep (oicc_inner.hip): the transport of the exchange
+int shard_broadcast_begin(oicc_problem* p) {
+  if (p->rccl_comm != nullptr && rccl_api().GroupStart() != ncclSuccess) { p->err = "ncclGroupStart failed"; return OICC_ERR_STATE; }
+  return OICC_OK;
+}
+int shard_broadcast(oicc_problem* p, double* ptr, int64_t count, int root, hipStream_t st) {
+  if (count <= 0) return OICC_OK;
+  const bool ok = p->rccl_comm != nullptr ? rccl_api().Broadcast(ptr, ptr, size_t(count), ncclDouble, root, static_cast<ncclComm_t>(p->rccl_comm), st) == ncclSuccess
+                                          : (p->exchange != nullptr && p->exchange(p->exchange_user, OICC_XCHG_BROADCAST, ptr, count, ptr, count, root, st) == 0);
+  if (!ok) { p->err = "broadcast of a piece of the parameter vector failed"; return OICC_ERR_STATE; }
+  return OICC_OK;
+}
+int shard_broadcast_end(oicc_problem* p) {
+  if (p->rccl_comm != nullptr && rccl_api().GroupEnd() != ncclSuccess) { p->err = "ncclGroupEnd failed"; return OICC_ERR_STATE; }
+  return OICC_OK;
 }
 int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved) {
   const oicc_problem::OwnerPlan& op = p->owner;
@@ -82,42 +123,57 @@ int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t*
   RcclApi& api = rccl_api();
   int64_t moved = 0;
   // (1) halo: partial rows of ranges this rank does not own go to their owners; what the others hold of this rank's range comes in
-  //     and is added.  Peers in ascending rank order on every rank, the lower rank of a pair sends first: no cyclic wait with a
-  //     blocking transport.
+  //     and is added.  ONE pack launch for all peers; native transport: every send and receive in ONE group (both neighbours at once:
+  //     round 4 ran one group per peer in rank order, a chain of N - 1 hand-overs).  Blocking hook transport: peers in ascending rank
+  //     order on every rank, the lower rank of a pair sends first -- no cyclic wait.
+  const int n_send = op.send_off[n], recv0 = op.recv_off[0];
+  launch_ne_pack_rows(ne, tl, p->d_xrows.p, n_send, p->d_xsend.p, st);
+  if (native) {
+    bool ok = api.GroupStart() == ncclSuccess;
+    for (int q = 0; q < n && ok; ++q) {
+      if (q == me) continue;
+      const int ns = op.send_off[q + 1] - op.send_off[q], nr = op.recv_off[q + 1] - op.recv_off[q];
+      if (ns) ok = ok && api.Send(p->d_xsend.p + int64_t(op.send_off[q]) * L, size_t(ns) * L, ncclDouble, q, comm, st) == ncclSuccess;
+      if (nr) ok = ok && api.Recv(p->d_xrecv.p + int64_t(op.recv_off[q] - recv0) * L, size_t(nr) * L, ncclDouble, q, comm, st) == ncclSuccess;
+    }
+    ok = (api.GroupEnd() == ncclSuccess) && ok;
+    if (!ok) { p->err = "ncclSend / ncclRecv of the halo rows failed"; return OICC_ERR_STATE; }
+  }
   for (int q = 0; q < n; ++q) {
     if (q == me) continue;
     const int ns = op.send_off[q + 1] - op.send_off[q], nr = op.recv_off[q + 1] - op.recv_off[q];
     if (ns == 0 && nr == 0) continue;
-    launch_ne_pack_rows(ne, tl, p->d_xrows.p + op.send_off[q], ns, p->d_xsend.p, st);
-    if (native) {
-      bool ok = api.GroupStart() == ncclSuccess;
-      if (ns) ok = ok && api.Send(p->d_xsend.p, size_t(ns) * L, ncclDouble, q, comm, st) == ncclSuccess;
-      if (nr) ok = ok && api.Recv(p->d_xrecv.p, size_t(nr) * L, ncclDouble, q, comm, st) == ncclSuccess;
-      ok = (api.GroupEnd() == ncclSuccess) && ok;
-      if (!ok) { p->err = "ncclSend / ncclRecv of the halo rows failed"; return OICC_ERR_STATE; }
-    } else if (p->exchange(p->exchange_user, OICC_XCHG_SENDRECV, p->d_xsend.p, int64_t(ns) * L, p->d_xrecv.p, int64_t(nr) * L, q, st) != 0) {
+    double* rbuf = p->d_xrecv.p + int64_t(op.recv_off[q] - recv0) * L;
+    if (!native && p->exchange(p->exchange_user, OICC_XCHG_SENDRECV, p->d_xsend.p + int64_t(op.send_off[q]) * L, int64_t(ns) * L, rbuf, int64_t(nr) * L, q, st) != 0) {
       p->err = "exchange callback (send / receive) failed"; return OICC_ERR_STATE; }
-    launch_ne_add_rows(ne, tl, p->d_xrows.p + op.recv_off[q], nr, p->d_xrecv.p, st);
+    launch_ne_add_rows(ne, tl, p->d_xrows.p + op.recv_off[q], nr, rbuf, st);   // (per peer: two peers may hold the same row of a narrow range)
     moved += int64_t(ns + nr) * L * int64_t(sizeof(double));
   }
-  // (2) gather: every rank's owned range -- its band rows (one contiguous piece), its entries of every arrow row and of the gradient --
-  //     broadcast from the owner, in place
-  auto bcast = [&](double* ptr, int64_t count, int root) -> bool {
-    if (count <= 0) return true;
-    if (root != me) moved += count * int64_t(sizeof(double));
-    if (native) return api.Broadcast(ptr, ptr, size_t(count), ncclDouble, root, comm, st) == ncclSuccess;
-    return p->exchange(p->exchange_user, OICC_XCHG_BROADCAST, ptr, count, ptr, count, root, st) == 0;
-  };
+  // (2) gather: every rank's owned range as ONE contiguous message of packed rows [band W | arrow a | g] (round 5; round 4 sent the
+  //     a + 2 strided pieces of a range as separate broadcasts: 88 collectives per pass at N = 8, a = 9, thousands under POINTS).
+  //     Slot k of the gather buffer belongs to rank k; native: one in-place ncclAllGather of equal (padded) slots, or one broadcast
+  //     per owner where that entry point is missing; hook transport: one broadcast per owner.
+  const int64_t piece = int64_t(std::max(op.max_owned, 1)) * L;
+  double* slots = p->d_xgather.p;
+  launch_ne_pack_range(ne, tl, op.cut[me], op.cut[me + 1] - op.cut[me], slots + int64_t(me) * piece, st);
   bool ok = true;
-  if (native) ok = api.GroupStart() == ncclSuccess;
-  for (int k = 0; k < n && ok; ++k) {
-    const int64_t r0 = op.cut[k], nr = op.cut[k + 1] - op.cut[k];
-    ok = ok && bcast(ne.band() + r0 * tl.W, nr * tl.W, k);
-    for (int c = 0; c < tl.a && ok; ++c) ok = bcast(ne.Et() + int64_t(c) * tl.Pb + r0, nr, k);
-    ok = ok && bcast(ne.g() + r0, nr, k);
+  if (native && api.AllGather != nullptr) {
+    ok = api.AllGather(slots + int64_t(me) * piece, slots, size_t(piece), ncclDouble, comm, st) == ncclSuccess;
+    moved += int64_t(n - 1) * piece * int64_t(sizeof(double));
+  } else {
+    if (native) ok = api.GroupStart() == ncclSuccess;
+    for (int k = 0; k < n && ok; ++k) {
+      const int64_t cnt = int64_t(op.cut[k + 1] - op.cut[k]) * L;
+      if (cnt <= 0) continue;
+      if (k != me) moved += cnt * int64_t(sizeof(double));
+      double* ptr = slots + int64_t(k) * piece;
+      ok = native ? api.Broadcast(ptr, ptr, size_t(cnt), ncclDouble, k, comm, st) == ncclSuccess
+                  : p->exchange(p->exchange_user, OICC_XCHG_BROADCAST, ptr, cnt, ptr, cnt, k, st) == 0;
+    }
+    if (native) ok = (api.GroupEnd() == ncclSuccess) && ok;
   }
-  if (native) ok = (api.GroupEnd() == ncclSuccess) && ok;
   if (!ok) { p->err = "gather of the owned band ranges failed"; return OICC_ERR_STATE; }
+  launch_ne_unpack_ranges(ne, tl, p->d_xcut.p, n, me, piece, slots, st);
   // (3) what every rank contributes to: the arrow corner, the arrow part of the gradient and the cost
   if (tl.a > 0 && p->reduce(p->reduce_user, ne.C(), int64_t(tl.a) * tl.a, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   if (p->reduce(p->reduce_user, ne.g() + tl.Pb, int64_t(tl.a) + 1, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }   // (the cost follows the gradient in the packed buffer)

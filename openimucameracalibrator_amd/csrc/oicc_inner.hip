@@ -294,8 +294,51 @@ int build_inner_plan(oicc_problem* p, int flags) {
 
 // One sweep of coordinate descent on the parameter vector `xv` (device, modified in place): the segment tables of xv, then ONE
 // launch per independent set (inner_iterations.hip); nothing comes back to the host.
-int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the problem whose measurements and plan are used (xv may belong to another problem with the same spline)
+// Owner-computes sweeps (round 5): on time-sharded ranks whose exchange is agreed on (oicc_exchange.hip) a rank
+// minimises only the knot blocks whose band rows it OWNS -- the sweep's work divides by the number of ranks -- plus the few blocks
+// every view / sample depends on (T_i_c, gravity, line delay, bias knots, IMU intrinsics: replicated, rank 0's result counts), and
+// after every independent set the owners broadcast what the set changed: their SO(3) / R^3 knot ranges (one contiguous piece each),
+// rank 0 the non-knot tail of the parameter vector.  The sets are independent sets of the WHOLE problem's Hessian graph (the plan
+// lives in `p`, the problem with every rank's measurements), so a block's minimisation reads only values that are current on its
+// owner: the iterates are those of one process.  `shard`: the sharded problem (owned ranges, transport).
+static int build_rank_part(oicc_problem* p, oicc_problem* shard) {
   oicc_problem::InnerPlan& ip = p->inner;
+  oicc_problem::InnerPlan::RankPart& rp = ip.rank_part;
+  const oicc_problem::OwnerPlan& op = shard->owner;
+  const int n = shard->shard_n, me = shard->shard_rank;
+  uint64_t key = 1469598103934665603ull; auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+  mix(uint64_t(n)); mix(uint64_t(me)); mix(uint64_t(op.hash)); mix(uint64_t(ip.layout_gen)); mix(uint64_t(ip.flags + 7)); mix(uint64_t(ip.wgs.size())); mix(uint64_t(shard->layout_gen));
+  if (rp.valid && rp.key == key) return OICC_OK;
+  const HostLayout& L = shard->L;    // (equal to p's: checked by oicc_optimize)
+  auto owner_of = [&](int32_t row) { int k = 0; while (k + 1 < n && row >= op.cut[k + 1]) ++k; return k; };
+  rp.so3_lo.assign(n, 1 << 30); rp.so3_hi.assign(n, -1); rp.r3_lo.assign(n, 1 << 30); rp.r3_hi.assign(n, -1);
+  for (size_t i = 0; i < L.so3.size(); ++i) if (L.so3[i] >= 0) { const int k = owner_of(L.so3[i]); rp.so3_lo[k] = std::min<int32_t>(rp.so3_lo[k], int32_t(i)); rp.so3_hi[k] = std::max<int32_t>(rp.so3_hi[k], int32_t(i) + 1); }
+  for (size_t i = 0; i < L.r3.size(); ++i) if (L.r3[i] >= 0) { const int k = owner_of(L.r3[i]); rp.r3_lo[k] = std::min<int32_t>(rp.r3_lo[k], int32_t(i)); rp.r3_hi[k] = std::max<int32_t>(rp.r3_hi[k], int32_t(i) + 1); }
+  rp.wgs.clear(); rp.group_wg0.assign(1, 0); rp.group_kinds.clear();
+  for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
+    uint8_t kinds = 0;
+    for (int w = ip.group_wg0[g]; w < ip.group_wg0[g + 1]; ++w) {
+      const InnerWg& wg = ip.wgs[size_t(w)]; const InnerBlock& b = ip.blocks[size_t(wg.block)];
+      bool mine = true;
+      if (b.kind == IK_SO3) { kinds |= 1; mine = L.so3[size_t(b.idx)] >= 0 && owner_of(L.so3[size_t(b.idx)]) == me; }
+      else if (b.kind == IK_R3) { kinds |= 2; mine = L.r3[size_t(b.idx)] >= 0 && owner_of(L.r3[size_t(b.idx)]) == me; }
+      else kinds |= 4;
+      if (mine) { rp.wgs.push_back(wg); if (b.kind != IK_SO3 && b.kind != IK_R3 && me != 0) rp.wgs.back().pad = 1; }   // (a replicated block's LM iterations are counted on rank 0 only)
+    }
+    rp.group_wg0.push_back(int32_t(rp.wgs.size())); rp.group_kinds.push_back(kinds);
+  }
+  if (!rp.d_wgs.upload(rp.wgs, p->stream)) { p->err = "hipMalloc inner-iteration workgroups of this rank"; return OICC_ERR_HIP; }
+  HIPCK(p, hipStreamSynchronize(p->stream));   // (the host vector may be rebuilt)
+  rp.key = key; rp.valid = true;
+  return OICC_OK;
+}
+
+int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard, bool* owner_computes) {   // p: the problem whose measurements and plan are used (xv may belong to another problem with the same spline)
+  oicc_problem::InnerPlan& ip = p->inner;
+  const bool owned = shard != nullptr && shard != p && shard->shard_n > 1 && shard->owner.valid && shard->owner.agreed && shard->owner.agreed_gen == shard->layout_gen &&
+                     shard->opt["owner_computes_sweeps"] != 0.0;
+  if (owner_computes) *owner_computes = owned;
+  if (owned) { const int rc = build_rank_part(p, shard); if (rc) return rc; }
   static_assert(std::is_trivially_copyable<InnerArgs>::value, "InnerArgs is copied bytewise");
   InnerArgs A; std::memset(&A, 0, sizeof(A));
   A.ctx = make_ctx(p, nullptr); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
@@ -317,7 +360,20 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st) {   // p: the probl
   for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
     long long* prof = nullptr;
     if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); prof = d_prof.p; }
-    launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st);
+    if (!owned) { launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st); continue; }
+    const oicc_problem::InnerPlan::RankPart& rp = ip.rank_part;
+    launch_inner_set(ip.d_args.p, xv, rp.d_wgs.p + rp.group_wg0[g], prof, rp.group_wg0[g + 1] - rp.group_wg0[g], ip.group_r3only[g] != 0, st);
+    // what the set changed, from its owners (every rank takes part, whether or not it had a block in the set)
+    const ParamLayout& pl = p->pl; const uint8_t kinds = rp.group_kinds[g]; const int n = shard->shard_n;
+    int rc = shard_broadcast_begin(shard);
+    for (int k = 0; k < n && !rc; ++k) {
+      if ((kinds & 1) && rp.so3_hi[k] > rp.so3_lo[k]) rc = shard_broadcast(shard, xv + pl.so3 + 4 * int64_t(rp.so3_lo[k]), 4 * int64_t(rp.so3_hi[k] - rp.so3_lo[k]), k, st);
+      if (!rc && (kinds & 2) && rp.r3_hi[k] > rp.r3_lo[k]) rc = shard_broadcast(shard, xv + pl.r3 + 3 * int64_t(rp.r3_lo[k]), 3 * int64_t(rp.r3_hi[k] - rp.r3_lo[k]), k, st);
+    }
+    if (!rc && (kinds & 4)) rc = shard_broadcast(shard, xv + pl.ab, pl.gi + 9 - pl.ab, 0, st);   // [bias knots | T_i_c | g | line delay | IMU intrinsics]: contiguous in the parameter vector
+    const int rc2 = shard_broadcast_end(shard);
+    if (rc || rc2) { p->err = shard->err; return rc ? rc : rc2; }
+    if (kinds & 1) launch_inner_seg(xv + pl.so3, std::max(pl.n_so3 - 1, 0), ip.d_seg.p, st);   // the segment tables of the knots that came in
   }
   HIPCK(p, hipGetLastError());
   if (prof_set >= 0 && d_prof.p) {

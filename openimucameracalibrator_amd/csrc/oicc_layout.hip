@@ -166,6 +166,13 @@ void build_owner_plan(oicc_problem* p) {
   op.send_off[n] = int32_t(op.flat.size());
   for (int q = 0; q < n; ++q) { op.recv_off[q] = int32_t(op.flat.size()); op.flat.insert(op.flat.end(), op.recv_rows[q].begin(), op.recv_rows[q].end()); op.max_rows = std::max(op.max_rows, int(op.recv_rows[q].size())); }
   op.recv_off[n] = int32_t(op.flat.size());
+  op.max_owned = 0; for (int k = 0; k < n; ++k) op.max_owned = std::max(op.max_owned, int(op.cut[k + 1] - op.cut[k]));
+  // what every rank must have derived identically: the cuts and, per pair, how many rows travel (a rank sends what its peer expects)
+  uint32_t h = 2166136261u; auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
+  for (int32_t c : op.cut) mix(uint32_t(c));
+  mix(uint32_t(L.Pb)); mix(uint32_t(L.a)); mix(uint32_t(L.hb));
+  for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != b) { uint32_t cnt = 0; for (int k = op.cut[b] / 3; k < op.cut[b + 1] / 3; ++k) cnt += touch[a][k]; mix(cnt); }   // rows rank a sends to rank b
+  op.hash = h;
   op.valid = true;
 }
 
@@ -258,8 +265,11 @@ int make_layout_device(oicc_problem* p, int flags) {
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   if (p->owner.valid) {   // row lists and message buffers of the owner-computes exchange
-    const size_t msg = size_t(std::max(p->owner.max_rows, 1)) * size_t(tl.W + tl.a + 1);
-    if (!p->d_xrows.upload(p->owner.flat, st) || !p->d_xsend.resize(msg) || !p->d_xrecv.resize(msg)) { p->err = "hipMalloc exchange buffers"; return OICC_ERR_HIP; }
+    const oicc_problem::OwnerPlan& op = p->owner;
+    const size_t Lr = size_t(tl.W + tl.a + 1);
+    const size_t nsend = size_t(std::max(op.send_off[size_t(p->shard_n)], 1)), nrecv = size_t(std::max(op.recv_off[size_t(p->shard_n)] - op.recv_off[0], 1));   // every peer's rows at once: one group of sends / receives
+    if (!p->d_xrows.upload(op.flat, st) || !p->d_xcut.upload(op.cut, st) || !p->d_xsend.resize(nsend * Lr) || !p->d_xrecv.resize(nrecv * Lr) ||
+        !p->d_xgather.resize(size_t(p->shard_n) * size_t(std::max(op.max_owned, 1)) * Lr)) { p->err = "hipMalloc exchange buffers"; return OICC_ERR_HIP; }
   }
   p->layout_flags = -1;   // (stays invalid if the tiles cannot be built)
   const double tl1 = now_s();

@@ -46,6 +46,8 @@ void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack
 void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hipStream_t st);
 void launch_ne_pack_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, double* buf, hipStream_t st);
 void launch_ne_add_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, const double* buf, hipStream_t st);
+void launch_ne_pack_range(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st);
+void launch_ne_unpack_ranges(const NormalEq& ne, const TangentLayout& tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
@@ -114,8 +116,11 @@ struct oicc_problem {
   // owner-computes exchange (oicc_set_shard): owned band-row ranges of all ranks, the rows this rank sends to / receives from every other rank
   int shard_n = 1, shard_rank = 0;
   oicc_exchange_fn exchange = nullptr; void* exchange_user = nullptr;
-  struct OwnerPlan { bool valid = false; std::vector<int32_t> cut; std::vector<std::vector<int32_t>> send_rows, recv_rows; std::vector<int32_t> flat, send_off, recv_off; int max_rows = 0; } owner;
-  DevBuf<int32_t> d_xrows; DevBuf<double> d_xsend, d_xrecv;
+  struct OwnerPlan { bool valid = false; std::vector<int32_t> cut; std::vector<std::vector<int32_t>> send_rows, recv_rows; std::vector<int32_t> flat, send_off, recv_off; int max_rows = 0;
+                     int max_owned = 0;            // rows of the largest owned range: one slot of the gather buffer
+                     int64_t agreed_gen = -1; bool agreed = false;   // all ranks agreed (once per layout, through the installed reduction) that every one of them can run the exchange on the same cuts
+                     uint32_t hash = 0; } owner;
+  DevBuf<int32_t> d_xrows, d_xcut; DevBuf<double> d_xsend, d_xrecv, d_xgather, d_xagree;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
   bool has_remote_views = false;   // other ranks hold views too: under SplineOptimFlags::POINTS every board point is a variable on every rank (which points they see is not declared)
   bool meas_dirty = true, groups_dirty = true;
@@ -169,6 +174,11 @@ struct oicc_problem {
     std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0; std::vector<char> group_r3only;   // set g holds nothing but R^3 knots of at most 1024 item slots: the 8-wave build of the kernel   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
     DevBuf<InnerBlock> d_blocks; DevBuf<InnerRun> d_runs; DevBuf<InnerWg> d_wgs; DevBuf<InnerCtl> d_ctls; DevBuf<unsigned long long> d_lm_iterations; DevBuf<double> d_seg; int n_ctls = 0;
     DevBuf<InnerArgs> d_args; std::unique_ptr<InnerArgs> h_args; bool args_valid = false;   // problem-constant kernel arguments in device memory (inner_plan.h)
+    // owner-computes sweeps on time-sharded ranks (round 5): this rank's workgroups of every set (the knot blocks whose rows it owns +
+    // the blocks every rank minimises redundantly), what a set changes (bit 0 SO(3) knots, 1 R^3 knots, 2 replicated blocks), and
+    // the knot ranges every rank owns ([n + 1] boundaries per spline)
+    struct RankPart { std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0; std::vector<uint8_t> group_kinds; std::vector<int32_t> so3_lo, so3_hi, r3_lo, r3_hi;
+                      DevBuf<InnerWg> d_wgs; uint64_t key = 0; bool valid = false; } rank_part;
     int flags = -2; int64_t layout_gen = -1; bool gs_unit = false;   // what the plan was built from: the tangent layout (make_layout generation) and the GS weighting
     size_t n_items = 0; int64_t lm_iterations = 0; int sweeps = 0;
   } inner;
@@ -189,6 +199,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["owner_computes_sweeps"] = 1;   // time-sharded ranks with the owner-computes exchange: a rank sweeps only the knot blocks it owns, owners broadcast after every set (0: replicated sweeps)
     opt["device_lm"] = 1;   // 1: plain Levenberg-Marquardt (no inner iterations / line search / collective) takes its trust-region decisions on the device
                             //    (LmCtl, lm_decide_kernel): the host enqueues iterations and polls a pinned word one iteration behind.  0: the host-driven loop
     opt["inner_shared_residency"] = 0.5;     // share of the device's resident workgroups the parts of a set's shared blocks (T_i_c, gravity, line delay, IMU intrinsics) may take together
@@ -248,7 +259,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
 InnerPlanOptions inner_plan_options(oicc_problem* p, int flags, int64_t layout_gen);
 void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen);
 int build_inner_plan(oicc_problem* p, int flags);
-int inner_sweep(oicc_problem* p, double* xv, hipStream_t st);
+int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard = nullptr, bool* owner_computes = nullptr);
 int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res = nullptr, double* dbg_jac = nullptr, int only_kind = -1,
               bool cost_already_zero = false, const NormalEq* target = nullptr, bool force_rs = false, long long* prof = nullptr, bool want_gmax = false,
               double* cost_out = nullptr, const LmCtl* ctl = nullptr);
@@ -259,5 +270,9 @@ int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stre
 int rccl_broadcast_from_root(oicc_problem* p, void* device_ptr, int64_t count_doubles, hipStream_t stream);
 int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st);
 bool owner_exchange_ready(const oicc_problem* p);
+int owner_exchange_agree(oicc_problem* p, hipStream_t st, bool* use);   // collective (every rank of a sharded problem calls it at the same point)
+int shard_broadcast_begin(oicc_problem* p);                                                      // pieces of the parameter vector from their owners, in place:
+int shard_broadcast(oicc_problem* p, double* ptr, int64_t count, int root, hipStream_t st);      // native RCCL (one group) or the transport hook
+int shard_broadcast_end(oicc_problem* p);
 int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved = nullptr);
 }  // namespace oicc

@@ -73,7 +73,10 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res, doubl
   if (p->reduce) {
     double* cdst = (!jac && cost_out) ? cost_out : ne.cost();
     int rc;
-    if (jac && owner_exchange_ready(p)) return owner_exchange(p, ne, st);       // owner-computes: halo rows, gather of the owned ranges, all-reduce of the corner
+    if (jac && p->shard_n > 1) {   // owner-computes: halo rows, gather of the owned ranges, all-reduce of the corner -- if ALL ranks can (agreed once per layout)
+      bool use = false; rc = owner_exchange_agree(p, st, &use); if (rc) return rc;
+      if (use) return owner_exchange(p, ne, st);
+    }
     rc = jac ? p->reduce(p->reduce_user, ne.base, ne.total, st) : p->reduce(p->reduce_user, cdst, 1, st);
     if (rc != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
   }
@@ -466,6 +469,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   double decrease_factor = 2.0; bool reuse_diagonal = false;
   double cost = 0.0, gmax = 0.0;
   const int inner_sweeps0 = (p->inner_src ? p->inner_src : p)->inner.sweeps; int64_t inner_lm0 = (p->inner_src ? p->inner_src : p)->inner.lm_iterations;
+  bool any_owned_sweep = false;   // owner-computes sweeps ran: this rank's counter of per-block LM iterations holds its own blocks only
   auto finish = [&](int term, const char* msg) {
     S.termination = term; S.final_cost = cost; S.final_radius = radius; S.final_gradient_max_norm = gmax;
     std::snprintf(S.message, sizeof(S.message), "%s", msg);
@@ -475,6 +479,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (swept) (void)hipMemcpyAsync(&lm_total, qs->inner.d_lm_iterations.p, sizeof(lm_total), hipMemcpyDeviceToHost, p->stream);
     int r2 = sync_params_to_host(p);   // (drains the stream)
     if (swept) qs->inner.lm_iterations = int64_t(lm_total);
+    if (swept && any_owned_sweep && p->reduce != nullptr && p->d_xagree.resize(4)) {   // the ranks' counts add up to the sweep's (every rank gets here: they take the same decisions)
+      double v = double(qs->inner.lm_iterations - inner_lm0);
+      if (hipMemcpyAsync(p->d_xagree.p, &v, sizeof(v), hipMemcpyHostToDevice, p->stream) == hipSuccess && p->reduce(p->reduce_user, p->d_xagree.p, 1, p->stream) == 0 &&
+          hipMemcpyAsync(&v, p->d_xagree.p, sizeof(v), hipMemcpyDeviceToHost, p->stream) == hipSuccess && hipStreamSynchronize(p->stream) == hipSuccess) inner_lm0 = qs->inner.lm_iterations - int64_t(v + 0.5);
+    }
     S.inner_sweeps = qs->inner.sweeps - inner_sweeps0; S.inner_lm_iterations = qs->inner.lm_iterations - inner_lm0; S.line_search_steps = int32_t(p->line_search_steps);
     S.seconds_total = now_s() - t_start; if (sum) *sum = S; return r2; };
 
@@ -690,8 +699,10 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       cand_before_inner = cand_cost_of();
       if (std::isfinite(cand_before_inner)) {
         HIPCK(p, hipEventRecord(ev[6], st));
-        rc = inner_sweep(q, p->d_xc.p, st); if (rc) { if (q != p) p->err = q->err; return rc; }
-        if (p->reduce != nullptr) { rc = make_rank_consistent(p, p->d_xc.p, false, st); if (rc) return rc; }   // (the shared blocks of a sweep sum with atomics: the ranks' swept candidates differ in the last bits)
+        bool owned_sweep = false;
+        rc = inner_sweep(q, p->d_xc.p, st, p, &owned_sweep); if (rc) { if (q != p) p->err = q->err; return rc; }
+        if (p->reduce != nullptr && !owned_sweep) { rc = make_rank_consistent(p, p->d_xc.p, false, st); if (rc) return rc; }   // (the shared blocks of a sweep sum with atomics: the ranks' swept candidates differ in the last bits; an owner-computes sweep ends consistent)
+        if (owned_sweep) any_owned_sweep = true;
         HIPCK(p, hipEventRecord(ev[7], st));
         p->seg_invalidate(p->d_xc.p);
         if (cost_in_state) HIPCK(p, hipMemsetAsync(&p->d_state.p->cand_cost, 0, sizeof(double), st));

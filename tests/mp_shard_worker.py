@@ -66,7 +66,7 @@ def main():
     s = tr.Optimize(iters, flags)
     it = tr.GetIterations()
     res = dict(rank=rank, blocks=cal.num_blocks, iterations=[dict(cost=i["cost"], ok=i["step_is_successful"], gmax=i["gradient_max_norm"]) for i in it],
-               final_cost=s["final_cost"], inner_sweeps=s["inner_sweeps"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"], hook_max_doubles=calls["max"], P=int(s["num_parameters_tangent"]), exchange=xch)
+               final_cost=s["final_cost"], inner_sweeps=s["inner_sweeps"], inner_lm_iterations=s["inner_lm_iterations"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"], hook_max_doubles=calls["max"], P=int(s["num_parameters_tangent"]), exchange=xch)
     json.dump(res, open(out, "w"))
     dist.barrier()
     dist.destroy_process_group()
