@@ -324,6 +324,10 @@ int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H_dense,
                   double* g, int32_t P_capacity);
 /* Cost-only pass (what LM runs for a candidate point). */
 int oicc_evaluate_cost(oicc_problem* p, int32_t flags, double* cost);
+/* One pass as oicc_evaluate, then n entries H(rows[k], cols[k]) of J^T J in the tangent ordering above (0 outside the band +
+ * arrow pattern) -- for problems whose dense P x P matrix does not fit (BASELINE config 5: P ~ 90 k), where parity tests compare
+ * sampled entries.  The reference has no counterpart (ceres::Problem::Evaluate returns a CRS Jacobian, not J^T J). */
+int oicc_evaluate_entries(oicc_problem* p, int32_t flags, int64_t n, const int32_t* rows, const int32_t* cols, double* values);
 /* Per-block residuals and tangent Jacobians for parity tests.
  * kind: 0 = camera views, 1 = accelerometer, 2 = gyroscope.
  * Camera: residuals [2*total_corners]; jacobian rows hold the block-local

@@ -88,6 +88,7 @@ SIGNATURES = {
     "get_tangent_layout": (C.c_int, [H, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p]),
     "evaluate": (C.c_int, [H, C.c_int32, c_dp, c_dp, c_dp, C.c_int32]),
     "evaluate_cost": (C.c_int, [H, C.c_int32, c_dp]),
+    "evaluate_entries": (C.c_int, [H, C.c_int32, C.c_int64, c_i32p, c_i32p, c_dp]),
     "evaluate_blocks": (C.c_int, [H, C.c_int32, C.c_int32, c_dp, c_dp]),
     "get_T_i_c": (C.c_int, [H, c_dp]),
     "get_gravity": (C.c_int, [H, c_dp]),

@@ -97,7 +97,35 @@ int sync_measurements(oicc_problem* p) {
   p->meas_dirty = false;
   return OICC_OK;
 }
-void sync_groups(oicc_problem* p) {   // host only: before anything that walks the IMU samples by runs
+// Measurements added out of time order (oicc_problem.h): stable sort of the host arrays by (SO(3) knot window, normalised time).
+template <class T> static void permute_vec(std::vector<T>& v, const std::vector<size_t>& perm) { std::vector<T> o(v.size()); for (size_t i = 0; i < perm.size(); ++i) o[i] = v[perm[i]]; v.swap(o); }
+static void sort_views_by_time(oicc_problem* p) {
+  const size_t nv = p->view_rs.size(), nc = p->corner_view.size();
+  std::vector<size_t> vperm(nv); for (size_t i = 0; i < nv; ++i) vperm[i] = i;
+  std::stable_sort(vperm.begin(), vperm.end(), [&](size_t a, size_t b) { return p->view_s_so3[a] != p->view_s_so3[b] ? p->view_s_so3[a] < p->view_s_so3[b] : p->view_u_so3[a] < p->view_u_so3[b]; });
+  if (p->corner_orig.empty()) { p->corner_orig.resize(nc); for (size_t c = 0; c < nc; ++c) p->corner_orig[c] = int64_t(c); }
+  std::vector<size_t> cperm; cperm.reserve(nc);
+  std::vector<int64_t> c0(1, 0);
+  for (size_t i = 0; i < nv; ++i) { const size_t v = vperm[i]; for (int64_t c = p->view_c0[v]; c < p->view_c0[v + 1]; ++c) cperm.push_back(size_t(c)); c0.push_back(int64_t(cperm.size())); }
+  permute_vec(p->corner_pt, cperm); permute_vec(p->cu, cperm); permute_vec(p->cv, cperm); permute_vec(p->cisx, cperm); permute_vec(p->cisy, cperm); permute_vec(p->corner_orig, cperm);
+  for (size_t i = 0; i < nv; ++i) for (int64_t c = c0[i]; c < c0[i + 1]; ++c) p->corner_view[size_t(c)] = int32_t(i);
+  p->view_c0 = c0;
+  permute_vec(p->view_s_so3, vperm); permute_vec(p->view_s_r3, vperm); permute_vec(p->view_u_so3, vperm); permute_vec(p->view_u_r3, vperm); permute_vec(p->view_rs, vperm);
+  p->views_unsorted = false; p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+}
+static void sort_imu_by_time(oicc_problem* p, ImuHost& h, std::vector<int32_t>& orig, bool* flag) {
+  const size_t n = h.size();
+  std::vector<size_t> perm(n); for (size_t i = 0; i < n; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return h.s_so3[a] != h.s_so3[b] ? h.s_so3[a] < h.s_so3[b] : h.u_so3[a] < h.u_so3[b]; });
+  if (orig.empty()) { orig.resize(n); for (size_t i = 0; i < n; ++i) orig[i] = int32_t(i); }
+  permute_vec(h.s_so3, perm); permute_vec(h.s_r3, perm); permute_vec(h.s_b, perm); permute_vec(h.u_so3, perm); permute_vec(h.u_r3, perm); permute_vec(h.u_b, perm);
+  permute_vec(h.mx, perm); permute_vec(h.my, perm); permute_vec(h.mz, perm); permute_vec(h.w, perm); permute_vec(orig, perm);
+  *flag = false; p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+}
+void sync_groups(oicc_problem* p) {   // host only: before anything that walks the measurements in time order / the IMU samples by runs
+  if (p->views_unsorted) sort_views_by_time(p);
+  if (p->acc_unsorted) sort_imu_by_time(p, p->acc, p->acc_orig, &p->acc_unsorted);
+  if (p->gyr_unsorted) sort_imu_by_time(p, p->gyr, p->gyr_orig, &p->gyr_unsorted);
   if (!p->groups_dirty) return;
   build_imu_groups(p->acc, true, p->acc_groups); build_imu_groups(p->gyr, false, p->gyr_groups);
   p->groups_dirty = false;

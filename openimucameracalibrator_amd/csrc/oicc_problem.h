@@ -110,6 +110,14 @@ struct oicc_problem {
   std::vector<uint8_t> view_rs;
   ImuHost acc, gyr;
   ImuGroups acc_groups, gyr_groups;   // (sync_measurements)
+  // Everything behind the ABI (layout, tiles, the inner-iteration plan, the creation order of the parameter blocks that breaks Ceres'
+  // degree ties) walks the measurements IN TIME ORDER.  Callers may add them in any order -- the reference iterates an unordered
+  // map of views, its application fills it in the string order of the corner file's keys -- so a call that arrives out of order
+  // raises a flag and sync_groups() sorts the host arrays (stable, by knot window and normalised time) before anything is derived
+  // from them; *_orig maps the sorted position back to the position in the caller's order (empty: identity) for the per-block
+  // dumps of oicc_evaluate_blocks, whose rows stay in the caller's order.
+  bool views_unsorted = false, acc_unsorted = false, gyr_unsorted = false;
+  std::vector<int64_t> corner_orig; std::vector<int32_t> acc_orig, gyr_orig;
   // knot windows of measurements held by OTHER ranks (multi-GPU): only for layout/bandwidth
   std::vector<int32_t> remote_so3, remote_r3;   // pairs; r3 = -1 for gyro
   std::vector<int32_t> remote_owner;            // the rank that holds the remote measurement (-1: not told; owner-computes exchange needs it)

@@ -296,7 +296,9 @@ static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, 
     if (accepted) accepted[v] = ok;
     if (!ok) continue;
     const int32_t vid = int32_t(p->view_rs.size());
+    if (vid > 0 && (s_so3 < p->view_s_so3.back() || (s_so3 == p->view_s_so3.back() && u_so3 < p->view_u_so3.back()))) p->views_unsorted = true;   // (sorted by sync_groups)
     for (int64_t c = coff[v]; c < coff[v + 1]; ++c) {
+      if (!p->corner_orig.empty()) p->corner_orig.push_back(int64_t(p->corner_view.size()));
       ARG(p, pidx[c] >= 0 && size_t(pidx[c]) < p->pts.size() / 4, "point index out of range (set_scene_points first)");
       p->corner_view.push_back(vid); p->corner_pt.push_back(pidx[c]); p->max_corner_pt = std::max(p->max_corner_pt, pidx[c]);
       p->cu.push_back(uv[2 * c]); p->cv.push_back(uv[2 * c + 1]);
@@ -327,6 +329,8 @@ int oicc_add_accelerometer_measurements(oicc_problem* p, int64_t n, const int64_
     if (accepted) accepted[i] = ok;
     if (!ok) continue;
     ImuHost& h = p->acc;
+    if (h.size() > 0 && (s_so3 < h.s_so3.back() || (s_so3 == h.s_so3.back() && u_so3 < h.u_so3.back()))) p->acc_unsorted = true;
+    if (!p->acc_orig.empty()) p->acc_orig.push_back(int32_t(h.size()));
     h.s_so3.push_back(int32_t(s_so3)); h.s_r3.push_back(int32_t(s_r3)); h.s_b.push_back(int32_t(s_b));
     h.u_so3.push_back(u_so3); h.u_r3.push_back(u_r3); h.u_b.push_back(u_b);
     h.mx.push_back(m[3 * i]); h.my.push_back(m[3 * i + 1]); h.mz.push_back(m[3 * i + 2]); h.w.push_back(w);
@@ -347,6 +351,8 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n, const int64_t* t
     if (accepted) accepted[i] = ok;
     if (!ok) continue;
     ImuHost& h = p->gyr;
+    if (h.size() > 0 && (s_so3 < h.s_so3.back() || (s_so3 == h.s_so3.back() && u_so3 < h.u_so3.back()))) p->gyr_unsorted = true;
+    if (!p->gyr_orig.empty()) p->gyr_orig.push_back(int32_t(h.size()));
     h.s_so3.push_back(int32_t(s_so3)); h.s_r3.push_back(0); h.s_b.push_back(int32_t(s_b));
     h.u_so3.push_back(u_so3); h.u_r3.push_back(0.0); h.u_b.push_back(u_b);
     h.mx.push_back(m[3 * i]); h.my.push_back(m[3 * i + 1]); h.mz.push_back(m[3 * i + 2]); h.w.push_back(w);
@@ -420,6 +426,27 @@ int oicc_evaluate(oicc_problem* p, int32_t flags, double* cost, double* H, doubl
   }
   return OICC_OK;
 }
+int oicc_evaluate_entries(oicc_problem* p, int32_t flags, int64_t n, const int32_t* rows, const int32_t* cols, double* values) {
+  ARG(p, n >= 0 && (n == 0 || (rows && cols && values)), "entries");
+  int rc = prepare(p, flags); if (rc) return rc;
+  rc = eval_pass(p, p->d_x.p, true); if (rc) return rc;
+  std::vector<double> h(p->ne.total);
+  HIPCK(p, hipMemcpyAsync(h.data(), p->ne.base, h.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCK(p, hipStreamSynchronize(p->stream));
+  const TangentLayout& tl = p->tl;
+  const int64_t P = tl.P, Pb = tl.Pb, a = tl.a, W = tl.W;
+  for (int64_t k = 0; k < n; ++k) {
+    int64_t i = rows[k], j = cols[k];
+    ARG(p, i >= 0 && j >= 0 && i < P && j < P, "entry index out of range");
+    if (i > j) std::swap(i, j);
+    double v = 0.0;
+    if (j < Pb) { if (j - i < W) v = h[size_t(i * W + (j - i))]; }
+    else if (i < Pb) v = h[size_t(p->ne.off_E + (j - Pb) * Pb + i)];
+    else v = h[size_t(p->ne.off_C + (i - Pb) * a + (j - Pb))];
+    values[k] = v;
+  }
+  return OICC_OK;
+}
 int oicc_evaluate_cost(oicc_problem* p, int32_t flags, double* cost) {
   int rc = prepare(p, flags); if (rc) return rc;
   rc = eval_pass(p, p->d_x.p, false); if (rc) return rc;
@@ -439,6 +466,17 @@ int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind, double* r
   HIPCK(p, hipMemcpyAsync(residuals, p->d_dbg_res.p, rows * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   if (jacobians) HIPCK(p, hipMemcpyAsync(jacobians, p->d_dbg_jac.p, rows * ncols * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   HIPCK(p, hipStreamSynchronize(p->stream));
+  // measurements that were added out of time order were sorted (sync_groups): the rows go back to the caller's order
+  const size_t rpi = kind == 0 ? 2 : 3, nitems = rows / rpi;
+  auto orig = [&](size_t i) -> size_t { return kind == 0 ? size_t(p->corner_orig[i]) : size_t(kind == 1 ? p->acc_orig[i] : p->gyr_orig[i]); };
+  if (!(kind == 0 ? p->corner_orig.empty() : (kind == 1 ? p->acc_orig.empty() : p->gyr_orig.empty()))) {
+    std::vector<double> r(residuals, residuals + rows), J; if (jacobians) J.assign(jacobians, jacobians + rows * ncols);
+    for (size_t i = 0; i < nitems; ++i) {
+      const size_t o = orig(i);
+      std::copy(r.begin() + rpi * i, r.begin() + rpi * (i + 1), residuals + rpi * o);
+      if (jacobians) std::copy(J.begin() + rpi * i * ncols, J.begin() + rpi * (i + 1) * ncols, jacobians + rpi * o * ncols);
+    }
+  }
   return OICC_OK;
 }
 

@@ -294,6 +294,13 @@ class SplineTrajectoryEstimator:
         self._ck(self._b.evaluate(self._h, int(flags), C.byref(cost), _dp(H) if want_H else None, _dp(g), P))
         return cost.value, H, g
 
+    def EvaluateEntries(self, flags, rows, cols):
+        """Sampled entries H(rows[k], cols[k]) of J^T J at the current parameters (oicc_evaluate_entries): large problems."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32); cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.zeros(len(rows))
+        self._ck(self._b.evaluate_entries(self._h, int(flags), len(rows), rows.ctypes.data_as(_abi.c_i32p), cols.ctypes.data_as(_abi.c_i32p), _dp(out)))
+        return out
+
     def EvaluateCost(self, flags):
         cost = C.c_double(0)
         self._ck(self._b.evaluate_cost(self._h, int(flags), C.byref(cost)))
@@ -526,7 +533,7 @@ class ImuCameraCalibrator:
         self.trajectory_ = trajectory if trajectory is not None else SplineTrajectoryEstimator(backend=backend, device=device)
         self.inital_cam_line_delay_s_ = 0.0
 
-    def BatchInitSpline(self, ds, shard=None, known_gravity=None, owner_computes=False):
+    def BatchInitSpline(self, ds, shard=None, known_gravity=None, owner_computes=False, gravity_from_accelerometer=False):
         """imu_camera_calibrator.cc:21-124 for a synthetic.Dataset.  ``shard``
         (rank, world) adds only that rank's time window of measurements; knots and
         calibration are initialised from the whole dataset on every rank."""
@@ -584,9 +591,30 @@ class ImuCameraCalibrator:
             to = (t[other] * S_TO_NS).astype(np.int64)
             tr.DeclareRemoteMeasurements(1, to); tr.DeclareRemoteMeasurements(2, to)
         tr.SetGravity(ds.gravity_init if known_gravity is None else known_gravity)
+        if gravity_from_accelerometer and known_gravity is None:
+            self.InitializeGravity(ds)
         self.num_blocks = int(self.views_accepted.sum() + self.accl_accepted.sum() + self.gyro_accepted.sum())
         self.num_corners = int(off[-1])
         return self
+
+    def InitializeGravity(self, ds):
+        """imu_camera_calibrator.cc:130-161: gravity in the world frame from the first accelerometer sample whose timestamp, TRUNCATED
+        TO WHOLE SECONDS (quirk Q5, :147), lies within 1/30 s of a camera timestamp; rotated by the view's orientation times the
+        initial T_i_c rotation.  BatchInitSpline(ds) uses the data set's own start value instead unless told otherwise
+        (gravity_from_accelerometer=True: what the reference and the C++ facade, csrc/host/estimator.hpp, do)."""
+        from .synthetic import mat_from_quat
+        q_ic = np.asarray(ds.q_i_c_init, dtype=np.float64); q_ic = q_ic / np.linalg.norm(q_ic)
+        R_ic = mat_from_quat(q_ic)
+        order = np.argsort(ds.view_t_s, kind="stable")
+        t_imu = np.asarray(ds.imu_t_s, dtype=np.float64)
+        for v in order:
+            R_ai = mat_from_quat(np.asarray(ds.view_q_wc[v], dtype=np.float64)) @ R_ic.T          # q_wc * q_ic^-1
+            hit = np.nonzero(np.abs(np.trunc(t_imu) - float(ds.view_t_s[v])) < 1.0 / 30.0)[0]
+            if len(hit):
+                g = R_ai @ np.asarray(ds.accel[hit[0]], dtype=np.float64)
+                self.trajectory_.SetGravity(g)
+                return g
+        return None
 
     def Optimize(self, iterations, optim_flags):
         """imu_camera_calibrator.cc:163-168: returns the mean reprojection error."""

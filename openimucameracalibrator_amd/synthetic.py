@@ -206,6 +206,24 @@ class Dataset:
     def num_corners(self):
         return len(self.corner_point)
 
+    def with_view_order(self, order):
+        """The same data set with its views (and their corners) listed in another order -- e.g. the string order of the corner
+        file's microsecond keys, in which the reference's application fills its reconstruction."""
+        import copy
+        order = np.asarray(order)
+        d = copy.copy(self)
+        d.view_t_s = self.view_t_s[order]; d.view_q_wc = self.view_q_wc[order]; d.view_p_wc = self.view_p_wc[order]
+        uv, pt, off = [], [], [0]
+        for v in order:
+            a, b = self.corner_offset[v], self.corner_offset[v + 1]
+            uv.append(self.corner_uv[a:b]); pt.append(self.corner_point[a:b]); off.append(off[-1] + (b - a))
+        d.corner_uv = np.concatenate(uv); d.corner_point = np.concatenate(pt).astype(self.corner_point.dtype); d.corner_offset = np.asarray(off, dtype=np.int64)
+        return d
+
+    def file_key_order(self):
+        """Order of the views as a string-keyed map of their microsecond timestamps lists them (nlohmann::json items())."""
+        return np.array(sorted(range(self.num_views), key=lambda v: str(int(round(self.view_t_s[v] * 1e6)))))
+
     def shard(self, rank, world):
         """Time-contiguous shard of the measurements: rank r owns
         the views and IMU samples of the r-th time window; parameters (knots,

@@ -96,7 +96,16 @@ inline void build_blocks(const Problem& p, const Layout& L, const Active& a, std
     if (*slot < 0) { PBlock b; b.kind = kind; b.idx = idx; b.dim = dim; b.off = off; b.order = int(B.size()); *slot = int(B.size()); B.push_back(b); }
     return *slot;
   };
-  for (size_t v = 0; v < p.views.size(); ++v) {
+  // Creation order: the reference's AddResidualBlock calls walk an UNORDERED map of views (image_data_.ViewIds(),
+  // imu_camera_calibrator.cc:89-98), so the order Ceres saw is not defined by the reference; the restatement (and the device
+  // library, which sorts what it is given) fixes it to TIME order, whatever order the caller added the measurements in.
+  std::vector<size_t> vorder(p.views.size()); for (size_t v = 0; v < vorder.size(); ++v) vorder[v] = v;
+  std::stable_sort(vorder.begin(), vorder.end(), [&](size_t x, size_t y) { return p.views[x].s_so3 != p.views[y].s_so3 ? p.views[x].s_so3 < p.views[y].s_so3 : p.views[x].u_so3 < p.views[y].u_so3; });
+  auto imu_order = [](const std::vector<ImuBlk>& b) { std::vector<size_t> o(b.size()); for (size_t i = 0; i < o.size(); ++i) o[i] = i;
+    std::stable_sort(o.begin(), o.end(), [&](size_t x, size_t y) { return b[x].s_so3 != b[y].s_so3 ? b[x].s_so3 < b[y].s_so3 : b[x].u_so3 < b[y].u_so3; }); return o; };
+  const std::vector<size_t> aorder = imu_order(p.acc), gorder = imu_order(p.gyr);
+  for (size_t vi = 0; vi < p.views.size(); ++vi) {
+    const size_t v = vorder[vi];
     const ViewBlk& vb = p.views[v];
     if (!view_has_weight(p, vb)) continue;                       // (GS views with HuberLoss(0): numerically no block, see view_has_weight)
     std::vector<int> ids;
@@ -107,8 +116,9 @@ inline void build_blocks(const Problem& p, const Layout& L, const Active& a, std
     for (int id : ids) if (id >= 0) B[id].views.push_back(int(v));
   }
   const size_t nimu = std::max(p.acc.size(), p.gyr.size());
-  for (size_t i = 0; i < nimu; ++i) {
-    if (i < p.acc.size()) {
+  for (size_t ii = 0; ii < nimu; ++ii) {
+    if (ii < p.acc.size()) {
+      const size_t i = aorder[ii];
       const ImuBlk& b = p.acc[i]; std::vector<int> ids;
       for (int k = 0; k < kN; ++k) ids.push_back(get(PB_SO3, int(b.s_so3 + k), 3, L.so3[b.s_so3 + k], &id_so3[b.s_so3 + k]));
       for (int k = 0; k < kN; ++k) ids.push_back(get(PB_R3, int(b.s_r3 + k), 3, L.r3[b.s_r3 + k], &id_r3[b.s_r3 + k]));
@@ -117,7 +127,8 @@ inline void build_blocks(const Problem& p, const Layout& L, const Active& a, std
       ids.push_back(get(PB_AI, 0, 6, L.other[3], &id_o[3]));
       for (int id : ids) if (id >= 0) B[id].accs.push_back(int(i));
     }
-    if (i < p.gyr.size()) {
+    if (ii < p.gyr.size()) {
+      const size_t i = gorder[ii];
       const ImuBlk& b = p.gyr[i]; std::vector<int> ids;
       for (int k = 0; k < kN; ++k) ids.push_back(get(PB_SO3, int(b.s_so3 + k), 3, L.so3[b.s_so3 + k], &id_so3[b.s_so3 + k]));
       for (int k = 0; k < kNb; ++k) ids.push_back(get(PB_GB, int(b.s_b + k), 3, L.gb[b.s_b + k], &id_gb[b.s_b + k]));

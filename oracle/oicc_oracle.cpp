@@ -622,6 +622,7 @@ const char* oicc_oracle_last_error(const oicc_problem* prob) { return prob->p.er
 const char* oicc_oracle_version(void) { return "oicc-oracle-cpu-1"; }
 
 int oicc_oracle_set_option(oicc_problem* prob, const char* name, double value) {
+  for (const char* device_only : {"solver_partitions", "solver_algorithm"}) if (std::strcmp(name, device_only) == 0) return OICC_OK;   // which linear solver the DEVICE library uses: accepted and ignored (the C++ application sets them, facade_on_oracle)
   auto it = P_.opt.find(name); CHECK_ARG(it != P_.opt.end(), "unknown option"); it->second = value; return OICC_OK; }
 
 // SetTimes, impl.h:38-51
@@ -772,6 +773,12 @@ int oicc_oracle_evaluate(oicc_problem* prob, int32_t flags, double* cost, double
   if (cost) *cost = ne.cost;
   if (H) { CHECK_ARG(Pcap >= L.P, "P_capacity"); for (int i = 0; i < L.P; ++i) for (int j = 0; j < L.P; ++j) H[size_t(i) * L.P + j] = ne.get(i, j); }
   if (g) { CHECK_ARG(Pcap >= L.P, "P_capacity"); std::copy(ne.g.begin(), ne.g.end(), g); }
+  return OICC_OK;
+}
+int oicc_oracle_evaluate_entries(oicc_problem* prob, int32_t flags, int64_t n, const int32_t* rows, const int32_t* cols, double* values) {
+  const Layout L = make_layout(P_, flags); const Active a = active_set(P_, flags);
+  NormalEq ne; build_normal_equations(P_, L, a, &ne);
+  for (int64_t k = 0; k < n; ++k) { CHECK_ARG(rows[k] >= 0 && cols[k] >= 0 && rows[k] < L.P && cols[k] < L.P, "entry index out of range"); values[k] = ne.get(rows[k], cols[k]); }
   return OICC_OK;
 }
 int oicc_oracle_evaluate_cost(oicc_problem* prob, int32_t flags, double* cost) {

@@ -1048,3 +1048,73 @@ def test_device_side_lm_control_takes_the_steps_of_the_host_loop(cfg, radius, it
     assert abs(d[6] - h[6]) < 1e-12
     if flags & E.IMU_BIASES:
         assert d[0]["num_unsuccessful_steps"] >= 4 and d[0]["num_successful_steps"] >= 5
+
+
+def test_c5_sampled_normal_equations_and_first_lm_iterate_match_the_jet_oracle():
+    """BASELINE config 5 at full size (P ~ 90 k: the dense matrix does not fit) beyond cost and gradient: 30 000 sampled entries of
+    J^T J -- band (every offset up to the half bandwidth), arrow rows, the arrow corner -- through oicc_evaluate_entries against
+    the oracle's forward-mode Jets, each to 1e-9 of sqrt(H_ii H_jj); and the first Levenberg-Marquardt iterate of the chained tile
+    pass + 12-level cyclic reduction against the oracle's band Cholesky: candidate cost 1e-9, step norm and rho 1e-6, the radius
+    update, the gradient norm at the accepted point."""
+    ds = synthetic.make_config("C5")
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    lay = gpu.trajectory_.GetTangentLayout(FLAGS1)
+    P = lay["P"]; Pb = 3 * int((lay["so3"] >= 0).sum() + (lay["r3"] >= 0).sum()); a = P - Pb
+    hb = gpu.trajectory_.Optimize(0, FLAGS1)["half_bandwidth"]
+    assert Pb > 85000 and a == 9 and 40 <= hb <= 64
+    rng = np.random.default_rng(7)
+    nb = 24000
+    i = rng.integers(0, Pb, nb); k = rng.integers(0, hb + 1, nb); j = np.minimum(i + k, Pb - 1)
+    ia = rng.integers(0, Pb, 5000); ja = Pb + rng.integers(0, a, 5000)
+    ic, jc = np.divmod(np.arange(a * a), a)
+    rows = np.concatenate([i, ia, Pb + ic, np.arange(0, Pb, 97)]); cols = np.concatenate([j, ja, Pb + jc, np.arange(0, Pb, 97)])
+    vg = gpu.trajectory_.EvaluateEntries(FLAGS1, rows, cols)
+    vc = cpu.trajectory_.EvaluateEntries(FLAGS1, rows, cols)
+    dg = gpu.trajectory_.EvaluateEntries(FLAGS1, np.concatenate([rows, cols]), np.concatenate([rows, cols]))     # the diagonal entries of the sampled rows and columns
+    scale = np.sqrt(np.abs(dg[:len(rows)] * dg[len(rows):])) + 1e-30
+    assert np.count_nonzero(vc) > 0.9 * len(vc)
+    err = np.abs(vg - vc) / scale
+    assert err.max() < 1e-9, (err.max(), rows[err.argmax()], cols[err.argmax()])
+    sg = gpu.trajectory_.Optimize(1, FLAGS1); sc = cpu.trajectory_.Optimize(1, FLAGS1)
+    ig, ic_ = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert len(ig) == len(ic_) == 2 and ig[1]["step_is_successful"] == ic_[1]["step_is_successful"] == 1
+    assert abs(ig[1]["cost"] - ic_[1]["cost"]) <= 1e-9 * ic_[1]["cost"], (ig[1], ic_[1])
+    assert abs(ig[1]["step_norm"] - ic_[1]["step_norm"]) <= 1e-6 * ic_[1]["step_norm"], (ig[1], ic_[1])
+    assert abs(ig[1]["relative_decrease"] - ic_[1]["relative_decrease"]) <= 1e-6, (ig[1], ic_[1])
+    assert abs(ig[1]["trust_region_radius"] - ic_[1]["trust_region_radius"]) <= 1e-5 * ic_[1]["trust_region_radius"]
+    assert abs(ig[1]["gradient_max_norm"] - ic_[1]["gradient_max_norm"]) <= 1e-6 * ic_[1]["gradient_max_norm"], (ig[1], ic_[1])
+    assert sg["termination"] == sc["termination"]
+
+
+def test_measurements_added_out_of_time_order():
+    """Views in the string order of the corner file's keys (what the reference's application produces) and IMU samples reversed:
+    the library sorts them (sync_groups) and every result is that of the time-ordered problem -- per-block residuals and Jacobians
+    come back in the CALLER's order (oicc_evaluate_blocks), normal equations and the reference-option solve (inner iterations:
+    plan, tiles and chains all walk the measurements in time order) against the oracle fed in the same shuffled order."""
+    ds = synthetic.make_config("C1")
+    d2 = ds.with_view_order(ds.file_key_order())
+    d2.imu_t_s = d2.imu_t_s[::-1].copy(); d2.accel = d2.accel[::-1].copy(); d2.gyro = d2.gyro[::-1].copy()
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(d2)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(d2)
+    flags = FLAGS1 | E.CAM_LINE_DELAY
+    nrows = {0: 2 * gpu.num_corners, 1: 3 * int(gpu.accl_accepted.sum()), 2: 3 * int(gpu.gyro_accepted.sum())}
+    for kind in (0, 1, 2):
+        rg, Jg = gpu.trajectory_.EvaluateBlocks(flags, kind, nrows[kind]); rc, Jc = cpu.trajectory_.EvaluateBlocks(flags, kind, nrows[kind])
+        assert np.abs(rg - rc).max() <= 1e-12 * (1 + np.abs(rc).max()), kind
+        scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc).max() + 1e-30
+        assert (np.abs(Jg - Jc) / scale).max() < 1e-8, kind
+    cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1); cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(gg, gc) < 1e-9 and rel_err(Hg, Hc) < 1e-9
+    # ... and equal to the time-ordered problem's
+    ref = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cr, Hr, gr = ref.trajectory_.Evaluate(FLAGS1)
+    assert abs(cg - cr) <= 1e-12 * cr and rel_err(Hg, Hr) < 1e-12
+    for c in (gpu, cpu, ref):
+        c.trajectory_.UseReferenceSolverOptions()
+    sg = gpu.trajectory_.Optimize(50, FLAGS1); sc = cpu.trajectory_.Optimize(50, FLAGS1); sr = ref.trajectory_.Optimize(50, FLAGS1)
+    assert sg["num_iterations"] == sc["num_iterations"] == sr["num_iterations"] and sg["inner_sweeps"] == sc["inner_sweeps"] >= 1
+    for a, b in zip(gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+    assert np.abs(gpu.trajectory_.GetT_i_c() - ref.trajectory_.GetT_i_c()).max() < 1e-6

@@ -100,3 +100,20 @@ def test_sets_are_independent(cfg):
         for b in blk:
             key = (int(b[1]), int(b[2])); assert key not in seen; seen.add(key)
     assert len(seen) == len(blocks)
+
+
+def test_views_added_out_of_time_order_give_the_plan_of_the_sorted_problem():
+    """The reference's application fills its reconstruction in the string order of the corner file's keys ("0", "100000", "1000000",
+    "1100000", ..., "200000", ...) and the estimator walks an unordered map: the library must not depend on the order of the
+    Add*Measurement calls.  It sorts what it is given by time (sync_groups); plan and creation order equal those of the time-ordered
+    problem, and the oracle -- which walks the views in time order when it numbers the parameter blocks -- agrees."""
+    ds = synthetic.make_config("C1")
+    order = ds.file_key_order()
+    assert not np.array_equal(order, np.arange(ds.num_views))
+    d2 = ds.with_view_order(order)
+    ref, ns_ref, _ = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(ds).trajectory_.plan(FLAGS1)
+    host = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(d2)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(d2)
+    blocks, ns, _ = host.trajectory_.plan(FLAGS1)
+    ord_, ns_o = _oracle_ordering(cpu, FLAGS1)
+    assert ns == ns_o == ns_ref and np.array_equal(blocks[:, :3], ord_[:, :3]) and np.array_equal(blocks[:, :5], ref[:, :5])
