@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"
 #include "block_items.cuh"
+#include "ba_math.cuh"   // homogeneous_plus4 / homogeneous_tangent_rows: the board points under SplineOptimFlags::POINTS
 #include "inner_plan.h"
 
 namespace oicc {
@@ -81,6 +82,28 @@ struct OneBlockSink {
     if (JS >= 9 && (kind == IK_AI || kind == IK_GI)) for (int r = 0; r < ROWS; ++r) for (int c = 0; c < n; ++c) J[r * JS + c] = d[r * n + c]; }
 };
 
+// Sink of a BOARD-POINT block (SplineOptimFlags::POINTS): of a corner's row pair only the derivative with respect to the corner's own
+// point matters -- and only if that point is the block's; every other column of view_item is switched off by the caller.
+template <class CFG>
+struct PointBlockSink {
+  static constexpr bool kWantsPoint = true;
+  using LaneCol = LaneColT<CFG::T>;
+  static constexpr int JS = CFG::JS;
+  bool mine; const double* X;   // the corner's point is the block's; its current value
+  LaneCol J, r_out;
+  __device__ __forceinline__ void res(const double* r) const { r_out[0] = r[0]; r_out[1] = r[1]; }
+  __device__ __forceinline__ void zero() const {}
+  __device__ __forceinline__ void so3(int, const double*) const {}
+  __device__ __forceinline__ void r3(const double*, const double*) const {}
+  __device__ __forceinline__ void tic(const double*) const {}
+  __device__ __forceinline__ void ld(const double*) const {}
+  __device__ __forceinline__ void pt(const double* jx) const {
+    if (!mine) return;
+    double Jt[6]; homogeneous_tangent_rows(X, jx, Jt);     // HomogeneousVectorParameterization::ComputeJacobian behind the ambient columns
+    for (int rr = 0; rr < 2; ++rr) for (int c = 0; c < 3; ++c) J[rr * JS + c] = Jt[rr * 3 + c];
+  }
+};
+
 // Sum over the 64 lanes (all active), wave uniform: four DPP row shifts (no LDS traffic) leave the sums of the 16-lane rows in
 // lanes 15, 31, 47, 63; v_readlane brings them together.  ~150 cycles against ~800 for six ds_bpermute steps.
 template <int CTRL>
@@ -124,6 +147,9 @@ __device__ __forceinline__ void block_plus(double* x, int kind, const double* d,
     double rt[3]; so3_rotate(q, dt, rt);
     const Quat r = so3_mul(q, dq);
     x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w; x[4] += rt[0]; x[5] += rt[1]; x[6] += rt[2];
+  } else if (D == 3 && kind == IK_PT) {   // ceres::HomogeneousVectorParameterization(4)::Plus
+    double o[4]; homogeneous_plus4(x, d, o);
+    x[0] = o[0]; x[1] = o[1]; x[2] = o[2]; x[3] = o[3];
   } else {
 #pragma unroll
     for (int c = 0; c < D; ++c) x[c] += d[c];
@@ -326,7 +352,7 @@ __device__ OICC_INNER_ADVANCE_ATTR int inner_lm_advance(InnerLm& S, int kind, in
 // (runs -> corner -> view -> ... is a chain of four dependent global loads) into the lane's column of an LDS array.
 struct ItemRec {
   int kind;              // 0 corner, 1 accelerometer sample, 2 gyroscope sample, -1 none
-  int s_so3, s_r3, sx;   // knot windows; sx: rolling-shutter flag (corner) / bias window (IMU)
+  int s_so3, s_r3, sx;   // knot windows; sx: rolling-shutter flag | board point << 1 (corner) / bias window (IMU)
   double d[10];          // corner: u_so3 u_r3 obs_u obs_v 1/sx 1/sy X[4];  IMU: u_so3 u_r3 u_b m[3] w
 };
 
@@ -345,7 +371,7 @@ __device__ __forceinline__ void inner_load_item(const InnerArgs& A, const double
   if (R.kind == 0) {
     const ViewData& vd = A.vd;
     const int v = vd.corner_view[idx];
-    R.s_so3 = vd.view_s_so3[v]; R.s_r3 = vd.view_s_r3[v]; R.sx = vd.view_rs[v] != 0;
+    R.s_so3 = vd.view_s_so3[v]; R.s_r3 = vd.view_s_r3[v]; R.sx = (vd.view_rs[v] != 0 ? 1 : 0) | (vd.corner_pt[idx] << 1);   // rolling-shutter flag, the corner's board point
     R.d[0] = vd.view_u_so3[v]; R.d[1] = vd.view_u_r3[v]; R.d[2] = vd.corner_u[idx]; R.d[3] = vd.corner_v[idx]; R.d[4] = vd.corner_isx[idx]; R.d[5] = vd.corner_isy[idx];
     const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)vd.corner_pt[idx];   // (the board points are the tail of the parameter vector)
     R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
@@ -358,7 +384,7 @@ __device__ __forceinline__ void inner_load_item(const InnerArgs& A, const double
 
 // residual (+ the Jacobian columns of block `blk`) of one item
 template <bool JAC, class CFG>
-__device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneColT<CFG::T>& J, const LaneColT<CFG::T>& r) {
+__device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const double* xv, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneColT<CFG::T>& J, const LaneColT<CFG::T>& r) {
   constexpr bool R3ONLY = CFG::JS == 3;   // every block of the set is an R^3 knot: the activity flags below are compile-time constants
   const EvalCtx& ctx = A.ctx;
   const int s_so3 = R.s_so3, s_r3 = R.s_r3;
@@ -374,8 +400,18 @@ __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const InnerB
     vc.tic_active = !R3ONLY && blk.kind == IK_TIC; vc.ld_active = !R3ONLY && blk.kind == IK_LD;
     const int bkind = R3ONLY ? int(IK_R3) : blk.kind;
     const OneBlockSink<2, CFG> sink{bkind, bkind == IK_SO3 ? blk.idx - s_so3 : (bkind == IK_R3 ? blk.idx - s_r3 : 0), J, r};
+    const bool rs = (R.sx & 1) != 0;
+    if (!R3ONLY && blk.kind == IK_PT) {   // a board point: every corner of the views that see it counts in the cost, its own corners carry the Jacobian
+      const bool mine = (R.sx >> 1) == blk.idx;
+      const double* xb = xv + blk.xoff;   // (the master writes candidates there; point blocks are never staged in LDS)
+      const double X[4] = {mine ? xb[0] : R.d[6], mine ? xb[1] : R.d[7], mine ? xb[2] : R.d[8], mine ? xb[3] : R.d[9]};
+      vc.spline_active = false; vc.no_so3_rows = true; vc.tic_active = false; vc.ld_active = false;
+      const PointBlockSink<CFG> psink{mine, X, J, r};
+      view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], rs, R.d[2], R.d[3], R.d[4], R.d[5], X, psink);
+      return;
+    }
     const double X[4] = {R.d[6], R.d[7], R.d[8], R.d[9]};
-    view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], R.sx != 0, R.d[2], R.d[3], R.d[4], R.d[5], X, sink);
+    view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], rs, R.d[2], R.d[3], R.d[4], R.d[5], X, sink);
     return;
   }
   const bool accel = R.kind == 1;
@@ -422,7 +458,7 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const doubl
     if (__ballot(R.kind >= 0) == 0ull) continue;   // (padding slots of the last wave of a run)
     if (JAC) for (int k = 0; k < 3 * JS; ++k) J[k] = 0.0;
     res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
-    if (R.kind >= 0) inner_eval_item<JAC, CFG>(A, blk, P, R, J, res);
+    if (R.kind >= 0) inner_eval_item<JAC, CFG>(A, xv, blk, P, R, J, res);
     const double r0 = res[0], r1 = res[1], r2 = res[2];
     const double c = wave_sum(0.5 * (r0 * r0 + r1 * r1 + r2 * r2));
     if (lane == 0) row[nv - 1] += c;
@@ -476,7 +512,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const In
   const int n_pairs = pl.n_so3 - 1, s_lo = blk.idx > 0 ? blk.idx - 1 : 0;   // SO(3) knot: table entries s_lo, s_lo + 1; it owns the pairs idx - 1 and idx
   // ---- the block's neighbourhood: knots, segment tables and scalars its items read -> LDS (one workgroup per block and the
   // ranges fit), else the items read the parameter vector
-  const bool local = ctl == nullptr && blk.nks <= kCapS && blk.nkr <= kCapR && blk.nkab <= kCapB && blk.nkgb <= kCapB;
+  const bool local = ctl == nullptr && blk.kind != IK_PT && blk.nks <= kCapS && blk.nkr <= kCapR && blk.nkab <= kCapB && blk.nkgb <= kCapB;
   ParamView P;
   if (local) {
     for (int e = tid; e < 4 * blk.nks; e += kInnerThreads) s_so3[e] = xv[pl.so3 + 4 * (int64_t)blk.ks0 + e];
@@ -563,6 +599,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const In
           case IK_LD: nc = inner_lm_advance<1, 1>(S, IK_LD, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_AI: nc = inner_lm_advance<6, 6>(S, IK_AI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_GI: nc = inner_lm_advance<9, 9>(S, IK_GI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_PT: nc = inner_lm_advance<3, 4>(S, IK_PT, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           default: nc = inner_lm_advance<3, 3>(S, blk.kind, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;   // R^3 knot, gravity, bias knots
         }
         s_cmd = nc;

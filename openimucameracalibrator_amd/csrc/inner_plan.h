@@ -7,7 +7,7 @@
 
 namespace oicc {
 
-enum InnerKind { IK_SO3 = 0, IK_R3, IK_TIC, IK_G, IK_LD, IK_AB, IK_GB, IK_AI, IK_GI };
+enum InnerKind { IK_SO3 = 0, IK_R3, IK_TIC, IK_G, IK_LD, IK_AB, IK_GB, IK_AI, IK_GI, IK_PT };   // IK_PT: a board point (SplineOptimFlags::POINTS, impl.h:136-153): homogeneous 4-vector, 3 tangent dimensions; idx = point index
 
 // A run of consecutive items (in the device arrays' order) that depend on one block:
 // kind 0 corners [first, first + count) (their views through ViewData::corner_view), 1 accelerometer samples, 2 gyroscope samples

@@ -29,6 +29,11 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
   const std::vector<int32_t>* Lc[4] = {&L.so3, &L.r3, &L.ab, &L.gb};
   std::vector<int> id[4] = {std::vector<int>(pl.n_so3, -1), std::vector<int>(pl.n_r3, -1), std::vector<int>(pl.n_ab, -1), std::vector<int>(pl.n_gb, -1)};
   int id_o[5] = {-1, -1, -1, -1, -1};                                          // T_i_c, gravity, line delay, accelerometer / gyroscope intrinsics
+  // SplineOptimFlags::POINTS (impl.h:136-153): the board points the views observe are blocks too (homogeneous 4-vectors, 3 tangent
+  // dimensions).  A view is ONE residual block over all its corners, so a point depends on every view that sees it, and the points of
+  // a view are neighbours of each other: no interval structure -- their edges are listed (xadj below), everything else stays as it is.
+  const bool pts_active = L.a_pts > 0;
+  std::vector<int> id_pt(pts_active ? L.pts.size() : 0, -1);
   struct Fam { std::vector<int32_t> lo[4], first, count; std::vector<uint8_t> ld; int cls[3], ncls, scal[3], nscal; size_t size() const { return first.size(); } };
   Fam F[3];
   F[0].ncls = 2; F[0].cls[0] = CS; F[0].cls[1] = CR; F[0].nscal = 2; F[0].scal[0] = 0; F[0].scal[1] = 2;                       // views: T_i_c, line delay (rolling shutter views)
@@ -65,6 +70,11 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
         if (o == 2 && !F[f].ld[g]) continue;
         if (id_o[o] < 0 && L.other[o] >= 0) id_o[o] = create(sc_kind[o], 0, sc_dim[o], sc_amb[o], sc_xoff[o]);
       }
+      if (f == 0 && pts_active)   // the view's tracks, behind the line delay (impl.h:583-589; the reference's order inside a view is that of an unordered map: here the corners' order)
+        for (int32_t c = F[0].first[g]; c < F[0].first[g] + F[0].count[g]; ++c) {
+          const int32_t pt = p->corner_pt[size_t(c)];
+          if (id_pt[size_t(pt)] < 0 && L.pts[size_t(pt)] >= 0) id_pt[size_t(pt)] = create(IK_PT, pt, 3, 4, pl.pts + 4 * int64_t(pt));
+        }
     };
     for (size_t g = 0; g < F[0].size(); ++g) visit(0, g);
     size_t ga = 0, gg = 0;
@@ -152,6 +162,29 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
       if (open) trun.push_back(TaggedRun{v, InnerRun{f, r0, r1 - r0, 0}});
     }
   }
+  // board points: listed edges (both directions), runs = the corners of every view that sees the point, the knots those views read
+  std::vector<std::vector<int>> xadj(pts_active ? size_t(n) : 0);
+  if (pts_active) {
+    std::vector<int> ids, pv; std::vector<char> in_view(L.pts.size(), 0);
+    std::vector<std::vector<InnerRun>> pruns{size_t(n)};
+    for (size_t g = 0; g < F[0].size(); ++g) {
+      ids.clear(); pv.clear();
+      for (int q = 0; q < F[0].ncls; ++q) { const int c = F[0].cls[q]; for (int32_t k = F[0].lo[c][g]; k < F[0].lo[c][g] + wcls[c]; ++k) if (id[c][k] >= 0) ids.push_back(id[c][k]); }
+      if (id_o[0] >= 0) ids.push_back(id_o[0]);
+      if (id_o[2] >= 0 && F[0].ld[g]) ids.push_back(id_o[2]);
+      for (int32_t c = F[0].first[g]; c < F[0].first[g] + F[0].count[g]; ++c) { const int32_t pt = p->corner_pt[size_t(c)]; if (!in_view[size_t(pt)] && id_pt[size_t(pt)] >= 0) { in_view[size_t(pt)] = 1; pv.push_back(id_pt[size_t(pt)]); } }
+      for (int v : pv) {
+        in_view[size_t(B[v].b.idx)] = 0;
+        for (int x : ids) { xadj[size_t(v)].push_back(x); xadj[size_t(x)].push_back(v); }
+        for (int w : pv) if (w != v) xadj[size_t(v)].push_back(w);
+        std::vector<InnerRun>& rr = pruns[size_t(v)];
+        if (!rr.empty() && rr.back().first + rr.back().count == F[0].first[g]) rr.back().count += F[0].count[g];
+        else rr.push_back(InnerRun{0, F[0].first[g], F[0].count[g], 0});
+        for (int q = 0; q < F[0].ncls; ++q) { const int c = F[0].cls[q]; hull(B[v], c, F[0].lo[c][g], F[0].lo[c][g] + wcls[c]); }
+      }
+    }
+    for (int v = 0; v < n; ++v) { auto& a = xadj[size_t(v)]; std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); for (const InnerRun& r : pruns[size_t(v)]) trun.push_back(TaggedRun{v, r}); }
+  }
   // per vertex: the families' intervals of one class merged (the families overlap), the knot ranges its items read, its degree
   std::vector<int> deg(n, 0);
   {   // gather the tagged runs and intervals per vertex (counting sort: generation order kept inside a vertex)
@@ -179,6 +212,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
     int d = 0;
     for (size_t k = size_t(iv_off[v]); k < iv.size(); ++k) { const Iv& x = iv[k]; const std::vector<int>& ids = id[x.c]; for (int32_t j = x.lo; j < x.hi; ++j) d += ids[j] >= 0 && ids[j] != v; }
     for (int o = 0; o < 5; ++o) if (scal_nb[v] & (1u << o)) ++d;
+    if (pts_active) d += int(xadj[size_t(v)].size());   // (edges to and between board points: disjoint from the interval / scalar edges)
     deg[v] = d;
   }
   iv_off[n] = int32_t(iv.size());
@@ -186,6 +220,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
   auto for_neighbours = [&](int v, auto&& fn) {
     for (int32_t k = iv_off[v]; k < iv_off[v + 1]; ++k) { const Iv& x = iv[k]; const std::vector<int>& ids = id[x.c]; for (int32_t j = x.lo; j < x.hi; ++j) { const int w = ids[j]; if (w >= 0 && w != v) fn(w); } }
     for (int o = 0; o < 5; ++o) if (scal_nb[v] & (1u << o)) fn(id_o[o]);
+    if (pts_active) for (int w : xadj[size_t(v)]) fn(w);
   };
   // Ceres' recursive independent-set ordering: round after round the greedy maximal independent set of what is left, vertices in
   // order of increasing degree (ties: creation order); degrees are kept up to date as vertices leave.  (Bucket sort by degree:

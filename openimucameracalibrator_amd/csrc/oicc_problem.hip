@@ -486,7 +486,6 @@ int oicc_evaluate_blocks(oicc_problem* p, int32_t flags, int32_t kind, double* r
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summary* sum) {
   const double t_start = now_s();
   struct PlanJoin { oicc_problem* q; ~PlanJoin() { q->wait_plan(); } } plan_join{p};   // (no exit of this call leaves the second thread running)
-  if ((flags & OICC_POINTS) && p->opt["inner_iterations"] != 0.0) { p->err = "OICC_POINTS with inner iterations is not supported (the reference's application never sets POINTS)"; return OICC_ERR_UNSUPPORTED; }
   if (p->opt["inner_iterations"] != 0.0 && p->inner_src == nullptr && p->reduce == nullptr) p->plan_wanted_flags = flags;   // the plan's host part runs under the set-up (prepare)
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;

@@ -34,7 +34,7 @@
 
 namespace inner {
 
-enum { PB_SO3 = 0, PB_R3, PB_TIC, PB_G, PB_LD, PB_AB, PB_GB, PB_AI, PB_GI };
+enum { PB_SO3 = 0, PB_R3, PB_TIC, PB_G, PB_LD, PB_AB, PB_GB, PB_AI, PB_GI, PB_PT };   // PB_PT: a board point under SplineOptimFlags::POINTS (impl.h:136-153)
 
 struct PBlock {
   int kind = 0, idx = 0, dim = 0, off = -1, order = 0;   // off: tangent offset in the layout, order: creation order in the reference
@@ -52,6 +52,7 @@ inline double* block_data(Problem& p, const PBlock& b, int* n) {
     case PB_AB: *n = 3; return &p.ab[3 * b.idx];
     case PB_GB: *n = 3; return &p.gb[3 * b.idx];
     case PB_AI: *n = 6; return p.acc_intr;
+    case PB_PT: *n = 4; return &p.pts[4 * b.idx];
     default: *n = 9; return p.gyr_intr;
   }
 }
@@ -78,6 +79,9 @@ inline void block_plus(Problem& p, const PBlock& b, const double* d) {
     const Quat<double> r = so3_mul(q, dq);
     p.T_i_c[0] = r.x; p.T_i_c[1] = r.y; p.T_i_c[2] = r.z; p.T_i_c[3] = r.w;
     for (int c = 0; c < 3; ++c) p.T_i_c[4 + c] += rt[c];
+  } else if (b.kind == PB_PT) {   // ceres::HomogeneousVectorParameterization(4)::Plus
+    double out[4]; homogeneous_plus(&p.pts[4 * b.idx], d, out);
+    for (int c = 0; c < 4; ++c) p.pts[4 * b.idx + c] = out[c];
   } else {
     int n; double* x = block_data(p, b, &n);
     for (int c = 0; c < n; ++c) x[c] += d[c];
@@ -90,7 +94,7 @@ inline void block_plus(Problem& p, const PBlock& b, const double* d) {
 inline void build_blocks(const Problem& p, const Layout& L, const Active& a, std::vector<PBlock>* out) {
   std::vector<PBlock>& B = *out; B.clear();
   const size_t ns = L.so3.size(), nr = L.r3.size(), nab = L.ab.size(), ngb = L.gb.size();
-  std::vector<int> id_so3(ns, -1), id_r3(nr, -1), id_ab(nab, -1), id_gb(ngb, -1); int id_o[5] = {-1, -1, -1, -1, -1};
+  std::vector<int> id_so3(ns, -1), id_r3(nr, -1), id_ab(nab, -1), id_gb(ngb, -1), id_pt(L.pts.size(), -1); int id_o[5] = {-1, -1, -1, -1, -1};
   auto get = [&](int kind, int idx, int dim, int off, int* slot) -> int {
     if (off < 0) return -1;
     if (*slot < 0) { PBlock b; b.kind = kind; b.idx = idx; b.dim = dim; b.off = off; b.order = int(B.size()); *slot = int(B.size()); B.push_back(b); }
@@ -113,6 +117,10 @@ inline void build_blocks(const Problem& p, const Layout& L, const Active& a, std
     for (int k = 0; k < kN; ++k) ids.push_back(get(PB_R3, int(vb.s_r3 + k), 3, L.r3[vb.s_r3 + k], &id_r3[vb.s_r3 + k]));
     ids.push_back(get(PB_TIC, 0, 6, L.other[0], &id_o[0]));
     if (vb.rs) ids.push_back(get(PB_LD, 0, 1, L.other[2], &id_o[2]));
+    // the view's tracks, behind the line delay (impl.h:583-589).  The reference lists them in the order of view->TrackIds(), an
+    // unordered map: not defined; here in the order of the view's corners.  A view's points all belong to ONE residual block:
+    // they are neighbours of each other in the Hessian graph.
+    if (a.pts) for (int64_t c = vb.c0; c < vb.c1; ++c) { const int pt = p.pidx[size_t(c)]; ids.push_back(get(PB_PT, pt, 3, L.pts[size_t(pt)], &id_pt[size_t(pt)])); }
     for (int id : ids) if (id >= 0) B[id].views.push_back(int(v));
   }
   const size_t nimu = std::max(p.acc.size(), p.gyr.size());

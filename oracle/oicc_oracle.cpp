@@ -870,7 +870,6 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   int iter = 0, invalid = 0;
   // inner iterations (ceres_inner.hpp): set up when the reduced program has at least two parameter blocks
   inner::Ordering ord; bool inner_enabled = false;
-  if (p.opt["inner_iterations"] != 0 && a.pts) { p.err = "POINTS with inner iterations is not restated (the reference never sets POINTS)"; return OICC_ERR_UNSUPPORTED; }
   if (p.opt["inner_iterations"] != 0) { inner::build_ordering(p, L, a, &ord); inner_enabled = ord.blocks.size() >= 2; }
   const double inner_tol = p.opt["inner_iteration_tolerance"];
   const bool line_search = p.opt["bounds_line_search"] != 0 && (a.ab || a.gb);   // is_constrained

@@ -68,7 +68,9 @@ def _pair(cfg, **kw):
 
 
 @pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES | E.CAM_LINE_DELAY | E.IMU_INTRINSICS), ("C1", FLAGS1 | E.CAM_LINE_DELAY),
-                                       ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES), ("C3", FLAGS1)])
+                                       ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES), ("C3", FLAGS1),
+                                       # SplineOptimFlags::POINTS: the board points as blocks (listed edges next to the intervals)
+                                       ("tiny", FLAGS1 | E.POINTS), ("tiny", E.T_I_C | E.POINTS), ("C1", FLAGS1 | E.POINTS | E.CAM_LINE_DELAY | E.IMU_BIASES)])
 def test_library_plan_equals_the_oracles_ordering(cfg, flags):
     ds, host, cpu = _pair(cfg)
     blocks, n_sets, n_wgs = host.trajectory_.plan(flags)
