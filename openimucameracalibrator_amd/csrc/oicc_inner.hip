@@ -439,11 +439,15 @@ int oicc_debug_create_host_only(oicc_problem** out) {   // a problem object with
 void oicc_debug_destroy_host_only(oicc_problem* p) { if (p) { p->wait_plan(); delete p; } }
 // per block, in processing order: [set, kind, idx, n_items, n_slots, first run's kind, first run's first item, nruns]; returns the number of blocks (or -needed)
 int oicc_debug_host_inner_plan(oicc_problem* p, int32_t flags, int32_t* out8, int32_t cap_blocks, int32_t* n_sets, int32_t* n_wgs) {
+  const double t0 = now_s();
   sync_groups(p);
+  const double t1 = now_s();
   make_layout_host(p, flags);
+  const double t2 = now_s();
   InnerPlanOptions o; o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = false; o.resident_wgs = 256; o.shared_share = 0.5; o.layout_gen = 0;
   double ms[3];
   build_inner_plan_host(p, o, ms);
+  if (p->opt["verbose"] >= 2.0) std::printf("[oicc] host only: runs of samples %.3f ms, host layout %.3f ms, plan: blocks + neighbourhoods %.3f, independent sets %.3f, runs + workgroups %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1), ms[0], ms[1], ms[2]);
   const oicc_problem::InnerPlan& ip = p->inner;
   if (n_sets) *n_sets = int32_t(ip.group_first.size()) - 1;
   if (n_wgs) *n_wgs = int32_t(ip.wgs.size());
