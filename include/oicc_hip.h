@@ -58,8 +58,9 @@ typedef enum oicc_camera_model {
 typedef enum oicc_optim_flags {
   OICC_POINTS = 1 << 0, /* impl.h:136-153: the board points the views observe become variables (homogeneous 4-vectors under
                          * ceres::HomogeneousVectorParameterization(4): 3 tangent dimensions each, the LAST arrow columns, in
-                         * point order).  Never set by the reference CLI; here: complete, not tuned (csrc/kernels_points.hip),
-                         * not combinable with the inner_iterations option (OICC_ERR_UNSUPPORTED). */
+                         * point order).  Never set by the reference CLI; here: complete, not tuned (csrc/kernels_points.hip).
+                         * With the inner_iterations option (round 5) every board point is one more block of the sweep: it
+                         * depends on every view that sees it and the points of a view are neighbours (one residual block). */
   OICC_T_I_C = 1 << 1,
   OICC_IMU_BIASES = 1 << 2,
   OICC_IMU_INTRINSICS = 1 << 3,
@@ -231,7 +232,14 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * before every candidate evaluation once bias knots with box bounds, impl.h:206-240, are variable).
  * projected_gradient_norm 0|1 (1 = gradient_max_norm of such a bounds-constrained program as Ceres computes it).
  * The applications set all three to 1 as the reference's Ceres behaves; the library default
- * is 0 so that plain LM steps stay available to callers and tests. */
+ * is 0 so that plain LM steps stay available to callers and tests.
+ * device_lm 1|0 (round 5): plain LM steps (none of the three above in effect, one rank, tile assembly) take their trust-region
+ * decisions ON THE DEVICE -- per iteration the host enqueues solve, retraction, ONE Jacobian pass at the candidate (cost, gradient
+ * and normal equations together) and a one-thread decision kernel (accept / reject, radius, tolerances: LmCtl, csrc/oicc_device.h)
+ * and polls a pinned word one iteration behind; 0 = the host-driven loop (a separate cost pass, one read-back per iteration).
+ * owner_computes_sweeps 1|0: see oicc_set_shard.
+ * Measurements may be added in any order (the reference walks an unordered map of views): the library sorts them by time before
+ * anything is derived from them; per-block dumps (oicc_evaluate_blocks) stay in the caller's order. */
 int oicc_set_option(oicc_problem* p, const char* name, double value);
 int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,
                   oicc_summary* summary);
@@ -285,7 +293,16 @@ int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double*
  *                         to rank `peer` and receive `recv_count` doubles from it (either may be 0); op OICC_XCHG_BROADCAST: `send`
  *                         (= `recv`) holds `send_count` doubles on rank `peer`, which every rank receives in place.  Ordered on the
  *                         given stream, like the all-reduce hook.
- * Without oicc_set_shard the all-reduce of the whole buffer ("v1") is what runs. */
+ * Without oicc_set_shard the all-reduce of the whole buffer ("v1") is what runs.
+ * Round 5: (a) an owner's range travels as ONE contiguous message of packed rows [band | arrow | gradient] -- one in-place
+ * ncclAllGather of equal slots (or one broadcast per owner: hook transport) instead of a + 2 strided pieces per owner --, the halo rows
+ * of all peers in ONE send / receive group; (b) whether the exchange is used is AGREED ON by all ranks once per layout (a sum of
+ * [ready, 1, hash, hash^2] through the installed reduction; any rank that is not ready or derived other cuts sends every rank to the
+ * all-reduce of the whole buffer): oicc_set_shard with nranks > 1 is therefore a collective statement -- every rank must make it;
+ * (c) with an inner-iteration source (oicc_set_inner_iteration_source) the SWEEPS are owner-computes too (option
+ * owner_computes_sweeps, default 1): a rank minimises only the knot blocks whose band rows it owns (plus the few blocks every view /
+ * sample depends on, replicated; rank 0's result counts) and after every independent set the owners broadcast the knot ranges the set
+ * changed -- the sweep's work divides by the number of ranks instead of being replicated. */
 enum { OICC_XCHG_SENDRECV = 0, OICC_XCHG_BROADCAST = 1 };
 typedef int (*oicc_exchange_fn)(void* user, int32_t op, void* send, int64_t send_count, void* recv, int64_t recv_count,
                                 int32_t peer, void* hip_stream);

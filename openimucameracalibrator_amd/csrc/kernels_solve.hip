@@ -550,10 +550,8 @@ __global__ void lm_decide_kernel(LmCtl* ctl, const LmState* st, int64_t off_cost
   c.done = done;
   c.seq = seq + 1;
   *ctl = c;
-  if (c.host != nullptr) {   // the host polls this one iteration behind
-    if (done != 0) __hip_atomic_store(&c.host->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&c.host->seq, seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (c.host != nullptr)   // the host polls this one iteration behind; it reads nothing else the device wrote, so no release fence
+    __hip_atomic_store(&c.host->word, ((long long)done << 32) | ((seq + 1) & 0xffffffffll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream) {
   hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(64), 0, stream, ctl, st, off_cost);

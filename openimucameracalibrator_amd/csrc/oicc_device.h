@@ -108,7 +108,7 @@ struct LmIterRec {            // = oicc_iteration (include/oicc_hip.h), checked 
   int32_t iteration, step_is_successful;
   double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
 };
-struct LmHostMsg { long long seq; int done; int pad; };   // pinned host memory, written by the device (system scope)
+struct LmHostMsg { long long word; long long pad; };   // pinned host memory, ONE 8-byte word written by the device: decisions taken so far (low 32 bits) | LmCtl::done << 32 -- a single relaxed system-scope store: no release fence (= an L2 write-back) in the decision kernel
 struct LmCtl {
   double* xp[2];              // parameter vectors: [0] current, [1] candidate
   double* nep[2];             // packed normal equations: [0] at the current point, [1] the Jacobian pass at the candidate fills this one

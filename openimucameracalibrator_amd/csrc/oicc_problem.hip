@@ -116,7 +116,7 @@ int device_lm_begin(oicc_problem* p, LmCtl h, int trace_cap) {
   h.segp[0] = s0 ? s0->buf.p : nullptr; h.segp[1] = s1 ? s1->buf.p : nullptr;
   h.done = 0; h.iter = 0; h.invalid = 0; h.num_successful = 0; h.num_unsuccessful = 0; h.seq = 0; h.trace_n = 0; h.trace_cap = trace_cap;
   h.trace = p->d_trace.p; h.stamps = p->d_stamps.p; h.host = p->hmsg_dev;
-  __atomic_store_n(&p->hmsg->seq, 0ll, __ATOMIC_RELAXED); __atomic_store_n(&p->hmsg->done, 0, __ATOMIC_RELEASE);
+  __atomic_store_n(&p->hmsg->word, 0ll, __ATOMIC_RELEASE);
   HIPCK(p, hipMemcpyAsync(p->d_ctl.p, &h, sizeof(LmCtl), hipMemcpyHostToDevice, st));
   HIPCK(p, hipStreamSynchronize(st));   // (h is a stack object; once per solve)
   return OICC_OK;
@@ -138,15 +138,15 @@ int device_lm_enqueue(oicc_problem* p, SolveBuffers sb, double min_diag, double 
 // then so that a device fault ends the wait instead of hanging it.
 int device_lm_wait(oicc_problem* p, long long want, int* done) {
   unsigned spins = 0;
+  auto look = [&](long long* seq) { const long long w = __atomic_load_n(&p->hmsg->word, __ATOMIC_ACQUIRE); *seq = w & 0xffffffffll; return int(w >> 32); };
   while (true) {
-    const int d = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE);
-    const long long s = __atomic_load_n(&p->hmsg->seq, __ATOMIC_ACQUIRE);
-    if (d != 0 || s >= want) { *done = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE); return OICC_OK; }
+    long long s; const int d = look(&s);
+    if (d != 0 || s >= want) { *done = d; return OICC_OK; }
     if ((++spins & 0xfff) == 0) {
       const hipError_t e = hipStreamQuery(p->stream);
       if (e == hipSuccess) {   // everything enqueued has run: the word is final
-        *done = __atomic_load_n(&p->hmsg->done, __ATOMIC_ACQUIRE);
-        if (*done != 0 || __atomic_load_n(&p->hmsg->seq, __ATOMIC_ACQUIRE) >= want) return OICC_OK;
+        *done = look(&s);
+        if (*done != 0 || s >= want) return OICC_OK;
         p->err = "device-side LM control: the stream drained without the awaited decision"; return OICC_ERR_STATE;
       }
       if (e != hipErrorNotReady) { p->err = std::string("device-side LM control: ") + hipGetErrorString(e); return OICC_ERR_HIP; }
