@@ -22,6 +22,7 @@
 #include <mutex>
 #include <unordered_map>
 #include "oicc_device.h"
+#include "lm_decide.cuh"
 
 namespace oicc {
 
@@ -744,17 +745,19 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
   }
 }
 
-// device-side LM control: the system to build, its radius and the reuse-diagonal flag come from the control block
-__device__ __forceinline__ bool lm_ctl_build_inputs(NormalEq& ne, SolveBuffers& sb, int& reuse_diagonal) {
+// device-side LM control: the system to build, its radius and the reuse-diagonal flag come from the control block -- as the host
+// or an earlier kernel left it, or derived here from the previous iteration's state and results (lm_decide.cuh)
+__device__ __forceinline__ bool lm_ctl_build_inputs(NormalEq& ne, SolveBuffers& sb, int& reuse_diagonal, bool writer) {
   if (sb.ctl == nullptr) return true;
-  if (sb.ctl->done != 0) return false;
-  ne.base = sb.ctl->nep[0]; sb.radius = sb.ctl->radius; reuse_diagonal = sb.ctl->reuse_diagonal;
+  __shared__ LmCtl s_c;
+  if (!lm_ctl_next_state(sb, writer, &s_c)) return false;
+  ne.base = s_c.nep[0]; sb.radius = s_c.radius; reuse_diagonal = s_c.reuse_diagonal;
   return true;
 }
 
 __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal, double min_diag,
                                  double max_diag, BcrArgs A) {
-  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal)) return;
+  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal, blockIdx.x == 0 && threadIdx.x == 0)) return;
   bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
@@ -763,7 +766,7 @@ __global__ void bcr_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb,
 // the build, which still writes every block for the later levels -- while the other workgroups build the system.
 __global__ __launch_bounds__(64 * kInvWaves) void bcri_build_invert_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                                                            double min_diag, double max_diag, BcrArgs A) {
-  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal)) return;
+  if (!lm_ctl_build_inputs(ne, sb, reuse_diagonal, (int)blockIdx.x == A.n / 2 && threadIdx.x == 0)) return;   // (the writer: thread 0 of the first build workgroup, which also resets LmState for this step)
   const int npiv = A.n / 2;
   if ((int)blockIdx.x >= npiv) {
     bcr_build_body(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, (int64_t)((int)blockIdx.x - npiv) * blockDim.x + threadIdx.x, (int64_t)((int)gridDim.x - npiv) * blockDim.x);

@@ -24,15 +24,17 @@
 #include "spline_math.cuh"
 #include "spline_seg.cuh"
 #include "ba_math.cuh"   // homogeneous_plus4: the board points under SplineOptimFlags::POINTS
+#include "lm_decide.cuh"
 
 namespace oicc {
 
 // ---- build the damped system  M = S H S + diag(D2),  rhs = -S g ----------------
 __global__ void lm_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                 double min_diag, double max_diag) {
-  if (sb.ctl != nullptr) {   // device-side LM control (oicc_device.h)
-    if (sb.ctl->done != 0) return;
-    ne.base = sb.ctl->nep[0]; sb.radius = sb.ctl->radius; reuse_diagonal = sb.ctl->reuse_diagonal;
+  if (sb.ctl != nullptr) {   // device-side LM control (oicc_device.h, lm_decide.cuh)
+    __shared__ LmCtl s_c;
+    if (!lm_ctl_next_state(sb, blockIdx.x == 0 && threadIdx.x == 0, &s_c)) return;
+    ne.base = s_c.nep[0]; sb.radius = s_c.radius; reuse_diagonal = s_c.reuse_diagonal;
   }
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -490,71 +492,17 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
 // LmState).  Mirrors the host loop of oicc_optimize = TrustRegionMinimizer::Minimize [EXT Ceres 2.1.0] with the reference's
 // options: invalid step -> shrink; parameter / function tolerance; IsStepSuccessful -> swap the buffers, StepAccepted(rho);
 // else StepRejected; then the tests Ceres makes before the next iteration (iterations, gradient tolerance, radius).
-__global__ void lm_decide_kernel(LmCtl* ctl, const LmState* st, int64_t off_cost) {
+__global__ void lm_decide_kernel(LmCtl* out, const LmCtl* prev, const LmState* st, int64_t off_cost) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  // ONE wide load of the control block and of the step's scalars (field-by-field reads behind the stores below would each wait for
-  // their own round trip: 4.8 us for this kernel in the first round-5 profile), the decision on the copies, one store back
-  LmCtl c = *ctl;
+  LmCtl c = *prev;                 // (one wide load of the control block and of the step's scalars, the decision on the copies, one store)
+  if (c.done != 0) { *out = c; return; }
   const LmState hs = *st;
-  if (c.done != 0) return;
-  const long long seq = c.seq;
-  const double cand_cost = c.nep[1][off_cost];
-  const double cost = c.cost;
-  double radius = c.radius;
-  int done = LM_RUNNING;
-  bool push = true;
-  LmIterRec rec;
-  const int iter = c.iter + 1;
-  c.iter = iter;
-  const double model_cost_change = hs.model_cost_change;
-  const bool ok = hs.chol_failed == 0 && isfinite(model_cost_change) && isfinite(hs.step_norm_sq) && model_cost_change > 0.0;
-  if (c.hold) {          // benchmark: the full decision arithmetic, no state change
-    const double rel = (cost - cand_cost) / model_cost_change;
-    rec = LmIterRec{iter, ok && rel > c.min_rel_dec ? 1 : 0, cand_cost, cost - cand_cost, hs.gradient_max_norm, sqrt(hs.step_norm_sq), rel, radius};
-    if (!ok) done = LM_DONE_INVALID_STEPS;   // (the benchmark's system must stay solvable)
-  } else if (!ok) {         // invalid step: LINEAR_SOLVER_FAILURE or a non-positive model decrease
-    c.invalid += 1;
-    if (c.invalid >= c.max_invalid) { done = LM_DONE_INVALID_STEPS; rec = LmIterRec{iter, 0, cost, 0.0, c.gmax, 0.0, 0.0, radius}; push = false; }
-    else {
-      radius /= c.decrease_factor; c.decrease_factor *= 2.0; c.reuse_diagonal = 1; c.num_unsuccessful += 1;
-      rec = LmIterRec{iter, 0, cost, 0.0, c.gmax, 0.0, 0.0, radius};
-    }
-  } else {
-    c.invalid = 0;
-    const double x_norm = sqrt(hs.x_norm_sq), step_norm = sqrt(hs.step_norm_sq);
-    const double cost_change = cost - cand_cost, rel_dec = cost_change / model_cost_change;
-    if (step_norm <= c.ptol * (x_norm + c.ptol)) { done = LM_DONE_PARAMETER_TOL; rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius}; }
-    else if (fabs(cost_change) <= c.ftol * cost) { done = LM_DONE_FUNCTION_TOL; rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius}; }
-    else if (rel_dec > c.min_rel_dec) {   // IsStepSuccessful: the candidate and its normal equations become current
-      double* t = c.xp[0]; c.xp[0] = c.xp[1]; c.xp[1] = t;
-      t = c.nep[0]; c.nep[0] = c.nep[1]; c.nep[1] = t;
-      t = c.segp[0]; c.segp[0] = c.segp[1]; c.segp[1] = t;
-      c.cost = cand_cost; c.gmax = hs.gradient_max_norm; c.num_successful += 1;
-      const double q = 2.0 * rel_dec - 1.0;
-      radius = fmin(c.max_radius, radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
-      c.decrease_factor = 2.0; c.reuse_diagonal = 0;
-      rec = LmIterRec{iter, 1, cand_cost, cost_change, hs.gradient_max_norm, step_norm, rel_dec, radius};
-    } else {
-      radius /= c.decrease_factor; c.decrease_factor *= 2.0; c.reuse_diagonal = 1; c.num_unsuccessful += 1;
-      rec = LmIterRec{iter, 0, cost, cost_change, c.gmax, step_norm, rel_dec, radius};
-    }
-  }
-  c.radius = radius;
-  if (push && c.trace != nullptr && c.trace_n < c.trace_cap) c.trace[c.trace_n++] = rec;
-  if (done == LM_RUNNING && !c.hold) {   // what the host loop tests before it starts the next iteration, in its order
-    if (iter >= c.max_iters) done = LM_DONE_MAX_ITERATIONS;
-    else if (radius <= c.min_radius) done = LM_DONE_MIN_RADIUS;
-    else if (rec.step_is_successful && c.gmax <= c.gtol) done = LM_DONE_GRADIENT_TOL;
-  }
-  if (c.stamps != nullptr && seq < c.trace_cap) c.stamps[3 * seq + 2] = wall_clock64();
-  c.done = done;
-  c.seq = seq + 1;
-  *ctl = c;
-  if (c.host != nullptr)   // the host polls this one iteration behind; it reads nothing else the device wrote, so no release fence
-    __hip_atomic_store(&c.host->word, ((long long)done << 32) | ((seq + 1) & 0xffffffffll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  LmIterRec rec; bool push = false;
+  lm_decide_compute(c, hs, c.nep[1][off_cost], &rec, &push);
+  lm_decide_publish(out, c, rec, push);
 }
-void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream) {
-  hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(64), 0, stream, ctl, st, off_cost);
+void launch_lm_decide(LmCtl* out, const LmCtl* prev, const LmState* st, int64_t off_cost, hipStream_t stream) {
+  hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(64), 0, stream, out, prev, st, off_cost);
 }
 
 }  // namespace oicc

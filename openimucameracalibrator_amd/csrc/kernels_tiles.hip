@@ -627,27 +627,27 @@ __global__ void __launch_bounds__(256) slab_merge_kernel(TileParams tp, NormalEq
     // slab offsets -> slab values) are issued for all of them before the first is needed (the kernel is latency bound otherwise)
     const int WA = tl.W + tl.a;
     const int64_t total = (int64_t)tp.n_merge_rows * WA, stride = (int64_t)nb_rows * 256;
-    int i[kMergeU], e[kMergeU], k0[kMergeU], k1[kMergeU]; bool ok[kMergeU];
+    int e[kMergeU]; bool ok[kMergeU]; int hh[kMergeU];
+    int64_t t0[kMergeU], s0[kMergeU], s1[kMergeU], s2[kMergeU];
 #pragma unroll
     for (int u = 0; u < kMergeU; ++u) {
       const int64_t idx = (int64_t)b * 256 + threadIdx.x + u * stride;
       ok[u] = idx < total;
       const int h = ok[u] ? int(idx / WA) : 0;
-      e[u] = ok[u] ? int(idx - (int64_t)h * WA) : 0;
-      i[u] = tp.merge_rows[h]; k0[u] = tp.merge_ptr[h]; k1[u] = ok[u] ? tp.merge_ptr[h + 1] : k0[u];
+      hh[u] = h; e[u] = ok[u] ? int(idx - (int64_t)h * WA) : 0;
+      const int64_t* t = tp.merge_tab + 4 * (int64_t)h;        // [row | count << 32, source 0, 1, 2]: one 32-byte record
+      t0[u] = t[0]; s0[u] = t[1]; s1[u] = t[2]; s2[u] = t[3];
     }
-    int64_t s0[kMergeU], s1[kMergeU];
+    double v0[kMergeU], v1[kMergeU], v2[kMergeU];
 #pragma unroll
-    for (int u = 0; u < kMergeU; ++u) { s0[u] = k1[u] > k0[u] ? tp.merge_src[k0[u]] : -1; s1[u] = k1[u] > k0[u] + 1 ? tp.merge_src[k0[u] + 1] : -1; }
-    double v0[kMergeU], v1[kMergeU];
-#pragma unroll
-    for (int u = 0; u < kMergeU; ++u) { v0[u] = s0[u] >= 0 ? tp.slabs[s0[u] + e[u]] : 0.0; v1[u] = s1[u] >= 0 ? tp.slabs[s1[u] + e[u]] : 0.0; }
+    for (int u = 0; u < kMergeU; ++u) { v0[u] = s0[u] >= 0 ? tp.slabs[s0[u] + e[u]] : 0.0; v1[u] = s1[u] >= 0 ? tp.slabs[s1[u] + e[u]] : 0.0; v2[u] = s2[u] >= 0 ? tp.slabs[s2[u] + e[u]] : 0.0; }
 #pragma unroll
     for (int u = 0; u < kMergeU; ++u) {
       if (!ok[u]) continue;
-      double s = v0[u] + v1[u];                                          // (tile order: a fixed summation order)
-      for (int k = k0[u] + 2; k < k1[u]; ++k) s += tp.slabs[tp.merge_src[k] + e[u]];
-      const int ii = i[u], ee = e[u];
+      double s = (v0[u] + v1[u]) + v2[u];                                 // (chain order: a fixed summation order)
+      const int cnt = int(t0[u] >> 32);
+      if (cnt > 3) { const int k0 = tp.merge_ptr[hh[u]]; for (int k = k0 + 3; k < k0 + cnt; ++k) s += tp.slabs[tp.merge_src[k] + e[u]]; }
+      const int ii = int(t0[u] & 0xffffffffll), ee = e[u];
       if (ee < tl.W) ne.band()[(int64_t)ii * tl.W + ee] = s;
       else ne.Et()[(int64_t)(ee - tl.W) * tl.Pb + ii] = s;
     }

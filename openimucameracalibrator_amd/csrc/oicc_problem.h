@@ -53,7 +53,7 @@ void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const
                        const NormalEq& ne, double max_ab, double max_gb, hipStream_t st, double alpha = 1.0, int with_model = 1, double* seg_out = nullptr);
 void launch_lm_step_slope(const double* g, const SolveBuffers& sb, int P, double* out, hipStream_t st);
 void launch_lm_projected_gradient(const double* x, const ParamLayout& pl, const TangentLayout& tl, const NormalEq& ne, double max_ab, double max_gb, LmState* s, hipStream_t st);
-void launch_lm_decide(LmCtl* ctl, const LmState* st, int64_t off_cost, hipStream_t stream);   // the trust-region decision on the device (kernels_solve.hip)
+void launch_lm_decide(LmCtl* out, const LmCtl* prev, const LmState* st, int64_t off_cost, hipStream_t stream);   // the trust-region decision on the device (kernels_solve.hip)
 }  // namespace oicc
 
 
@@ -166,13 +166,14 @@ struct oicc_problem {
   DevBuf<LmState> d_state; DevBuf<double> d_ls; int64_t line_search_steps = 0;   // d_ls: slope and max norm of the step (bounds line search)
   // device-side LM control (oicc_device.h: LmCtl): the control block, the iteration records and kernel time stamps it fills, and the
   // pinned word the decision kernel writes for the host (polled one iteration behind; no copy, no event in the loop)
+  LmState* lm_state_cur = nullptr;   // device-side control: the LmState slot of the iteration being enqueued (the control block and LmState alternate between two slots)
   DevBuf<LmCtl> d_ctl; DevBuf<LmIterRec> d_trace; DevBuf<long long> d_stamps; LmHostMsg* hmsg = nullptr; LmHostMsg* hmsg_dev = nullptr; double wall_clock_hz = 1e8;
   struct HostPin { LmState st; double cost; double radius; double ls[2]; };
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_tile_rows, h_merge_rows; std::vector<uint8_t> h_row_direct;
-  DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src;
+  DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src, d_merge_tab; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src, h_merge_tab;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_tile_rows; DevBuf<double> d_slabs;
   RowFmt fv{}, fa{}, fg{}; TileParams tp{};
   std::unique_ptr<TileStatic> h_tstatic; DevBuf<TileStatic> d_tstatic; bool tstatic_valid = false;   // problem-constant kernel arguments in device memory

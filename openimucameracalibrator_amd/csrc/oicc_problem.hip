@@ -59,7 +59,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res, doubl
       dyn.seg = sgt->buf.p;
     }
     dyn.x = x; dyn.ne_base = ne.base; dyn.cost_out = (!jac && cost_out) ? cost_out : ne.cost(); dyn.dbg_res = dbg_res; dyn.dbg_jac = dbg_jac; dyn.prof = prof; dyn.only_kind = only_kind;
-    dyn.gmax = p->gmax_folded ? &p->d_state.p->gradient_max_norm : nullptr;
+    dyn.gmax = p->gmax_folded ? &(p->lm_state_cur ? p->lm_state_cur : p->d_state.p)->gradient_max_norm : nullptr;
     dyn.view_rs = force_rs ? p->d_view_rs_all.p : p->d_view_rs.p;
     if (launch_tile_pass(*p->h_tstatic, p->d_tstatic.p, dyn, jac, st) != 0) {
       p->err = "tile kernel launch failed"; return OICC_ERR_HIP; }
@@ -110,27 +110,39 @@ bool device_lm_applicable(oicc_problem* p, bool inner, bool line_search, bool pr
 // Upload the control block: current = d_x / ne, candidate = d_xc / ne2.
 int device_lm_begin(oicc_problem* p, LmCtl h, int trace_cap) {
   hipStream_t st = p->stream;
-  if (!p->d_ctl.resize(1) || !p->d_trace.resize(size_t(std::max(trace_cap, 1))) || !p->d_stamps.resize(size_t(3) * std::max(trace_cap, 1))) { p->err = "hipMalloc LM control"; return OICC_ERR_HIP; }
+  if (!p->d_ctl.resize(2) || !p->d_trace.resize(size_t(std::max(trace_cap, 1))) || !p->d_stamps.resize(size_t(3) * std::max(trace_cap, 1))) { p->err = "hipMalloc LM control"; return OICC_ERR_HIP; }
   h.xp[0] = p->d_x.p; h.xp[1] = p->d_xc.p; h.nep[0] = p->ne.base; h.nep[1] = p->ne2.base;
   oicc_problem::SegTable* s0 = p->seg_of(p->d_x.p); oicc_problem::SegTable* s1 = p->seg_of(p->d_xc.p);
   h.segp[0] = s0 ? s0->buf.p : nullptr; h.segp[1] = s1 ? s1->buf.p : nullptr;
   h.done = 0; h.iter = 0; h.invalid = 0; h.num_successful = 0; h.num_unsuccessful = 0; h.seq = 0; h.trace_n = 0; h.trace_cap = trace_cap;
   h.trace = p->d_trace.p; h.stamps = p->d_stamps.p; h.host = p->hmsg_dev;
   __atomic_store_n(&p->hmsg->word, 0ll, __ATOMIC_RELEASE);
-  HIPCK(p, hipMemcpyAsync(p->d_ctl.p, &h, sizeof(LmCtl), hipMemcpyHostToDevice, st));
+  HIPCK(p, hipMemcpyAsync(p->d_ctl.p, &h, sizeof(LmCtl), hipMemcpyHostToDevice, st));   // slot 0: the state iteration 0 runs with
+  HIPCK(p, hipMemsetAsync(p->d_state.p, 0, 2 * sizeof(LmState), st));
   HIPCK(p, hipStreamSynchronize(st));   // (h is a stack object; once per solve)
   return OICC_OK;
 }
-// One iteration: damped solve -> retraction -> Jacobian pass at the candidate (its merge leaves the candidate's cost and max |g|) ->
-// the decision.  Nothing here waits for the device.
-int device_lm_enqueue(oicc_problem* p, SolveBuffers sb, double min_diag, double max_diag) {
+// Iteration k: damped solve -> retraction -> Jacobian pass at the candidate (its merge leaves the candidate's cost and max |g|).  The
+// DECISION of iteration k - 1 is taken inside this iteration's build kernel (every workgroup derives the state from the previous
+// one, lm_decide.cuh): no kernel of its own.  The control block and LmState alternate between two slots.  Nothing here waits.
+int device_lm_enqueue(oicc_problem* p, SolveBuffers sb, double min_diag, double max_diag, int k) {
   hipStream_t st = p->stream;
-  sb.ctl = p->d_ctl.p;
+  LmCtl* const cur = p->d_ctl.p + (k & 1); LmState* const stc = p->d_state.p + (k & 1);
+  sb.ctl = cur; sb.st = stc; sb.off_cost = p->ne.off_cost;
+  sb.ctl_prev = k > 0 ? p->d_ctl.p + ((k - 1) & 1) : nullptr; sb.st_prev = k > 0 ? p->d_state.p + ((k - 1) & 1) : nullptr;
   if (launch_lm_solve(p->ne, p->tl, sb, 0.0, 0, min_diag, max_diag, st) != 0) {
     p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)"; return OICC_ERR_UNSUPPORTED; }
   launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, p->tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, p->seg_precomputed() ? p->seg_tab[0].buf.p : nullptr);
-  int rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true, nullptr, p->d_ctl.p); if (rc) return rc;
-  launch_lm_decide(p->d_ctl.p, p->d_state.p, p->ne.off_cost, st);
+  p->lm_state_cur = stc;
+  const int rc = eval_pass(p, p->d_xc.p, true, nullptr, nullptr, -1, false, &p->ne2, false, nullptr, true, nullptr, cur);
+  p->lm_state_cur = nullptr;
+  if (rc) return rc;
+  HIPCK(p, hipGetLastError());
+  return OICC_OK;
+}
+// The decision of the LAST enqueued iteration (k_last): a kernel of its own, into the slot the next iteration would have run with.
+int device_lm_settle(oicc_problem* p, int k_last) {
+  launch_lm_decide(p->d_ctl.p + ((k_last + 1) & 1), p->d_ctl.p + (k_last & 1), p->d_state.p + (k_last & 1), p->ne.off_cost, p->stream);
   HIPCK(p, hipGetLastError());
   return OICC_OK;
 }
@@ -157,9 +169,9 @@ int device_lm_wait(oicc_problem* p, long long want, int* done) {
   }
 }
 // After the loop: the control block as the device left it; the problem's buffers take the roles it ended with.
-int device_lm_end(oicc_problem* p, LmCtl* out, std::vector<LmIterRec>* trace, std::vector<long long>* stamps) {
+int device_lm_end(oicc_problem* p, int k_last, LmCtl* out, std::vector<LmIterRec>* trace, std::vector<long long>* stamps) {
   hipStream_t st = p->stream;
-  HIPCK(p, hipMemcpyAsync(out, p->d_ctl.p, sizeof(LmCtl), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipMemcpyAsync(out, p->d_ctl.p + ((k_last + 1) & 1), sizeof(LmCtl), hipMemcpyDeviceToHost, st));
   HIPCK(p, hipStreamSynchronize(st));
   const int n = std::min(out->trace_n, out->trace_cap);
   if (trace) { trace->resize(size_t(n)); if (n > 0) HIPCK(p, hipMemcpyAsync(trace->data(), p->d_trace.p, size_t(n) * sizeof(LmIterRec), hipMemcpyDeviceToHost, st)); }
@@ -589,10 +601,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
   }
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
-  // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide_kernel).  Per iteration the host enqueues
-  // solve -> retraction -> Jacobian pass at the candidate (cost, gradient, normal equations in one pass: no separate cost pass) ->
-  // decision, and looks at a pinned word the decision kernel wrote ONE ITERATION EARLIER: no copy, no event, no synchronisation
-  // inside the loop; the iteration enqueued past the end returns at its first instruction (LmCtl::done).
+  // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide.cuh).  Per iteration the host enqueues
+  // solve -> retraction -> Jacobian pass at the candidate (cost, gradient, normal equations in one pass: no separate cost pass); the
+  // decision of an iteration is taken inside the NEXT iteration's build kernel (a kernel of its own only behind the last one), and the
+  // host looks at a pinned word that kernel wrote, two iterations behind what it has enqueued: no copy, no event, no synchronisation
+  // inside the loop; iterations enqueued past the end return at their first instruction (LmCtl::done).
   if (device_lm_applicable(p, inner_enabled || p->opt["inner_iterations"] != 0.0, line_search, projected_gmax)) {
     LmCtl h; std::memset(&h, 0, sizeof(h));
     h.radius = radius; h.decrease_factor = 2.0; h.cost = cost; h.gmax = gmax;
@@ -601,13 +614,15 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     if (max_iters <= 0) return finish(OICC_NO_CONVERGENCE, "Maximum number of iterations reached.");
     if (radius <= min_radius) return finish(OICC_CONVERGENCE, "Minimum trust region radius reached.");
     rc = device_lm_begin(p, h, max_iters); if (rc) return rc;
-    int done = 0;
+    int done = 0, k_last = -1;
     for (int k = 0; k < max_iters && done == 0; ++k) {
-      rc = device_lm_enqueue(p, sb, min_diag, max_diag); if (rc) return rc;
-      if (k >= 1) { rc = device_lm_wait(p, k, &done); if (rc) return rc; }   // the decision of iteration k - 1
+      rc = device_lm_enqueue(p, sb, min_diag, max_diag, k); if (rc) return rc;
+      k_last = k;
+      if (k >= 2) { rc = device_lm_wait(p, k - 1, &done); if (rc) return rc; }   // the decision of iteration k - 2 (taken by the build kernel of iteration k - 1): the host stays two iterations ahead
     }
+    rc = device_lm_settle(p, k_last); if (rc) return rc;
     std::vector<LmIterRec> recs; std::vector<long long> stamps;
-    rc = device_lm_end(p, &h, &recs, &stamps); if (rc) return rc;
+    rc = device_lm_end(p, k_last, &h, &recs, &stamps); if (rc) return rc;
     for (const LmIterRec& r : recs) { oicc_iteration it; std::memcpy(&it, &r, sizeof(it)); p->trace.push_back(it);
       if (verbose) std::printf("[oicc] iter %d %s cost %.12e change %.3e rho %.3f |step| %.3e gmax %.3e radius %.3e (device-side control)\n", it.iteration, it.step_is_successful ? "ok " : "rej", it.cost, it.cost_change, it.relative_decrease, it.step_norm, it.gradient_max_norm, it.trust_region_radius); }
     const double tick = 1.0 / p->wall_clock_hz;
@@ -858,12 +873,14 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
     h.min_radius = p->opt["min_trust_region_radius"]; h.max_radius = p->opt["max_trust_region_radius"]; h.min_rel_dec = p->opt["min_relative_decrease"];
     h.max_iters = steps; h.max_invalid = int(p->opt["max_num_consecutive_invalid_steps"]); h.hold = 1;
     rc = device_lm_begin(p, h, steps); if (rc) return rc;
-    int done = 0;
+    int done = 0, k_last = -1;
     for (int it = 0; it < steps && done == 0; ++it) {
-      rc = device_lm_enqueue(p, sb, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"]); if (rc) return rc;
-      if (it >= 1) { rc = device_lm_wait(p, it, &done); if (rc) return rc; }
+      rc = device_lm_enqueue(p, sb, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], it); if (rc) return rc;
+      k_last = it;
+      if (it >= 2) { rc = device_lm_wait(p, it - 1, &done); if (rc) return rc; }
     }
-    rc = device_lm_end(p, &h, nullptr, nullptr); if (rc) return rc;
+    if (k_last >= 0) { rc = device_lm_settle(p, k_last); if (rc) return rc; }
+    rc = device_lm_end(p, std::max(k_last, 0), &h, nullptr, nullptr); if (rc) return rc;
     if (h.done != 0 || h.seq != steps) { p->err = "Cholesky failed in benchmark iteration"; return OICC_ERR_STATE; }
     return OICC_OK;
   }

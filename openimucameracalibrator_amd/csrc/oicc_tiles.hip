@@ -293,6 +293,12 @@ int build_tiles(oicc_problem* p) {
     if (!std::binary_search(p->h_merge_rows.begin(), p->h_merge_rows.begin() + tp.n_merge_rows, i)) { p->h_merge_rows.push_back(i); p->h_merge_ptr.push_back(int32_t(p->h_merge_src.size())); }
   }
   tp.n_merge_rows = int32_t(p->h_merge_rows.size());
+  p->h_merge_tab.assign(size_t(4) * std::max(tp.n_merge_rows, 1), -1);   // (tiles.h: merge_tab)
+  for (int h = 0; h < tp.n_merge_rows; ++h) {
+    const int32_t k0 = p->h_merge_ptr[size_t(h)], k1 = p->h_merge_ptr[size_t(h) + 1];
+    p->h_merge_tab[size_t(4) * h] = int64_t(uint32_t(p->h_merge_rows[size_t(h)])) | (int64_t(k1 - k0) << 32);
+    for (int k = 0; k < 3 && k0 + k < k1; ++k) p->h_merge_tab[size_t(4) * h + 1 + k] = p->h_merge_src[size_t(k0 + k)];
+  }
   if (p->h_merge_rows.empty()) p->h_merge_rows.push_back(0);
   if (p->h_merge_src.empty()) p->h_merge_src.push_back(0);
   if (p->h_tile_rows.empty()) p->h_tile_rows.push_back(0);
@@ -312,12 +318,12 @@ int build_tiles(oicc_problem* p) {
   hipStream_t st = p->stream;
   DevArena& TA = p->tile_arena;
   TA.add(p->d_tiles, p->h_tiles); TA.add(p->d_units, p->h_units); TA.add(p->d_tile_rows, p->h_tile_rows); TA.add(p->d_merge_rows, p->h_merge_rows);
-  TA.add(p->d_merge_ptr, p->h_merge_ptr); TA.add(p->d_merge_src, p->h_merge_src); TA.add(p->d_row_direct, p->h_row_direct);
+  TA.add(p->d_merge_ptr, p->h_merge_ptr); TA.add(p->d_merge_src, p->h_merge_src); TA.add(p->d_merge_tab, p->h_merge_tab); TA.add(p->d_row_direct, p->h_row_direct);
   if (!TA.commit(st) ||
       !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_chains) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows in %d chains of %d, %d waves, %d units, accumulator %d rows x %d (+%d), slab %d rows, %d of %d rows merged, row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
                                            tp.n_tiles, T, tp.n_chains, tp.chain_len, tp.n_waves, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, tp.slab_rows, tp.n_merge_rows, tl.Pb, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
-  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.tile_rows = p->d_tile_rows.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.row_direct = p->d_row_direct.p;
+  tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.tile_rows = p->d_tile_rows.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.merge_tab = p->d_merge_tab.p; tp.row_direct = p->d_row_direct.p;
   return OICC_OK;
 }
 

@@ -89,6 +89,8 @@ struct TileParams {
   const int32_t* tile_rows;                           // see TileDesc::rows_off
   const int32_t* merge_rows; int32_t n_merge_rows;   // the band rows the merge kernel sums from slabs (every row that more than one chain touches)
   const int32_t* merge_ptr; const int64_t* merge_src; // CSR over merge_rows: offsets (in doubles) of the slab rows to add, in chain order
+  const int64_t* merge_tab;                           // round 5: per merge row ONE 32-byte record [row | count << 32, source 0, 1, 2] (-1: none): the merge kernel's
+                                                      // entries take two dependent load levels (record -> slabs) instead of four (rows / offsets -> sources -> slabs -> third source -> slab); a fourth and further sources come from the CSR
   const uint8_t* row_direct;                          // per band row: 1 = stored by its chain
 };
 
