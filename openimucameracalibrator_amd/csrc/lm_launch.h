@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <vector>
+#include <utility>
 #include <cstring>
 #include "oicc_device.h"
 
@@ -57,17 +58,20 @@ struct DevBuf {
 // measurement arrays of the GoPro9 configuration).  add() registers an array, commit() packs them into a host staging block
 // (256-byte aligned pieces), grows the device block if needed, copies once and points every DevBuf at its piece.
 struct DevArena {
-  struct Item { const void* src; size_t bytes, off; void (*attach)(void* buf, void* dev, size_t count); void* buf; size_t count; size_t rbytes = 0; };   // rbytes: size of a piece without host data
+  struct Item { const void* src; size_t bytes, off; void (*attach)(void* buf, void* dev, size_t count); void* buf; size_t count; size_t rbytes = 0; void (*detach)(void* buf) = nullptr; };   // rbytes: size of a piece without host data
   std::vector<Item> items; std::vector<unsigned char> stage; unsigned char* dev = nullptr; size_t cap = 0;
+  std::vector<std::pair<void*, void (*)(void*)>> attached;   // the buffers the last commit() pointed into this block, and how to detach one (p = nullptr, n = 0)
   ~DevArena() { if (dev) (void)hipFree(dev); }
   template <class T>
   void add(DevBuf<T>& b, const std::vector<T>& h) {
     items.push_back(Item{h.data(), h.size() * sizeof(T), 0, [](void* buf, void* d, size_t c) { static_cast<DevBuf<T>*>(buf)->attach(static_cast<T*>(d), c); }, &b, std::max<size_t>(h.size(), 1)});
+    items.back().detach = [](void* buf) { DevBuf<T>* q = static_cast<DevBuf<T>*>(buf); if (!q->owned) { q->p = nullptr; q->n = 0; q->owned = true; } };
   }
   template <class T>
   void reserve(DevBuf<T>& b, size_t count) {   // a piece without host data (workspace)
     items.push_back(Item{nullptr, 0, 0, [](void* buf, void* d, size_t c) { static_cast<DevBuf<T>*>(buf)->attach(static_cast<T*>(d), c); }, &b, std::max<size_t>(count, 1)});
     items.back().rbytes = std::max<size_t>(count, 1) * sizeof(T);
+    items.back().detach = [](void* buf) { DevBuf<T>* q = static_cast<DevBuf<T>*>(buf); if (!q->owned) { q->p = nullptr; q->n = 0; q->owned = true; } };
   }
   bool commit(hipStream_t st) {   // (the staging block outlives the asynchronous copy: it belongs to the arena)
     size_t total = 0;
@@ -99,7 +103,11 @@ struct DevArena {
       if (open && hipMemcpyAsync(dev + run0, stage.data() + run0, run1 - run0, hipMemcpyHostToDevice, st) != hipSuccess) return false;
     }
     (void)staged_end;
-    for (const Item& it : items) it.attach(it.buf, dev + it.off, it.count);
+    // a buffer that pointed into this block after the LAST commit and is not part of this one would keep a pointer into space that
+    // is laid out anew (the advisor's finding: d_tl_pts is only registered under POINTS): detach it first
+    for (const auto& a : attached) { bool again = false; for (const Item& it : items) again = again || it.buf == a.first; if (!again) a.second(a.first); }
+    attached.clear();
+    for (const Item& it : items) { it.attach(it.buf, dev + it.off, it.count); attached.emplace_back(it.buf, it.detach); }
     items.clear();
     return true;
   }

@@ -219,12 +219,14 @@ int oicc_set_shard(oicc_problem* p, int32_t nranks, int32_t rank) {
 
 int oicc_set_exchange(oicc_problem* p, oicc_exchange_fn fn, void* user) { p->exchange = fn; p->exchange_user = user; return OICC_OK; }
 
+namespace { struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } }; }   // (destroyed on every exit of the timing entry points)
+
 int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes) {
   int rc = prepare(p, flags); if (rc) return rc;
   if (!p->reduce) { p->err = "no reduction path installed (oicc_rccl_init / oicc_set_allreduce)"; return OICC_ERR_STATE; }
   hipStream_t st = p->stream;
   HIPCK(p, hipMemsetAsync(p->d_ne2.p, 0, p->ne.total * sizeof(double), st));   // (the second buffer: the current system stays intact)
-  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  EventPair ev; HIPCK(p, hipEventCreate(&ev.a)); HIPCK(p, hipEventCreate(&ev.b)); hipEvent_t e0 = ev.a, e1 = ev.b;
   if (p->reduce(p->reduce_user, p->d_ne2.p, p->ne.total, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }   // warm-up (connection set-up)
   HIPCK(p, hipEventRecord(e0, st));
   for (int i = 0; i < repeats; ++i) if (p->reduce(p->reduce_user, p->d_ne2.p, p->ne.total, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
@@ -232,7 +234,6 @@ int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double*
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   if (ms_per_call) *ms_per_call = double(ms) / std::max(repeats, 1);
   if (bytes) *bytes = int64_t(p->ne.total) * int64_t(sizeof(double));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return OICC_OK;
 }
 
@@ -242,7 +243,7 @@ int oicc_time_exchange(oicc_problem* p, int32_t flags, int32_t repeats, double* 
   if (repeats < 0) return OICC_OK;                                               // (a local question: is the exchange set up? nothing is sent)
   hipStream_t st = p->stream;
   HIPCK(p, hipMemsetAsync(p->d_ne2.p, 0, p->ne.total * sizeof(double), st));   // (the second buffer: the current system stays intact)
-  hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
+  EventPair ev; HIPCK(p, hipEventCreate(&ev.a)); HIPCK(p, hipEventCreate(&ev.b)); hipEvent_t e0 = ev.a, e1 = ev.b;
   int64_t moved = 0;
   rc = owner_exchange(p, p->ne2, st, &moved); if (rc) return rc;                  // warm-up (connection set-up)
   HIPCK(p, hipEventRecord(e0, st));
@@ -251,7 +252,6 @@ int oicc_time_exchange(oicc_problem* p, int32_t flags, int32_t repeats, double* 
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   if (ms_per_call) *ms_per_call = double(ms) / std::max(repeats, 1);
   if (bytes_moved) *bytes_moved = moved;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return OICC_OK;
 }
 

@@ -241,7 +241,13 @@ void make_layout_host(oicc_problem* p, int flags) {
   if (a.pts) {
     // (time shards: the ranks must agree on the layout, and a rank does not know which points the other ranks' views see -- all
     // points then; one that no view sees anywhere keeps a zero gradient and never moves)
-    if (p->has_remote_views) std::fill(L.pts.begin(), L.pts.end(), 0);
+    // Round 5 (the advisor's finding: unobserved points entered the layout and |x| of the sharded run only): with a reduction
+    // installed the ranks sum a mask of the points their own views see once per set of measurements (prepare()), and every rank
+    // lays out exactly the observed points, as one process holding all views does.
+    if (p->has_remote_views) {
+      if (p->pts_seen_global.size() == L.pts.size() && p->pts_seen_meas_gen == p->meas_gen) { for (size_t i = 0; i < L.pts.size(); ++i) if (p->pts_seen_global[i]) L.pts[i] = 0; }
+      else std::fill(L.pts.begin(), L.pts.end(), 0);
+    }
     for (int32_t id : p->corner_pt) L.pts[id] = 0;
     for (int32_t& o : L.pts) if (o == 0) { o = off; off += 3; L.a_pts += 3; }
   }
@@ -318,6 +324,19 @@ int prepare(oicc_problem* p, int flags) {
   if (plan_wanted != flags) p->wait_plan();   // (a plan job of an earlier call reads what this call may rebuild)
   sync_groups(p);
   const bool current = p->layout_flags == flags && p->layout_ld_zero == (p->x[p->pl.ld] == 0.0) && p->layout_opt_gen == p->opt_gen;   // layout, buffers and tiles are current
+  if (!current && (flags & OICC_POINTS) && p->has_remote_views && p->reduce != nullptr && p->pts_seen_meas_gen != p->meas_gen && p->pl.n_pts > 0) {
+    // which board points the views of ANY rank observe: a sum of per-rank masks through the installed reduction (a collective: every
+    // rank prepares the same flags at the same point of its program, as it does for every pass)
+    std::vector<double> m(size_t(p->pl.n_pts), 0.0);
+    for (int32_t id : p->corner_pt) m[size_t(id)] = 1.0;
+    if (!p->d_xagree.resize(m.size())) { p->err = "hipMalloc point mask"; return OICC_ERR_HIP; }
+    HIPCK(p, hipMemcpyAsync(p->d_xagree.p, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    if (p->reduce(p->reduce_user, p->d_xagree.p, int64_t(m.size()), p->stream) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+    HIPCK(p, hipMemcpyAsync(m.data(), p->d_xagree.p, m.size() * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    p->pts_seen_global.assign(m.size(), 0); for (size_t i = 0; i < m.size(); ++i) p->pts_seen_global[i] = m[i] > 0.0;
+    p->pts_seen_meas_gen = p->meas_gen;
+  }
   if (!current) make_layout_host(p, flags);
   // The inner-iteration plan of the solve that called (oicc_optimize announces it) only needs the host layout: its host part runs
   // on a second thread under the uploads and the tiles below (build_inner_plan joins it).

@@ -130,6 +130,7 @@ struct oicc_problem {
                      uint32_t hash = 0; } owner;
   DevBuf<int32_t> d_xrows, d_xcut; DevBuf<double> d_xsend, d_xrecv, d_xgather, d_xagree;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
+  std::vector<uint8_t> pts_seen_global; int64_t pts_seen_meas_gen = -1, meas_gen = 0;   // SplineOptimFlags::POINTS on time shards: which board points ANY rank's views observe (summed once through the reduction, prepare()); meas_gen counts the Add* calls
   bool has_remote_views = false;   // other ranks hold views too: under SplineOptimFlags::POINTS every board point is a variable on every rank (which points they see is not declared)
   bool meas_dirty = true, groups_dirty = true;
   std::thread plan_thread; InnerPlanOptions plan_job{}; bool plan_job_valid = false; double plan_ms[3] = {0, 0, 0};   // the plan's host part on a second thread (start_inner_plan)

@@ -322,7 +322,7 @@ static int add_views(oicc_problem* p, bool rs, int64_t nv, const int64_t* t_ns, 
     for (int i = 0; i < kN; ++i) { p->so3_in[s_so3 + i] = 1; p->r3_in[s_r3 + i] = 1; }
     p->has_tic_block = true; if (rs) p->has_ld_block = true;
   }
-  p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2;
+  p->meas_dirty = true; p->groups_dirty = true; p->layout_flags = -1; p->inner.flags = -2; ++p->meas_gen;
   return OICC_OK;
 }
 int oicc_add_rs_camera_measurements(oicc_problem* p, int64_t nv, const int64_t* t, const int64_t* co, const double* uv, const double* cov,
