@@ -21,6 +21,7 @@
 // SO(3) knots change the segment tables (spline_seg.cuh) of their two knot pairs: the block's master rewrites those two
 // entries with every candidate (and restores them on a rejected step), the table stays current across the sets.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "oicc_device.h"
 #include "block_items.cuh"
 #include "ba_math.cuh"   // homogeneous_plus4 / homogeneous_tangent_rows: the board points under SplineOptimFlags::POINTS
@@ -33,15 +34,18 @@ namespace oicc {
 // 45 % of a sweep when they ran on the general build: a knot's ~360 items are six waves = two rounds there): the blocks' Jacobian
 // columns are coefficient x 3-vector of the FORWARD pass, so the backward pass and every other parameter group compile away, the
 // kernel fits 256 VGPRs and runs 512 threads = 8 waves -- all items of a knot in one round.
-template <bool R3ONLY>
+template <int MODE>   // 0: general, 1: every block an R^3 knot, 2: general + board-point blocks (SplineOptimFlags::POINTS: plans that hold point blocks only)
 struct InnerCfg {
+  static constexpr bool R3ONLY = MODE == 1;
   static constexpr int T = R3ONLY ? 512 : 256;      // threads of a workgroup
   static constexpr int SLOTS = R3ONLY ? 1024 : 512;  // item slots of a block staged in LDS (two per lane); larger blocks re-read their items
   static constexpr int JS = R3ONLY ? 3 : 9;          // columns kept per Jacobian row of the block
   static constexpr int NJ = 3 * JS + 3;              // per lane: 3 rows x JS columns, then the residuals
+  static constexpr bool R3 = R3ONLY;                 // every block of the launch is an R^3 knot: the activity flags of the item functions are compile-time constants
+  static constexpr bool POINTS = MODE == 2;          // the point path (a second instantiation of view_item behind a call) exists in this build only: with it the general
+                                                     // build spills 380 instead of 129 SGPRs and carries 836 B of scratch (measured on the code object)
 };
 
-constexpr int kCapS = 24, kCapR = 16, kCapB = 8; // knots of the block's neighbourhood staged in LDS (SO(3), R^3, each bias spline)
 enum { INNER_CMD_JAC = 0, INNER_CMD_COST = 1, INNER_CMD_DONE = 2 };
 
 namespace {
@@ -382,10 +386,22 @@ __device__ __forceinline__ void inner_load_item(const InnerArgs& A, const double
   }
 }
 
+// a corner of a view that sees board point blk.idx (SplineOptimFlags::POINTS)
+template <bool JAC, class CFG>
+__device__ __noinline__ void inner_eval_point_corner(ViewConst vc, const double* xv, const InnerBlock& blk, const double* q0, const PSeg sg, const PR3 kr, const ItemRec& R,
+                                                      const LaneColT<CFG::T> J, const LaneColT<CFG::T> r) {
+  const bool rs = (R.sx & 1) != 0, mine = (R.sx >> 1) == blk.idx;
+  const double* xb = xv + blk.xoff;   // (the master writes candidates there; point blocks are never staged in LDS)
+  const double X[4] = {mine ? xb[0] : R.d[6], mine ? xb[1] : R.d[7], mine ? xb[2] : R.d[8], mine ? xb[3] : R.d[9]};
+  vc.spline_active = false; vc.no_so3_rows = true; vc.tic_active = false; vc.ld_active = false;
+  const PointBlockSink<CFG> psink{mine, X, J, r};
+  view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], rs, R.d[2], R.d[3], R.d[4], R.d[5], X, psink);
+}
+
 // residual (+ the Jacobian columns of block `blk`) of one item
 template <bool JAC, class CFG>
 __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const double* xv, const InnerBlock& blk, const ParamView& P, const ItemRec& R, const LaneColT<CFG::T>& J, const LaneColT<CFG::T>& r) {
-  constexpr bool R3ONLY = CFG::JS == 3;   // every block of the set is an R^3 knot: the activity flags below are compile-time constants
+  constexpr bool R3ONLY = CFG::R3;   // every block of the set is an R^3 knot: the activity flags below are compile-time constants
   const EvalCtx& ctx = A.ctx;
   const int s_so3 = R.s_so3, s_r3 = R.s_r3;
   const double* q0 = P.so3 + 4 * (s_so3 - P.ks0);
@@ -401,13 +417,8 @@ __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const double
     const int bkind = R3ONLY ? int(IK_R3) : blk.kind;
     const OneBlockSink<2, CFG> sink{bkind, bkind == IK_SO3 ? blk.idx - s_so3 : (bkind == IK_R3 ? blk.idx - s_r3 : 0), J, r};
     const bool rs = (R.sx & 1) != 0;
-    if (!R3ONLY && blk.kind == IK_PT) {   // a board point: every corner of the views that see it counts in the cost, its own corners carry the Jacobian
-      const bool mine = (R.sx >> 1) == blk.idx;
-      const double* xb = xv + blk.xoff;   // (the master writes candidates there; point blocks are never staged in LDS)
-      const double X[4] = {mine ? xb[0] : R.d[6], mine ? xb[1] : R.d[7], mine ? xb[2] : R.d[8], mine ? xb[3] : R.d[9]};
-      vc.spline_active = false; vc.no_so3_rows = true; vc.tic_active = false; vc.ld_active = false;
-      const PointBlockSink<CFG> psink{mine, X, J, r};
-      view_item<JAC>(vc, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], R.d[1], rs, R.d[2], R.d[3], R.d[4], R.d[5], X, psink);
+    if (CFG::POINTS && blk.kind == IK_PT) {   // a board point: every corner of the views that see it counts in the cost, its own corners carry the Jacobian
+      inner_eval_point_corner<JAC, CFG>(vc, xv, blk, q0, sg, kr, R, J, r);   // (a real call: the second instantiation of view_item stays out of this function's register allocation)
       return;
     }
     const double X[4] = {R.d[6], R.d[7], R.d[8], R.d[9]};
@@ -479,6 +490,179 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const doubl
 
 }  // namespace
 
+// ---- one WAVE per block (round 5) ------------------------------------------------------------------------------------------------
+// A sweep of a large problem is throughput bound (BASELINE config 5: 30 011 blocks, sets of 1700-3300): with one workgroup per
+// block four SIMDs share a block whose items fill 62 % of their lanes, wait at workgroup barriers and idle while ONE lane advances the
+// block's Levenberg-Marquardt loop.  Here a block is minimised by ONE wave (a workgroup = 4 / 8 independent blocks, no workgroup
+// barrier anywhere): the items are walked in rounds of 64 lanes (every run of a residual family padded to 64: a round evaluates one
+// family), read as per-item records with one coalesced load per round (InnerItemRec: nothing of the items lives in LDS), the sums
+// of a round go to the wave's LDS row, lane 0 advances the loop, two lanes refresh the segment-table entries of an SO(3) knot.
+// Same item functions, same advance function, same order of the sums inside a block as the workgroup kernel (a fixed order: lanes, then
+// rounds) -- the host takes this kernel for sets of knot blocks that are large enough to fill the device (oicc_inner.hip).
+template <bool R3ONLY>
+struct InnerWaveCfg {
+  static constexpr int T = R3ONLY ? 512 : 256;   // threads of a workgroup = blocks x 64
+  static constexpr int JS = 3;                    // knot blocks only: three tangent dimensions
+  static constexpr int NJ = 3 * JS + 3;
+  static constexpr int SLOTS = 0;                 // (nothing staged)
+  static constexpr bool R3 = R3ONLY;
+  static constexpr bool POINTS = false;           // (knot blocks only)
+};
+namespace {
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+// slot i of the block -> its record (slot layout as inner_load_item: every run starts at a multiple of 64)
+__device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R) {
+  R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
+  if (i >= blk.n_slots) return;
+  int idx = 0, off = i;
+  for (int r = 0; r < blk.nruns; ++r) {
+    const InnerRun run = A.runs[blk.run0 + r];
+    if (R.kind < 0 && off >= 0 && off < run.count) { R.kind = run.kind; idx = run.first + off; }
+    off -= (run.count + 63) & ~63;
+  }
+  if (R.kind < 0) return;
+  const InnerItemRec q = A.rec[R.kind][idx];
+  R.s_so3 = q.s_so3; R.s_r3 = q.s_r3; R.sx = q.sx;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) R.d[k] = q.d[k];
+  if (R.kind == 0) {
+    const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)(q.sx >> 1);
+    R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
+  }
+}
+}  // namespace
+
+__global__ void inner_records_kernel(ViewData vd, ImuData ia, ImuData ig, InnerItemRec* rc, InnerItemRec* ra, InnerItemRec* rg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < vd.n_corners) {
+    const int v = vd.corner_view[i];
+    InnerItemRec q; q.s_so3 = vd.view_s_so3[v]; q.s_r3 = vd.view_s_r3[v]; q.sx = (vd.view_rs[v] != 0 ? 1 : 0) | (vd.corner_pt[i] << 1); q.pad = 0;
+    q.d[0] = vd.view_u_so3[v]; q.d[1] = vd.view_u_r3[v]; q.d[2] = vd.corner_u[i]; q.d[3] = vd.corner_v[i]; q.d[4] = vd.corner_isx[i]; q.d[5] = vd.corner_isy[i]; q.d[6] = 0.0;
+    rc[i] = q;
+  }
+  for (int s = 0; s < 2; ++s) {
+    const ImuData& id = s == 0 ? ia : ig;
+    if (i < id.n) {
+      InnerItemRec q; q.s_so3 = id.s_so3[i]; q.s_r3 = s == 0 ? id.s_r3[i] : 0; q.sx = id.s_b[i]; q.pad = 0;
+      q.d[0] = id.u_so3[i]; q.d[1] = s == 0 ? id.u_r3[i] : 0.0; q.d[2] = id.u_b[i]; q.d[3] = id.mx[i]; q.d[4] = id.my[i]; q.d[5] = id.mz[i]; q.d[6] = id.w[i];
+      (s == 0 ? ra : rg)[i] = q;
+    }
+  }
+}
+
+// wave w of workgroup g: block b0 + g * (T / 64) + w of the plan (a set's knot blocks are contiguous there)
+template <bool R3ONLY>
+__global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(const InnerArgs* __restrict__ Sp, double* xv, int b0, int n_blocks) {
+  using CFG = InnerWaveCfg<R3ONLY>;
+  constexpr int T = CFG::T, NW = T / 64;
+  __shared__ double s_J[CFG::NJ * T];
+  __shared__ double s_so3[NW][4 * kCapS], s_seg[NW][kSegStride * kCapS], s_r3[NW][3 * kCapR], s_ab[NW][3 * kCapB], s_gb[NW][3 * kCapB], s_scal[NW][26];
+  __shared__ double s_row[NW][16];
+  __shared__ InnerLm S_all[NW];
+  __shared__ int s_cmd[NW];
+  const InnerArgs& A = *Sp;
+  const ParamLayout& pl = A.ctx.pl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bi = (int)blockIdx.x * NW + wave;
+  if (bi >= n_blocks) return;                       // (whole waves: no workgroup barrier below)
+  const InnerBlock blk = A.blocks[b0 + bi];
+  InnerLm& S = S_all[wave];
+  const int d = blk.dim, nv = d * (d + 1) / 2 + d + 1;
+  const bool so3 = !R3ONLY && blk.kind == IK_SO3;
+  const int n_pairs = pl.n_so3 - 1, s_lo = blk.idx > 0 ? blk.idx - 1 : 0;
+  // the block's neighbourhood -> the wave's LDS copy (the host only sends blocks whose ranges fit)
+  for (int e = lane; e < 4 * blk.nks; e += 64) s_so3[wave][e] = xv[pl.so3 + 4 * (int64_t)blk.ks0 + e];
+  for (int e = lane; e < kSegStride * (blk.nks - 1); e += 64) s_seg[wave][e] = A.seg[(size_t)blk.ks0 * kSegStride + e];
+  for (int e = lane; e < 3 * blk.nkr; e += 64) s_r3[wave][e] = xv[pl.r3 + 3 * (int64_t)blk.kr0 + e];
+  for (int e = lane; e < 3 * blk.nkab; e += 64) s_ab[wave][e] = xv[pl.ab + 3 * (int64_t)blk.kab0 + e];
+  for (int e = lane; e < 3 * blk.nkgb; e += 64) s_gb[wave][e] = xv[pl.gb + 3 * (int64_t)blk.kgb0 + e];
+  if (lane < 26) s_scal[wave][lane] = xv[pl.tic + lane];
+  const ParamView P{s_so3[wave], s_seg[wave], s_r3[wave], s_ab[wave], s_gb[wave], s_scal[wave], blk.ks0, blk.kr0, blk.kab0, blk.kgb0};
+  double* xl = nullptr;
+  switch (blk.kind) {
+    case IK_SO3: xl = s_so3[wave] + 4 * (blk.idx - blk.ks0); break;
+    case IK_R3: xl = s_r3[wave] + 3 * (blk.idx - blk.kr0); break;
+    case IK_AB: xl = s_ab[wave] + 3 * (blk.idx - blk.kab0); break;
+    default: xl = s_gb[wave] + 3 * (blk.idx - blk.kgb0); break;
+  }
+  if (lane == 0) {
+    S.radius = 1e4; S.decrease_factor = 2.0; S.cost = 0.0; S.x_norm = 0.0; S.model = 0.0;
+    S.iter = 0; S.invalid = 0; S.reuse_diagonal = 0; S.first = 1; S.seg_action = 0;
+  }
+  if (lane < blk.ambient) S.xcur[lane] = xv[blk.xoff + lane];
+  if (so3) {
+    const double* q = xv + pl.so3;
+    if (lane >= 16 && lane < 20) S.qprev[lane - 16] = blk.idx > 0 ? q[4 * (int64_t)(blk.idx - 1) + (lane - 16)] : 0.0;
+    if (lane >= 20 && lane < 24) S.qnext[lane - 20] = blk.idx + 1 < pl.n_so3 ? q[4 * (int64_t)(blk.idx + 1) + (lane - 20)] : 0.0;
+    if (lane >= 24 && lane < 24 + 2 * kSegStride) { const int e = lane - 24; S.segcur[e] = s_lo * kSegStride + e < n_pairs * kSegStride ? A.seg[(size_t)s_lo * kSegStride + e] : 0.0; }
+  }
+  wave_sync();
+  const LaneColT<T> J{s_J + tid}, res{s_J + 3 * CFG::JS * T + tid};
+  double* const row = s_row[wave];
+  int cmd = INNER_CMD_JAC;
+  while (true) {
+    if (lane < 16) row[lane] = 0.0;
+    wave_sync();
+    for (int base = 0; base < blk.n_slots; base += 64) {
+      ItemRec R; inner_load_item_rec(A, xv, blk, base + lane, R);
+      if (__ballot(R.kind >= 0) == 0ull) continue;
+      if (cmd == INNER_CMD_JAC) for (int k = 0; k < 3 * CFG::JS; ++k) J[k] = 0.0;
+      res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
+      if (R.kind >= 0) { if (cmd == INNER_CMD_JAC) inner_eval_item<true, CFG>(A, xv, blk, P, R, J, res); else inner_eval_item<false, CFG>(A, xv, blk, P, R, J, res); }
+      const double r0 = res[0], r1 = res[1], r2 = res[2];
+      const double c = wave_sum(0.5 * (r0 * r0 + r1 * r1 + r2 * r2));
+      if (lane == 0) row[nv - 1] += c;
+      if (cmd == INNER_CMD_JAC) {
+        int k = 0;
+        for (int x = 0; x < d; ++x)
+          for (int y = x; y < d; ++y, ++k) {
+            const double h = wave_sum(J[x] * J[y] + J[CFG::JS + x] * J[CFG::JS + y] + J[2 * CFG::JS + x] * J[2 * CFG::JS + y]);
+            if (lane == 0) row[k] += h;
+          }
+        for (int x = 0; x < d; ++x, ++k) {
+          const double g = wave_sum(J[x] * r0 + J[CFG::JS + x] * r1 + J[2 * CFG::JS + x] * r2);
+          if (lane == 0) row[k] += g;
+        }
+      }
+    }
+    wave_sync();
+    if (lane == 0) {
+      double* x = xv + blk.xoff;
+      int nc;
+      if (R3ONLY) nc = inner_lm_advance<3, 3>(S, IK_R3, cmd, row, x, xl, A.max_ab, A.max_gb);
+      else if (blk.kind == IK_SO3) nc = inner_lm_advance<3, 4>(S, IK_SO3, cmd, row, x, xl, A.max_ab, A.max_gb);
+      else nc = inner_lm_advance<3, 3>(S, blk.kind, cmd, row, x, xl, A.max_ab, A.max_gb);
+      s_cmd[wave] = nc;
+    }
+    wave_sync();
+    if (so3) {
+      const int act = S.seg_action;
+      if (act == 1 && lane < 2) {
+        const int pair = s_lo + lane;
+        if (pair < n_pairs && pair <= blk.idx) {
+          const double* a4 = pair == blk.idx ? S.xcur : S.qprev;
+          const double* b4 = pair == blk.idx ? S.qnext : S.xcur;
+          so3_segment_prepare(Quat{a4[0], a4[1], a4[2], a4[3]}, Quat{b4[0], b4[1], b4[2], b4[3]}, S.segcur + lane * kSegStride);
+        }
+      }
+      wave_sync();
+      if (act != 0 && lane < 2 * kSegStride) {
+        const int pair = s_lo + lane / kSegStride;
+        if (pair < n_pairs && pair <= blk.idx) {
+          A.seg[(size_t)s_lo * kSegStride + lane] = S.segcur[lane];
+          if (pair >= blk.ks0 && pair - blk.ks0 < blk.nks - 1) s_seg[wave][(pair - blk.ks0) * kSegStride + (lane - (pair - s_lo) * kSegStride)] = S.segcur[lane];
+        }
+      }
+      wave_sync();
+    }
+    cmd = s_cmd[wave];
+    if (cmd == INNER_CMD_DONE) break;
+  }
+  if (lane == 0 && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
+}
+
 __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
@@ -488,9 +672,10 @@ __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
 
 // workgroup = (block of the set, part): the block's whole Levenberg-Marquardt loop
 // prof: debug (option debug_inner_profile): shader clock of workgroup 0 / thread 0 at every phase boundary, [0] = count
-template <bool R3ONLY>
-__global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const InnerArgs* __restrict__ Sp, double* xv, const InnerWg* __restrict__ wgs, long long* prof_buf) {
-  using CFG = InnerCfg<R3ONLY>;
+template <int MODE>
+__global__ void __launch_bounds__(InnerCfg<MODE>::T) inner_set_kernel(const InnerArgs* __restrict__ Sp, double* xv, const InnerWg* __restrict__ wgs, long long* prof_buf) {
+  using CFG = InnerCfg<MODE>;
+  constexpr bool R3ONLY = CFG::R3ONLY;
   const InnerArgs& A = *Sp;
   constexpr int kInnerThreads = CFG::T, kInnerSlots = CFG::SLOTS;
   __shared__ double s_J[CFG::NJ * kInnerThreads];  // per lane: Jacobian columns of the block (3 x JS) and the residuals
@@ -599,7 +784,7 @@ __global__ void __launch_bounds__(InnerCfg<R3ONLY>::T) inner_set_kernel(const In
           case IK_LD: nc = inner_lm_advance<1, 1>(S, IK_LD, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_AI: nc = inner_lm_advance<6, 6>(S, IK_AI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
           case IK_GI: nc = inner_lm_advance<9, 9>(S, IK_GI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_PT: nc = inner_lm_advance<3, 4>(S, IK_PT, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
+          case IK_PT: nc = CFG::POINTS ? inner_lm_advance<3, 4>(S, IK_PT, cmd, s_tot, x, xl, A.max_ab, A.max_gb) : int(INNER_CMD_DONE); break;
           default: nc = inner_lm_advance<3, 3>(S, blk.kind, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;   // R^3 knot, gravity, bias knots
         }
         s_cmd = nc;
@@ -663,16 +848,26 @@ __global__ void inner_diff_norm_kernel(const double* x, const double* xc, const 
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st) {
   if (n_pairs > 0) hipLaunchKernelGGL(inner_seg_kernel, dim3((n_pairs + 127) / 128), dim3(128), 0, st, so3, n_pairs, seg);
 }
-void launch_inner_set(const InnerArgs* dA, double* xv, const InnerWg* wgs, long long* prof, int n_wgs, bool r3_only, hipStream_t st) {   // r3_only: every block of the set is an R^3 knot with at most 1024 item slots
+void launch_inner_set(const InnerArgs* dA, double* xv, const InnerWg* wgs, long long* prof, int n_wgs, int mode, hipStream_t st) {   // mode (InnerCfg): 1 = every block of the set is an R^3 knot with at most 1024 item slots, 2 = the plan holds board-point blocks
   if (n_wgs <= 0) return;
-  if (r3_only) hipLaunchKernelGGL(inner_set_kernel<true>, dim3(n_wgs), dim3(InnerCfg<true>::T), 0, st, dA, xv, wgs, prof);
-  else hipLaunchKernelGGL(inner_set_kernel<false>, dim3(n_wgs), dim3(InnerCfg<false>::T), 0, st, dA, xv, wgs, prof);
+  if (mode == 1) hipLaunchKernelGGL(inner_set_kernel<1>, dim3(n_wgs), dim3(InnerCfg<1>::T), 0, st, dA, xv, wgs, prof);
+  else if (mode == 2) hipLaunchKernelGGL(inner_set_kernel<2>, dim3(n_wgs), dim3(InnerCfg<2>::T), 0, st, dA, xv, wgs, prof);
+  else hipLaunchKernelGGL(inner_set_kernel<0>, dim3(n_wgs), dim3(InnerCfg<0>::T), 0, st, dA, xv, wgs, prof);
+}
+void launch_inner_records(const ViewData& vd, const ImuData& ia, const ImuData& ig, InnerItemRec* rc, InnerItemRec* ra, InnerItemRec* rg, hipStream_t st) {
+  const int64_t n = std::max<int64_t>(vd.n_corners, std::max<int64_t>(ia.n, ig.n));
+  if (n > 0) hipLaunchKernelGGL(inner_records_kernel, dim3(int((n + 255) / 256)), dim3(256), 0, st, vd, ia, ig, rc, ra, rg);
+}
+void launch_inner_wave(const InnerArgs* dA, double* xv, int b0, int n_blocks, bool r3_only, hipStream_t st) {   // one wave per block: blocks [b0, b0 + n_blocks) of the plan
+  if (n_blocks <= 0) return;
+  if (r3_only) hipLaunchKernelGGL(inner_wave_kernel<true>, dim3((n_blocks + 7) / 8), dim3(512), 0, st, dA, xv, b0, n_blocks);
+  else hipLaunchKernelGGL(inner_wave_kernel<false>, dim3((n_blocks + 3) / 4), dim3(256), 0, st, dA, xv, b0, n_blocks);
 }
 // Workgroups of the general build that are resident at the same time on `n_cu` compute units (occupancy query, not an assumption: the
 // workgroups that share a block spin on each other, so a set's shared parts must all fit next to whatever else runs on the device)
 int inner_set_resident_capacity(int n_cu) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inner_set_kernel<false>, InnerCfg<false>::T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inner_set_kernel<0>, InnerCfg<0>::T, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   return per_cu * n_cu;
 }
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st) {

@@ -7,6 +7,8 @@
 
 namespace oicc {
 
+constexpr int kCapS = 24, kCapR = 16, kCapB = 8; // knots of a block's neighbourhood that fit its LDS copy (SO(3), R^3, each bias spline); beyond that the items read the parameter vector
+
 enum InnerKind { IK_SO3 = 0, IK_R3, IK_TIC, IK_G, IK_LD, IK_AB, IK_GB, IK_AI, IK_GI, IK_PT };   // IK_PT: a board point (SplineOptimFlags::POINTS, impl.h:136-153): homogeneous 4-vector, 3 tangent dimensions; idx = point index
 
 // A run of consecutive items (in the device arrays' order) that depend on one block:
@@ -38,6 +40,12 @@ struct InnerCtl {
   unsigned int pad[2];
 };
 
+// What an item contributes that no parameter block changes, gathered ONCE per plan into one record per corner / IMU sample
+// (inner_records_kernel): the wave-per-block kernel reads an item with one coalesced load per evaluation round instead of keeping
+// the block's items in LDS.  Corner: sx = rolling-shutter flag | board point << 1, d = u_so3 u_r3 obs_u obs_v 1/sx 1/sy -;  IMU
+// sample: sx = bias window, d = u_so3 u_r3 u_b m[3] w.
+struct InnerItemRec { int32_t s_so3, s_r3, sx, pad; double d[7]; };
+
 // Arguments of inner_set_kernel that only change with the problem / the plan (~0.9 KB): they live in DEVICE memory and are read
 // where they are needed (round 5; by value the kernel's prologue loaded and spilled them lane by lane -- 326 spilled SGPRs, the
 // round-2 finding of the tile kernel).  What changes from launch to launch travels by value: the parameter vector the sweep works
@@ -49,6 +57,7 @@ struct InnerArgs {
   const InnerBlock* blocks; const InnerRun* runs; InnerCtl* ctls;
   unsigned long long* lm_iterations;
   double max_ab, max_gb;
+  const InnerItemRec* rec[3];   // per-item records of the wave-per-block kernel: corners, accelerometer samples, gyroscope samples
 };
 
 }  // namespace oicc

@@ -249,7 +249,8 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
   // processing order: last set first; blocks of a set contiguous.  Per block its runs and its workgroups -- one for a knot block;
   // the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on each other: all of them
   // must be resident, so a set's shared blocks split the CUs and come first in the launch).
-  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.n_ctls = 0;
+  ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.group_wave.clear(); ip.n_ctls = 0;
+  ip.has_points = pts_active;
   constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
   const int resident_wgs = o.resident_wgs; const double shared_share = o.shared_share;
   for (auto it = rounds.rbegin(); it != rounds.rend(); ++it) {
@@ -281,7 +282,11 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
       }
     char r3only = !o.general_kernel;
     for (int b = b0; b < b1; ++b) r3only = r3only && ip.blocks[b].kind == IK_R3 && ip.blocks[b].n_slots <= 1024;
-    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only);
+    // one wave per block (inner_wave_kernel): knot blocks with one workgroup each whose neighbourhood fits the LDS copy, and enough of them
+    char wave = o.wave_blocks != 2 && (o.wave_blocks == 1 || b1 - b0 >= 4 * o.n_cu);
+    for (int b = b0; b < b1 && wave; ++b) { const InnerBlock& k = ip.blocks[b];
+      wave = (k.kind == IK_SO3 || k.kind == IK_R3) && k.ctl < 0 && k.nks <= kCapS && k.nkr <= kCapR && k.nkab <= kCapB && k.nkgb <= kCapB && k.nks >= 1; }
+    ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only); ip.group_wave.push_back(wave);
   }
   t_plan3 = now_s();
   t_ms[0] = 1e3 * (t_plan1 - t_plan0); t_ms[1] = 1e3 * (t_plan2 - t_plan1); t_ms[2] = 1e3 * (t_plan3 - t_plan2);
@@ -290,6 +295,7 @@ InnerPlanOptions inner_plan_options(oicc_problem* p, int flags, int64_t layout_g
   InnerPlanOptions o;
   o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = p->opt["debug_inner_general_kernel"] != 0.0;
   o.resident_wgs = inner_set_resident_capacity(p->n_cu); o.shared_share = std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"])); o.layout_gen = layout_gen;
+  o.wave_blocks = int(p->opt["inner_wave_blocks"]); o.n_cu = p->n_cu;
   return o;
 }
 void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen) {
@@ -318,7 +324,10 @@ int build_inner_plan(oicc_problem* p, int flags) {
   DevArena& PA = p->plan_arena;
   PA.add(ip.d_blocks, ip.blocks); PA.add(ip.d_runs, ip.runs); PA.add(ip.d_wgs, ip.wgs);
   PA.reserve(ip.d_ctls, size_t(std::max(ip.n_ctls, 1))); PA.reserve(ip.d_lm_iterations, 1); PA.reserve(ip.d_seg, size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles);
+  bool any_wave = false; for (char w : ip.group_wave) any_wave = any_wave || w;
+  if (any_wave) { PA.reserve(ip.d_rec[0], p->corner_view.size()); PA.reserve(ip.d_rec[1], p->acc.size()); PA.reserve(ip.d_rec[2], p->gyr.size()); }
   if (!PA.commit(st)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
+  if (any_wave) launch_inner_records(view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), ip.d_rec[0].p, ip.d_rec[1].p, ip.d_rec[2].p, st);   // (the measurements are on the device: prepare() ran)
   HIPCK(p, hipMemsetAsync(ip.d_lm_iterations.p, 0, sizeof(unsigned long long), st));
   ip.lm_iterations = 0;                 // host mirror of the device counter that was just cleared (oicc_optimize reports the difference)
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] inner plan: %zu blocks, %zu sets, %zu workgroups; host ms: blocks + neighbourhoods %.3f, independent sets %.3f, runs + workgroups %.3f (%s: waited %.3f), device buffers %.3f\n",
@@ -379,6 +388,7 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
   A.ctx = make_ctx(p, nullptr); A.vd = view_data(p); A.ia = imu_data(p->acc, p->d_acc); A.ig = imu_data(p->gyr, p->d_gyr);
   A.seg = ip.d_seg.p; A.blocks = ip.d_blocks.p; A.runs = ip.d_runs.p; A.ctls = ip.d_ctls.p;
   A.lm_iterations = ip.d_lm_iterations.p; A.max_ab = p->max_ab; A.max_gb = p->max_gb;
+  for (int k = 0; k < 3; ++k) A.rec[k] = ip.d_rec[k].p;
   if (!ip.h_args) { ip.h_args.reset(new InnerArgs); std::memset(ip.h_args.get(), 0, sizeof(InnerArgs)); ip.args_valid = false; }
   if (!ip.args_valid || std::memcmp(&A, ip.h_args.get(), sizeof(A)) != 0) {   // (rare: plan, layout or measurement changes)
     if (!ip.d_args.resize(1)) { p->err = "hipMalloc inner-iteration arguments"; return OICC_ERR_HIP; }
@@ -395,9 +405,14 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
   for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
     long long* prof = nullptr;
     if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); prof = d_prof.p; }
-    if (!owned) { launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], ip.group_r3only[g] != 0, st); continue; }
+    const int mode = ip.group_r3only[g] ? 1 : (ip.has_points ? 2 : 0);
+    if (!owned) {
+      if (ip.group_wave[g] && prof == nullptr) launch_inner_wave(ip.d_args.p, xv, ip.group_first[g], ip.group_first[g + 1] - ip.group_first[g], ip.group_r3only[g] != 0, st);   // one wave per block: large sets of knot blocks
+      else launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], mode, st);
+      continue;
+    }
     const oicc_problem::InnerPlan::RankPart& rp = ip.rank_part;
-    launch_inner_set(ip.d_args.p, xv, rp.d_wgs.p + rp.group_wg0[g], prof, rp.group_wg0[g + 1] - rp.group_wg0[g], ip.group_r3only[g] != 0, st);
+    launch_inner_set(ip.d_args.p, xv, rp.d_wgs.p + rp.group_wg0[g], prof, rp.group_wg0[g + 1] - rp.group_wg0[g], mode, st);
     // what the set changed, from its owners (every rank takes part, whether or not it had a block in the set)
     const ParamLayout& pl = p->pl; const uint8_t kinds = rp.group_kinds[g]; const int n = shard->shard_n;
     int rc = shard_broadcast_begin(shard);

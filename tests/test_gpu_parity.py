@@ -754,6 +754,36 @@ def test_both_builds_of_the_inner_kernel_give_the_same_sweeps():
     assert np.abs(t0 - t1).max() < 1e-8
 
 
+@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES | E.CAM_LINE_DELAY), ("C3", FLAGS1), ("C4", FLAGS1)])
+def test_one_wave_per_block_gives_the_sweeps_of_one_workgroup_per_block(cfg, flags):
+    """Round 5: large sets of knot blocks (>= 4 x compute units: BASELINE config 5) are minimised with ONE WAVE per block
+    (inner_wave_kernel: four / eight independent blocks per workgroup, items read as per-item records in rounds of 64, no workgroup
+    barrier) instead of one workgroup per block.  Option inner_wave_blocks = 1 sends every eligible set of the smaller configurations
+    through it: the sweeps of the workgroup kernel (= 2: never), hence of the oracle -- same outer iterates, sweep counts, per-block LM
+    iteration totals, extrinsics; with the bias knots / line delay free (shared blocks stay on the workgroup kernel), on C3 / C4
+    (R^3 knots with up to 17 views per window), and against the oracle on tiny and C2."""
+    ds = synthetic.make_config(cfg)
+    out = []
+    for mode in (1, 2):
+        c = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        c.trajectory_.UseReferenceSolverOptions(); c.trajectory_.SetOption("inner_wave_blocks", mode)
+        s_ = c.trajectory_.Optimize(50, flags)
+        out.append((s_, c.trajectory_.GetIterations(), c.trajectory_.GetT_i_c(), c.trajectory_.GetKnots()))
+    (s0, i0, t0, k0), (s1, i1, t1, k1) = out
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["inner_sweeps"] == s1["inner_sweeps"] >= 1, (s0, s1)
+    assert abs(s0["inner_lm_iterations"] - s1["inner_lm_iterations"]) <= 0.002 * s1["inner_lm_iterations"] + 1, (s0["inner_lm_iterations"], s1["inner_lm_iterations"])
+    assert all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(i0, i1)), (i0, i1)
+    assert np.abs(t0 - t1).max() < 1e-8 and np.abs(k0[0] - k1[0]).max() < 1e-8 and np.abs(k0[1] - k1[1]).max() < 1e-8
+    if cfg in ("tiny", "C2") and flags == FLAGS1:
+        cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+        cpu.trajectory_.UseReferenceSolverOptions()
+        sc = cpu.trajectory_.Optimize(50, flags)
+        assert sc["num_iterations"] == s0["num_iterations"] and sc["inner_sweeps"] == s0["inner_sweeps"]
+        for a, b in zip(i0, cpu.trajectory_.GetIterations()):
+            assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+        assert np.abs(t0 - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+
+
 # ---- Ceres' bounds line search (box-bounded bias knots, impl.h:206-240): host-driven Armijo search of oicc_optimize ----
 @pytest.mark.parametrize("cfg,flags,inner", [("C1", FLAGS1 | E.ACC_BIAS, 0), ("C1", FLAGS1 | E.ACC_BIAS, 1), ("tiny", FLAGS1 | E.IMU_BIASES, 1)])
 def test_bounds_line_search_matches_the_oracle(cfg, flags, inner):
