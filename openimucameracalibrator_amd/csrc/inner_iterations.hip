@@ -504,14 +504,17 @@ struct InnerWaveCfg {
   static constexpr int T = R3ONLY ? 512 : 256;   // threads of a workgroup = blocks x 64
   static constexpr int JS = 3;                    // knot blocks only: three tangent dimensions
   static constexpr int NJ = 3 * JS + 3;
-  static constexpr int SLOTS = 0;                 // (nothing staged)
+  static constexpr int SLOTS = 0;                 // (not used: the workgroup kernel's staging)
   static constexpr bool R3 = R3ONLY;
   static constexpr bool POINTS = false;           // (knot blocks only)
+  static constexpr int OCC = 2;                   // waves per SIMD the builds are compiled for: 8 x 64 threads, 4 x 64 threads twice per CU (256 VGPRs; one
+                                                  // wave per SIMD with all 394 registers it would like is 17 % slower: the evaluation waits on its own loads)
+  static constexpr int PCAP = 64;                 // board points kept in LDS (the whole board of the BASELINE configurations: 48)
 };
 namespace {
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 // slot i of the block -> its record (slot layout as inner_load_item: every run starts at a multiple of 64)
-__device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R) {
+__device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R, bool with_point) {
   R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
 #pragma unroll
   for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
@@ -527,7 +530,7 @@ __device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const do
   R.s_so3 = q.s_so3; R.s_r3 = q.s_r3; R.sx = q.sx;
 #pragma unroll
   for (int k = 0; k < 7; ++k) R.d[k] = q.d[k];
-  if (R.kind == 0) {
+  if (R.kind == 0 && with_point) {
     const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)(q.sx >> 1);
     R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
   }
@@ -554,7 +557,7 @@ __global__ void inner_records_kernel(ViewData vd, ImuData ia, ImuData ig, InnerI
 
 // wave w of workgroup g: block b0 + g * (T / 64) + w of the plan (a set's knot blocks are contiguous there)
 template <bool R3ONLY>
-__global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(const InnerArgs* __restrict__ Sp, double* xv, int b0, int n_blocks) {
+__global__ void __launch_bounds__((InnerWaveCfg<R3ONLY>::T), (InnerWaveCfg<R3ONLY>::OCC)) inner_wave_kernel(const InnerArgs* __restrict__ Sp, double* xv, int b0, int n_blocks) {
   using CFG = InnerWaveCfg<R3ONLY>;
   constexpr int T = CFG::T, NW = T / 64;
   __shared__ double s_J[CFG::NJ * T];
@@ -562,6 +565,7 @@ __global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(con
   __shared__ double s_row[NW][16];
   __shared__ InnerLm S_all[NW];
   __shared__ int s_cmd[NW];
+  __shared__ double s_pts[4 * CFG::PCAP];
   const InnerArgs& A = *Sp;
   const ParamLayout& pl = A.ctx.pl;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -598,6 +602,8 @@ __global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(con
     if (lane >= 20 && lane < 24) S.qnext[lane - 20] = blk.idx + 1 < pl.n_so3 ? q[4 * (int64_t)(blk.idx + 1) + (lane - 20)] : 0.0;
     if (lane >= 24 && lane < 24 + 2 * kSegStride) { const int e = lane - 24; S.segcur[e] = s_lo * kSegStride + e < n_pairs * kSegStride ? A.seg[(size_t)s_lo * kSegStride + e] : 0.0; }
   }
+  const bool pts_lds = pl.n_pts <= CFG::PCAP;       // the board in LDS (every wave writes ALL entries, the same values: no barrier needed beyond its own)
+  if (pts_lds) for (int e = lane; e < 4 * pl.n_pts; e += 64) s_pts[e] = xv[pl.pts + e];
   wave_sync();
   const LaneColT<T> J{s_J + tid}, res{s_J + 3 * CFG::JS * T + tid};
   double* const row = s_row[wave];
@@ -606,7 +612,9 @@ __global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(con
     if (lane < 16) row[lane] = 0.0;
     wave_sync();
     for (int base = 0; base < blk.n_slots; base += 64) {
-      ItemRec R; inner_load_item_rec(A, xv, blk, base + lane, R);
+      ItemRec R;
+      inner_load_item_rec(A, xv, blk, base + lane, R, false);
+      if (R.kind == 0) { const double* X = pts_lds ? s_pts + 4 * (R.sx >> 1) : xv + pl.pts + 4 * (int64_t)(R.sx >> 1); R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3]; }
       if (__ballot(R.kind >= 0) == 0ull) continue;
       if (cmd == INNER_CMD_JAC) for (int k = 0; k < 3 * CFG::JS; ++k) J[k] = 0.0;
       res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
@@ -661,6 +669,97 @@ __global__ void __launch_bounds__(InnerWaveCfg<R3ONLY>::T) inner_wave_kernel(con
     if (cmd == INNER_CMD_DONE) break;
   }
   if (lane == 0 && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
+}
+
+// ---- the blocks EVERY view / sample depends on, at scale (round 5) -------------------------------------------------------------------
+// inner_set_kernel minimises such a block (T_i_c, gravity, line delay, IMU intrinsics, a bias knot) with up to one workgroup per CU that
+// stay resident, spin on each other and may together take only half the device (another problem on the same device must still fit):
+// at BASELINE config 5 that is 64 workgroups walking 500 000 corners -- 1.8 ms of a 5.9 ms sweep.  Above a size threshold the host
+// (oicc_inner.hip) runs the block's loop as a SEQUENCE OF LAUNCHES instead: `inner_shared_eval_kernel` evaluates all items of the
+// set's shared blocks with as many workgroups as there is work (nobody waits for anybody: no residency limit), each workgroup
+// leaves its 56 partial sums in its own row of a global array (no atomics: a fixed order); `inner_shared_advance_kernel` (one wave per
+// block) adds the rows, advances the block's Levenberg-Marquardt loop -- its state lives in global memory between the launches --
+// and publishes the next command.  The host enqueues a few (evaluation, advance) pairs -- pairs behind the end of the loop return at
+// once -- and then looks at the command words.
+namespace {
+template <int MODE>
+__device__ __forceinline__ int inner_advance_dispatch(InnerLm& S, const InnerBlock& blk, int cmd, const double* tot, double* x, double* xl, double max_ab, double max_gb) {
+  using CFG = InnerCfg<MODE>;
+  if (CFG::R3ONLY) return inner_lm_advance<3, 3>(S, IK_R3, cmd, tot, x, xl, max_ab, max_gb);
+  switch (blk.kind) {
+    case IK_SO3: return inner_lm_advance<3, 4>(S, IK_SO3, cmd, tot, x, xl, max_ab, max_gb);
+    case IK_TIC: return inner_lm_advance<6, 7>(S, IK_TIC, cmd, tot, x, xl, max_ab, max_gb);
+    case IK_LD: return inner_lm_advance<1, 1>(S, IK_LD, cmd, tot, x, xl, max_ab, max_gb);
+    case IK_AI: return inner_lm_advance<6, 6>(S, IK_AI, cmd, tot, x, xl, max_ab, max_gb);
+    case IK_GI: return inner_lm_advance<9, 9>(S, IK_GI, cmd, tot, x, xl, max_ab, max_gb);
+    case IK_PT: return CFG::POINTS ? inner_lm_advance<3, 4>(S, IK_PT, cmd, tot, x, xl, max_ab, max_gb) : int(INNER_CMD_DONE);
+    default: return inner_lm_advance<3, 3>(S, blk.kind, cmd, tot, x, xl, max_ab, max_gb);   // R^3 knot, gravity, bias knots
+  }
+}
+}  // namespace
+
+// workgroup = (shared block, part): the part's items at the block's current command, sums -> row `part` of the block's partial-sum table
+__global__ void __launch_bounds__((InnerCfg<0>::T), 2) inner_shared_eval_kernel(const InnerArgs* __restrict__ Sp, double* xv, const InnerWg* __restrict__ wgs, double* partials, int max_parts) {
+  using CFG = InnerCfg<0>;
+  constexpr int T = CFG::T;
+  __shared__ double s_J[CFG::NJ * T];
+  __shared__ double s_part[T / 64][56];
+  const InnerArgs& A = *Sp;
+  const InnerWg wg = wgs[blockIdx.x];
+  const InnerBlock blk = A.blocks[wg.block];
+  const InnerCtl* const ctl = A.ctls + blk.ctl;
+  const int cmd = int(ctl->word & 3u);
+  if (cmd == INNER_CMD_DONE) return;
+  const ParamLayout& pl = A.ctx.pl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ParamView P{xv + pl.so3, A.seg, xv + pl.r3, xv + pl.ab, xv + pl.gb, xv + pl.tic, 0, 0, 0, 0};
+  if (lane < 56) s_part[wave][lane] = 0.0;
+  if (cmd == INNER_CMD_JAC) inner_eval_items<true, CFG>(A, xv, blk, P, wg.part, wg.nparts, false, nullptr, nullptr, s_part[wave], s_J);
+  else inner_eval_items<false, CFG>(A, xv, blk, P, wg.part, wg.nparts, false, nullptr, nullptr, s_part[wave], s_J);
+  __syncthreads();
+  if (tid < 56) { double t = 0.0; for (int w = 0; w < T / 64; ++w) t += s_part[w][tid]; partials[((size_t)blk.ctl * max_parts + wg.part) * 56 + tid] = t; }
+}
+// one wave per shared block of the set: the rows of its parts added in order, the loop advanced, the next command published
+__global__ void __launch_bounds__(512) inner_shared_advance_kernel(const InnerArgs* __restrict__ Sp, double* xv, const int32_t* __restrict__ block_ids, const int32_t* __restrict__ block_parts,
+                                                                   const double* partials, int max_parts, InnerLm* states, int count_iterations) {
+  const InnerArgs& A = *Sp;
+  const InnerBlock blk = A.blocks[block_ids[blockIdx.x]];
+  InnerCtl* const ctl = A.ctls + blk.ctl;
+  const unsigned word = ctl->word;
+  const int cmd = int(word & 3u);
+  if (cmd == INNER_CMD_DONE) return;
+  constexpr int NW = 8;
+  __shared__ double s_w[NW][64], s_tot[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nparts = block_parts[blockIdx.x];
+  {   // wave w adds rows w, w + 8, ... (eight loads in flight), then the eight sums in order: a fixed order, whatever the launch
+    const double* rows = partials + (size_t)blk.ctl * max_parts * 56 + lane;
+    double t = 0.0;
+    if (lane < 56) {
+      int q = wave;
+      for (; q + 7 * NW < nparts; q += 8 * NW) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = rows[(size_t)(q + k * NW) * 56];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+      }
+      for (; q < nparts; q += NW) t += rows[(size_t)q * 56];
+    }
+    s_w[wave][lane] = t;
+  }
+  InnerLm& S = states[blk.ctl];
+  if ((word >> 2) == 0u) {       // first advance of this sweep: the loop's state
+    if (tid == 0) { S.radius = 1e4; S.decrease_factor = 2.0; S.cost = 0.0; S.x_norm = 0.0; S.model = 0.0; S.iter = 0; S.invalid = 0; S.reuse_diagonal = 0; S.first = 1; S.seg_action = 0; }
+    if (tid < blk.ambient) S.xcur[tid] = xv[blk.xoff + tid];
+  }
+  __syncthreads();
+  if (tid < 64) { double t = 0.0; for (int w = 0; w < NW; ++w) t += s_w[w][tid]; s_tot[tid] = t; }
+  __syncthreads();
+  if (tid == 0) {
+    const int nc = inner_advance_dispatch<0>(S, blk, cmd, s_tot, xv + blk.xoff, nullptr, A.max_ab, A.max_gb);
+    if (nc == INNER_CMD_DONE && count_iterations && A.lm_iterations != nullptr) atomicAdd(A.lm_iterations, (unsigned long long)S.iter);
+    ctl->word = (((word >> 2) + 1u) << 2) | (unsigned)nc;
+  }
 }
 
 __global__ void inner_seg_kernel(const double* so3, int n_pairs, double* seg) {
@@ -776,17 +875,7 @@ __global__ void __launch_bounds__(InnerCfg<MODE>::T) inner_set_kernel(const Inne
     if (master) {
       if (tid == 0) {
         double* x = xv + blk.xoff;
-        int nc = INNER_CMD_DONE;
-        if (R3ONLY) nc = inner_lm_advance<3, 3>(S, IK_R3, cmd, s_tot, x, xl, A.max_ab, A.max_gb);
-        else switch (blk.kind) {
-          case IK_SO3: nc = inner_lm_advance<3, 4>(S, IK_SO3, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_TIC: nc = inner_lm_advance<6, 7>(S, IK_TIC, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_LD: nc = inner_lm_advance<1, 1>(S, IK_LD, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_AI: nc = inner_lm_advance<6, 6>(S, IK_AI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_GI: nc = inner_lm_advance<9, 9>(S, IK_GI, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;
-          case IK_PT: nc = CFG::POINTS ? inner_lm_advance<3, 4>(S, IK_PT, cmd, s_tot, x, xl, A.max_ab, A.max_gb) : int(INNER_CMD_DONE); break;
-          default: nc = inner_lm_advance<3, 3>(S, blk.kind, cmd, s_tot, x, xl, A.max_ab, A.max_gb); break;   // R^3 knot, gravity, bias knots
-        }
+        const int nc = inner_advance_dispatch<MODE>(S, blk, cmd, s_tot, x, xl, A.max_ab, A.max_gb);
         s_cmd = nc;
       }
       INNER_MARK();
@@ -858,6 +947,13 @@ void launch_inner_records(const ViewData& vd, const ImuData& ia, const ImuData& 
   const int64_t n = std::max<int64_t>(vd.n_corners, std::max<int64_t>(ia.n, ig.n));
   if (n > 0) hipLaunchKernelGGL(inner_records_kernel, dim3(int((n + 255) / 256)), dim3(256), 0, st, vd, ia, ig, rc, ra, rg);
 }
+void launch_inner_shared_eval(const InnerArgs* dA, double* xv, const InnerWg* wgs, int n_wgs, double* partials, int max_parts, hipStream_t st) {
+  if (n_wgs > 0) hipLaunchKernelGGL(inner_shared_eval_kernel, dim3(n_wgs), dim3(InnerCfg<0>::T), 0, st, dA, xv, wgs, partials, max_parts);
+}
+void launch_inner_shared_advance(const InnerArgs* dA, double* xv, const int32_t* block_ids, const int32_t* block_parts, int n_blocks, const double* partials, int max_parts, void* states, bool count_iterations, hipStream_t st) {
+  if (n_blocks > 0) hipLaunchKernelGGL(inner_shared_advance_kernel, dim3(n_blocks), dim3(512), 0, st, dA, xv, block_ids, block_parts, partials, max_parts, static_cast<InnerLm*>(states), count_iterations ? 1 : 0);
+}
+size_t inner_lm_state_bytes() { return sizeof(InnerLm); }
 void launch_inner_wave(const InnerArgs* dA, double* xv, int b0, int n_blocks, bool r3_only, hipStream_t st) {   // one wave per block: blocks [b0, b0 + n_blocks) of the plan
   if (n_blocks <= 0) return;
   if (r3_only) hipLaunchKernelGGL(inner_wave_kernel<true>, dim3((n_blocks + 7) / 8), dim3(512), 0, st, dA, xv, b0, n_blocks);

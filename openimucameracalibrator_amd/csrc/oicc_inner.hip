@@ -250,6 +250,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
   // the blocks all views / all samples depend on are shared by up to one workgroup per CU (they spin on each other: all of them
   // must be resident, so a set's shared blocks split the CUs and come first in the launch).
   ip.blocks.clear(); ip.group_first.assign(1, 0); ip.runs.clear(); ip.wgs.clear(); ip.group_wg0.assign(1, 0); ip.group_r3only.clear(); ip.group_wave.clear(); ip.n_ctls = 0;
+  ip.big_wgs.clear(); ip.group_bigwg0.assign(1, 0); ip.big_blocks.clear(); ip.big_parts.clear(); ip.group_bigb0.assign(1, 0); ip.big_max_parts = 1;
   ip.has_points = pts_active;
   constexpr int kThreads = 256, kSharedAbove = 4 * kThreads;
   const int resident_wgs = o.resident_wgs; const double shared_share = o.shared_share;
@@ -263,7 +264,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
       for (int k = 0; k < h.nruns; ++k) { const InnerRun& r = hruns[size_t(h.run0 + k)]; ip.runs.push_back(r); b.n_items += r.count; b.n_slots += (r.count + 63) & ~63; }
       b.ks0 = h.s1 >= 0 ? h.s0 : 0; b.nks = h.s1 >= 0 ? h.s1 - h.s0 : 0; b.kr0 = h.r1 >= 0 ? h.r0 : 0; b.nkr = h.r1 >= 0 ? h.r1 - h.r0 : 0;
       b.kab0 = h.a1 >= 0 ? h.a0 : 0; b.nkab = h.a1 >= 0 ? h.a1 - h.a0 : 0; b.kgb0 = h.g1 >= 0 ? h.g0 : 0; b.nkgb = h.g1 >= 0 ? h.g1 - h.g0 : 0;
-      if (b.n_slots > kSharedAbove) ++n_shared;
+      if (b.n_slots > kSharedAbove && !(o.big_slots > 0 && b.n_slots >= o.big_slots)) ++n_shared;
       ip.blocks.push_back(b);
     }
     const int b1 = int(ip.blocks.size());
@@ -276,6 +277,13 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
         InnerBlock& blk = ip.blocks[b];
         const bool shared = blk.n_slots > kSharedAbove;
         if (shared != (pass == 0)) continue;
+        if (shared && o.big_slots > 0 && blk.n_slots >= o.big_slots) {   // a sequence of launches over the whole device (inner_shared_eval_kernel): 1024 item slots per part
+          const int np = std::min(1024, (blk.n_slots + 4 * kThreads - 1) / (4 * kThreads));
+          blk.ctl = ip.n_ctls++;
+          for (int q = 0; q < np; ++q) ip.big_wgs.push_back(InnerWg{b, q, np, 0});
+          ip.big_blocks.push_back(b); ip.big_parts.push_back(np); ip.big_max_parts = std::max(ip.big_max_parts, np);
+          continue;
+        }
         const int nparts = shared ? std::min(cap, (blk.n_slots + kThreads - 1) / kThreads) : 1;
         if (nparts > 1) blk.ctl = ip.n_ctls++;
         for (int q = 0; q < nparts; ++q) ip.wgs.push_back(InnerWg{b, q, nparts, 0});
@@ -287,6 +295,7 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
     for (int b = b0; b < b1 && wave; ++b) { const InnerBlock& k = ip.blocks[b];
       wave = (k.kind == IK_SO3 || k.kind == IK_R3) && k.ctl < 0 && k.nks <= kCapS && k.nkr <= kCapR && k.nkab <= kCapB && k.nkgb <= kCapB && k.nks >= 1; }
     ip.group_first.push_back(int32_t(ip.blocks.size())); ip.group_wg0.push_back(int32_t(ip.wgs.size())); ip.group_r3only.push_back(r3only); ip.group_wave.push_back(wave);
+    ip.group_bigwg0.push_back(int32_t(ip.big_wgs.size())); ip.group_bigb0.push_back(int32_t(ip.big_blocks.size()));
   }
   t_plan3 = now_s();
   t_ms[0] = 1e3 * (t_plan1 - t_plan0); t_ms[1] = 1e3 * (t_plan2 - t_plan1); t_ms[2] = 1e3 * (t_plan3 - t_plan2);
@@ -295,7 +304,7 @@ InnerPlanOptions inner_plan_options(oicc_problem* p, int flags, int64_t layout_g
   InnerPlanOptions o;
   o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = p->opt["debug_inner_general_kernel"] != 0.0;
   o.resident_wgs = inner_set_resident_capacity(p->n_cu); o.shared_share = std::min(1.0, std::max(0.0, p->opt["inner_shared_residency"])); o.layout_gen = layout_gen;
-  o.wave_blocks = int(p->opt["inner_wave_blocks"]); o.n_cu = p->n_cu;
+  o.wave_blocks = int(p->opt["inner_wave_blocks"]); o.n_cu = p->n_cu; o.big_slots = int(p->opt["inner_shared_launch_slots"]);
   return o;
 }
 void start_inner_plan(oicc_problem* p, int flags, int64_t layout_gen) {
@@ -324,6 +333,10 @@ int build_inner_plan(oicc_problem* p, int flags) {
   DevArena& PA = p->plan_arena;
   PA.add(ip.d_blocks, ip.blocks); PA.add(ip.d_runs, ip.runs); PA.add(ip.d_wgs, ip.wgs);
   PA.reserve(ip.d_ctls, size_t(std::max(ip.n_ctls, 1))); PA.reserve(ip.d_lm_iterations, 1); PA.reserve(ip.d_seg, size_t(std::max(pl.n_so3 - 1, 1)) * kSegDoubles);
+  if (!ip.big_blocks.empty()) {
+    PA.add(ip.d_big_wgs, ip.big_wgs); PA.add(ip.d_big_blocks, ip.big_blocks); PA.add(ip.d_big_parts, ip.big_parts);
+    PA.reserve(ip.d_partials, size_t(std::max(ip.n_ctls, 1)) * size_t(ip.big_max_parts) * 56); PA.reserve(ip.d_lm_states, size_t(std::max(ip.n_ctls, 1)) * inner_lm_state_bytes());
+  }
   bool any_wave = false; for (char w : ip.group_wave) any_wave = any_wave || w;
   if (any_wave) { PA.reserve(ip.d_rec[0], p->corner_view.size()); PA.reserve(ip.d_rec[1], p->acc.size()); PA.reserve(ip.d_rec[2], p->gyr.size()); }
   if (!PA.commit(st)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
@@ -351,7 +364,7 @@ static int build_rank_part(oicc_problem* p, oicc_problem* shard) {
   const oicc_problem::OwnerPlan& op = shard->owner;
   const int n = shard->shard_n, me = shard->shard_rank;
   uint64_t key = 1469598103934665603ull; auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
-  mix(uint64_t(n)); mix(uint64_t(me)); mix(uint64_t(op.hash)); mix(uint64_t(ip.layout_gen)); mix(uint64_t(ip.flags + 7)); mix(uint64_t(ip.wgs.size())); mix(uint64_t(shard->layout_gen));
+  mix(uint64_t(n)); mix(uint64_t(me)); mix(uint64_t(op.hash)); mix(uint64_t(ip.layout_gen)); mix(uint64_t(ip.flags + 7)); mix(uint64_t(ip.wgs.size())); mix(uint64_t(ip.big_wgs.size())); mix(uint64_t(shard->layout_gen));
   if (rp.valid && rp.key == key) return OICC_OK;
   const HostLayout& L = shard->L;    // (equal to p's: checked by oicc_optimize)
   auto owner_of = [&](int32_t row) { int k = 0; while (k + 1 < n && row >= op.cut[k + 1]) ++k; return k; };
@@ -360,7 +373,7 @@ static int build_rank_part(oicc_problem* p, oicc_problem* shard) {
   for (size_t i = 0; i < L.r3.size(); ++i) if (L.r3[i] >= 0) { const int k = owner_of(L.r3[i]); rp.r3_lo[k] = std::min<int32_t>(rp.r3_lo[k], int32_t(i)); rp.r3_hi[k] = std::max<int32_t>(rp.r3_hi[k], int32_t(i) + 1); }
   rp.wgs.clear(); rp.group_wg0.assign(1, 0); rp.group_kinds.clear();
   for (size_t g = 0; g + 1 < ip.group_wg0.size(); ++g) {
-    uint8_t kinds = 0;
+    uint8_t kinds = ip.group_bigb0[g + 1] > ip.group_bigb0[g] ? 4 : 0;   // (large shared blocks: replicated, on every rank)
     for (int w = ip.group_wg0[g]; w < ip.group_wg0[g + 1]; ++w) {
       const InnerWg& wg = ip.wgs[size_t(w)]; const InnerBlock& b = ip.blocks[size_t(wg.block)];
       bool mine = true;
@@ -406,6 +419,21 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
     long long* prof = nullptr;
     if (int(g) == prof_set && d_prof.resize(64)) { HIPCK(p, hipMemsetAsync(d_prof.p, 0, 64 * sizeof(long long), st)); prof = d_prof.p; }
     const int mode = ip.group_r3only[g] ? 1 : (ip.has_points ? 2 : 0);
+    if (ip.group_bigb0[g + 1] > ip.group_bigb0[g]) {   // the set's LARGE shared blocks: (evaluation, advance) launches until every loop says done
+      const int nbb = ip.group_bigb0[g + 1] - ip.group_bigb0[g], nbw = ip.group_bigwg0[g + 1] - ip.group_bigwg0[g];
+      const bool count = !owned || shard->shard_rank == 0;
+      std::vector<unsigned char> hc(size_t(ip.n_ctls) * sizeof(InnerCtl));
+      for (int pairs = 0, batch = 6; pairs < 256; pairs += batch, batch = 2) {   // two or three LM iterations = four or six pairs are the rule; pairs behind the end return at once (~3 us each, against ~30 us for another look at the command words)
+        for (int k = 0; k < batch; ++k) {
+          launch_inner_shared_eval(ip.d_args.p, xv, ip.d_big_wgs.p + ip.group_bigwg0[g], nbw, ip.d_partials.p, ip.big_max_parts, st);
+          launch_inner_shared_advance(ip.d_args.p, xv, ip.d_big_blocks.p + ip.group_bigb0[g], ip.d_big_parts.p + ip.group_bigb0[g], nbb, ip.d_partials.p, ip.big_max_parts, ip.d_lm_states.p, count, st);
+        }
+        HIPCK(p, hipMemcpyAsync(hc.data(), ip.d_ctls.p, hc.size(), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
+        bool all_done = true;
+        for (int k = 0; k < nbb; ++k) { const InnerBlock& bb = ip.blocks[size_t(ip.big_blocks[size_t(ip.group_bigb0[g] + k)])]; all_done = all_done && (reinterpret_cast<const InnerCtl*>(hc.data())[bb.ctl].word & 3u) == 2u; }
+        if (all_done) break;
+      }
+    }
     if (!owned) {
       if (ip.group_wave[g] && prof == nullptr) launch_inner_wave(ip.d_args.p, xv, ip.group_first[g], ip.group_first[g + 1] - ip.group_first[g], ip.group_r3only[g] != 0, st);   // one wave per block: large sets of knot blocks
       else launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], mode, st);

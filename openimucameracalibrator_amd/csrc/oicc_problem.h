@@ -42,6 +42,9 @@ void launch_point_columns(const EvalCtx& ctx, const ViewData& vd, const uint8_t*
 void launch_inner_seg(const double* so3, int n_pairs, double* seg, hipStream_t st);
 void launch_inner_set(const InnerArgs* dA, double* xv, const InnerWg* wgs, long long* prof, int n_wgs, int mode, hipStream_t st);
 void launch_inner_wave(const InnerArgs* dA, double* xv, int b0, int n_blocks, bool r3_only, hipStream_t st);
+void launch_inner_shared_eval(const InnerArgs* dA, double* xv, const InnerWg* wgs, int n_wgs, double* partials, int max_parts, hipStream_t st);
+void launch_inner_shared_advance(const InnerArgs* dA, double* xv, const int32_t* block_ids, const int32_t* block_parts, int n_blocks, const double* partials, int max_parts, void* states, bool count_iterations, hipStream_t st);
+size_t inner_lm_state_bytes();
 void launch_inner_records(const ViewData& vd, const ImuData& ia, const ImuData& ig, InnerItemRec* rc, InnerItemRec* ra, InnerItemRec* rg, hipStream_t st);
 int inner_set_resident_capacity(int n_cu);
 void launch_rank_pack(const double* x, int64_t n, const LmState* s, double* pack, hipStream_t st);
@@ -86,7 +89,7 @@ struct HostLayout {
 
 using namespace oicc;
 
-struct InnerPlanOptions { int flags; bool gs_unit; bool general_kernel; int resident_wgs; double shared_share; int64_t layout_gen; int wave_blocks = 0; int n_cu = 256; };   // what the host part of the inner-iteration plan is built from (build_inner_plan_host)
+struct InnerPlanOptions { int flags; bool gs_unit; bool general_kernel; int resident_wgs; double shared_share; int64_t layout_gen; int wave_blocks = 0; int n_cu = 256; int big_slots = 65536; };   // what the host part of the inner-iteration plan is built from (build_inner_plan_host)
 
 struct oicc_problem {
   int device = 0;
@@ -185,6 +188,10 @@ struct oicc_problem {
   struct InnerPlan {
     std::vector<InnerBlock> blocks; std::vector<int32_t> group_first; std::vector<InnerRun> runs; std::vector<InnerWg> wgs; std::vector<int32_t> group_wg0; std::vector<char> group_r3only;   // set g holds nothing but R^3 knots of at most 1024 item slots: the 8-wave build of the kernel   // workgroups of set g: wgs[group_wg0[g] .. group_wg0[g + 1])
     DevBuf<InnerBlock> d_blocks; DevBuf<InnerRun> d_runs; DevBuf<InnerWg> d_wgs; DevBuf<InnerCtl> d_ctls; DevBuf<unsigned long long> d_lm_iterations; DevBuf<double> d_seg; int n_ctls = 0;
+    // shared blocks above a size threshold run as a SEQUENCE of launches (inner_shared_eval_kernel / inner_shared_advance_kernel): their parts
+    // (as many as there is work: no residency limit), the blocks and their part counts per set, the partial-sum rows, the loops' states
+    std::vector<InnerWg> big_wgs; std::vector<int32_t> group_bigwg0, big_blocks, big_parts, group_bigb0; int big_max_parts = 1;
+    DevBuf<InnerWg> d_big_wgs; DevBuf<int32_t> d_big_blocks, d_big_parts; DevBuf<double> d_partials; DevBuf<unsigned char> d_lm_states;
     std::vector<char> group_wave;   // set g runs on the wave-per-block kernel (inner_wave_kernel: knot blocks whose neighbourhood fits the LDS copy, enough of them to fill the device)
     bool has_points = false;        // the plan holds board-point blocks (SplineOptimFlags::POINTS): the general build with the point path
     DevBuf<InnerItemRec> d_rec[3];  // per-item records of the wave-per-block kernel (corners, accelerometer, gyroscope samples)
@@ -215,6 +222,7 @@ struct oicc_problem {
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
     opt["owner_computes_sweeps"] = 1;   // time-sharded ranks with the owner-computes exchange: a rank sweeps only the knot blocks it owns, owners broadcast after every set (0: replicated sweeps)
+    opt["inner_shared_launch_slots"] = 65536;   // a block every view / sample depends on with at least this many item slots is minimised by a sequence of launches over the whole device instead of resident workgroups that wait for each other (0: never)
     opt["inner_wave_blocks"] = 0;   // inner sweeps, which sets run one WAVE per block (inner_wave_kernel) instead of one workgroup: 0 = sets of at least 4 x compute units knot blocks (throughput bound), 1 = every eligible set, 2 = none
     opt["device_lm"] = 1;   // 1: plain Levenberg-Marquardt (no inner iterations / line search / collective) takes its trust-region decisions on the device
                             //    (LmCtl, lm_decide_kernel): the host enqueues iterations and polls a pinned word one iteration behind.  0: the host-driven loop

@@ -773,8 +773,38 @@ def test_one_wave_per_block_gives_the_sweeps_of_one_workgroup_per_block(cfg, fla
     assert s0["num_iterations"] == s1["num_iterations"] and s0["inner_sweeps"] == s1["inner_sweeps"] >= 1, (s0, s1)
     assert abs(s0["inner_lm_iterations"] - s1["inner_lm_iterations"]) <= 0.002 * s1["inner_lm_iterations"] + 1, (s0["inner_lm_iterations"], s1["inner_lm_iterations"])
     assert all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(i0, i1)), (i0, i1)
-    assert np.abs(t0 - t1).max() < 1e-8 and np.abs(k0[0] - k1[0]).max() < 1e-7 and np.abs(k0[1] - k1[1]).max() < 1e-7   # (the last knots, past the last view, are held by a few IMU samples only)
+    assert np.abs(t0 - t1).max() < 1e-8 and np.abs(k0[0][:-1] - k1[0][:-1]).max() < 1e-7 and np.abs(k0[0][-1] - k1[0][-1]).max() < 1e-5 and (np.abs(k0[1] - k1[1]) <= 1e-7 * (1 + np.abs(k1[1]))).all()   # (the last knots, past the last view, are held by a few IMU samples only)
     if cfg in ("tiny", "C2") and flags == FLAGS1:
+        cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+        cpu.trajectory_.UseReferenceSolverOptions()
+        sc = cpu.trajectory_.Optimize(50, flags)
+        assert sc["num_iterations"] == s0["num_iterations"] and sc["inner_sweeps"] == s0["inner_sweeps"]
+        for a, b in zip(i0, cpu.trajectory_.GetIterations()):
+            assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+        assert np.abs(t0 - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("tiny", FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS), ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_INTRINSICS), ("C3", FLAGS1)])
+def test_shared_blocks_by_a_sequence_of_launches_give_the_sweeps_of_resident_workgroups(cfg, flags):
+    """Round 5: a block every view / sample depends on (T_i_c, gravity, IMU intrinsics, bias knots) above a size threshold
+    (option inner_shared_launch_slots, default 65536 item slots: BASELINE config 5) is minimised by a SEQUENCE OF LAUNCHES over the
+    whole device -- inner_shared_eval_kernel leaves one row of partial sums per part, inner_shared_advance_kernel adds the rows in
+    order and advances the loop, whose state lives in global memory -- instead of resident workgroups that wait for each other.
+    Threshold 1 sends every shared block of the smaller configurations through it: the sweeps of the resident workgroups (0: never),
+    hence of the oracle -- same outer iterates, sweep counts, per-block LM iteration totals, extrinsics."""
+    ds = synthetic.make_config(cfg)
+    out = []
+    for slots in (1, 0):
+        c = E.ImuCameraCalibrator().BatchInitSpline(ds)
+        c.trajectory_.UseReferenceSolverOptions(); c.trajectory_.SetOption("inner_shared_launch_slots", slots)
+        s_ = c.trajectory_.Optimize(50, flags)
+        out.append((s_, c.trajectory_.GetIterations(), c.trajectory_.GetT_i_c(), c.trajectory_.GetKnots()))
+    (s0, i0, t0, k0), (s1, i1, t1, k1) = out
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["inner_sweeps"] == s1["inner_sweeps"] >= 1, (s0, s1)
+    assert abs(s0["inner_lm_iterations"] - s1["inner_lm_iterations"]) <= 0.002 * s1["inner_lm_iterations"] + 1, (s0["inner_lm_iterations"], s1["inner_lm_iterations"])
+    assert all(a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] for a, b in zip(i0, i1)), (i0, i1)
+    assert np.abs(t0 - t1).max() < 1e-8 and np.abs(k0[0][:-1] - k1[0][:-1]).max() < 1e-7 and np.abs(k0[0][-1] - k1[0][-1]).max() < 1e-5 and (np.abs(k0[1] - k1[1]) <= 1e-7 * (1 + np.abs(k1[1]))).all()   # (relative: the last R^3 knots, held by a few accelerometer samples only, run away to 1e4 and more)
+    if cfg == "tiny":
         cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
         cpu.trajectory_.UseReferenceSolverOptions()
         sc = cpu.trajectory_.Optimize(50, flags)
