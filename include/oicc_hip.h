@@ -238,6 +238,10 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * and normal equations together) and a one-thread decision kernel (accept / reject, radius, tolerances: LmCtl, csrc/oicc_device.h)
  * and polls a pinned word one iteration behind; 0 = the host-driven loop (a separate cost pass, one read-back per iteration).
  * owner_computes_sweeps 1|0: see oicc_set_shard.
+ * Inner iterations at scale (round 5; both are read when the plan of the sweeps is built): inner_wave_blocks 0|1|2 (0: sets of knot
+ * blocks with at least 4 x compute-unit-count blocks run one wave per block, 1: every eligible set, 2: never),
+ * inner_shared_launch_slots 65536 (a block every view / sample depends on with at least this many item slots is minimised by a
+ * sequence of launches over the whole device instead of resident workgroups; 0: never).  Neither changes what is computed.
  * Measurements may be added in any order (the reference walks an unordered map of views): the library sorts them by time before
  * anything is derived from them; per-block dumps (oicc_evaluate_blocks) stay in the caller's order. */
 int oicc_set_option(oicc_problem* p, const char* name, double value);
