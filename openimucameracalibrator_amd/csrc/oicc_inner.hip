@@ -488,6 +488,7 @@ int oicc_debug_host_inner_plan(oicc_problem* p, int32_t flags, int32_t* out8, in
   make_layout_host(p, flags);
   const double t2 = now_s();
   InnerPlanOptions o; o.flags = flags; o.gs_unit = p->opt["gs_unit_loss"] != 0.0; o.general_kernel = false; o.resident_wgs = 256; o.shared_share = 0.5; o.layout_gen = 0;
+  o.wave_blocks = int(p->opt["inner_wave_blocks"]); o.n_cu = 256; o.big_slots = int(p->opt["inner_shared_launch_slots"]);   // (an MI355X's compute units: there is no device to ask)
   double ms[3];
   build_inner_plan_host(p, o, ms);
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] host only: runs of samples %.3f ms, host layout %.3f ms, plan: blocks + neighbourhoods %.3f, independent sets %.3f, runs + workgroups %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1), ms[0], ms[1], ms[2]);
@@ -504,6 +505,25 @@ int oicc_debug_host_inner_plan(oicc_problem* p, int32_t flags, int32_t* out8, in
       o8[5] = k.nruns > 0 ? ip.runs[size_t(k.run0)].kind : -1; o8[6] = k.nruns > 0 ? ip.runs[size_t(k.run0)].first : -1; o8[7] = k.nruns;
     }
   return nb;
+}
+// What the round-5 kernels get of the plan oicc_debug_host_inner_plan built last: out6 = [sets on the one-wave-per-block kernel, large
+// shared blocks (sequence of launches), their parts in all, the largest part count, control blocks, workgroups of the set kernel];
+// parts_of_block[b] (may be null, `cap` entries) = parts of block b if it is a large shared block, else 0
+int oicc_debug_host_inner_plan_shape(oicc_problem* p, int32_t* out6, int32_t* parts_of_block, int32_t cap) {
+  const oicc_problem::InnerPlan& ip = p->inner;
+  int nw = 0; for (char w : ip.group_wave) nw += w ? 1 : 0;
+  out6[0] = nw; out6[1] = int32_t(ip.big_blocks.size()); out6[2] = int32_t(ip.big_wgs.size()); out6[3] = ip.big_max_parts; out6[4] = ip.n_ctls; out6[5] = int32_t(ip.wgs.size());
+  if (parts_of_block) {
+    for (int32_t b = 0; b < cap && b < int32_t(ip.blocks.size()); ++b) parts_of_block[b] = 0;
+    for (size_t k = 0; k < ip.big_blocks.size(); ++k) if (ip.big_blocks[k] < cap) parts_of_block[ip.big_blocks[k]] = ip.big_parts[k];
+    // (every part of a large block appears exactly once in the workgroup table of its set)
+    std::vector<int> seen(ip.blocks.size(), 0);
+    for (const InnerWg& w : ip.big_wgs) { if (w.part < 0 || w.part >= w.nparts) return -1; ++seen[size_t(w.block)]; }
+    for (size_t k = 0; k < ip.big_blocks.size(); ++k) if (seen[size_t(ip.big_blocks[k])] != ip.big_parts[k]) return -2;
+    for (size_t g = 0; g + 1 < ip.group_bigb0.size(); ++g)
+      for (int k = ip.group_bigb0[g]; k < ip.group_bigb0[g + 1]; ++k) { const int b = ip.big_blocks[size_t(k)]; if (b < ip.group_first[g] || b >= ip.group_first[g + 1]) return -3; }
+  }
+  return int(ip.blocks.size());
 }
 }  // extern "C"
 

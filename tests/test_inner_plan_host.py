@@ -41,6 +41,16 @@ class _HostOnly(E.SplineTrajectoryEstimator):
         if getattr(self, "_h", None):
             self._raw.oicc_debug_destroy_host_only(self._h); self._h = None
 
+    def plan_shape(self, n_blocks):
+        """[sets on the wave kernel, large shared blocks, their parts, largest part count, control blocks, set-kernel workgroups], parts per block"""
+        raw = self._raw
+        raw.oicc_debug_host_inner_plan_shape.restype = C.c_int
+        raw.oicc_debug_host_inner_plan_shape.argtypes = [_abi.H, _abi.c_i32p, _abi.c_i32p, C.c_int32]
+        out = np.zeros(6, dtype=np.int32); parts = np.zeros(n_blocks, dtype=np.int32)
+        n = raw.oicc_debug_host_inner_plan_shape(self._h, out.ctypes.data_as(_abi.c_i32p), parts.ctypes.data_as(_abi.c_i32p), n_blocks)
+        assert n == n_blocks, n
+        return out, parts
+
     def plan(self, flags):
         cap = 1 << 17
         out = np.zeros((cap, 8), dtype=np.int32); ns = C.c_int32(0); nw = C.c_int32(0)
@@ -119,3 +129,36 @@ def test_views_added_out_of_time_order_give_the_plan_of_the_sorted_problem():
     blocks, ns, _ = host.trajectory_.plan(FLAGS1)
     ord_, ns_o = _oracle_ordering(cpu, FLAGS1)
     assert ns == ns_o == ns_ref and np.array_equal(blocks[:, :3], ord_[:, :3]) and np.array_equal(blocks[:, :5], ref[:, :5])
+
+
+def test_plan_at_scale_marks_wave_sets_and_large_shared_blocks():
+    """Round 5: at BASELINE config 5 (30 011 blocks) the plan sends the sets of knot blocks that fill the device (>= 4 x 256 blocks) to
+    the one-wave-per-block kernel and the two blocks every view / sample depends on (T_i_c: 500 000 corners, gravity: 200 000
+    accelerometer samples) to the sequence-of-launches path, split into parts of 1024 item slots that cover the block exactly once;
+    with both options off, and at config 2 with the defaults, everything stays on the set kernel (the shared blocks on resident
+    workgroups with a control block each)."""
+    ds = synthetic.make_config("C5")
+    host = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(ds)
+    tr = host.trajectory_
+    blocks, n_sets, n_wgs = tr.plan(FLAGS1)
+    shape, parts = tr.plan_shape(len(blocks))
+    kinds = blocks[:, 1]
+    big = np.nonzero(parts)[0]
+    assert shape[0] >= 12 and shape[1] == 2 == len(big) and shape[4] == 2                       # the 6 + 6 knot sets at least; T_i_c, gravity
+    assert sorted(kinds[big]) == sorted([2, 3])                                                   # InnerKind: IK_TIC, IK_G
+    for b in big:
+        slots = int(blocks[b, 4])
+        assert slots >= 65536 and parts[b] == min(1024, -(-slots // 1024))
+    assert shape[2] == parts.sum() and shape[3] == parts.max() and shape[5] == n_wgs
+    assert blocks[big[0], 0] == blocks[big[1], 0]                                                 # one set: Ceres puts the two in the same independent set
+    # every other block keeps exactly its workgroups of the set kernel (one each here: no resident sharing left)
+    assert n_wgs == len(blocks) - 2
+    tr.SetOption("inner_wave_blocks", 2); tr.SetOption("inner_shared_launch_slots", 0)
+    blocks2, n_sets2, n_wgs2 = tr.plan(FLAGS1)
+    shape2, parts2 = tr.plan_shape(len(blocks2))
+    assert np.array_equal(blocks2, blocks) and n_sets2 == n_sets
+    assert shape2[0] == 0 and shape2[1] == 0 and shape2[2] == 0 and shape2[4] == 2 and not parts2.any() and n_wgs2 > len(blocks)   # resident parts of the two shared blocks
+    small = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(synthetic.make_config("C2"))
+    b3, _, w3 = small.trajectory_.plan(FLAGS1)
+    shape3, parts3 = small.trajectory_.plan_shape(len(b3))
+    assert shape3[0] == 0 and shape3[1] == 0 and shape3[4] == 2 and w3 > len(b3)
