@@ -514,7 +514,7 @@ struct InnerWaveCfg {
 namespace {
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 // slot i of the block -> its record (slot layout as inner_load_item: every run starts at a multiple of 64)
-__device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R, bool with_point) {
+__device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const InnerBlock& blk, int i, ItemRec& R) {   // (a corner's board point is NOT part of the record: the caller adds it)
   R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
 #pragma unroll
   for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
@@ -530,10 +530,6 @@ __device__ __forceinline__ void inner_load_item_rec(const InnerArgs& A, const do
   R.s_so3 = q.s_so3; R.s_r3 = q.s_r3; R.sx = q.sx;
 #pragma unroll
   for (int k = 0; k < 7; ++k) R.d[k] = q.d[k];
-  if (R.kind == 0 && with_point) {
-    const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)(q.sx >> 1);
-    R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3];
-  }
 }
 }  // namespace
 
@@ -613,7 +609,7 @@ __global__ void __launch_bounds__((InnerWaveCfg<R3ONLY>::T), (InnerWaveCfg<R3ONL
     wave_sync();
     for (int base = 0; base < blk.n_slots; base += 64) {
       ItemRec R;
-      inner_load_item_rec(A, xv, blk, base + lane, R, false);
+      inner_load_item_rec(A, blk, base + lane, R);
       if (R.kind == 0) { const double* X = pts_lds ? s_pts + 4 * (R.sx >> 1) : xv + pl.pts + 4 * (int64_t)(R.sx >> 1); R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3]; }
       if (__ballot(R.kind >= 0) == 0ull) continue;
       if (cmd == INNER_CMD_JAC) for (int k = 0; k < 3 * CFG::JS; ++k) J[k] = 0.0;
