@@ -132,7 +132,7 @@ __device__ __forceinline__ void se3_exp_local(const double a6[6], Quat* q, doubl
   if (theta < kSophusEps) so3_matrix(*q, V);
   else {
     const double tsq = theta * theta;
-    double s, c; sincos(theta, &s, &c);
+    double s, c; fast_sincos(theta, &s, &c);
     const double c1 = (1.0 - c) / tsq, c2 = (theta - s) / (tsq * theta);
     const double x = om[0], y = om[1], z = om[2];
     V[0] = 1.0 - c2 * (y * y + z * z); V[1] = -c1 * z + c2 * x * y;       V[2] = c1 * y + c2 * x * z;

@@ -122,7 +122,7 @@ __device__ __forceinline__ void se3_exp_dev(const double a6[6], Quat* q, double 
     so3_matrix(*q, V);
   } else {
     const double tsq = theta * theta;
-    double s, c; sincos(theta, &s, &c);
+    double s, c; fast_sincos(theta, &s, &c);
     const double c1 = (1.0 - c) / tsq, c2 = (theta - s) / (tsq * theta);
     const double x = om[0], y = om[1], z = om[2];
     // I + c1 [om]x + c2 [om]x^2

@@ -77,26 +77,6 @@ OICC_DEV void seg_kJr(const double* n, double k, double th_half, double inv_thet
   J[6] = ax * z + a1 * y;   J[7] = ay * z - a1 * x;       J[8] = k + (a2 * z * z - a2);
 }
 
-// sin and cos of a segment's half angle k theta / 2: branch free and short (~50 fp64 / integer instructions against the ~110 and two
-// branches of sincos(), five times per item).  Argument reduction by the nearest multiple of pi / 2 with pi / 2 in two pieces
-// (fdlibm e_rem_pio2.c: the first 33 bits, so n * piece is exact, and the rest) -- |x| stays below a few pi here (knots less than 180
-// degrees apart, k in [0, 1] up to the rolling-shutter shift), absolute error of the reduced argument < 1e-25 -- then the two kernel
-// polynomials of fdlibm on [-pi/4, pi/4] (k_sin.c / k_cos.c: < 1 ulp) and the quadrant by selects.
-OICC_DEV void seg_sincos(double x, double* sn, double* cs) {
-  const double fn = rint(x * 6.36619772367581382433e-01);
-  const double r = fma(-fn, 6.07710050650619224932e-11, fma(-fn, 1.57079632673412561417e+00, x));
-  const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
-  const double sr = fma(r * z, fma(z, ps, -1.66666666666666324348e-01), r);
-  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-  const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cr = w + (((1.0 - w) - hz) + z * pc);     // (k_cos.c: the rounding error of 1 - z/2 is put back)
-  const int n = (int)fn;
-  const double a = (n & 1) ? cr : sr, b = (n & 1) ? sr : cr;
-  *sn = (n & 2) ? -a : a;
-  *cs = ((n + 1) & 2) ? -b : b;
-}
-
 // Forward pass over the five segments of a window.  SEG(i) -> pointer to the table entry of segment i.
 struct So3FwdS {
   Quat R; double w[3];
@@ -116,7 +96,7 @@ OICC_DEV void so3_forward_seg(const Quat& R0, const SegAcc& SEG, double u, doubl
   for (int i = 0; i < 5; ++i) {
     const double* s = SEG(i);
     double sh, ch;
-    seg_sincos(F.k[i + 1] * s[kSegTh], &sh, &ch);
+    fast_sincos(F.k[i + 1] * s[kSegTh], &sh, &ch);
     F.sh[i] = sh; F.ch[i] = ch;
     if (WANT_VAL) acc = quat_mul_raw(acc, Quat{sh * s[kSegN], sh * s[kSegN + 1], sh * s[kSegN + 2], ch});
     if (WANT_VEL) {
