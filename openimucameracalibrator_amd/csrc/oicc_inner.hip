@@ -272,13 +272,18 @@ void build_inner_plan_host(oicc_problem* p, const InnerPlanOptions& o, double t_
     // occupancy query says are resident at once: a second problem on the same device -- another rank, another stream -- that runs
     // the same kind of set at the same time still fits next to it, so neither can strand the other's spinning parts)
     const int cap = std::max(1, int(double(resident_wgs) * shared_share) / std::max(n_shared, 1));
+    // large shared blocks (sequence of launches): parts sized so that ALL of the set's parts are resident at once -- two workgroups of
+    // inner_shared_eval_kernel per compute unit -- instead of a second, partly filled round (config 5: 457 parts of 1536 slots, not 685 of 1024)
+    int64_t big_total = 0;
+    for (int b = b0; b < b1; ++b) if (o.big_slots > 0 && ip.blocks[b].n_slots > kSharedAbove && ip.blocks[b].n_slots >= o.big_slots) big_total += ip.blocks[b].n_slots;
+    const int big_per_part = std::max<int64_t>(4 * kThreads, ((big_total + 2 * o.n_cu - 1) / (2 * o.n_cu) + kThreads - 1) / kThreads * kThreads);
     for (int pass = 0; pass < 2; ++pass)        // shared blocks first
       for (int b = b0; b < b1; ++b) {
         InnerBlock& blk = ip.blocks[b];
         const bool shared = blk.n_slots > kSharedAbove;
         if (shared != (pass == 0)) continue;
-        if (shared && o.big_slots > 0 && blk.n_slots >= o.big_slots) {   // a sequence of launches over the whole device (inner_shared_eval_kernel): 1024 item slots per part
-          const int np = std::min(1024, (blk.n_slots + 4 * kThreads - 1) / (4 * kThreads));
+        if (shared && o.big_slots > 0 && blk.n_slots >= o.big_slots) {   // a sequence of launches over the whole device (inner_shared_eval_kernel): at least 1024 item slots per part
+          const int np = std::min(1024, (blk.n_slots + big_per_part - 1) / big_per_part);
           blk.ctl = ip.n_ctls++;
           for (int q = 0; q < np; ++q) ip.big_wgs.push_back(InnerWg{b, q, np, 0});
           ip.big_blocks.push_back(b); ip.big_parts.push_back(np); ip.big_max_parts = std::max(ip.big_max_parts, np);

@@ -134,7 +134,8 @@ def test_views_added_out_of_time_order_give_the_plan_of_the_sorted_problem():
 def test_plan_at_scale_marks_wave_sets_and_large_shared_blocks():
     """Round 5: at BASELINE config 5 (30 011 blocks) the plan sends the sets of knot blocks that fill the device (>= 4 x 256 blocks) to
     the one-wave-per-block kernel and the two blocks every view / sample depends on (T_i_c: 500 000 corners, gravity: 200 000
-    accelerometer samples) to the sequence-of-launches path, split into parts of 1024 item slots that cover the block exactly once;
+    accelerometer samples) to the sequence-of-launches path, split into parts (of at least 1024 item slots, few enough to be resident
+    together) that cover the block exactly once;
     with both options off, and at config 2 with the defaults, everything stays on the set kernel (the shared blocks on resident
     workgroups with a control block each)."""
     ds = synthetic.make_config("C5")
@@ -146,9 +147,12 @@ def test_plan_at_scale_marks_wave_sets_and_large_shared_blocks():
     big = np.nonzero(parts)[0]
     assert shape[0] >= 12 and shape[1] == 2 == len(big) and shape[4] == 2                       # the 6 + 6 knot sets at least; T_i_c, gravity
     assert sorted(kinds[big]) == sorted([2, 3])                                                   # InnerKind: IK_TIC, IK_G
+    total = int(blocks[big, 4].sum())
+    per_part = max(1024, -(-(-(-total // 512)) // 256) * 256)       # all parts resident at once: two workgroups per compute unit (256 of them)
     for b in big:
         slots = int(blocks[b, 4])
-        assert slots >= 65536 and parts[b] == min(1024, -(-slots // 1024))
+        assert slots >= 65536 and parts[b] == min(1024, -(-slots // per_part))
+    assert parts.sum() <= 512
     assert shape[2] == parts.sum() and shape[3] == parts.max() and shape[5] == n_wgs
     assert blocks[big[0], 0] == blocks[big[1], 0]                                                 # one set: Ceres puts the two in the same independent set
     # every other block keeps exactly its workgroups of the set kernel (one each here: no resident sharing left)
