@@ -493,15 +493,16 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const doubl
 // ---- one WAVE per block (round 5) ------------------------------------------------------------------------------------------------
 // A sweep of a large problem is throughput bound (BASELINE config 5: 30 011 blocks, sets of 1700-3300): with one workgroup per
 // block four SIMDs share a block whose items fill 62 % of their lanes, wait at workgroup barriers and idle while ONE lane advances the
-// block's Levenberg-Marquardt loop.  Here a block is minimised by ONE wave (a workgroup = 4 / 8 independent blocks, no workgroup
-// barrier anywhere): the items are walked in rounds of 64 lanes (every run of a residual family padded to 64: a round evaluates one
+// block's Levenberg-Marquardt loop.  Here a block is minimised by ONE wave (a workgroup = NWV independent blocks -- one, as launched -- and no
+// workgroup barrier anywhere): the items are walked in rounds of 64 lanes (every run of a residual family padded to 64: a round evaluates one
 // family), read as per-item records with one coalesced load per round (InnerItemRec: nothing of the items lives in LDS), the sums
 // of a round go to the wave's LDS row, lane 0 advances the loop, two lanes refresh the segment-table entries of an SO(3) knot.
 // Same item functions, same advance function, same order of the sums inside a block as the workgroup kernel (a fixed order: lanes, then
 // rounds) -- the host takes this kernel for sets of knot blocks that are large enough to fill the device (oicc_inner.hip).
-template <bool R3ONLY>
+template <bool R3ONLY, int NWV>
 struct InnerWaveCfg {
-  static constexpr int T = R3ONLY ? 512 : 256;   // threads of a workgroup = blocks x 64
+  static constexpr int T = 64 * NWV;              // threads of a workgroup = blocks x 64.  The launcher takes NWV = 1: a finished block's slot is refilled
+                                                  // at once (four / eight blocks per workgroup wait for the slowest: 3.70 against 3.65 ms per C5 sweep), 15 KB of LDS
   static constexpr int JS = 3;                    // knot blocks only: three tangent dimensions
   static constexpr int NJ = 3 * JS + 3;
   static constexpr int SLOTS = 0;                 // (not used: the workgroup kernel's staging)
@@ -552,9 +553,9 @@ __global__ void inner_records_kernel(ViewData vd, ImuData ia, ImuData ig, InnerI
 }
 
 // wave w of workgroup g: block b0 + g * (T / 64) + w of the plan (a set's knot blocks are contiguous there)
-template <bool R3ONLY>
-__global__ void __launch_bounds__((InnerWaveCfg<R3ONLY>::T), (InnerWaveCfg<R3ONLY>::OCC)) inner_wave_kernel(const InnerArgs* __restrict__ Sp, double* xv, int b0, int n_blocks) {
-  using CFG = InnerWaveCfg<R3ONLY>;
+template <bool R3ONLY, int NWV>
+__global__ void __launch_bounds__((InnerWaveCfg<R3ONLY, NWV>::T), (InnerWaveCfg<R3ONLY, NWV>::OCC)) inner_wave_kernel(const InnerArgs* __restrict__ Sp, double* xv, int b0, int n_blocks) {
+  using CFG = InnerWaveCfg<R3ONLY, NWV>;
   constexpr int T = CFG::T, NW = T / 64;
   __shared__ double s_J[CFG::NJ * T];
   __shared__ double s_so3[NW][4 * kCapS], s_seg[NW][kSegStride * kCapS], s_r3[NW][3 * kCapR], s_ab[NW][3 * kCapB], s_gb[NW][3 * kCapB], s_scal[NW][26];
@@ -952,8 +953,8 @@ void launch_inner_shared_advance(const InnerArgs* dA, double* xv, const int32_t*
 size_t inner_lm_state_bytes() { return sizeof(InnerLm); }
 void launch_inner_wave(const InnerArgs* dA, double* xv, int b0, int n_blocks, bool r3_only, hipStream_t st) {   // one wave per block: blocks [b0, b0 + n_blocks) of the plan
   if (n_blocks <= 0) return;
-  if (r3_only) hipLaunchKernelGGL(inner_wave_kernel<true>, dim3((n_blocks + 7) / 8), dim3(512), 0, st, dA, xv, b0, n_blocks);
-  else hipLaunchKernelGGL(inner_wave_kernel<false>, dim3((n_blocks + 3) / 4), dim3(256), 0, st, dA, xv, b0, n_blocks);
+  if (r3_only) hipLaunchKernelGGL((inner_wave_kernel<true, 1>), dim3(n_blocks), dim3(64), 0, st, dA, xv, b0, n_blocks);
+  else hipLaunchKernelGGL((inner_wave_kernel<false, 1>), dim3(n_blocks), dim3(64), 0, st, dA, xv, b0, n_blocks);
 }
 // Workgroups of the general build that are resident at the same time on `n_cu` compute units (occupancy query, not an assumption: the
 // workgroups that share a block spin on each other, so a set's shared parts must all fit next to whatever else runs on the device)

@@ -757,7 +757,7 @@ def test_both_builds_of_the_inner_kernel_give_the_same_sweeps():
 @pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES), ("C3", FLAGS1), ("C4", FLAGS1)])
 def test_one_wave_per_block_gives_the_sweeps_of_one_workgroup_per_block(cfg, flags):
     """Round 5: large sets of knot blocks (>= 4 x compute units: BASELINE config 5) are minimised with ONE WAVE per block
-    (inner_wave_kernel: four / eight independent blocks per workgroup, items read as per-item records in rounds of 64, no workgroup
+    (inner_wave_kernel: a workgroup is one wave, items read as per-item records in rounds of 64, no workgroup
     barrier) instead of one workgroup per block.  Option inner_wave_blocks = 1 sends every eligible set of the smaller configurations
     through it: the sweeps of the workgroup kernel (= 2: never), hence of the oracle -- same outer iterates, sweep counts, per-block LM
     iteration totals, extrinsics; with the bias knots free (shared blocks stay on the workgroup kernel), on C3 / C4
