@@ -57,11 +57,14 @@ def main():
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds, shard=(rank, world) if world > 1 else None, owner_computes=bool(owner))
     tr = cal.trajectory_
     tr.SetOption("bounds_line_search", ls); tr.SetOption("inner_iterations", inner)
+    shared_launch = os.environ.get("OICC_TEST_SHARED_LAUNCH_SLOTS")     # (tests: the shared blocks of the sweeps as a sequence of launches at any size)
+    if shared_launch is not None: tr.SetOption("inner_shared_launch_slots", int(shared_launch))
     if world > 1:
         tr.SetAllReduce(allreduce)
         if owner: tr.SetExchange(exchange)
         if inner:
             whole = E.ImuCameraCalibrator().BatchInitSpline(ds)
+            if shared_launch is not None: whole.trajectory_.SetOption("inner_shared_launch_slots", int(shared_launch))   # (the plan of the sweeps belongs to the source problem)
             tr.SetInnerIterationSource(whole.trajectory_)
     s = tr.Optimize(iters, flags)
     it = tr.GetIterations()

@@ -874,6 +874,15 @@ def test_four_and_eight_processes_on_one_gpu_with_owned_ranges_in_the_middle(cfg
     _sharded_processes_take_the_steps_of_one(cfg, flags, 0, inner, owner, tmp_path, nproc)
 
 
+def test_owner_computes_sweeps_with_the_shared_blocks_as_a_sequence_of_launches(tmp_path, monkeypatch):
+    """Round 5: on sharded ranks with owner-computes sweeps the blocks every view / sample depends on are replicated -- every rank
+    minimises them, rank 0's count of LM iterations is the one that is reported, the non-knot tail of the parameter vector is
+    broadcast from rank 0 after the set.  With the threshold at 1 slot those blocks take the sequence-of-launches path
+    (inner_shared_eval_kernel / inner_shared_advance_kernel) on every rank: two processes still take the steps of one."""
+    monkeypatch.setenv("OICC_TEST_SHARED_LAUNCH_SLOTS", "1")
+    _sharded_processes_take_the_steps_of_one("C1", FLAGS1, 0, 1, 1, tmp_path, 2)
+
+
 def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_path, nproc):
     """Rank r of `nproc` PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
     all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
