@@ -250,6 +250,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags,
 /* Trace of the last oicc_optimize call; returns number of entries written. */
 int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out,
                         int32_t capacity);
+/* Debug read-out of the inner iterations (option "debug_inner_set_costs" = 1; Ceres' CoordinateDescentMinimizer has no counterpart,
+ * it is how a test names the independent set at which two implementations part): for every sweep of the last oicc_optimize call
+ * the pair [-1, total cost before the sweep] followed by one pair [number of parameter blocks in the set, total cost behind the
+ * set] per independent set, in processing order.  Returns the number of doubles available (written: min(capacity, that)). */
+int oicc_get_inner_set_costs(const oicc_problem* p, double* out, int32_t capacity);
 
 /* ---- multi-GPU: residual blocks are sharded by the caller (each
  * rank adds only its own views / IMU samples, all ranks hold all parameters).

@@ -85,6 +85,7 @@ SIGNATURES = {
     "add_gyroscope_measurements": (C.c_int, [H, C.c_int64, c_i64p, c_dp, C.c_double, c_u8p]),
     "optimize": (C.c_int, [H, C.c_int32, C.c_int32, C.POINTER(Summary)]),
     "get_iterations": (C.c_int, [H, C.POINTER(Iteration), C.c_int32]),
+    "get_inner_set_costs": (C.c_int, [H, c_dp, C.c_int32]),
     "get_tangent_layout": (C.c_int, [H, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p]),
     "evaluate": (C.c_int, [H, C.c_int32, c_dp, c_dp, c_dp, C.c_int32]),
     "evaluate_cost": (C.c_int, [H, C.c_int32, c_dp]),

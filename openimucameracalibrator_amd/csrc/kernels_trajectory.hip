@@ -62,3 +62,26 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
 }
 
 }  // namespace oicc
+
+// ---- debug entry point outside include/oicc_hip.h (tests/test_gpu_c5_reference_options.py): the DEVICE build of fast_sincos
+// (spline_math.cuh) on an array of arguments, so that it can be held against libm directly and not only through the residuals ----
+namespace oicc {
+__global__ void fast_sincos_kernel(int64_t n, const double* x, double* s, double* c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fast_sincos(x[i], s + i, c + i);
+}
+}  // namespace oicc
+extern "C" int oicc_debug_fast_sincos(int32_t device, int64_t n, const double* x, double* s, double* c) {
+  if (n <= 0 || !x || !s || !c) return 2;
+  if (hipSetDevice(device) != hipSuccess) return 5;
+  double* d = nullptr;
+  if (hipMalloc(&d, size_t(3) * size_t(n) * sizeof(double)) != hipSuccess) return 4;
+  bool ok = hipMemcpy(d, x, size_t(n) * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(oicc::fast_sincos_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, nullptr, n, d, d + n, d + 2 * n);
+    ok = hipGetLastError() == hipSuccess && hipMemcpy(s, d + n, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(c, d + 2 * n, size_t(n) * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d);
+  return ok ? 0 : 4;
+}

@@ -384,7 +384,7 @@ static int build_rank_part(oicc_problem* p, oicc_problem* shard) {
       bool mine = true;
       if (b.kind == IK_SO3) { kinds |= 1; mine = L.so3[size_t(b.idx)] >= 0 && owner_of(L.so3[size_t(b.idx)]) == me; }
       else if (b.kind == IK_R3) { kinds |= 2; mine = L.r3[size_t(b.idx)] >= 0 && owner_of(L.r3[size_t(b.idx)]) == me; }
-      else kinds |= 4;
+      else { kinds |= 4; if (b.kind == IK_PT) kinds |= 8; }   // (8: board points -- they live behind the IMU intrinsics in the parameter vector)
       if (mine) { rp.wgs.push_back(wg); if (b.kind != IK_SO3 && b.kind != IK_R3 && me != 0) rp.wgs.back().pad = 1; }   // (a replicated block's LM iterations are counted on rank 0 only)
     }
     rp.group_wg0.push_back(int32_t(rp.wgs.size())); rp.group_kinds.push_back(kinds);
@@ -416,6 +416,18 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
     ip.args_valid = true;
   }
   ++ip.sweeps;
+  // debug_inner_set_costs: the total cost before the sweep and behind every independent set (one cost pass + one read-back each)
+  const bool trace_sets = p->opt["debug_inner_set_costs"] != 0.0 && (shard == nullptr || shard == p);
+  auto trace_cost = [&](double nblocks) -> int {
+    if (!p->d_dbg_cost.resize(1)) { p->err = "hipMalloc debug cost"; return OICC_ERR_HIP; }
+    HIPCK(p, hipMemsetAsync(p->d_dbg_cost.p, 0, sizeof(double), st));
+    p->seg_invalidate(xv);
+    int rc = eval_pass(p, xv, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, p->d_dbg_cost.p); if (rc) return rc;
+    double c = 0.0;
+    HIPCK(p, hipMemcpyAsync(&c, p->d_dbg_cost.p, sizeof(double), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
+    p->inner_set_costs.push_back(nblocks); p->inner_set_costs.push_back(c);
+    return OICC_OK; };
+  if (trace_sets) { const int rc = trace_cost(-1.0); if (rc) return rc; }
   launch_inner_seg(xv + p->pl.so3, std::max(p->pl.n_so3 - 1, 0), ip.d_seg.p, st);
   if (ip.n_ctls > 0) HIPCK(p, hipMemsetAsync(ip.d_ctls.p, 0, size_t(ip.n_ctls) * sizeof(InnerCtl), st));
   const int prof_set = int(p->opt["debug_inner_profile"]) - 1;   // debug: phase clocks of workgroup 0 of this set
@@ -437,11 +449,13 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
         bool all_done = true;
         for (int k = 0; k < nbb; ++k) { const InnerBlock& bb = ip.blocks[size_t(ip.big_blocks[size_t(ip.group_bigb0[g] + k)])]; all_done = all_done && (reinterpret_cast<const InnerCtl*>(hc.data())[bb.ctl].word & 3u) == 2u; }
         if (all_done) break;
+        if (pairs + batch >= 256) { p->err = "inner iterations: a shared block's Levenberg-Marquardt loop did not end within 256 (evaluation, advance) launches"; return OICC_ERR_STATE; }
       }
     }
     if (!owned) {
       if (ip.group_wave[g] && prof == nullptr) launch_inner_wave(ip.d_args.p, xv, ip.group_first[g], ip.group_first[g + 1] - ip.group_first[g], ip.group_r3only[g] != 0, st);   // one wave per block: large sets of knot blocks
       else launch_inner_set(ip.d_args.p, xv, ip.d_wgs.p + ip.group_wg0[g], prof, ip.group_wg0[g + 1] - ip.group_wg0[g], mode, st);
+      if (trace_sets) { const int rc = trace_cost(double(ip.group_first[g + 1] - ip.group_first[g])); if (rc) return rc; }
       continue;
     }
     const oicc_problem::InnerPlan::RankPart& rp = ip.rank_part;
@@ -454,6 +468,7 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
       if (!rc && (kinds & 2) && rp.r3_hi[k] > rp.r3_lo[k]) rc = shard_broadcast(shard, xv + pl.r3 + 3 * int64_t(rp.r3_lo[k]), 3 * int64_t(rp.r3_hi[k] - rp.r3_lo[k]), k, st);
     }
     if (!rc && (kinds & 4)) rc = shard_broadcast(shard, xv + pl.ab, pl.gi + 9 - pl.ab, 0, st);   // [bias knots | T_i_c | g | line delay | IMU intrinsics]: contiguous in the parameter vector
+    if (!rc && (kinds & 8) && pl.n_pts > 0) rc = shard_broadcast(shard, xv + pl.pts, 4 * int64_t(pl.n_pts), 0, st);   // SplineOptimFlags::POINTS: the board points are replicated blocks too (advisor, round 5)
     const int rc2 = shard_broadcast_end(shard);
     if (rc || rc2) { p->err = shard->err; return rc ? rc : rc2; }
     if (kinds & 1) launch_inner_seg(xv + pl.so3, std::max(pl.n_so3 - 1, 0), ip.d_seg.p, st);   // the segment tables of the knots that came in

@@ -143,6 +143,7 @@ struct oicc_problem {
   int plan_wanted_flags = -2;   // oicc_optimize -> prepare: build the inner-iteration plan for these flags under the set-up
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
+  std::vector<double> inner_set_costs; DevBuf<double> d_dbg_cost;   // option debug_inner_set_costs: per sweep [-1, cost before], then per independent set [blocks, cost behind it] (oicc_get_inner_set_costs)
   oicc_allreduce_fn reduce = nullptr; void* reduce_user = nullptr;
   void* rccl_comm = nullptr;   // ncclComm_t of oicc_rccl_init
   int rccl_nranks = 1;
@@ -228,6 +229,7 @@ struct oicc_problem {
                             //    (LmCtl, lm_decide_kernel): the host enqueues iterations and polls a pinned word one iteration behind.  0: the host-driven loop
     opt["inner_shared_residency"] = 0.5;     // share of the device's resident workgroups the parts of a set's shared blocks (T_i_c, gravity, line delay, IMU intrinsics) may take together
     opt["debug_inner_general_kernel"] = 0;   // 1: sets of R^3 knots run on the general 4-wave build of the inner kernel too (tests: both builds give the same sweep)
+    opt["debug_inner_set_costs"] = 0;   // 1: a cost pass behind every independent set of every sweep (tests: a mismatch with the checker names the set); oicc_get_inner_set_costs
     opt["debug_inner_profile"] = 0;   // g + 1: print the phase clocks of workgroup 0 of independent set g after every sweep
     opt["projected_gradient_norm"] = 0;   // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x; only the 1e-10 gradient tolerance and the iteration trace see it)
     opt["bounds_line_search"] = 0;   // 1: Ceres' Armijo search along the projected path before every candidate evaluation when bias knots (box bounded, impl.h:206-240) are active

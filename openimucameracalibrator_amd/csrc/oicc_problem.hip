@@ -508,7 +508,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   S.num_parameters_tangent = P; S.band_dim = tl.Pb; S.arrow_dim = tl.a; S.half_bandwidth = tl.hb;
   S.num_residual_blocks = int64_t(p->view_rs.size() + p->acc.size() + p->gyr.size());
   S.num_residuals = int64_t(2 * p->corner_view.size() + 3 * p->acc.size() + 3 * p->gyr.size());
-  p->trace.clear(); p->line_search_steps = 0;
+  p->trace.clear(); p->line_search_steps = 0; p->inner_set_costs.clear();
   const double ftol = p->opt["function_tolerance"], ptol = p->opt["parameter_tolerance"], gtol = p->opt["gradient_tolerance"];
   double radius = p->opt["initial_trust_region_radius"]; const double max_radius = p->opt["max_trust_region_radius"];
   const double min_radius = p->opt["min_trust_region_radius"], min_rel_dec = p->opt["min_relative_decrease"];
@@ -589,6 +589,8 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       if (q->device != p->device || q->pl.total != p->pl.total || q->pl.n_so3 != p->pl.n_so3 || q->pl.n_r3 != p->pl.n_r3 || q->dt_so3 != p->dt_so3 || q->dt_r3 != p->dt_r3 || q->start_ns != p->start_ns) {
         p->err = "inner iteration source: different device or spline"; return OICC_ERR_INVALID_ARG; }
       for (const char* name : {"gs_unit_loss", "rs_time_in_seconds", "inner_iteration_tolerance", "inner_shared_residency"}) q->opt[name] = p->opt[name];
+      for (const char* name : {"inner_wave_blocks", "inner_shared_launch_slots"})   // plan options set on the shard (as oicc_hip.h documents): a change rebuilds the source's plan
+        if (q->opt[name] != p->opt[name]) { q->opt[name] = p->opt[name]; ++q->opt_gen; }
       q->max_ab = p->max_ab; q->max_gb = p->max_gb;   // the box of the bias knots the sweeps project onto
       q->cam_model = p->cam_model; q->n_intr = p->n_intr; std::memcpy(q->intr, p->intr, sizeof(q->intr));
       q->x[q->pl.ld] = p->x[p->pl.ld];   // (active_set looks at the zero-ness of the line delay)
@@ -842,6 +844,9 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
 }
 int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out, int32_t cap) {
   const int n = std::min<int>(cap, int(p->trace.size())); std::copy(p->trace.begin(), p->trace.begin() + n, out); return n; }
+int oicc_get_inner_set_costs(const oicc_problem* p, double* out, int32_t cap) {
+  const oicc_problem* q = p;   // (recorded on unsharded problems only: inner_sweep)
+  const int n = std::min<int>(cap, int(q->inner_set_costs.size())); if (out) std::copy(q->inner_set_costs.begin(), q->inner_set_costs.begin() + n, out); return int(q->inner_set_costs.size()); }
 
 
 // The device work + host synchronisation of ONE successful LM iteration (Jacobian
@@ -851,6 +856,7 @@ int oicc_get_iterations(const oicc_problem* p, oicc_iteration* out, int32_t cap)
 // this as its "step"; it is exactly the loop body of oicc_optimize.
 int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
   int rc = prepare(p, flags); if (rc) return rc;
+  if (steps <= 0) return OICC_OK;   // (nothing to enqueue: the device-side control block would be read uninitialised)
   hipStream_t st = p->stream;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { p->err = "no variable parameters"; return OICC_ERR_STATE; }

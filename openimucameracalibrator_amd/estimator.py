@@ -245,6 +245,19 @@ class SplineTrajectoryEstimator:
         n = self._b.get_iterations(self._h, arr, capacity)
         return [arr[i].as_dict() for i in range(n)]
 
+    def GetInnerSetCosts(self):
+        """Option debug_inner_set_costs: per sweep of the last Optimize a list of (blocks in the set, cost behind it); the first
+        entry of a sweep is (-1, cost before the sweep)."""
+        n = self._b.get_inner_set_costs(self._h, None, 0)
+        buf = np.zeros(max(n, 1))
+        self._b.get_inner_set_costs(self._h, buf.ctypes.data_as(_abi.c_dp), n)
+        sweeps = []
+        for k in range(0, n, 2):
+            if buf[k] < 0:
+                sweeps.append([])
+            sweeps[-1].append((int(buf[k]), float(buf[k + 1])))
+        return sweeps
+
     def SetAllReduce(self, fn):
         """fn(device_ptr:int, count:int, stream:int) -> None, sums fp64 in place across ranks."""
         if fn is None:
@@ -614,7 +627,11 @@ class ImuCameraCalibrator:
                 g = R_ai @ np.asarray(ds.accel[hit[0]], dtype=np.float64)
                 self.trajectory_.SetGravity(g)
                 return g
-        return None
+        # no accelerometer sample next to a view: the reference still calls trajectory_.SetGravity(gravity_init_) (cc:160; its member
+        # is uninitialised then) -- here with the data set's start value, as the C++ facade does with its default
+        g = np.asarray(ds.gravity_init, dtype=np.float64)
+        self.trajectory_.SetGravity(g)
+        return g
 
     def Optimize(self, iterations, optim_flags):
         """imu_camera_calibrator.cc:163-168: returns the mean reprojection error."""

@@ -268,15 +268,17 @@ inline int solve_block(Problem& p, const Layout& L, const Active& a, const PBloc
 }
 
 // CoordinateDescentMinimizer::Minimize: the independent sets in order, the blocks of a set in parallel
-inline void sweep(Problem& p, const Layout& L, const Active& a, const Ordering& ord, int nthreads, int64_t* lm_iterations) {
+inline void sweep(Problem& p, const Layout& L, const Active& a, const Ordering& ord, int nthreads, int64_t* lm_iterations, std::vector<double>* set_costs = nullptr) {
   int64_t total = 0;
   refresh_segment_table(p);   // analytic CPU path: the sweep starts from the candidate, whose knots differ from the last Jacobian pass
+  if (set_costs) { set_costs->push_back(-1.0); set_costs->push_back(total_cost(p, L, a)); }   // option debug_inner_set_costs (the device library records the same pairs)
 
   for (const std::vector<int>& set : ord.groups) {
     const int64_t n = int64_t(set.size());
     int most = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total) reduction(max : most)
     for (int64_t i = 0; i < n; ++i) { const int it = solve_block(p, L, a, ord.blocks[set[i]]); total += it; most = std::max(most, it); }
+    if (set_costs) { set_costs->push_back(double(n)); set_costs->push_back(total_cost(p, L, a)); }
     if (std::getenv("OICC_ORACLE_TRACE_SWEEP")) std::printf("[oracle] sweep: set of %lld blocks (first kind %d), at most %d LM iterations per block -> cost %.9e\n", (long long)n, ord.blocks[set[0]].kind, most, total_cost(p, L, a));
   }
   if (lm_iterations) *lm_iterations += total;

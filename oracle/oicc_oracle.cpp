@@ -61,6 +61,7 @@ struct Problem {
   std::vector<int> remote_so3, remote_r3;
   std::map<std::string, double> opt;
   std::vector<oicc_iteration> trace;
+  std::vector<double> inner_set_costs;     // option debug_inner_set_costs (oicc_oracle_get_inner_set_costs)
   mutable std::vector<double> seg_table;   // analytic CPU path: per-knot-pair tables of the current SO(3) knots (cpu_analytic::segment_table)
   Problem() {
     opt["function_tolerance"] = 1e-4; opt["parameter_tolerance"] = 1e-7; opt["gradient_tolerance"] = 1e-10;
@@ -71,6 +72,7 @@ struct Problem {
     opt["verbose"] = 0; opt["num_threads"] = 0; opt["analytic_jacobians"] = 0;
     opt["inner_iterations"] = 0;            // 1: Ceres' use_inner_iterations = true (impl.h:266), ceres_inner.hpp
     opt["inner_iteration_tolerance"] = 1e-3; // Solver::Options default
+    opt["debug_inner_set_costs"] = 0;       // 1: record the total cost before every sweep and behind every independent set
     opt["projected_gradient_norm"] = 0;     // 1: gradient_max_norm of a bounds-constrained program as Ceres reports it (ambient max norm of Plus(x, -g) - x)
     opt["bounds_line_search"] = 0;          // 1: Ceres' Armijo search along the projected path when bias knots are box bounded
   }
@@ -828,7 +830,7 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
   S.num_parameters_tangent = P; S.band_dim = L.P_band; S.arrow_dim = L.arrow; S.half_bandwidth = L.hb;
   S.num_residual_blocks = int64_t(p.views.size() + p.acc.size() + p.gyr.size());
   S.num_residuals = int64_t(p.uv.size() + 3 * p.acc.size() + 3 * p.gyr.size());
-  p.trace.clear();
+  p.trace.clear(); p.inner_set_costs.clear();
   const double ftol = p.opt["function_tolerance"], ptol = p.opt["parameter_tolerance"], gtol = p.opt["gradient_tolerance"];
   double radius = p.opt["initial_trust_region_radius"]; const double max_radius = p.opt["max_trust_region_radius"];
   const double min_radius = p.opt["min_trust_region_radius"], min_rel_dec = p.opt["min_relative_decrease"];
@@ -931,7 +933,7 @@ int oicc_oracle_optimize(oicc_problem* prob, int32_t max_iters, int32_t flags, o
     bool inner_useful = false;
     if (inner_enabled && std::isfinite(cand_cost)) {   // TrustRegionMinimizer::DoInnerIterationsIfNeeded
       t0 = now_s();
-      inner::sweep(p, L, a, ord, num_threads(p), &inner_lm_iterations); ++inner_sweeps;
+      inner::sweep(p, L, a, ord, num_threads(p), &inner_lm_iterations, p.opt["debug_inner_set_costs"] != 0 ? &p.inner_set_costs : nullptr); ++inner_sweeps;
       const double inner_cost = total_cost(p, L, a);
       S.seconds_residual += now_s() - t0; S.seconds_inner += now_s() - t0;
       model_cost_change += cand_cost - inner_cost;
@@ -984,6 +986,39 @@ double oicc_oracle_ls_next_step_size(const double init[3], const double* prev, i
 }
 int oicc_oracle_get_iterations(const oicc_problem* prob, oicc_iteration* out, int32_t cap) {
   const int n = std::min<int>(cap, int(prob->p.trace.size())); std::copy(prob->p.trace.begin(), prob->p.trace.begin() + n, out); return n; }
+int oicc_oracle_get_inner_set_costs(const oicc_problem* prob, double* out, int32_t cap) {
+  const std::vector<double>& v = prob->p.inner_set_costs;
+  const int n = std::min<int>(cap, int(v.size())); if (out) std::copy(v.begin(), v.begin() + n, out); return int(v.size()); }
+// Checker-only hook (no counterpart in include/oicc_hip.h): cost, gradient and Gauss-Newton matrix of single parameter blocks of the
+// inner iterations -- what ceres_inner.hpp's per-block Levenberg-Marquardt loop is built on -- with forward-mode Jets
+// (analytic = 0) or with the closed-form Jacobians (analytic = 1), at the current parameters.  `which[k]` indexes the blocks in
+// creation order; out = 94 doubles per block: [kind, knot / point index, tangent dimension, cost, g[9], H[81] (row major d x d)].
+// The tests use it to hold the closed-form sweep of BASELINE config 5 (Jets are too slow for T_i_c's 500 000 corners per
+// evaluation) against Jets on a sample of blocks.
+int oicc_oracle_debug_inner_block_evals(oicc_problem* prob, int32_t flags, int32_t n, const int32_t* which, int32_t analytic, double* out) {
+  Problem& p = P_;
+  const Layout L = make_layout(p, flags); const Active a = active_set(p, flags);
+  std::vector<inner::PBlock> blocks; inner::build_blocks(p, L, a, &blocks);
+  const double keep = p.opt["analytic_jacobians"];
+  p.opt["analytic_jacobians"] = analytic ? 1.0 : 0.0;
+  refresh_segment_table(p);
+  int rc = OICC_OK;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads(p))
+  for (int k = 0; k < n; ++k) {
+    double* o = out + size_t(94) * size_t(k);
+    if (which[k] < 0 || which[k] >= int(blocks.size())) { rc = OICC_ERR_INVALID_ARG; continue; }
+    const inner::PBlock& b = blocks[size_t(which[k])];
+    inner::SmallEval E; inner::eval_block(p, L, a, b, true, &E);
+    std::fill(o, o + 94, 0.0);
+    o[0] = b.kind; o[1] = b.idx; o[2] = b.dim; o[3] = E.cost;
+    std::copy(E.g, E.g + b.dim, o + 4); std::copy(E.H, E.H + b.dim * b.dim, o + 13);
+  }
+  p.opt["analytic_jacobians"] = keep;
+  return n < 0 ? int(blocks.size()) : rc;
+}
+int oicc_oracle_debug_num_inner_blocks(oicc_problem* prob, int32_t flags) {
+  Problem& p = P_; const Layout L = make_layout(p, flags); const Active a = active_set(p, flags);
+  std::vector<inner::PBlock> blocks; inner::build_blocks(p, L, a, &blocks); return int(blocks.size()); }
 
 int oicc_oracle_get_T_i_c(const oicc_problem* prob, double x[7]) { std::memcpy(x, prob->p.T_i_c, 7 * sizeof(double)); return OICC_OK; }
 int oicc_oracle_get_gravity(const oicc_problem* prob, double g[3]) { std::memcpy(g, prob->p.g, 3 * sizeof(double)); return OICC_OK; }

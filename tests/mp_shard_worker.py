@@ -64,7 +64,7 @@ def main():
         if owner: tr.SetExchange(exchange)
         if inner:
             whole = E.ImuCameraCalibrator().BatchInitSpline(ds)
-            if shared_launch is not None: whole.trajectory_.SetOption("inner_shared_launch_slots", int(shared_launch))   # (the plan of the sweeps belongs to the source problem)
+            # (the plan of the sweeps belongs to the source problem; oicc_optimize forwards the shard's plan options to it: round 6)
             tr.SetInnerIterationSource(whole.trajectory_)
     s = tr.Optimize(iters, flags)
     it = tr.GetIterations()
