@@ -41,6 +41,12 @@ struct BcrArgs {
   int s;                       // stride of this level
   int64_t offS_in, offS_out;   // first coupling of this level / of the next one
   int top;                     // bcri_invert_kernel<LAST>: the one pivot of the top level (> 0), whose back substitution block 0's workgroup does as well
+  // Distributed reduction (round 6, launch_bcr_dist_*): this system is the block range [b0, b0 + n) of a longer band.  `ghost`: the
+  // range has a right neighbour outside -- the first block of the next rank's range -- which is never a pivot here: it sits at
+  // storage index n (D, F start at zero and collect this range's Schur updates for its owner; x holds its solution for the back
+  // substitution), it is the right neighbour of whichever local block is the last active one, and the coupling to it is always
+  // stored local-variable major.  b0 = 0, ghost = 0: the whole band, as before.
+  int b0, ghost;
   const LmCtl* ctl;            // device-side LM control (oicc_device.h): every kernel returns at once when the loop is done
 };
 #define BCR_RETURN_IF_DONE(A) do { if ((A).ctl != nullptr && (A).ctl->done != 0) return; } while (0)
@@ -451,8 +457,18 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int a1 = A.a + 1, rtf = A.rtf, s = A.s;
+  if ((int)blockIdx.y == (int)gridDim.y - 1 && A.top < 0) {
+    // distributed reduction, odd number of active blocks: the last one is no pivot at this level, its coupling to the ghost block
+    // moves on to the next level's table unchanged (the workgroups of this extra row of the grid copy it)
+    const int m = -A.top;
+    const double* src = A.S + (A.offS_in + (m - 1)) * 4096; double* dst = A.S + (A.offS_out + (m - 1) / 2) * 4096;
+    for (int e = (int)blockIdx.x * 256 + tid; e < 4096; e += (int)gridDim.x * 256) dst[e] = src[e];
+    return;
+  }
   const int i = s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
-  const bool hasR = ir < A.n;                       // (a pivot always has its left neighbour)
+  const bool ghostR = A.ghost != 0 && ir >= A.n;    // the right neighbour is the next rank's first block
+  const bool hasR = ir < A.n || ghostR;             // (a pivot always has its left neighbour)
+  const int irs = ir < A.n ? ir : A.n;              // where the right neighbour's D / F live
   // group -> row tile (kind xk: 0 left, 1 right, 2 arrow rows / rhs; index xt), column tiles (kind yk, ny of them), and who stores T
   int g = (int)blockIdx.x, xk, xt, yk, ny; bool store_t;
   if (g < 4) { xk = 0; xt = g; yk = 0; ny = g + 1; store_t = true; }
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
   const int yt = wave;
   // orientation of the new coupling (il, ir): the pivot of the next level is the one at an odd position
   const bool il_is_pivot = ((il / (2 * s)) & 1) != 0;
-  const bool swap = xk == 1 && yk == 0 && !il_is_pivot;
+  const bool swap = xk == 1 && yk == 0 && !il_is_pivot && !ghostR;
   double vt[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) vt[kk] = Ts[li][4 * kk + lq];
@@ -523,8 +539,8 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
   }
   gq += gq2;
   // not swapped: gq[r] <-> (x row li, y row lq + 4 r); swapped: (y row li, x row lq + 4 r)
-  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)ir * 4096;
-  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)ir * 64 * a1;
+  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)irs * 4096;
+  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)irs * 64 * a1;
   double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -556,8 +572,9 @@ __global__ __launch_bounds__(64 * kBackWaves) void bcri_backward_kernel(BcrArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = A.a, a1 = a + 1, s = A.s;
-  const int i = s * (2 * (int)blockIdx.x + 1), il = i - s, ir = i + s;
-  const bool hasR = ir < A.n;
+  const int i = s * (2 * (int)blockIdx.x + 1), il = i - s;
+  const bool hasR = i + s < A.n || A.ghost != 0;
+  const int ir = i + s < A.n ? i + s : A.n;         // (distributed reduction: the ghost block's solution sits behind the local blocks)
   const double* Tg = A.Lf + (int64_t)i * (192 + a1) * 64 + 4096;
   constexpr int RW = 192 / kBackWaves;
   double lv[RW];
@@ -682,6 +699,7 @@ __global__ __launch_bounds__(1024) void bcri_backward2_kernel(BcrArgs A, int npi
 __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                                                double max_diag, const BcrArgs& A, const int64_t tid, const int64_t nthreads) {
   const int Pb = tl.Pb, a = tl.a, W = tl.W, a1 = a + 1, hb = tl.hb, n = A.n;
+  const int64_t r0 = (int64_t)A.b0 * 64;             // first band row of this system (distributed reduction: the rank's block range)
   const double radius = sb.radius;
   if (tid == 0) {   // results of the step that starts here
     sb.st->radius = radius; sb.st->model_cost_change = 0.0; sb.st->step_norm_sq = 0.0; sb.st->x_norm_sq = 0.0; sb.st->cand_cost = 0.0; sb.st->chol_failed = 0;
@@ -703,7 +721,7 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
   for (int64_t e = tid; e < (int64_t)n * 4096; e += nthreads) {
     const int blk = int(e >> 12), c = int(e >> 6) & 63, r = int(e) & 63;
     {
-      const int64_t gc = (int64_t)blk * 64 + c, gr = (int64_t)blk * 64 + r;
+      const int64_t gc = r0 + (int64_t)blk * 64 + c, gr = r0 + (int64_t)blk * 64 + r;
       double v = 0.0;
       if (r >= c) {
         const int k = r - c;
@@ -714,11 +732,11 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
       }
       A.D[e] = v;
     }
-    if (blk < n - 1) {
-      // coupling (blk, blk+1): the pivot of level 0 is the odd one
-      const bool right = (blk & 1) != 0;     // pivot = blk, neighbour = blk+1 (its right)
-      const int64_t gr = (int64_t)(blk + 1) * 64 + (right ? r : c);
-      const int64_t gc = (int64_t)blk * 64 + (right ? c : r);
+    if (blk < n - 1 || A.ghost != 0) {
+      // coupling (blk, blk+1): the pivot of level 0 is the odd one (the ghost block behind the last local one never is)
+      const bool right = (blk & 1) != 0 || blk == n - 1;     // pivot = blk, neighbour = blk+1 (its right)
+      const int64_t gr = r0 + (int64_t)(blk + 1) * 64 + (right ? r : c);
+      const int64_t gc = r0 + (int64_t)blk * 64 + (right ? c : r);
       const int64_t k = gr - gc;
       double v = 0.0;
       if (gr < Pb && k <= hb) v = ne.band()[gc * W + k] * sb.scale[gc] * sb.scale[gr];
@@ -727,15 +745,20 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
   }
   // border rows: arrow + rhs
   for (int64_t e = tid; e < (int64_t)n * 64 * a1; e += nthreads) {
-    const int64_t gi = e / a1; const int q = int(e - gi * a1);
+    const int64_t li = e / a1; const int q = int(e - li * a1); const int64_t gi = r0 + li;
     double v = 0.0;
     if (gi < Pb) v = q < a ? ne.Et()[(int64_t)q * Pb + gi] * sb.scale[gi] * sb.scale[Pb + q] : -ne.g()[gi] * sb.scale[gi];
     A.F[e] = v;
+  }
+  if (A.ghost != 0) {   // the ghost block collects this range's Schur updates for its owner: starts at zero
+    for (int64_t e = tid; e < 4096; e += nthreads) A.D[(int64_t)n * 4096 + e] = 0.0;
+    for (int64_t e = tid; e < (int64_t)64 * a1; e += nthreads) A.F[(int64_t)n * 64 * a1 + e] = 0.0;
   }
   // corner (same format as lm_build_kernel's Mc)
   for (int64_t e = tid; e < (int64_t)a1 * a1; e += nthreads) {
     const int r = int(e / a1), c = int(e - (int64_t)r * a1);
     double v = 0.0;
+    if (A.b0 != 0) { sb.Mc[e] = 0.0; continue; }   // (distributed reduction: the corner itself enters on the rank of block 0, the others hold their Schur updates only)
     if (r < a && c < a) {
       v = ne.C()[r * a + c] * sb.scale[Pb + r] * sb.scale[Pb + c];
       if (r == c) v += damp(Pb + r, ne.C()[r * a + r]);
@@ -778,7 +801,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void bcri_build_invert_kernel(Norma
   const double* band = ne.band();
   bcri_invert_body<false, false>(A, i, [&](int e) -> double {
     const int c = e >> 6, r = e & 63, k = r - c;
-    const int64_t gc = (int64_t)i * 64 + c, gr = (int64_t)i * 64 + r;
+    const int64_t gc = (int64_t)(A.b0 + i) * 64 + c, gr = (int64_t)(A.b0 + i) * 64 + r;
     if (k < 0) return 0.0;
     if (gr >= Pb) return (gc >= Pb && k == 0) ? 1.0 : 0.0;   // identity padding of the last block
     const double sc = sb.scale[gc];
@@ -808,6 +831,14 @@ static void bcr_allow_lds(const void* fn, size_t bytes) {
 
 
 static inline int bcr_blocks(int Pb) { return (Pb + 63) / 64; }
+static size_t bcr_lds_inv() { return ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double); }
+static void bcr_carve(BcrArgs& A, double* w, int nblk, int a1) {   // nblk: blocks incl. a ghost
+  A.D = w; w += (int64_t)nblk * 4096;
+  A.F = w; w += (int64_t)nblk * 64 * a1;
+  A.S = w; w += (int64_t)(2 * nblk + 40) * 4096;
+  A.Lf = w;
+}
+static int64_t bcr_carve_doubles(int nblk, int a1) { return (int64_t)nblk * 4096 + (int64_t)nblk * 64 * a1 + (int64_t)(2 * nblk + 40) * 4096 + (int64_t)nblk * (192 + a1) * 64 + 64; }
 // Arrow limit: the kernels take up to 63 arrow columns (four 16-row border tiles).  Round 2 saw sporadic NaN pivots with more than
 // two border tiles; the cause was the in-place read of the panel's diagonal block by waves that start a panel late (see the panel
 // factorisation and tests/test_gpu_parity.py::test_bcr_wide_borders_and_the_panel_hazard, which makes it deterministic); with the
@@ -817,79 +848,226 @@ bool bcr_applicable(const TangentLayout& tl) { return tl.Pb >= 1 && tl.hb <= 64 
 int64_t bcr_workspace_doubles(const TangentLayout& tl) {
   if (!bcr_applicable(tl)) return 0;
   const int64_t n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
-  return n * 4096 + n * 64 * a1 + 2 * n * 4096 + n * (192 + a1) * 64 + 64;
+  return bcr_carve_doubles(int(n), int(a1));
+}
+
+// ---- the launch sequence in pieces (shared by the one-GPU solve and the distributed one) ----
+struct BcrLevels { int strides[40]; int npivs[40]; int nlev = 0; int64_t off_end = 0; };   // off_end: index of the coupling table behind the last level (distributed: the final coupling (block 0, ghost))
+// the damped system in block form (+ the inversions of level 0 in the same launch when they fit the chip at once); returns whether level 0 is inverted
+static bool bcr_launch_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag, double max_diag, BcrArgs A, hipStream_t st) {
+  const int n = A.n;
+  const bool fused_build = n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
+  const int64_t work = (int64_t)(n + A.ghost) * 4096;
+  A.s = 1; A.offS_in = 0; A.offS_out = 0;
+  if (fused_build) {
+    int grid = int((work + 1023) / 1024); if (grid > 1024) grid = 1024;
+    bcr_allow_lds(reinterpret_cast<const void*>(bcri_build_invert_kernel), bcr_lds_inv());
+    hipLaunchKernelGGL(bcri_build_invert_kernel, dim3(n / 2 + grid), dim3(64 * kInvWaves), bcr_lds_inv(), st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+  } else {
+    int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
+  }
+  return fused_build;
+}
+// forward levels while more than one (local) block is active: inversions of the pivots, Schur complements onto their neighbours
+static void bcr_launch_forward(BcrArgs A, bool level0_inverted, BcrLevels& L, hipStream_t st) {
+  using KernelFn = void (*)(BcrArgs);
+  KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>;
+  bcr_allow_lds(reinterpret_cast<const void*>(k_inv), bcr_lds_inv());
+  const int n = A.n, g = A.ghost != 0 ? 1 : 0;
+  int64_t off = 0; L.nlev = 0;
+  for (int s = 1; s < n; s *= 2) {
+    const int m = (n + s - 1) / s;          // active blocks
+    const int npiv = m / 2;
+    A.s = s; A.offS_in = off; A.offS_out = off + (m - 1 + g);
+    const bool carry = g != 0 && (m & 1) != 0;   // the last active block is no pivot: its coupling to the ghost block moves on unchanged
+    A.top = carry ? -m : 0;
+    {
+      BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
+      if (!(level0_inverted && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(64 * kInvWaves), bcr_lds_inv(), st, Ai);
+      hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A);
+    }
+    L.strides[L.nlev] = s; L.npivs[L.nlev] = npiv; ++L.nlev;
+    off += m - 1 + g;
+  }
+  L.off_end = off;
+}
+// block 0 with the arrow corner, then the back substitution below the top level: two levels per launch from the bottom up
+static void bcr_launch_last_and_back(BcrArgs A, const BcrLevels& L, hipStream_t st) {
+  using KernelFn = void (*)(BcrArgs);
+  KernelFn k_inv_last = bcri_invert_kernel<true, false>;
+  const size_t lds_inv_last = bcr_lds_inv() + (size_t)64 * 65 * sizeof(double);
+  bcr_allow_lds(reinterpret_cast<const void*>(k_inv_last), lds_inv_last);
+  const int nlev = L.nlev;
+  A.s = 0; A.offS_in = 0; A.offS_out = 0;
+  A.top = nlev >= 1 ? L.strides[nlev - 1] : 0;     // (the top level has one pivot, block `stride`)
+  hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(64 * kInvWaves), lds_inv_last, st, A);
+  int l = nlev - 2;        // (the top level went with block 0)
+  if (l >= 0 && !(l & 1)) { A.s = L.strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(L.npivs[l]), dim3(64 * kBackWaves), 0, st, A); --l; }
+  for (; l >= 1; l -= 2) {
+    const int s = L.strides[l - 1];
+    int orphan = -1;      // the lower pivot s (2 c + 1), c even, whose upper neighbour would be block >= n
+    if (L.npivs[l - 1] > 2 * L.npivs[l]) orphan = s * (2 * (L.npivs[l - 1] - 1) + 1);    // (4 q + 2 active blocks at the lower level)
+    A.s = s;
+    hipLaunchKernelGGL(bcri_backward2_kernel, dim3(L.npivs[l] + (orphan >= 0 ? 1 : 0)), dim3(1024), 0, st, A, L.npivs[l], orphan);
+  }
 }
 
 // build + factor + solve; the solution lands in sb.step_s.  Returns 0, or -1 if not applicable.
 int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal,
                      double min_diag, double max_diag, hipStream_t st) {
   if (!bcr_applicable(tl) || tl.a + 1 > sb.bcr_max_border || sb.ws == nullptr || sb.ws_doubles < bcr_workspace_doubles(tl)) return -1;
+  if (sb.algo != 0 && sb.algo != 4) return -1;   // (algorithms 2 and 3 -- the factor-based levels of rounds 1-2 and their parallel form -- left the library in round 4)
   const int n = bcr_blocks(tl.Pb), a1 = tl.a + 1;
   BcrArgs A{};
-  double* w = sb.ws;
-  A.D = w; w += (int64_t)n * 4096;
-  A.F = w; w += (int64_t)n * 64 * a1;
-  A.S = w; w += (int64_t)2 * n * 4096;
-  if (sb.algo != 0 && sb.algo != 4) return -1;   // (algorithms 2 and 3 -- the factor-based levels of rounds 1-2 and their parallel form -- left the library in round 4)
-  A.Lf = w; w += (int64_t)n * (192 + a1) * 64 + 64;
+  bcr_carve(A, sb.ws, n, a1);
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
   A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.delay = sb.bcr_delay;
   A.rtf = (a1 + 15) / 16; A.ctl = sb.ctl;
-  const bool inv = true;
-  const size_t lds_inv = ((size_t)64 * kInvLD + 64 + 8 + 256) * sizeof(double), lds_inv_last = lds_inv + (size_t)64 * 65 * sizeof(double);
-  const bool fused_build = n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
-  {
-    int64_t work = (int64_t)n * 4096;
-    A.s = 1; A.offS_in = 0; A.offS_out = 0;
-    if (fused_build) {
-      int grid = int((work + 1023) / 1024); if (grid > 1024) grid = 1024;
-      bcr_allow_lds(reinterpret_cast<const void*>(bcri_build_invert_kernel), lds_inv);
-      hipLaunchKernelGGL(bcri_build_invert_kernel, dim3(n / 2 + grid), dim3(64 * kInvWaves), lds_inv, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
-    } else {
-      int grid = int((work + 255) / 256); if (grid > 4096) grid = 4096;
-      hipLaunchKernelGGL(bcr_build_kernel, dim3(grid), dim3(256), 0, st, ne, tl, sb, reuse_diagonal, min_diag, max_diag, A);
-    }
-  }
-  using KernelFn = void (*)(BcrArgs);
-  // cyclic reduction through the inverses of the pivot blocks (see bcri_invert_kernel)
-  KernelFn k_inv = A.prof ? bcri_invert_kernel<false, true> : bcri_invert_kernel<false, false>, k_inv_last = bcri_invert_kernel<true, false>;
-  if (inv) {
-    bcr_allow_lds(reinterpret_cast<const void*>(k_inv), lds_inv);
-    bcr_allow_lds(reinterpret_cast<const void*>(k_inv_last), lds_inv_last);
-  }
-  const int inv_threads = 64 * kInvWaves;
-  // forward: levels while more than one block is active
-  int strides[40]; int npivs[40]; int nlev = 0;
-  int64_t off = 0;
-  for (int s = 1; s < n; s *= 2) {
-    const int m = (n + s - 1) / s;          // active blocks
-    const int npiv = m / 2;
-    A.s = s; A.offS_in = off; A.offS_out = off + (m - 1);
-    {
-      BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
-      if (!(fused_build && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(inv_threads), lds_inv, st, Ai);
-      hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv), dim3(256), 0, st, A);
-    }
-    strides[nlev] = s; npivs[nlev] = npiv; ++nlev;
-    off += m - 1;
-  }
-  A.s = 0; A.offS_in = 0; A.offS_out = 0;
-  A.top = nlev >= 1 ? strides[nlev - 1] : 0;     // (the top level has one pivot, block `stride`)
-  hipLaunchKernelGGL(k_inv_last, dim3(1), dim3(inv_threads), lds_inv_last, st, A);
-  {
-    // back substitution below the top level: two levels per launch from the bottom up (an odd count: the uppermost alone, first)
-    int l = nlev - 2;        // (the top level went with block 0)
-    if (l >= 0 && !(l & 1)) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); --l; }
-    for (; l >= 1; l -= 2) {
-      const int s = strides[l - 1];
-      int orphan = -1;      // the lower pivot s (2 c + 1), c even, whose upper neighbour would be block >= n
-      if (npivs[l - 1] > 2 * npivs[l]) orphan = s * (2 * (npivs[l - 1] - 1) + 1);    // (4 q + 2 active blocks at the lower level)
-      A.s = s;
-      hipLaunchKernelGGL(bcri_backward2_kernel, dim3(npivs[l] + (orphan >= 0 ? 1 : 0)), dim3(1024), 0, st, A, npivs[l], orphan);
-    }
-    return 0;
-  }
+  const bool inverted = bcr_launch_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, st);
+  BcrLevels L;
+  bcr_launch_forward(A, inverted, L, st);
+  bcr_launch_last_and_back(A, L, st);
   return 0;
+}
+
+// =================================================================================================================================
+// Distributed block cyclic reduction (round 6; SURVEY 8(e) "v2 ... Solve: partitioned"; the reference's solve is one
+// SPARSE_NORMAL_CHOLESKY on one host, spline_trajectory_estimator.impl.h:257-272).  N ranks, rank k owns the blocks [b_k, b_k+1) of
+// the band (the cuts of the owner-computes exchange lie on multiples of 64 rows) and holds the complete rows of its range only.
+//   forward, no communication: rank k reduces ITS blocks with the kernels above down to its first block (the range's separator);
+//     the pivots at the right end of the range have the next rank's first block as their right neighbour -- the ghost block, never a
+//     pivot, whose D / F start at zero and collect this rank's Schur updates for their owner.
+//   ONE all-gather of [D_sep, F_sep, coupling (sep, ghost), D_ghost, F_ghost, this rank's Schur updates of the arrow corner]
+//     (3 x 4096 + 2 x 64 (a + 1) + (a + 1)^2 doubles per rank: 0.11 MB) -- the band itself never travels;
+//   the top system -- the N separators, block tridiagonal again, + the corner -- is assembled and solved by EVERY rank (log2 N levels
+//     + block 0: the same kernels), which leaves x of all separators and of the arrow on every rank;
+//   backward, no communication: the local levels in reverse; then ONE all-gather of the ranks' solutions (<= 0.72 MB in all at
+//     BASELINE config 5) puts the step on every rank.
+// Per-rank depth: ceil(log2(n / N)) + ceil(log2 N) + 1 inversions instead of ceil(log2 n) + 1, each over 1 / N of the pivots.
+// =================================================================================================================================
+__global__ void bcr_dist_pack_kernel(BcrArgs A, int64_t off_final, double* msg) {   // this rank's slot of the first gather
+  const int a1 = A.a + 1; const int64_t fsz = (int64_t)64 * a1;
+  const int64_t total = 3 * 4096 + 2 * fsz + (int64_t)a1 * a1;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    double v;
+    if (e < 4096) v = A.D[e];
+    else if (e < 4096 + fsz) v = A.F[e - 4096];
+    else if (e < 2 * 4096 + fsz) v = A.ghost ? A.S[off_final * 4096 + (e - 4096 - fsz)] : 0.0;
+    else if (e < 3 * 4096 + fsz) v = A.ghost ? A.D[(int64_t)A.n * 4096 + (e - 2 * 4096 - fsz)] : 0.0;
+    else if (e < 3 * 4096 + 2 * fsz) v = A.ghost ? A.F[(int64_t)A.n * fsz + (e - 3 * 4096 - fsz)] : 0.0;
+    else v = A.Mc[e - 3 * 4096 - 2 * fsz];
+    msg[e] = v;
+  }
+}
+// the top system from the gathered slots: T.D[k] = D_sep(k) + D_ghost(k - 1) (lower part), T.F likewise, the level-0 couplings in the
+// orientation the build gives them (pivot-variable major, the pivot is the odd block), the corner = the sum of the ranks' parts in rank order
+__global__ void bcr_dist_top_kernel(BcrArgs T, const double* msgs, int64_t piece) {
+  const int N = T.n, a1 = T.a + 1; const int64_t fsz = (int64_t)64 * a1;
+  const int64_t nD = (int64_t)N * 4096, nF = (int64_t)N * fsz, nS = (int64_t)(N - 1) * 4096, nC = (int64_t)a1 * a1;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nD + nF + nS + nC; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < nD) {
+      const int k = int(e >> 12); const int64_t o = e & 4095;
+      T.D[e] = msgs[k * piece + o] + (k > 0 ? msgs[(k - 1) * piece + 2 * 4096 + fsz + o] : 0.0);
+    } else if (e < nD + nF) {
+      const int64_t f = e - nD; const int k = int(f / fsz); const int64_t o = f - k * fsz;
+      T.F[f] = msgs[k * piece + 4096 + o] + (k > 0 ? msgs[(k - 1) * piece + 3 * 4096 + fsz + o] : 0.0);
+    } else if (e < nD + nF + nS) {
+      const int64_t f = e - nD - nF; const int k = int(f >> 12), c = int(f >> 6) & 63, r = int(f) & 63;
+      const double* src = msgs + k * piece + 4096 + fsz;       // Q[c = separator k variable][r = separator k + 1 variable]
+      T.S[f] = (k & 1) ? src[c * 64 + r] : src[r * 64 + c];    // (pivot = k + 1 when k is even: transposed)
+    } else {
+      const int64_t f = e - nD - nF - nS;
+      double v = 0.0;
+      for (int k = 0; k < N; ++k) v += msgs[k * piece + 3 * 4096 + 2 * fsz + f];
+      T.Mc[f] = v;
+    }
+  }
+}
+// the separators' and the arrow's solution into the local system: x of block 0, of the ghost block, the arrow part
+__global__ void bcr_dist_scatter_kernel(BcrArgs A, const double* xt, int N, int rank) {
+  const int t = threadIdx.x;
+  if (t < 64) A.x[t] = xt[rank * 64 + t];
+  else if (t < 128) { if (A.ghost) A.x[(int64_t)A.n * 64 + (t - 64)] = xt[(rank + 1) * 64 + (t - 64)]; }
+  else if (t < 128 + A.a) A.x[A.Pb + (t - 128)] = xt[N * 64 + (t - 128)];
+}
+__global__ void bcr_dist_pack_x_kernel(BcrArgs A, double* slot, int64_t arrow_at) {   // this rank's slot of the second gather: [its blocks' solution | arrow]
+  const int64_t nx = (int64_t)A.n * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nx + A.a; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < nx) slot[e] = A.x[e]; else slot[arrow_at + (e - nx)] = A.x[A.Pb + (e - nx)];
+  }
+}
+__global__ void bcr_dist_unpack_x_kernel(const double* slots, int64_t piece, const int32_t* b0s, int N, int Pb, int a, int64_t arrow_at, double* x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)Pb + a; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i >= Pb) { x[i] = slots[arrow_at + (i - Pb)]; continue; }     // (the arrow part: rank 0's -- every rank solved the same top system, up to the order of its atomics)
+    const int blk = int(i >> 6); int k = 0; while (k + 1 < N && blk >= b0s[k + 1]) ++k;
+    x[i] = slots[k * piece + (i - (int64_t)b0s[k] * 64)];
+  }
+}
+
+int64_t bcr_dist_workspace_doubles(const TangentLayout& tl, int n_loc, int nranks) {
+  const int a1 = tl.a + 1;
+  return bcr_carve_doubles(n_loc + 1, a1) + ((int64_t)(n_loc + 1) * 64 + tl.a + 8) + bcr_carve_doubles(nranks, a1) + ((int64_t)nranks * 64 + tl.a + 8) + 2 * (int64_t)a1 * a1 + 64;
+}
+int64_t bcr_dist_msg_doubles(const TangentLayout& tl) { const int a1 = tl.a + 1; return 3 * 4096 + 2 * (int64_t)64 * a1 + (int64_t)a1 * a1; }
+
+namespace {
+struct DistViews { BcrArgs A, T; double* xt; };
+DistViews bcr_dist_views(const TangentLayout& tl, const SolveBuffers& sb, const BcrDist& d) {
+  const int a1 = tl.a + 1, ghost = d.rank + 1 < d.nranks ? 1 : 0;
+  DistViews v{};
+  double* w = d.ws;
+  BcrArgs& A = v.A;
+  bcr_carve(A, w, d.n_loc + 1, a1); w += bcr_carve_doubles(d.n_loc + 1, a1);
+  A.x = w; w += (int64_t)(d.n_loc + 1) * 64 + tl.a + 8;
+  A.Mc = w; w += (int64_t)a1 * a1;
+  A.fail = &sb.st->chol_failed; A.prof = nullptr; A.n = d.n_loc; A.a = tl.a; A.Pb = (d.n_loc + ghost) * 64; A.delay = sb.bcr_delay;
+  A.rtf = (a1 + 15) / 16; A.ctl = nullptr; A.b0 = d.b0; A.ghost = ghost;
+  BcrArgs& T = v.T;
+  bcr_carve(T, w, d.nranks, a1); w += bcr_carve_doubles(d.nranks, a1);
+  T.x = w; w += (int64_t)d.nranks * 64 + tl.a + 8;
+  T.Mc = w; w += (int64_t)a1 * a1;
+  T.fail = A.fail; T.prof = nullptr; T.n = d.nranks; T.a = tl.a; T.Pb = d.nranks * 64; T.delay = sb.bcr_delay; T.rtf = A.rtf; T.ctl = nullptr; T.b0 = 0; T.ghost = 0;
+  v.xt = T.x;
+  return v;
+}
+}  // namespace
+
+// rank-local part of the forward reduction; leaves this rank's slot of the first gather in d.msg
+int launch_bcr_dist_forward(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb_in, int reuse_diagonal, double min_diag, double max_diag, const BcrDist& d, hipStream_t st) {
+  if (!bcr_applicable(tl) || tl.a + 1 > sb_in.bcr_max_border || d.ws == nullptr || d.n_loc < 1 || d.nranks < 2 || d.ws_doubles < bcr_dist_workspace_doubles(tl, d.n_loc, d.nranks)) return -1;
+  DistViews v = bcr_dist_views(tl, sb_in, d);
+  SolveBuffers sb = sb_in; sb.Mc = v.A.Mc; sb.ctl = nullptr;   // (the build writes the corner where the Schur kernels add to it)
+  const bool inverted = bcr_launch_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, v.A, st);
+  BcrLevels L;
+  bcr_launch_forward(v.A, inverted, L, st);
+  const int64_t total = bcr_dist_msg_doubles(tl);
+  hipLaunchKernelGGL(bcr_dist_pack_kernel, dim3(int((total + 255) / 256)), dim3(256), 0, st, v.A, L.off_end, d.msg + (int64_t)d.rank * d.msg_piece);
+  return 0;
+}
+// between the gathers: the top system and its solution (replicated), the local back substitution, this rank's slot of the second gather
+int launch_bcr_dist_middle(const TangentLayout& tl, const SolveBuffers& sb, const BcrDist& d, hipStream_t st) {
+  DistViews v = bcr_dist_views(tl, sb, d);
+  const int a1 = tl.a + 1, N = d.nranks;
+  const int64_t work = (int64_t)N * 4096 + (int64_t)N * 64 * a1 + (int64_t)(N - 1) * 4096 + (int64_t)a1 * a1;
+  hipLaunchKernelGGL(bcr_dist_top_kernel, dim3(int(std::min<int64_t>(1024, (work + 255) / 256))), dim3(256), 0, st, v.T, d.msg, d.msg_piece);
+  BcrLevels LT;
+  bcr_launch_forward(v.T, false, LT, st);
+  bcr_launch_last_and_back(v.T, LT, st);
+  hipLaunchKernelGGL(bcr_dist_scatter_kernel, dim3(1), dim3(256), 0, st, v.A, v.xt, N, d.rank);
+  // the local levels in reverse (the strides follow from the block count alone)
+  BcrArgs A = v.A;
+  int strides[40], npivs[40], nlev = 0;
+  for (int s = 1; s < A.n; s *= 2) { const int m = (A.n + s - 1) / s; strides[nlev] = s; npivs[nlev] = m / 2; ++nlev; }
+  for (int l = nlev - 1; l >= 0; --l) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); }
+  const int64_t nx = (int64_t)A.n * 64 + A.a;
+  hipLaunchKernelGGL(bcr_dist_pack_x_kernel, dim3(int((nx + 255) / 256)), dim3(256), 0, st, v.A, d.xg + (int64_t)d.rank * d.x_piece, (int64_t)d.max_loc * 64);
+  return 0;
+}
+// behind the second gather: the step of every rank's range -> sb.step_s
+void launch_bcr_dist_finish(const TangentLayout& tl, const SolveBuffers& sb, const BcrDist& d, hipStream_t st) {
+  const int64_t n = (int64_t)tl.Pb + tl.a;
+  hipLaunchKernelGGL(bcr_dist_unpack_x_kernel, dim3(int(std::min<int64_t>(1024, (n + 255) / 256))), dim3(256), 0, st, d.xg, d.x_piece, d.d_b0, d.nranks, tl.Pb, tl.a, (int64_t)d.max_loc * 64, sb.step_s);
 }
 
 }  // namespace oicc

@@ -430,6 +430,30 @@ __global__ void ne_unpack_ranges_kernel(NormalEq ne, TangentLayout tl, const int
     if (e < tl.W) ne.band()[r * tl.W + e] = v; else if (e < tl.W + tl.a) ne.Et()[(int64_t)(e - tl.W) * tl.Pb + r] = v; else ne.g()[r] = v;
   }
 }
+// Distributed solve (round 6): the band rows stay with their owners; what every rank still needs of ALL rows is the diagonal (Jacobi
+// scaling, the clamped Levenberg-Marquardt diagonal) and the gradient (its norm, the model cost change, line-search slopes): two
+// doubles per row travel instead of W + a + 1.
+__global__ void ne_pack_diag_g_kernel(NormalEq ne, TangentLayout tl, int row0, int n_rows, double* buf) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = row0 + k; buf[2 * k] = ne.band()[r * tl.W]; buf[2 * k + 1] = ne.g()[r];
+  }
+}
+__global__ void ne_unpack_diag_g_kernel(NormalEq ne, TangentLayout tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < tl.Pb; r += (int64_t)gridDim.x * blockDim.x) {
+    int k = 0; while (k + 1 < n && r >= cut[k + 1]) ++k;
+    if (k == me) continue;
+    const double* src = buf + (int64_t)k * piece + 2 * (r - cut[k]);
+    ne.band()[r * tl.W] = src[0]; ne.g()[r] = src[1];
+  }
+}
+void launch_ne_pack_diag_g(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st) {
+  if (n_rows <= 0) return;
+  hipLaunchKernelGGL(ne_pack_diag_g_kernel, dim3(int(std::min<int64_t>(1024, (n_rows + 255) / 256))), dim3(256), 0, st, ne, tl, row0, n_rows, buf);
+}
+void launch_ne_unpack_diag_g(const NormalEq& ne, const TangentLayout& tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf, hipStream_t st) {
+  if (tl.Pb <= 0) return;
+  hipLaunchKernelGGL(ne_unpack_diag_g_kernel, dim3(int(std::min<int64_t>(1024, (tl.Pb + 255) / 256))), dim3(256), 0, st, ne, tl, cut, n, me, piece, buf);
+}
 void launch_ne_pack_range(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st) {
   if (n_rows <= 0) return;
   const int64_t work = (int64_t)n_rows * (tl.W + tl.a + 1);

@@ -21,6 +21,13 @@ void launch_lm_solve_residual(const NormalEq& ne, const TangentLayout& tl, const
 int64_t bcr_workspace_doubles(const TangentLayout& tl);
 int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag,
                      double max_diag, hipStream_t st);
+bool bcr_applicable(const TangentLayout& tl);
+// distributed block cyclic reduction (kernels_bcr.hip): rank-local forward part / top system + local back substitution / the gathered step
+int64_t bcr_dist_workspace_doubles(const TangentLayout& tl, int n_loc, int nranks);
+int64_t bcr_dist_msg_doubles(const TangentLayout& tl);
+int launch_bcr_dist_forward(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag, double max_diag, const BcrDist& d, hipStream_t st);
+int launch_bcr_dist_middle(const TangentLayout& tl, const SolveBuffers& sb, const BcrDist& d, hipStream_t st);
+void launch_bcr_dist_finish(const TangentLayout& tl, const SolveBuffers& sb, const BcrDist& d, hipStream_t st);
 // damped system + factorisation + solve (solution in sb.step_s): block cyclic reduction when the
 // geometry allows (hb <= 64, arrow <= 63 columns), else the time-partitioned band sweep
 static inline int launch_lm_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb_in, double radius, int reuse_diagonal,

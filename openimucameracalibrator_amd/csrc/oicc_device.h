@@ -152,4 +152,15 @@ struct SolveBuffers {
   const LmCtl* ctl_prev = nullptr; const LmState* st_prev = nullptr; int64_t off_cost = 0;
 };
 
+// One rank's part of the distributed block cyclic reduction (kernels_bcr.hip: launch_bcr_dist_*; host side oicc_exchange.hip)
+struct BcrDist {
+  int nranks = 1, rank = 0;
+  int b0 = 0, n_loc = 0;      // this rank's blocks [b0, b0 + n_loc) of the band's 64-column blocks
+  int max_loc = 0;            // the largest block count of a rank: one slot of the solution gather
+  const int32_t* d_b0 = nullptr;   // device: first block of every rank, [nranks + 1]
+  double* ws = nullptr; int64_t ws_doubles = 0;
+  double* msg = nullptr; int64_t msg_piece = 0;   // first gather (separators, ghost blocks, corner parts): nranks slots
+  double* xg = nullptr; int64_t x_piece = 0;      // second gather (solutions): nranks slots
+};
+
 }  // namespace oicc

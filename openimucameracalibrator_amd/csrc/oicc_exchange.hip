@@ -85,7 +85,7 @@ int owner_exchange_agree(oicc_problem* p, hipStream_t st, bool* use) {
   if (p->shard_n <= 1 || p->reduce == nullptr) return OICC_OK;
   oicc_problem::OwnerPlan& op = p->owner;
   if (op.agreed_gen == p->layout_gen) { *use = op.agreed; return OICC_OK; }
-  const double h = double(op.valid ? (op.hash & 0xfffffu) : 0u);
+  const double h = double(op.valid ? ((op.hash ^ (p->opt["distributed_solve"] != 0.0 ? 0x5bd1eu : 0u)) & 0xfffffu) : 0u);   // (the choice of solve is part of what the ranks must agree on)
   double v[4] = {owner_exchange_ready(p) ? 1.0 : 0.0, 1.0, h, h * h};
   if (!p->d_xagree.resize(4)) { p->err = "hipMalloc exchange agreement"; return OICC_ERR_HIP; }
   HIPCK(p, hipMemcpyAsync(p->d_xagree.p, v, sizeof(v), hipMemcpyHostToDevice, st));
@@ -114,6 +114,75 @@ int shard_broadcast_end(oicc_problem* p) {
   if (p->rccl_comm != nullptr && rccl_api().GroupEnd() != ncclSuccess) { p->err = "ncclGroupEnd failed"; return OICC_ERR_STATE; }
   return OICC_OK;
 }
+// Equal pieces from every rank into every rank's copy of `slots` (slot k = rank k's, `piece` doubles apart; this rank's slot is filled):
+// one in-place ncclAllGather, or one broadcast per owner where that entry point is missing / on the hook transport.
+static int shard_allgather(oicc_problem* p, double* slots, int64_t piece, hipStream_t st) {
+  const int n = p->shard_n, me = p->shard_rank;
+  RcclApi& api = rccl_api();
+  const bool native = p->rccl_comm != nullptr;
+  ncclComm_t comm = static_cast<ncclComm_t>(p->rccl_comm);
+  bool ok = true;
+  if (native && api.AllGather != nullptr) ok = api.AllGather(slots + int64_t(me) * piece, slots, size_t(piece), ncclDouble, comm, st) == ncclSuccess;
+  else {
+    if (native) ok = api.GroupStart() == ncclSuccess;
+    for (int k = 0; k < n && ok; ++k) {
+      double* ptr = slots + int64_t(k) * piece;
+      ok = native ? api.Broadcast(ptr, ptr, size_t(piece), ncclDouble, k, comm, st) == ncclSuccess
+                  : (p->exchange != nullptr && p->exchange(p->exchange_user, OICC_XCHG_BROADCAST, ptr, piece, ptr, piece, k, st) == 0);
+    }
+    if (native) ok = (api.GroupEnd() == ncclSuccess) && ok;
+  }
+  if (!ok) { p->err = "all-gather between the ranks failed"; return OICC_ERR_STATE; }
+  return OICC_OK;
+}
+
+// ---- distributed linear solve (round 6): see kernels_bcr.hip, "Distributed block cyclic reduction" ----
+// Usable when the ranks agreed on the exchange (same cuts everywhere), the geometry is the cyclic reduction's, and every rank owns
+// at least one 64-column block: all of it derived from agreed data, so every rank answers alike.
+bool dist_solve_usable(oicc_problem* p) {
+  oicc_problem::DistSolve& ds = p->dist;
+  const oicc_problem::OwnerPlan& op = p->owner;
+  if (ds.gen == p->layout_gen) return ds.usable;
+  ds.gen = p->layout_gen; ds.usable = false;
+  const TangentLayout& tl = p->tl;
+  const int n = p->shard_n;
+  if (n < 2 || n > 64 || !op.valid || !op.agreed || op.agreed_gen != p->layout_gen || p->opt["distributed_solve"] == 0.0) return false;
+  const int algo = int(p->opt["solver_algorithm"]);
+  if (!bcr_applicable(tl) || tl.a + 1 > int(p->opt["bcr_max_border"]) || (algo != 0 && algo != 4)) return false;
+  const int nblk = (tl.Pb + 63) / 64;
+  ds.b0.assign(size_t(n) + 1, 0);
+  for (int k = 0; k <= n; ++k) ds.b0[size_t(k)] = k == n ? nblk : op.cut[size_t(k)] / 64;
+  int max_loc = 0;
+  for (int k = 0; k < n; ++k) { const int c = ds.b0[size_t(k) + 1] - ds.b0[size_t(k)]; if (c < 1 || (k > 0 && op.cut[size_t(k)] % 64 != 0)) return false; max_loc = std::max(max_loc, c); }
+  BcrDist& d = ds.d;
+  d.nranks = n; d.rank = p->shard_rank; d.b0 = ds.b0[size_t(d.rank)]; d.n_loc = ds.b0[size_t(d.rank) + 1] - d.b0; d.max_loc = max_loc;
+  d.ws_doubles = bcr_dist_workspace_doubles(tl, d.n_loc, n);
+  d.msg_piece = (bcr_dist_msg_doubles(tl) + 7) / 8 * 8; d.x_piece = (int64_t(max_loc) * 64 + tl.a + 7) / 8 * 8;
+  if (!ds.ws.resize(size_t(d.ws_doubles)) || !ds.msg.resize(size_t(d.msg_piece) * size_t(n)) || !ds.xg.resize(size_t(d.x_piece) * size_t(n)) || !ds.d_b0.upload(ds.b0, p->stream)) return false;
+  if (hipStreamSynchronize(p->stream) != hipSuccess) return false;   // (b0 may be reassigned)
+  d.ws = ds.ws.p; d.msg = ds.msg.p; d.xg = ds.xg.p; d.d_b0 = ds.d_b0.p;
+  ds.usable = true;
+  return true;
+}
+int dist_solve(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb_in, double radius, int reuse_diagonal, double min_diag, double max_diag, hipStream_t st) {
+  oicc_problem::DistSolve& ds = p->dist;
+  SolveBuffers sb = sb_in; sb.radius = radius;
+  if (launch_bcr_dist_forward(ne, p->tl, sb, reuse_diagonal, min_diag, max_diag, ds.d, st) != 0) { p->err = "distributed solve: geometry / workspace"; return OICC_ERR_STATE; }
+  int rc = shard_allgather(p, ds.d.msg, ds.d.msg_piece, st); if (rc) return rc;
+  if (launch_bcr_dist_middle(p->tl, sb, ds.d, st) != 0) { p->err = "distributed solve: top system"; return OICC_ERR_STATE; }
+  rc = shard_allgather(p, ds.d.xg, ds.d.x_piece, st); if (rc) return rc;
+  launch_bcr_dist_finish(p->tl, sb, ds.d, st);
+  HIPCK(p, hipGetLastError());
+  ++ds.solves;
+  return OICC_OK;
+}
+int lm_solve_any(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb, double radius, int reuse_diagonal, double min_diag, double max_diag, hipStream_t st) {
+  if (p->shard_n > 1 && p->reduce != nullptr && dist_solve_usable(p)) return dist_solve(p, ne, sb, radius, reuse_diagonal, min_diag, max_diag, st);
+  if (launch_lm_solve(ne, p->tl, sb, radius, reuse_diagonal, min_diag, max_diag, st) != 0) {
+    p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)"; return OICC_ERR_UNSUPPORTED; }
+  return OICC_OK;
+}
+
 int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved) {
   const oicc_problem::OwnerPlan& op = p->owner;
   const TangentLayout& tl = p->tl;
@@ -153,8 +222,22 @@ int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t*
   //     a + 2 strided pieces of a range as separate broadcasts: 88 collectives per pass at N = 8, a = 9, thousands under POINTS).
   //     Slot k of the gather buffer belongs to rank k; native: one in-place ncclAllGather of equal (padded) slots, or one broadcast
   //     per owner where that entry point is missing; hook transport: one broadcast per owner.
-  const int64_t piece = int64_t(std::max(op.max_owned, 1)) * L;
   double* slots = p->d_xgather.p;
+  if (dist_solve_usable(p)) {
+    // distributed solve (round 6): the band rows stay where they are -- the owner eliminates them; every rank still needs the
+    // diagonal (Jacobi scaling, Levenberg-Marquardt diagonal) and the gradient of ALL rows: two doubles per row
+    const int64_t piece2 = int64_t(std::max(op.max_owned, 1)) * 2;
+    launch_ne_pack_diag_g(ne, tl, op.cut[me], op.cut[me + 1] - op.cut[me], slots + int64_t(me) * piece2, st);
+    const int rcg = shard_allgather(p, slots, piece2, st); if (rcg) return rcg;
+    moved += int64_t(n - 1) * piece2 * int64_t(sizeof(double));
+    launch_ne_unpack_diag_g(ne, tl, p->d_xcut.p, n, me, piece2, slots, st);
+    if (tl.a > 0 && p->reduce(p->reduce_user, ne.C(), int64_t(tl.a) * tl.a, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+    if (p->reduce(p->reduce_user, ne.g() + tl.Pb, int64_t(tl.a) + 1, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
+    moved += 2 * (int64_t(tl.a) * tl.a + tl.a + 1) * int64_t(sizeof(double));
+    if (bytes_moved) *bytes_moved = moved;
+    return OICC_OK;
+  }
+  const int64_t piece = int64_t(std::max(op.max_owned, 1)) * L;
   launch_ne_pack_range(ne, tl, op.cut[me], op.cut[me + 1] - op.cut[me], slots + int64_t(me) * piece, st);
   bool ok = true;
   if (native && api.AllGather != nullptr) {
@@ -218,6 +301,12 @@ int oicc_set_shard(oicc_problem* p, int32_t nranks, int32_t rank) {
 }
 
 int oicc_set_exchange(oicc_problem* p, oicc_exchange_fn fn, void* user) { p->exchange = fn; p->exchange_user = user; return OICC_OK; }
+// debug read-out (outside include/oicc_hip.h; tests, bench.py): out4 = [distributed solves run so far, this rank's first block, its block count, ranks]
+int oicc_debug_dist_solve_info(const oicc_problem* p, int64_t out4[4]) {
+  if (!p || !out4) return OICC_ERR_INVALID_ARG;
+  out4[0] = p->dist.solves; out4[1] = p->dist.d.b0; out4[2] = p->dist.d.n_loc; out4[3] = p->dist.usable ? p->dist.d.nranks : 0;
+  return OICC_OK;
+}
 
 namespace { struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } }; }   // (destroyed on every exit of the timing entry points)
 

@@ -179,15 +179,19 @@ void build_owner_plan(oicc_problem* p) {
   for (int k = 1; k < n; ++k) {
     prev_hi = std::max(prev_hi, hi[k - 1]);
     int c = lo[k] < nk ? (std::min(lo[k], prev_hi) + std::max(lo[k], prev_hi)) / 2 : prev_hi;   // middle of the overlap (or of the gap)
-    c = std::min(std::max(c, op.cut[k - 1] / 3), nk);
-    op.cut[k] = 3 * c;
+    c = std::min(c, nk);
+    // Round 6: a cut lies on a multiple of 64 ROWS (possibly inside a knot's three rows) -- the blocks of the cyclic reduction
+    // (kernels_bcr.hip) are 64 columns, and a rank eliminates the blocks of its own range (distributed solve, oicc_dist_solve.hip)
+    int32_t row = int32_t((int64_t(3) * c + 32) / 64) * 64;
+    row = std::min<int32_t>(std::max<int32_t>(row, op.cut[k - 1]), int32_t((L.Pb / 64) * 64));
+    op.cut[k] = row;
   }
   op.cut[n] = L.Pb;
   op.send_rows.assign(size_t(n), {}); op.recv_rows.assign(size_t(n), {});
   for (int q = 0; q < n; ++q) {
     if (q == me) continue;
-    for (int k = op.cut[q] / 3; k < op.cut[q + 1] / 3; ++k) if (touch[me][k]) for (int r = 0; r < 3; ++r) op.send_rows[q].push_back(3 * k + r);
-    for (int k = op.cut[me] / 3; k < op.cut[me + 1] / 3; ++k) if (touch[q][k]) for (int r = 0; r < 3; ++r) op.recv_rows[q].push_back(3 * k + r);
+    for (int r = op.cut[q]; r < op.cut[q + 1]; ++r) if (touch[me][r / 3]) op.send_rows[q].push_back(r);
+    for (int r = op.cut[me]; r < op.cut[me + 1]; ++r) if (touch[q][r / 3]) op.recv_rows[q].push_back(r);
   }
   op.flat.clear(); op.send_off.assign(size_t(n) + 1, 0); op.recv_off.assign(size_t(n) + 1, 0); op.max_rows = 0;
   for (int q = 0; q < n; ++q) { op.send_off[q] = int32_t(op.flat.size()); op.flat.insert(op.flat.end(), op.send_rows[q].begin(), op.send_rows[q].end()); op.max_rows = std::max(op.max_rows, int(op.send_rows[q].size())); }
@@ -199,7 +203,7 @@ void build_owner_plan(oicc_problem* p) {
   uint32_t h = 2166136261u; auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
   for (int32_t c : op.cut) mix(uint32_t(c));
   mix(uint32_t(L.Pb)); mix(uint32_t(L.a)); mix(uint32_t(L.hb));
-  for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != b) { uint32_t cnt = 0; for (int k = op.cut[b] / 3; k < op.cut[b + 1] / 3; ++k) cnt += touch[a][k]; mix(cnt); }   // rows rank a sends to rank b
+  for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != b) { uint32_t cnt = 0; for (int r = op.cut[b]; r < op.cut[b + 1]; ++r) cnt += touch[a][r / 3]; mix(cnt); }   // rows rank a sends to rank b
   op.hash = h;
   op.valid = true;
 }

@@ -52,6 +52,8 @@ void launch_rank_unpack(double* x, int64_t n, LmState* s, const double* pack, hi
 void launch_ne_pack_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, double* buf, hipStream_t st);
 void launch_ne_add_rows(const NormalEq& ne, const TangentLayout& tl, const int32_t* rows, int n_rows, const double* buf, hipStream_t st);
 void launch_ne_pack_range(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st);
+void launch_ne_pack_diag_g(const NormalEq& ne, const TangentLayout& tl, int row0, int n_rows, double* buf, hipStream_t st);
+void launch_ne_unpack_diag_g(const NormalEq& ne, const TangentLayout& tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf, hipStream_t st);
 void launch_ne_unpack_ranges(const NormalEq& ne, const TangentLayout& tl, const int32_t* cut, int n, int me, int64_t piece, const double* buf, hipStream_t st);
 void launch_inner_diff_norm(const double* x, const double* xc, const InnerBlock* blocks, int nb, double* step_norm_sq, hipStream_t st);
 void launch_lm_retract(const double* x, double* xc, const ParamLayout& pl, const TangentLayout& tl, const SolveBuffers& sb,
@@ -134,6 +136,9 @@ struct oicc_problem {
                      int64_t agreed_gen = -1; bool agreed = false;   // all ranks agreed (once per layout, through the installed reduction) that every one of them can run the exchange on the same cuts
                      uint32_t hash = 0; } owner;
   DevBuf<int32_t> d_xrows, d_xcut; DevBuf<double> d_xsend, d_xrecv, d_xgather, d_xagree;
+  // distributed linear solve (round 6; kernels_bcr.hip launch_bcr_dist_*, oicc_exchange.hip dist_solve): every rank reduces the 64-column
+  // blocks of its own range, the ranks' separators are gathered and solved by all, the step is gathered -- the band never travels
+  struct DistSolve { bool usable = false; int64_t gen = -1; BcrDist d; std::vector<int32_t> b0; DevBuf<int32_t> d_b0; DevBuf<double> ws, msg, xg; double ms_forward = 0, ms_gather = 0, ms_middle = 0, ms_gather_x = 0; int64_t solves = 0; } dist;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
   std::vector<uint8_t> pts_seen_global; int64_t pts_seen_meas_gen = -1, meas_gen = 0;   // SplineOptimFlags::POINTS on time shards: which board points ANY rank's views observe (summed once through the reduction, prepare()); meas_gen counts the Add* calls
   bool has_remote_views = false;   // other ranks hold views too: under SplineOptimFlags::POINTS every board point is a variable on every rank (which points they see is not declared)
@@ -222,6 +227,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["distributed_solve"] = 1;       // time-sharded ranks with the owner-computes exchange: every rank eliminates the blocks of its own band range, only the ranks' separator blocks and the step travel (0: the band is gathered and every rank solves the whole system)
     opt["owner_computes_sweeps"] = 1;   // time-sharded ranks with the owner-computes exchange: a rank sweeps only the knot blocks it owns, owners broadcast after every set (0: replicated sweeps)
     opt["inner_shared_launch_slots"] = 65536;   // a block every view / sample depends on with at least this many item slots is minimised by a sequence of launches over the whole device instead of resident workgroups that wait for each other (0: never)
     opt["inner_wave_blocks"] = 0;   // inner sweeps, which sets run one WAVE per block (inner_wave_kernel) instead of one workgroup: 0 = sets of at least 4 x compute units knot blocks (throughput bound), 1 = every eligible set, 2 = none
@@ -301,4 +307,7 @@ int shard_broadcast_begin(oicc_problem* p);                                     
 int shard_broadcast(oicc_problem* p, double* ptr, int64_t count, int root, hipStream_t st);      // native RCCL (one group) or the transport hook
 int shard_broadcast_end(oicc_problem* p);
 int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t* bytes_moved = nullptr);
+bool dist_solve_usable(oicc_problem* p);   // (after the exchange is agreed on: derived from what all ranks agreed on, so every rank answers alike)
+int dist_solve(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb, double radius, int reuse_diagonal, double min_diag, double max_diag, hipStream_t st);
+int lm_solve_any(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb, double radius, int reuse_diagonal, double min_diag, double max_diag, hipStream_t st);   // the distributed solve on agreed shards, else launch_lm_solve
 }  // namespace oicc

@@ -679,9 +679,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
 #endif
     HIPCK(p, hipEventRecord(ev[0], st));
     if (p->opt["debug_poison_lds"] != 0.0) launch_lds_poison(st);
-    if (launch_lm_solve(p->ne, tl, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st) != 0) {
-      p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)";
-      return OICC_ERR_UNSUPPORTED; }
+    rc = lm_solve_any(p, p->ne, sb, radius, reuse_diagonal ? 1 : 0, min_diag, max_diag, st); if (rc) return rc;   // (agreed shards: the distributed cyclic reduction, oicc_exchange.hip)
     {   // the retraction also leaves the candidate's segment tables (one kernel fewer per cost pass)
       oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
       launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, (sgt && p->seg_precomputed()) ? sgt->buf.p : nullptr);
@@ -891,7 +889,7 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
     return OICC_OK;
   }
   for (int it = 0; it < steps; ++it) {
-    if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+    rc = lm_solve_any(p, p->ne, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st); if (rc) return rc;
     {
       oicc_problem::SegTable* sgt = p->seg_of(p->d_xc.p);
       launch_lm_retract(p->d_x.p, p->d_xc.p, p->pl, tl, sb, p->ne, p->max_ab, p->max_gb, st, 1.0, 1, (sgt && p->seg_precomputed()) ? sgt->buf.p : nullptr);
@@ -939,7 +937,10 @@ int oicc_time_jacobian_pass(oicc_problem* p, int32_t flags, int32_t repeats, dou
 int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_solve) {
   int rc = prepare(p, flags); if (rc) return rc;
   hipStream_t st = p->stream;
-  auto saved = p->reduce; p->reduce = nullptr;
+  // time-sharded ranks (oicc_set_shard + a reduction): the pass runs with its exchange and the solve is the one oicc_optimize
+  // uses there -- the distributed cyclic reduction where the ranks agreed on it -- so every rank must make this call
+  const bool sharded = p->shard_n > 1 && p->reduce != nullptr;
+  auto saved = p->reduce; if (!sharded) p->reduce = nullptr;
   rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
   const TangentLayout& tl = p->tl;
   if (tl.P == 0) { if (ms_per_solve) *ms_per_solve = 0; return OICC_OK; }
@@ -948,10 +949,10 @@ int oicc_time_linear_solve(oicc_problem* p, int32_t flags, int32_t repeats, doub
   LmState hs; std::memset(&hs, 0, sizeof(hs)); hs.radius = p->opt["initial_trust_region_radius"];
   HIPCK(p, hipMemcpyAsync(p->d_state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
   hipEvent_t e0, e1; HIPCK(p, hipEventCreate(&e0)); HIPCK(p, hipEventCreate(&e1));
-  if (launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st) != 0) { p->err = "solver geometry unsupported"; return OICC_ERR_UNSUPPORTED; }
+  rc = lm_solve_any(p, p->ne, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st); if (rc) return rc;
   HIPCK(p, hipEventRecord(e0, st));
   for (int i = 0; i < repeats; ++i) {
-    launch_lm_solve(p->ne, tl, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st);
+    rc = lm_solve_any(p, p->ne, sb, p->opt["initial_trust_region_radius"], 0, p->opt["min_lm_diagonal"], p->opt["max_lm_diagonal"], st); if (rc) return rc;
   }
   HIPCK(p, hipEventRecord(e1, st)); HIPCK(p, hipEventSynchronize(e1));
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);

@@ -883,7 +883,39 @@ def test_owner_computes_sweeps_with_the_shared_blocks_as_a_sequence_of_launches(
     _sharded_processes_take_the_steps_of_one("C1", FLAGS1, 0, 1, 1, tmp_path, 2)
 
 
-def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_path, nproc):
+@pytest.mark.parametrize("cfg,nproc,iters", [("C1", 2, 6), ("C1", 4, 6), ("C2", 2, 6), ("C2", 4, 6), ("C2", 8, 6), ("C3", 4, 4), ("C5", 2, 1), ("C5", 4, 1)])
+def test_distributed_cyclic_reduction_takes_the_steps_of_one_process(cfg, nproc, iters, tmp_path):
+    """Round 6, SURVEY 8(e) "v2 ... Solve": with the owner-computes exchange agreed on, every rank eliminates the 64-column blocks of
+    ITS band range (kernels_bcr.hip: launch_bcr_dist_*; the last pivots of a range have the next rank's first block as a ghost
+    neighbour), the ranks' separator blocks (+ ghost blocks, final couplings, corner parts: 0.11 MB per rank) are gathered, every rank
+    solves the N-block top system, back-substitutes its own range, and the step is gathered -- the band itself is NEVER gathered:
+    besides its own rows a rank only receives the halo rows of its own range, two doubles per foreign row (diagonal, gradient) and
+    the solution.  2 / 4 / 8 processes on one GPU through the transport hooks take the steps of ONE process (costs 1e-8, T_i_c 1e-7);
+    every solve of every rank ran distributed; no broadcast as large as a rank's band range happened; and with distributed_solve = 0
+    the same shards fall back to the gathered band (the larger messages come back)."""
+    parts, whole = _sharded_processes_take_the_steps_of_one(cfg, FLAGS1, 0, 0, 1, tmp_path, nproc, iters=iters)
+    nit = len(whole["iterations"])
+    assert all(p_["dist_ranks"] == nproc and p_["dist_solves"] >= nit - 1 and p_["dist_blocks"] >= 1 for p_ in parts), [(p_["dist_ranks"], p_["dist_solves"], p_["dist_blocks"]) for p_ in parts]
+    assert sum(p_["dist_blocks"] for p_ in parts) == (whole["band_dim"] + 63) // 64 and [p_["dist_first_block"] for p_ in parts] == sorted(p_["dist_first_block"] for p_ in parts)
+    # the largest message any rank received: one of the three gathers (top-system slot, solution slot, diagonal + gradient), never a band range
+    a1 = parts[0]["P"] - whole["band_dim"] + 1
+    most = max(p_["dist_blocks"] for p_ in parts)
+    limit = max(3 * 4096 + 128 * a1 + a1 * a1 + 8, 64 * most + a1 + 8, 2 * 64 * most)
+    assert all(p_["exchange"]["max_broadcast"] <= limit for p_ in parts), ([p_["exchange"]["max_broadcast"] for p_ in parts], limit)
+    rows = whole["band_dim"] // nproc
+    if cfg != "C1":
+        assert limit < 0.5 * rows * parts[0]["band_row_doubles"]      # (... which would be this large)
+    if cfg == "C2" and nproc == 2:
+        import os
+        os.environ["OICC_TEST_DISTRIBUTED_SOLVE"] = "0"
+        try:
+            parts0, _ = _sharded_processes_take_the_steps_of_one(cfg, FLAGS1, 0, 0, 1, tmp_path, nproc, iters=iters)
+        finally:
+            del os.environ["OICC_TEST_DISTRIBUTED_SOLVE"]
+        assert all(p_["dist_solves"] == 0 and p_["exchange"]["max_broadcast"] > 0.5 * rows * p_["band_row_doubles"] > limit for p_ in parts0)
+
+
+def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_path, nproc, iters=6):
     """Rank r of `nproc` PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
     all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
     LmState) after every cost pass, slopes of the bounds line search.  RCCL refuses two ranks on one device, so the hook stages
@@ -902,9 +934,9 @@ def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_p
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world), LOCAL_RANK="0")
             out = str(tmp_path / ("w%d_r%d.json" % (world, r))); outs.append(out)
-            procs.append(subprocess.Popen([_sys.executable, worker, cfg, str(int(flags)), "6", str(ls), out, str(inner), str(owner)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+            procs.append(subprocess.Popen([_sys.executable, worker, cfg, str(int(flags)), str(iters), str(ls), out, str(inner), str(owner)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         for p_ in procs:
-            o, _ = p_.communicate(timeout=240)
+            o, _ = p_.communicate(timeout=400)
             assert p_.returncode == 0, o.decode()[-2000:]
         return [_json.load(open(o)) for o in outs]
 
@@ -930,6 +962,7 @@ def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_p
             assert a["ok"] == b["ok"] and abs(a["cost"] - b["cost"]) <= (1e-7 if inner else 1e-8) * b["cost"], (a, b)
         assert np.abs(np.array(p_["T_i_c"]) - np.array(whole["T_i_c"])).max() < (1e-6 if inner else 1e-7)
     assert all(np.abs(np.array(parts[0]["T_i_c"]) - np.array(p_["T_i_c"])).max() < 1e-9 for p_ in parts[1:])
+    return parts, whole
 
 
 
