@@ -186,6 +186,16 @@ def main():
             ok = all_ok(ok)
         if ok:
             assembly_path = "owner-computes exchange"
+            # ... and one trial of the distributed linear solve (round 6: two all-gathers inside the solve) -- a rank that fails takes
+            # every rank back to the gathered band + replicated solve (option distributed_solve = 0 is part of what the ranks agree on)
+            ok2 = True
+            try:
+                tr.TimeLinearSolve(flags, repeats=1)
+            except Exception as e:
+                ok2 = False
+                sys.stderr.write("rank %d: trial of the distributed solve failed (%s)\n" % (rank, e))
+            if not all_ok(ok2):
+                tr.SetOption("distributed_solve", 0)
         else:
             tr.SetShard(1, 0)
 
@@ -230,6 +240,22 @@ def main():
                 exchange_ms, exchange_bytes = tr.TimeExchange(flags, repeats=10)
             except Exception as e:
                 sys.stderr.write("rank %d: exchange timing failed (%s)\n" % (rank, e))
+        barrier()
+
+    # N > 1, round 6: the linear solve the timed steps ran -- on agreed shards the DISTRIBUTED cyclic reduction (every rank reduces its
+    # own band range, gathered separators, replicated top system, gathered step) -- timed on every rank by HIP events (a collective)
+    dist_solve = None
+    if world > 1 and assembly_path == "owner-computes exchange":
+        try:
+            mine = tr.TimeLinearSolve(flags, repeats=10)
+            info = tr.DistributedSolveInfo()
+            v = torch.tensor([mine, float(info["blocks"]), float(info["ranks"])], dtype=torch.float64, device="cuda")
+            allv = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(allv, v)
+            dist_solve = dict(solve_ms_per_rank=[float(t[0]) for t in allv], blocks_per_rank=[int(t[1]) for t in allv], distributed=bool(info["ranks"] == world),
+                              note="HIP events around 10 solves on every rank's stream, both gathers included; distributed = False: the band was gathered and every rank solved the whole system")
+        except Exception as e:
+            sys.stderr.write("rank %d: solve timing failed (%s)\n" % (rank, e))
         barrier()
 
     # N > 1: the SAME workload on ONE GPU, measured in the same run -- rank 0 builds the whole (unsharded) C5 problem and times the
@@ -357,12 +383,12 @@ def main():
             out["n1_same_workload"] = n1_same
             out["scaling_note"] = "no multi-GPU node was available while this was built: the N > 1 path has run on hardware only through the driver; the curve is unmeasured until SCALE_rNN.json exists"
         if use_dist:   # where a rank's iteration goes: its shard's Jacobian pass and the replicated solve alone (HIP events, no collective), the rest = all-reduce of the packed system + cost, broadcast, cost pass, retraction
-            out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=solve_ms, step_ms=ms_per_step,
+            out["per_rank"] = dict(jacobian_pass_ms=pass_ms, solve_ms=(max(dist_solve["solve_ms_per_rank"]) if dist_solve else solve_ms), solve_ms_whole_system_on_one_rank=solve_ms, distributed_solve=dist_solve, step_ms=ms_per_step,
                                    allreduce_ms=allreduce_ms, allreduce_bytes=allreduce_bytes, allreduce_timing="HIP events around 10 all-reduces of the packed normal equations on the library's stream (%s)" % reduce_path,
                                    exchange_ms=exchange_ms, exchange_bytes=exchange_bytes,
-                                   exchange="owner-computes (what the timed steps ran): halo rows to their owners (ncclSend / ncclRecv), gather of the owned band ranges (ncclBroadcast per owner), all-reduce of the arrow corner" if exchange_ms is not None else "all-reduce of the whole packed buffer (owner-computes exchange not available on this path)",
+                                   exchange=("owner-computes (what the timed steps ran): halo rows to their owners (ncclSend / ncclRecv), all-gather of the diagonal and the gradient (the band rows stay with their owners: distributed solve), all-reduce of the arrow corner" if (dist_solve and dist_solve["distributed"]) else "owner-computes (what the timed steps ran): halo rows to their owners (ncclSend / ncclRecv), gather of the owned band ranges, all-reduce of the arrow corner") if exchange_ms is not None else "all-reduce of the whole packed buffer (owner-computes exchange not available on this path)",
                                    roofline_per_rank=dict(fp64_frac=kernels["blocks"]["fp64_TFLOPs"] / 78.6, hbm_frac=kernels["blocks"]["hbm_GBps"] / 8000.0, note="this rank's shard: algorithmic FLOPs / bytes of its Jacobian pass over the pass time by HIP events"),
-                                   rest_ms=max(0.0, ms_per_step - pass_ms - solve_ms - (allreduce_ms or 0.0)))
+                                   rest_ms=max(0.0, ms_per_step - pass_ms - (max(dist_solve["solve_ms_per_rank"]) if dist_solve else solve_ms) - ((exchange_ms if exchange_ms is not None else allreduce_ms) or 0.0)))
         if summ is not None:
             out["full_calibration"] = dict(full_ref, solver_options="reference: inner iterations + bounds line search + projected gradient norm (impl.h:255-276)",
                                            plain_lm=dict(full_plain, solver_options="plain Levenberg-Marquardt steps (no inner sweeps)"))

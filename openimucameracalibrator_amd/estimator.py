@@ -361,6 +361,15 @@ class SplineTrajectoryEstimator:
         self._keep.append(cb)
         self._ck(self._b.set_exchange(self._h, cb, None))
 
+    def DistributedSolveInfo(self):
+        """Debug read-out of the distributed linear solve on time-sharded ranks (device library only): solves run so far, this
+        rank's first 64-column block, its block count, the ranks that take part (0: the solve is replicated)."""
+        fn = self._b.lib.oicc_debug_dist_solve_info
+        fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        out = (C.c_int64 * 4)()
+        self._ck(fn(self._h, out))
+        return dict(solves=int(out[0]), first_block=int(out[1]), blocks=int(out[2]), ranks=int(out[3]))
+
     def TimeExchange(self, flags, repeats=10):
         """(ms per owner-computes exchange of the packed normal equations, bytes this rank moved); a collective: every rank calls it."""
         ms = C.c_double(0.0); nb = C.c_int64(0)

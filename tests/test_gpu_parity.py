@@ -903,7 +903,7 @@ def test_distributed_cyclic_reduction_takes_the_steps_of_one_process(cfg, nproc,
     limit = max(3 * 4096 + 128 * a1 + a1 * a1 + 8, 64 * most + a1 + 8, 2 * 64 * most)
     assert all(p_["exchange"]["max_broadcast"] <= limit for p_ in parts), ([p_["exchange"]["max_broadcast"] for p_ in parts], limit)
     rows = whole["band_dim"] // nproc
-    if cfg != "C1":
+    if cfg not in ("C1",) and not (cfg == "C2" and nproc == 8):   # (C1, and C2 on eight ranks -- 228 rows each: a rank's band range is no larger than a top-system slot)
         assert limit < 0.5 * rows * parts[0]["band_row_doubles"]      # (... which would be this large)
     if cfg == "C2" and nproc == 2:
         import os
