@@ -267,6 +267,7 @@ int owner_exchange(oicc_problem* p, const NormalEq& ne, hipStream_t st, int64_t*
 
 }  // namespace oicc
 
+namespace { struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } }; }   // (destroyed on every exit of the timing entry points)
 extern "C" {
 
 int oicc_rccl_get_unique_id(uint8_t id[128]) {
@@ -301,6 +302,61 @@ int oicc_set_shard(oicc_problem* p, int32_t nranks, int32_t rank) {
 }
 
 int oicc_set_exchange(oicc_problem* p, oicc_exchange_fn fn, void* user) { p->exchange = fn; p->exchange_user = user; return OICC_OK; }
+// Debug / measurement entry (outside include/oicc_hip.h; tests, bench.py): the DISTRIBUTED cyclic reduction of `nranks` ranks run by ONE
+// process on the unsharded problem -- every rank's forward part in turn (into its slot of the gather buffer: the "all-gather" is a
+// no-op in one address space), then every rank's top system + local back substitution, then the step -- and checked against the
+// packed normal equations: out[0] = ||M delta - rhs|| / ||rhs||, out[1] = Cholesky failure flag, then per rank r
+// out[2 + 2 r] = ms of its forward part, out[3 + 2 r] = ms of its top system + back substitution (HIP events, the rank alone on the
+// device: what ONE rank of an N-GPU run spends in the solve besides the two gathers).  Block ranges: equal split of the blocks.
+int oicc_debug_dist_solve_emulated(oicc_problem* p, int32_t flags, int32_t nranks, double radius, int32_t repeats, double* out) {
+  int rc = prepare(p, flags); if (rc) return rc;
+  hipStream_t st = p->stream;
+  auto saved = p->reduce; p->reduce = nullptr;
+  rc = eval_pass(p, p->d_x.p, true); p->reduce = saved; if (rc) return rc;
+  const TangentLayout& tl = p->tl;
+  const int nblk = (tl.Pb + 63) / 64;
+  ARG(p, out != nullptr && nranks >= 2 && nranks <= 64 && nranks <= nblk && bcr_applicable(tl) && tl.a + 1 <= int(p->opt["bcr_max_border"]), "distributed solve: ranks / geometry");
+  SolveBuffers sb = solve_buffers(p); sb.radius = radius;
+  launch_lm_scale(p->ne, tl, sb.scale, p->opt["jacobi_scaling"] != 0, st);
+  HIPCK(p, hipMemsetAsync(p->d_state.p, 0, sizeof(LmState), st));
+  std::vector<int32_t> b0(size_t(nranks) + 1); int max_loc = 0;
+  for (int k = 0; k <= nranks; ++k) b0[size_t(k)] = int32_t(int64_t(nblk) * k / nranks);
+  for (int k = 0; k < nranks; ++k) max_loc = std::max(max_loc, int(b0[size_t(k) + 1] - b0[size_t(k)]));
+  DevBuf<int32_t> d_b0; DevBuf<double> msg, xg; std::vector<DevBuf<double>> ws(static_cast<size_t>(nranks));
+  const int64_t msg_piece = (bcr_dist_msg_doubles(tl) + 7) / 8 * 8, x_piece = (int64_t(max_loc) * 64 + tl.a + 7) / 8 * 8;
+  if (!d_b0.upload(b0, st) || !msg.resize(size_t(msg_piece) * size_t(nranks)) || !xg.resize(size_t(x_piece) * size_t(nranks))) { p->err = "hipMalloc distributed solve"; return OICC_ERR_HIP; }
+  std::vector<BcrDist> ds(static_cast<size_t>(nranks));
+  for (int k = 0; k < nranks; ++k) {
+    BcrDist& d = ds[size_t(k)];
+    d.nranks = nranks; d.rank = k; d.b0 = b0[size_t(k)]; d.n_loc = b0[size_t(k) + 1] - d.b0; d.max_loc = max_loc; d.d_b0 = d_b0.p;
+    d.ws_doubles = bcr_dist_workspace_doubles(tl, d.n_loc, nranks);
+    if (!ws[size_t(k)].resize(size_t(d.ws_doubles))) { p->err = "hipMalloc distributed solve"; return OICC_ERR_HIP; }
+    d.ws = ws[size_t(k)].p; d.msg = msg.p; d.msg_piece = msg_piece; d.xg = xg.p; d.x_piece = x_piece;
+  }
+  EventPair ev; HIPCK(p, hipEventCreate(&ev.a)); HIPCK(p, hipEventCreate(&ev.b));
+  const double min_diag = p->opt["min_lm_diagonal"], max_diag = p->opt["max_lm_diagonal"];
+  const int reps = std::max<int>(repeats, 1);
+  for (int phase = 0; phase < 2; ++phase)
+    for (int k = 0; k < nranks; ++k) {
+      for (int it = 0; it < reps + 1; ++it) {     // (the first run is the warm-up; every run leaves the same results)
+        if (it == 1) HIPCK(p, hipEventRecord(ev.a, st));
+        const int r2 = phase == 0 ? launch_bcr_dist_forward(p->ne, tl, sb, 0, min_diag, max_diag, ds[size_t(k)], st) : launch_bcr_dist_middle(tl, sb, ds[size_t(k)], st);
+        if (r2 != 0) { p->err = "distributed solve: geometry / workspace"; return OICC_ERR_STATE; }
+      }
+      HIPCK(p, hipEventRecord(ev.b, st)); HIPCK(p, hipEventSynchronize(ev.b));
+      float ms = 0; (void)hipEventElapsedTime(&ms, ev.a, ev.b);
+      out[2 + 2 * k + phase] = double(ms) / reps;
+    }
+  launch_bcr_dist_finish(tl, sb, ds[0], st);
+  DevBuf<double> acc; if (!acc.resize(2 + size_t(tl.a))) return OICC_ERR_HIP;
+  launch_lm_solve_residual(p->ne, tl, sb, acc.p, st);
+  double h[2] = {0, 0}; LmState hs;
+  HIPCK(p, hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipMemcpyAsync(&hs, p->d_state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+  HIPCK(p, hipStreamSynchronize(st));
+  out[0] = h[1] > 0.0 ? std::sqrt(h[0] / h[1]) : std::sqrt(h[0]); out[1] = double(hs.chol_failed);
+  return OICC_OK;
+}
 // debug read-out (outside include/oicc_hip.h; tests, bench.py): out4 = [distributed solves run so far, this rank's first block, its block count, ranks]
 int oicc_debug_dist_solve_info(const oicc_problem* p, int64_t out4[4]) {
   if (!p || !out4) return OICC_ERR_INVALID_ARG;
@@ -308,7 +364,6 @@ int oicc_debug_dist_solve_info(const oicc_problem* p, int64_t out4[4]) {
   return OICC_OK;
 }
 
-namespace { struct EventPair { hipEvent_t a = nullptr, b = nullptr; ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } }; }   // (destroyed on every exit of the timing entry points)
 
 int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double* ms_per_call, int64_t* bytes) {
   int rc = prepare(p, flags); if (rc) return rc;

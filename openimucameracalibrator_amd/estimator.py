@@ -370,6 +370,16 @@ class SplineTrajectoryEstimator:
         self._ck(fn(self._h, out))
         return dict(solves=int(out[0]), first_block=int(out[1]), blocks=int(out[2]), ranks=int(out[3]))
 
+    def DistributedSolveEmulated(self, flags, nranks, radius=1e4, repeats=3):
+        """Debug / measurement (device library only): the distributed cyclic reduction of `nranks` ranks run by this one process
+        on the unsharded problem.  Returns (relative residual of the step against the packed normal equations, failure flag,
+        per-rank ms of the forward part, per-rank ms of top system + back substitution)."""
+        fn = self._b.lib.oicc_debug_dist_solve_emulated
+        fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, _abi.c_dp]
+        out = np.zeros(2 + 2 * nranks)
+        self._ck(fn(self._h, flags, nranks, float(radius), repeats, _dp(out)))
+        return float(out[0]), bool(out[1]), out[2::2].copy(), out[3::2].copy()
+
     def TimeExchange(self, flags, repeats=10):
         """(ms per owner-computes exchange of the packed normal equations, bytes this rank moved); a collective: every rank calls it."""
         ms = C.c_double(0.0); nb = C.c_int64(0)

@@ -347,6 +347,23 @@ def test_linear_solvers_leave_a_small_residual_at_full_size(cfg):
             assert not failed and rhs_norm > 0 and res < bound, (cfg, algo, radius, res)
 
 
+@pytest.mark.parametrize("cfg,ranks", [("C1", (2, 3, 5)), ("C2", (2, 3, 5, 8, 29)), ("C3", (4, 7)), ("C4", (8,)), ("C5", (2, 7, 8, 64))])
+def test_distributed_cyclic_reduction_leaves_a_small_residual_at_full_size(cfg, ranks):
+    """The distributed cyclic reduction (round 6) as ONE process runs it for N ranks on the unsharded problem (oicc_debug_dist_solve_
+    emulated: every rank's forward part into its slot, every rank's top system + back substitution, the gathered step): the step
+    against the packed normal equations themselves, ||M d - rhs|| / ||rhs|| < 1e-12 like the one-GPU cyclic reduction -- block ranges
+    of unequal length (7 ranks on 1407 blocks), one block per rank (29 ranks on C2's 29 blocks: no local level at all), ranges whose
+    active block counts are odd at some level (the coupling to the ghost block carried on), 64 ranks (six levels of the top system);
+    with Ceres' initial radius and (almost) undamped."""
+    ds = synthetic.make_config(cfg)
+    cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    for n in ranks:
+        for radius in (1e4, 1e16):
+            res, failed, fwd, mid = cal.trajectory_.DistributedSolveEmulated(FLAGS1, n, radius, repeats=1)
+            assert not failed and res < 1e-12, (cfg, n, radius, res)
+            assert len(fwd) == n and (fwd > 0).all() and (mid > 0).all()
+
+
 def test_cyclic_reduction_on_c3_through_rejected_steps():
     """C3 (606 + 306 knots: 43 blocks, 6 levels of the cyclic reduction through the pivot inverses) against the partitioned band sweep,
     with LDS poisoned before every solve and through rejected steps (a start far from the valley)."""
