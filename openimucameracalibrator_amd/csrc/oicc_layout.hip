@@ -77,9 +77,9 @@ void build_imu_groups(const ImuHost& h, bool accel, ImuGroups& g) {
   }
 }
 
-int sync_measurements(oicc_problem* p) {
+int sync_measurements(oicc_problem* p, hipStream_t st_in) {
   if (!p->meas_dirty) return OICC_OK;
-  hipStream_t st = p->stream;
+  hipStream_t st = st_in ? st_in : p->stream;
   // one device block, one copy for all measurement arrays (lm_launch.h DevArena)
   DevArena& A = p->meas_arena;
   A.add(p->d_corner_view, p->corner_view); A.add(p->d_corner_pt, p->corner_pt); A.add(p->d_cu, p->cu); A.add(p->d_cv, p->cv);
@@ -346,13 +346,33 @@ int prepare(oicc_problem* p, int flags) {
   // on a second thread under the uploads and the tiles below (build_inner_plan joins it).
   if (plan_wanted == flags) start_inner_plan(p, flags, current ? p->layout_gen : p->layout_gen + 1);
   const double t0 = now_s();
-  int rc = sync_measurements(p); if (rc) return rc;
+  // Round 6: a large set of measurements (BASELINE config 5: 47 MB of pageable host arrays, 3 ms of staged copies that block the
+  // calling thread) travels on a thread and a stream of its own while this thread lays out the buffers and builds the tiles -- none of
+  // which touches the device copies of the measurements; joined (thread and stream) before prepare returns.
+  const size_t meas_bytes = p->corner_view.size() * 40 + (p->acc.size() + p->gyr.size()) * 68;
+  const bool side_upload = p->meas_dirty && !current && meas_bytes >= (size_t(4) << 20) && p->opt["debug_sync"] == 0.0;
+  std::thread up; int up_rc = OICC_OK; double up_ms = 0.0;
+  int rc = OICC_OK;
+  if (side_upload) {
+    if (p->upload_stream == nullptr) HIPCK(p, hipStreamCreateWithFlags(&p->upload_stream, hipStreamNonBlocking));
+    up = std::thread([p, &up_rc, &up_ms]() {
+      const double ta = now_s();
+      if (hipSetDevice(p->device) != hipSuccess) { up_rc = OICC_ERR_HIP; return; }
+      up_rc = sync_measurements(p, p->upload_stream);
+      if (up_rc == OICC_OK && hipStreamSynchronize(p->upload_stream) != hipSuccess) up_rc = OICC_ERR_HIP;
+      up_ms = 1e3 * (now_s() - ta);
+    });
+  } else { rc = sync_measurements(p, nullptr); if (rc) return rc; }
+  struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{up};   // (no exit leaves the thread running)
   const double t1 = now_s();
   rc = sync_params_to_device(p); if (rc) return rc;
   const double t2 = now_s();
   if (current) return OICC_OK;
   rc = make_layout_device(p, flags);
-  if (timing) std::printf("[oicc] prepare: runs of samples + host layout %.3f ms, measurements %.3f ms, parameters %.3f ms, buffers + tiles %.3f ms\n", 1e3 * (t0 - t00), 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
+  const double t3 = now_s();
+  if (up.joinable()) up.join();
+  if (rc == OICC_OK && up_rc != OICC_OK) { if (p->err.empty()) p->err = "device upload of measurements failed"; rc = up_rc; p->layout_flags = -1; }
+  if (timing) std::printf("[oicc] prepare: runs of samples + host layout %.3f ms, measurements %.3f ms%s, parameters %.3f ms, buffers + tiles %.3f ms, waited for the measurements %.3f ms\n", 1e3 * (t0 - t00), side_upload ? up_ms : 1e3 * (t1 - t0), side_upload ? " (on a second thread and stream)" : "", 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now_s() - t3));
   return rc;
 }
 

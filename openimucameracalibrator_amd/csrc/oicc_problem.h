@@ -97,6 +97,7 @@ struct oicc_problem {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t upload_stream = nullptr;   // large measurement uploads run on a thread and stream of their own under the set-up (prepare)
   std::string err;
   // spline meta (impl.h:38-51)
   int64_t dt_so3 = 0, dt_r3 = 0, start_ns = 0, end_ns = 0;
@@ -276,7 +277,7 @@ void rebuild_param_layout(oicc_problem* p, int64_t n_so3, int64_t n_r3, int64_t 
 int sync_params_to_device(oicc_problem* p);
 int sync_params_to_host(oicc_problem* p);
 void build_imu_groups(const ImuHost& h, bool accel, ImuGroups& g);
-int sync_measurements(oicc_problem* p);
+int sync_measurements(oicc_problem* p, hipStream_t st = nullptr);   // (st: the stream the copies go to; null = the problem's)
 void sync_groups(oicc_problem* p);
 Active active_set(const oicc_problem* p, int flags);
 void build_owner_plan(oicc_problem* p);

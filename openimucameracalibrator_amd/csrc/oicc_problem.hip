@@ -217,6 +217,7 @@ void oicc_destroy(oicc_problem* p) {
   p->wait_plan();
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->upload_stream) (void)hipStreamDestroy(p->upload_stream);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   rccl_release(p);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -581,7 +582,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
   HIPCK(p, hipMemcpyAsync(p->d_xc.p, p->d_x.p, p->pl.total * sizeof(double), hipMemcpyDeviceToDevice, st));   // inactive entries of the candidate
   p->seg_invalidate(p->d_xc.p);
   int iter = 0, invalid = 0;
-  bool inner_enabled = false;
+  bool inner_enabled = false, plan_pending = false;
   oicc_problem* const q = p->inner_src ? p->inner_src : p;   // whose measurements the sweeps run over (a time-sharded rank: the problem with every rank's measurements)
   if (p->opt["inner_iterations"] != 0.0) {
     if (p->reduce && q == p) { p->err = "inner iterations on a time-sharded problem need oicc_set_inner_iteration_source (a sweep minimises a block over ALL its residual blocks)"; return OICC_ERR_UNSUPPORTED; }
@@ -597,11 +598,16 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
       rc = prepare(q, flags); if (rc) { p->err = "inner iteration source: " + q->err; return rc; }
       if (q->L.P != p->L.P || q->L.Pb != p->L.Pb) { p->err = "inner iteration source: its measurements give a different tangent layout (declare the remote measurements on the shard)"; return OICC_ERR_STATE; }
     }
-    { const double t_plan = now_s(); rc = build_inner_plan(q, flags); S.seconds_setup += now_s() - t_plan; }
-    if (rc) { if (q != p) p->err = q->err; return rc; }
+    plan_pending = true;   // (round 6) the plan's host part runs on the second thread since prepare(): it is joined where the first sweep needs it,
+                           // behind the first trust-region step's solve / retraction / cost pass, which the device works on meanwhile
+  }
+  auto join_plan = [&]() -> int {
+    plan_pending = false;
+    const double t_plan = now_s(); const int r = build_inner_plan(q, flags); S.seconds_setup += now_s() - t_plan;
+    if (r) { if (q != p) p->err = q->err; return r; }
     inner_lm0 = q->inner.lm_iterations;   // (a rebuilt plan restarts the device counter)
     inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
-  }
+    return OICC_OK; };
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
   // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide.cuh).  Per iteration the host enqueues
   // solve -> retraction -> Jacobian pass at the candidate (cost, gradient, normal equations in one pass: no separate cost pass); the
@@ -746,6 +752,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     // Inner iterations (TrustRegionMinimizer::DoInnerIterationsIfNeeded): one coordinate descent sweep from the candidate; its
     // cost decrease is credited to the model, the candidate becomes the swept point.
     double cand_before_inner = 0.0; bool inner_ran = false;
+    if (plan_pending) { rc = join_plan(); if (rc) return rc; }
     if (inner_enabled) {
       rc = read_back(); if (rc) return rc;
       cand_before_inner = cand_cost_of();
