@@ -77,9 +77,9 @@ void build_imu_groups(const ImuHost& h, bool accel, ImuGroups& g) {
   }
 }
 
-int sync_measurements(oicc_problem* p, hipStream_t st_in) {
+int sync_measurements(oicc_problem* p) {
   if (!p->meas_dirty) return OICC_OK;
-  hipStream_t st = st_in ? st_in : p->stream;
+  hipStream_t st = p->stream;
   // one device block, one copy for all measurement arrays (lm_launch.h DevArena)
   DevArena& A = p->meas_arena;
   A.add(p->d_corner_view, p->corner_view); A.add(p->d_corner_pt, p->corner_pt); A.add(p->d_cu, p->cu); A.add(p->d_cv, p->cv);
@@ -274,7 +274,20 @@ void make_layout_host(oicc_problem* p, int flags) {
   build_owner_plan(p);
 }
 // ... and device part: offsets, buffers of the normal equations and the solve, tiles
-int make_layout_device(oicc_problem* p, int flags) {
+// the numbers of the tangent layout and of the packed normal equations (no device pointers yet): what the host part of the tiles needs
+void layout_scalars(oicc_problem* p) {
+  const HostLayout& L = p->L;
+  TangentLayout& tl = p->tl;
+  tl.tic = L.other[0]; tl.g = L.other[1]; tl.ld = L.other[2]; tl.ai = L.other[3]; tl.gi = L.other[4];
+  tl.P = L.P; tl.Pb = L.Pb; tl.a = L.a; tl.hb = L.hb; tl.W = L.hb + 1;
+  tl.pts = nullptr; tl.n_pts = L.a_pts > 0 ? int32_t(L.pts.size()) : 0; tl.a_pts = L.a_pts;
+  NormalEq& ne = p->ne;
+  const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
+  ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
+  // the tile pass assembles everything but the point columns: the same layout without the last a_pts arrow columns (kernels_points.hip)
+  p->tl_tiles = tl; p->tl_tiles.a = tl.a - tl.a_pts; p->tl_tiles.P = tl.P - tl.a_pts; p->tl_tiles.a_pts = 0; p->tl_tiles.n_pts = 0; p->tl_tiles.pts = nullptr;
+}
+int make_layout_device(oicc_problem* p, int flags, std::thread* tiles_thread, int* tiles_rc) {
   HostLayout& L = p->L;
   const bool timing = p->opt["verbose"] >= 2.0; const double tl0 = now_s();
   // device copies
@@ -283,23 +296,18 @@ int make_layout_device(oicc_problem* p, int flags) {
   LA.add(p->d_tl_so3, L.so3); LA.add(p->d_tl_r3, L.r3); LA.add(p->d_tl_ab, L.ab); LA.add(p->d_tl_gb, L.gb);
   if (L.a_pts > 0) LA.add(p->d_tl_pts, L.pts);
   TangentLayout& tl = p->tl;
-  tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
-  tl.tic = L.other[0]; tl.g = L.other[1]; tl.ld = L.other[2]; tl.ai = L.other[3]; tl.gi = L.other[4];
-  tl.P = L.P; tl.Pb = L.Pb; tl.a = L.a; tl.hb = L.hb; tl.W = L.hb + 1;
-  tl.pts = nullptr; tl.n_pts = L.a_pts > 0 ? int32_t(L.pts.size()) : 0; tl.a_pts = L.a_pts;
   NormalEq& ne = p->ne;
-  const int64_t nband = int64_t(tl.Pb) * tl.W, nE = int64_t(tl.a) * tl.Pb, nC = int64_t(tl.a) * tl.a;
-  ne.off_E = nband; ne.off_C = nband + nE; ne.off_g = ne.off_C + nC; ne.off_cost = ne.off_g + tl.P; ne.total = ne.off_cost + 1;
+  const int64_t nband = int64_t(tl.Pb) * tl.W;
   const int ar = tl.a + 1;
   LA.reserve(p->d_ne, ne.total); LA.reserve(p->d_ne2, ne.total); LA.reserve(p->d_Mb, std::max<int64_t>(nband, 1)); LA.reserve(p->d_Mt, std::max<int64_t>(int64_t(ar) * tl.Pb, 1));
   LA.reserve(p->d_Mc, int64_t(ar) * ar); LA.reserve(p->d_scale, std::max(tl.P, 1)); LA.reserve(p->d_diag, std::max(tl.P, 1));
   LA.reserve(p->d_D2, std::max(tl.P, 1)); LA.reserve(p->d_step, std::max(tl.P, 1)); LA.reserve(p->d_state, 2);   /* two slots: device-side LM control alternates them (lm_decide.cuh); the host-driven loop uses the first */ LA.reserve(p->d_ls, 2);
   LA.reserve(p->d_ws, size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))));
   if (!LA.commit(st)) { p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
+  if (tiles_thread && tiles_thread->joinable()) tiles_thread->join();   // (the host part of the tiles reads tl_tiles: the pointers go in behind it)
   tl.so3 = p->d_tl_so3.p; tl.r3 = p->d_tl_r3.p; tl.ab = p->d_tl_ab.p; tl.gb = p->d_tl_gb.p;
   tl.pts = L.a_pts > 0 ? p->d_tl_pts.p : nullptr;
-  // the tile pass assembles everything but the point columns: the same layout without the last a_pts arrow columns (kernels_points.hip)
-  p->tl_tiles = tl; p->tl_tiles.a = tl.a - tl.a_pts; p->tl_tiles.P = tl.P - tl.a_pts; p->tl_tiles.a_pts = 0; p->tl_tiles.n_pts = 0; p->tl_tiles.pts = nullptr;
+  p->tl_tiles.so3 = tl.so3; p->tl_tiles.r3 = tl.r3; p->tl_tiles.ab = tl.ab; p->tl_tiles.gb = tl.gb;
   ne.base = p->d_ne.p;
   p->ne2 = ne; p->ne2.base = p->d_ne2.p;
   if (p->owner.valid) {   // row lists and message buffers of the owner-computes exchange
@@ -311,7 +319,8 @@ int make_layout_device(oicc_problem* p, int flags) {
   }
   p->layout_flags = -1;   // (stays invalid if the tiles cannot be built)
   const double tl1 = now_s();
-  const int rc = build_tiles(p);
+  int rc = tiles_rc ? *tiles_rc : build_tiles_host(p);
+  if (rc == OICC_OK) rc = build_tiles_device(p);
   if (timing) std::printf("[oicc] layout: uploads + buffers %.3f ms, tiles %.3f ms\n", 1e3 * (tl1 - tl0), 1e3 * (now_s() - tl1));
   if (rc == OICC_OK) { p->layout_flags = flags; p->layout_ld_zero = p->x[p->pl.ld] == 0.0; p->layout_opt_gen = p->opt_gen; ++p->layout_gen; }
   return rc;
@@ -346,33 +355,28 @@ int prepare(oicc_problem* p, int flags) {
   // on a second thread under the uploads and the tiles below (build_inner_plan joins it).
   if (plan_wanted == flags) start_inner_plan(p, flags, current ? p->layout_gen : p->layout_gen + 1);
   const double t0 = now_s();
-  // Round 6: a large set of measurements (BASELINE config 5: 47 MB of pageable host arrays, 3 ms of staged copies that block the
-  // calling thread) travels on a thread and a stream of its own while this thread lays out the buffers and builds the tiles -- none of
-  // which touches the device copies of the measurements; joined (thread and stream) before prepare returns.
-  const size_t meas_bytes = p->corner_view.size() * 40 + (p->acc.size() + p->gyr.size()) * 68;
-  const bool side_upload = p->meas_dirty && !current && meas_bytes >= (size_t(4) << 20) && p->opt["debug_sync"] == 0.0;
-  std::thread up; int up_rc = OICC_OK; double up_ms = 0.0;
-  int rc = OICC_OK;
-  if (side_upload) {
-    if (p->upload_stream == nullptr) HIPCK(p, hipStreamCreateWithFlags(&p->upload_stream, hipStreamNonBlocking));
-    up = std::thread([p, &up_rc, &up_ms]() {
-      const double ta = now_s();
-      if (hipSetDevice(p->device) != hipSuccess) { up_rc = OICC_ERR_HIP; return; }
-      up_rc = sync_measurements(p, p->upload_stream);
-      if (up_rc == OICC_OK && hipStreamSynchronize(p->upload_stream) != hipSuccess) up_rc = OICC_ERR_HIP;
-      up_ms = 1e3 * (now_s() - ta);
-    });
-  } else { rc = sync_measurements(p, nullptr); if (rc) return rc; }
-  struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{up};   // (no exit leaves the thread running)
+  // Round 6: the host part of the tiles (work lists, ring slots, merge tables: 1.8 ms at BASELINE config 5) needs the tangent layout's
+  // numbers only -- it runs on a thread of its own (host work, no device calls) while this thread moves the measurements (47 MB of
+  // pageable arrays: 3 ms of staged copies that block the caller) and allocates the buffers; joined before the tile tables travel.
+  // (Measured and not kept: the measurement copies on a second thread + stream instead -- 11 ms there against 3.2 ms here: the staged
+  // copies of one thread and the allocations of the other serialise inside the runtime.)
+  std::thread tiles_thread; int tiles_rc = OICC_OK; bool tiles_started = false;
+  struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{tiles_thread};   // (no exit leaves the thread running)
+  if (!current) {
+    layout_scalars(p);
+    int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); p->n_cu = n_cu < 1 ? 256 : n_cu;
+    tiles_started = true;
+    if (p->corner_view.size() + p->acc.size() + p->gyr.size() >= 100000 && p->opt["debug_sync"] == 0.0) tiles_thread = std::thread([p, &tiles_rc]() { tiles_rc = build_tiles_host(p); });
+    else tiles_rc = build_tiles_host(p);
+  }
+  int rc = sync_measurements(p); if (rc) return rc;
   const double t1 = now_s();
   rc = sync_params_to_device(p); if (rc) return rc;
   const double t2 = now_s();
   if (current) return OICC_OK;
-  rc = make_layout_device(p, flags);
-  const double t3 = now_s();
-  if (up.joinable()) up.join();
-  if (rc == OICC_OK && up_rc != OICC_OK) { if (p->err.empty()) p->err = "device upload of measurements failed"; rc = up_rc; p->layout_flags = -1; }
-  if (timing) std::printf("[oicc] prepare: runs of samples + host layout %.3f ms, measurements %.3f ms%s, parameters %.3f ms, buffers + tiles %.3f ms, waited for the measurements %.3f ms\n", 1e3 * (t0 - t00), side_upload ? up_ms : 1e3 * (t1 - t0), side_upload ? " (on a second thread and stream)" : "", 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now_s() - t3));
+  rc = make_layout_device(p, flags, &tiles_thread, &tiles_rc);
+  (void)tiles_started;
+  if (timing) std::printf("[oicc] prepare: runs of samples + host layout %.3f ms, measurements %.3f ms, parameters %.3f ms, buffers + tiles %.3f ms\n", 1e3 * (t0 - t00), 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now_s() - t2));
   return rc;
 }
 

@@ -97,7 +97,6 @@ struct oicc_problem {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t upload_stream = nullptr;   // large measurement uploads run on a thread and stream of their own under the set-up (prepare)
   std::string err;
   // spline meta (impl.h:38-51)
   int64_t dt_so3 = 0, dt_r3 = 0, start_ns = 0, end_ns = 0;
@@ -188,7 +187,7 @@ struct oicc_problem {
   std::vector<TileDesc> h_tiles; std::vector<UnitDesc> h_units; std::vector<int32_t> h_tile_rows, h_merge_rows; std::vector<uint8_t> h_row_direct;
   DevBuf<int32_t> d_merge_rows, d_merge_ptr; DevBuf<int64_t> d_merge_src, d_merge_tab; DevBuf<uint8_t> d_row_direct; std::vector<int32_t> h_merge_ptr; std::vector<int64_t> h_merge_src, h_merge_tab;
   DevBuf<TileDesc> d_tiles; DevBuf<UnitDesc> d_units; DevBuf<int32_t> d_tile_rows; DevBuf<double> d_slabs;
-  RowFmt fv{}, fa{}, fg{}; TileParams tp{};
+  RowFmt fv{}, fa{}, fg{}; TileParams tp{}; int tile_T = 0;   // tile_T: knot windows per tile as chosen by the host part of the tiles
   std::unique_ptr<TileStatic> h_tstatic; DevBuf<TileStatic> d_tstatic; bool tstatic_valid = false;   // problem-constant kernel arguments in device memory
   bool gmax_folded = false;   // the last Jacobian pass already left max |g| in LmState (slab merge), no lm_gradmax launch needed
   // inner iterations (inner_plan.h): blocks in processing order, independent sets, item -> block maps per set
@@ -277,13 +276,15 @@ void rebuild_param_layout(oicc_problem* p, int64_t n_so3, int64_t n_r3, int64_t 
 int sync_params_to_device(oicc_problem* p);
 int sync_params_to_host(oicc_problem* p);
 void build_imu_groups(const ImuHost& h, bool accel, ImuGroups& g);
-int sync_measurements(oicc_problem* p, hipStream_t st = nullptr);   // (st: the stream the copies go to; null = the problem's)
+int sync_measurements(oicc_problem* p);
 void sync_groups(oicc_problem* p);
 Active active_set(const oicc_problem* p, int flags);
 void build_owner_plan(oicc_problem* p);
 void make_layout_host(oicc_problem* p, int flags);
-int make_layout_device(oicc_problem* p, int flags);
-int build_tiles(oicc_problem* p);
+void layout_scalars(oicc_problem* p);
+int make_layout_device(oicc_problem* p, int flags, std::thread* tiles_thread = nullptr, int* tiles_rc = nullptr);
+int build_tiles_host(oicc_problem* p);
+int build_tiles_device(oicc_problem* p);
 int prepare(oicc_problem* p, int flags);
 EvalCtx make_ctx(oicc_problem* p, const double* x);
 ViewData view_data(oicc_problem* p, bool force_rs = false);

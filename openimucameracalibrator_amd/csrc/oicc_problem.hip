@@ -217,7 +217,6 @@ void oicc_destroy(oicc_problem* p) {
   p->wait_plan();
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  if (p->upload_stream) (void)hipStreamDestroy(p->upload_stream);
   if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
   rccl_release(p);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);

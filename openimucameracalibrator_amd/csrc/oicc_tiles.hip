@@ -134,7 +134,8 @@ void make_tiles(const oicc_problem* p, int T, TileBuild* out) {
   }
 }
 
-int build_tiles(oicc_problem* p) {
+// host part: everything but the device copies (may run on a thread of its own: prepare)
+int build_tiles_host(oicc_problem* p) {
   const TangentLayout& tl = p->tl_tiles; const Active& a = p->act;   // (without the board-point columns: kernels_points.hip adds those)
   p->fv = view_row_fmt(tl, a.spline);
   const int wide_max = p->opt["wide_cells"] != 0.0 ? 8 : 0;
@@ -189,8 +190,7 @@ int build_tiles(oicc_problem* p) {
   // (a corner ~800 cycles, an accelerometer sample ~1300, a gyroscope sample ~800, +15 % imbalance): the candidates are tried in
   // order of rounds * (3 / w + T) until one fits LDS.  One-round problems thus get the shortest tile that still is one round,
   // multi-round problems the best trade of round count against round length (C5: T = 10, 8 rounds, over T = 14, 6 rounds).
-  int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); if (n_cu < 1) n_cu = 256;
-  p->n_cu = n_cu;
+  const int n_cu = p->n_cu;   // (asked of the runtime by prepare)
   const double work_cycles = 800.0 * double(p->corner_view.size()) + 1300.0 * double(p->acc.size()) + 800.0 * double(p->gyr.size());
   const double w_us = std::min(50.0, std::max(1.0, 1.15 * work_cycles / double(std::max<int64_t>(n_windows, 1)) / 4 / 2400.0));
   bool fits = false;
@@ -315,6 +315,12 @@ int build_tiles(oicc_problem* p) {
     }
     if (2 * good >= tp.n_tiles) { tp.affine = 1; tp.td0 = b; tp.tds = d; }
   }
+  p->tile_T = T;
+  return OICC_OK;
+}
+// ... and the device copies of what the host part left
+int build_tiles_device(oicc_problem* p) {
+  const TangentLayout& tl = p->tl_tiles; TileParams& tp = p->tp;
   hipStream_t st = p->stream;
   DevArena& TA = p->tile_arena;
   TA.add(p->d_tiles, p->h_tiles); TA.add(p->d_units, p->h_units); TA.add(p->d_tile_rows, p->h_tile_rows); TA.add(p->d_merge_rows, p->h_merge_rows);
@@ -322,7 +328,7 @@ int build_tiles(oicc_problem* p) {
   if (!TA.commit(st) ||
       !p->d_slabs.resize(size_t(std::max<int64_t>(1, tp.direct ? 1 : int64_t(tp.n_chains) * tp.slab_stride)))) { p->err = "hipMalloc tiles"; return OICC_ERR_HIP; }
   if (p->opt["verbose"] >= 2.0) std::printf("[oicc] tiles: %d tiles of %d windows in %d chains of %d, %d waves, %d units, accumulator %d rows x %d (+%d), slab %d rows, %d of %d rows merged, row buffer %d doubles, items per unit view %d accel %d gyro %d (wide +%d / +%d), LDS %d B, direct %d\n",
-                                           tp.n_tiles, T, tp.n_chains, tp.chain_len, tp.n_waves, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, tp.slab_rows, tp.n_merge_rows, tl.Pb, rb, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
+                                           tp.n_tiles, p->tile_T, tp.n_chains, tp.chain_len, tp.n_waves, tp.n_units, tp.acc_rows, tp.Wl, tp.corner, tp.slab_rows, tp.n_merge_rows, tl.Pb, tp.rb_doubles, p->fv.cap, p->fa.cap, p->fg.cap, p->fa.ks_extra, p->fg.ks_extra, tp.lds_bytes, tp.direct);
   tp.tiles = p->d_tiles.p; tp.units = p->d_units.p; tp.tile_rows = p->d_tile_rows.p; tp.slabs = p->d_slabs.p; tp.merge_rows = p->d_merge_rows.p; tp.merge_ptr = p->d_merge_ptr.p; tp.merge_src = p->d_merge_src.p; tp.merge_tab = p->d_merge_tab.p; tp.row_direct = p->d_row_direct.p;
   return OICC_OK;
 }
