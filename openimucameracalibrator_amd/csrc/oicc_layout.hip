@@ -366,7 +366,7 @@ int prepare(oicc_problem* p, int flags) {
     layout_scalars(p);
     int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device); p->n_cu = n_cu < 1 ? 256 : n_cu;
     tiles_started = true;
-    if (p->corner_view.size() + p->acc.size() + p->gyr.size() >= 100000 && p->opt["debug_sync"] == 0.0) tiles_thread = std::thread([p, &tiles_rc]() { tiles_rc = build_tiles_host(p); });
+    if (p->corner_view.size() + p->acc.size() + p->gyr.size() >= 100000 && p->opt["debug_sync"] == 0.0 && p->opt["setup_threads"] != 0.0) tiles_thread = std::thread([p, &tiles_rc]() { tiles_rc = build_tiles_host(p); });
     else tiles_rc = build_tiles_host(p);
   }
   int rc = sync_measurements(p); if (rc) return rc;

@@ -227,6 +227,7 @@ struct oicc_problem {
     opt["inner_iterations"] = 0;   // 1: Ceres' use_inner_iterations = true as the reference sets it (impl.h:266): a block coordinate descent sweep after every
                                    //    trust-region candidate (inner_iterations.hip); the applications switch it on, the bare C-ABI default is off
     opt["inner_iteration_tolerance"] = 1e-3;
+    opt["setup_threads"] = 1;           // 1: large problems build the host part of the tiles on a thread of its own under the measurement copies (prepare); 0: inline
     opt["distributed_solve"] = 1;       // time-sharded ranks with the owner-computes exchange: every rank eliminates the blocks of its own band range, only the ranks' separator blocks and the step travel (0: the band is gathered and every rank solves the whole system)
     opt["owner_computes_sweeps"] = 1;   // time-sharded ranks with the owner-computes exchange: a rank sweeps only the knot blocks it owns, owners broadcast after every set (0: replicated sweeps)
     opt["inner_shared_launch_slots"] = 65536;   // a block every view / sample depends on with at least this many item slots is minimised by a sequence of launches over the whole device instead of resident workgroups that wait for each other (0: never)
