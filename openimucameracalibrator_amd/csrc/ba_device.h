@@ -6,7 +6,7 @@
 
 namespace oicc {
 
-constexpr int kBaIntr = 10;   // intrinsics slots (= kBaMaxIntr of ba_math.cuh)
+constexpr int kBaIntr = 10;   // intrinsics slots (= kBaMaxIntr of ba_math.h)
 
 // x = [pose 6 nv (position, angle axis) | intrinsics 10 | board points 4 np]; observations sorted by view
 struct BaData {

@@ -7,9 +7,9 @@
 //   r   = CameraToPixelCoordinates(intr, p_c) - feature
 //   d p_c / d C = -X.w R,   d p_c / d w = -R [a]x Jr(w)   (additive increment of the angle axis, as Ceres takes it)
 //   d px / d intr: closed forms per camera model below.
-// Host-compilable under OICC_HOST_MATH like spline_math.cuh (CPU cross-check against forward-mode Jets).
+// Host-compilable under OICC_HOST_MATH like spline_math.h (CPU cross-check against forward-mode Jets).
 #pragma once
-#include "spline_math.cuh"
+#include "spline_math.h"
 
 namespace oicc {
 

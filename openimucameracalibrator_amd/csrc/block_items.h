@@ -19,8 +19,8 @@
 //   sink.intr(n, d)       ROWS x n, d[r*n+c]
 //   sink.res(r)           residuals;    sink.zero()  all Jacobian entries of the item are zero
 #pragma once
-#include "spline_math.cuh"
-#include "spline_seg.cuh"
+#include "spline_math.h"
+#include "spline_seg.h"
 
 namespace oicc {
 

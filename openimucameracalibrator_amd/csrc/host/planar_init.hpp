@@ -14,7 +14,7 @@
 #include <vector>
 
 #define OICC_HOST_MATH 1
-#include "../ba_math.cuh"       // camera_project, angle_axis_matrix: the forward model of the device kernels on the host
+#include "../ba_math.h"       // camera_project, angle_axis_matrix: the forward model of the device kernels on the host
 
 namespace oicc_planar {
 

@@ -10,7 +10,7 @@
 //   * a knot block (SO(3) / R^3 / bias knot: the ~240-360 corners and IMU samples of its six knot windows) is ONE WORKGROUP
 //     that runs the block's WHOLE loop out of LDS: the items' measurements and the knots / segment tables / calibration
 //     scalars they read are staged once; lane = item -> residual and the Jacobian columns of this one block
-//     (block_items.cuh with a one-block sink), H_bb / g_b / cost_b by DPP row reductions and per-wave LDS rows (fixed
+//     (block_items.h with a one-block sink), H_bb / g_b / cost_b by DPP row reductions and per-wave LDS rows (fixed
 //     order: deterministic), thread 0 solves the damped d x d system in registers, writes the candidate (LDS copy and
 //     parameter vector), all lanes evaluate the cost there, thread 0 accepts / rejects exactly as TrustRegionMinimizer
 //     does -- until the block terminates.  No global atomics, no host;
@@ -18,13 +18,13 @@
 //     shared by up to one workgroup per CU: partial sums by fp64 atomics on a control block, an arrival counter, the master
 //     workgroup (part 0) advances the loop and publishes the next command (release / acquire at agent scope); their items
 //     read the parameters from global memory.
-// SO(3) knots change the segment tables (spline_seg.cuh) of their two knot pairs: the block's master rewrites those two
+// SO(3) knots change the segment tables (spline_seg.h) of their two knot pairs: the block's master rewrites those two
 // entries with every candidate (and restores them on a rejected step), the table stays current across the sets.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "oicc_device.h"
-#include "block_items.cuh"
-#include "ba_math.cuh"   // homogeneous_plus4 / homogeneous_tangent_rows: the board points under SplineOptimFlags::POINTS
+#include "block_items.h"
+#include "ba_math.h"   // homogeneous_plus4 / homogeneous_tangent_rows: the board points under SplineOptimFlags::POINTS
 #include "inner_plan.h"
 
 namespace oicc {
@@ -59,7 +59,7 @@ struct ParamView {
 struct PSeg { const double* base; __device__ __forceinline__ const double* operator()(int i) const { return base + i * kSegStride; } };
 struct PR3 { const double* base; __device__ __forceinline__ const double* operator()(int j) const { return base + 3 * j; } };
 
-// Sink of block_items.cuh that keeps the columns of ONE parameter block: J[r][c], r < ROWS, c < dim <= 9, in the lane's
+// Sink of block_items.h that keeps the columns of ONE parameter block: J[r][c], r < ROWS, c < dim <= 9, in the lane's
 // column of an LDS array (element e of the lane at J[e * kInnerThreads]: conflict free, and the sums over (x, y) below are
 // plain run-time loops instead of 54 unrolled register reductions).
 template <int T>

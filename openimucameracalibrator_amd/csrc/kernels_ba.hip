@@ -16,8 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include "oicc_device.h"
-#include "ba_math.cuh"
-#include "gram.cuh"
+#include "ba_math.h"
+#include "gram.h"
 #include "ba_device.h"
 
 namespace oicc {

@@ -22,7 +22,7 @@
 #include <mutex>
 #include <unordered_map>
 #include "oicc_device.h"
-#include "lm_decide.cuh"
+#include "lm_decide.h"
 
 namespace oicc {
 
@@ -769,7 +769,7 @@ __device__ __forceinline__ void bcr_build_body(const NormalEq& ne, const Tangent
 }
 
 // device-side LM control: the system to build, its radius and the reuse-diagonal flag come from the control block -- as the host
-// or an earlier kernel left it, or derived here from the previous iteration's state and results (lm_decide.cuh)
+// or an earlier kernel left it, or derived here from the previous iteration's state and results (lm_decide.h)
 __device__ __forceinline__ bool lm_ctl_build_inputs(NormalEq& ne, SolveBuffers& sb, int& reuse_diagonal, bool writer) {
   if (sb.ctl == nullptr) return true;
   __shared__ LmCtl s_c;

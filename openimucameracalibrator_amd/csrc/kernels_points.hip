@@ -5,16 +5,16 @@
 // complete-but-plain route, not a tuned one: the tile pass (kernels_tiles.hip) assembles the normal equations of every other
 // block exactly as without the flag -- it works on the tangent layout WITHOUT the point columns, which are the last a_pts arrow
 // columns -- and the kernel below adds what the points contribute: per corner (one thread) the full Jacobian row pair is
-// re-evaluated through the same item function (block_items.cuh, view_item with a sink that wants the point derivative), reduced to
-// the tangent of the corner's point (ba_math.cuh: the Householder form Ceres uses) and the products J_p^T [J_x | J_p | r] go into
+// re-evaluated through the same item function (block_items.h, view_item with a sink that wants the point derivative), reduced to
+// the tangent of the corner's point (ba_math.h: the Householder form Ceres uses) and the products J_p^T [J_x | J_p | r] go into
 // the arrow rows (Et), the arrow corner (C) and the gradient with fp64 atomics.  Those parts of the packed buffer are cleared by
 // the host before the tile pass; the slab merge writes (not adds) its corner block first, this kernel runs behind it.
 // A corner sees one point, so the point block of C is block diagonal (3 x 3 per point); the linear solve treats the points as
 // ordinary arrow columns (a > 63: the band sweep / global-memory solver instead of the block cyclic reduction).
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"
-#include "block_items.cuh"
-#include "ba_math.cuh"
+#include "block_items.h"
+#include "ba_math.h"
 
 namespace oicc {
 namespace {

@@ -21,17 +21,17 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "oicc_device.h"
-#include "spline_math.cuh"
-#include "spline_seg.cuh"
-#include "ba_math.cuh"   // homogeneous_plus4: the board points under SplineOptimFlags::POINTS
-#include "lm_decide.cuh"
+#include "spline_math.h"
+#include "spline_seg.h"
+#include "ba_math.h"   // homogeneous_plus4: the board points under SplineOptimFlags::POINTS
+#include "lm_decide.h"
 
 namespace oicc {
 
 // ---- build the damped system  M = S H S + diag(D2),  rhs = -S g ----------------
 __global__ void lm_build_kernel(NormalEq ne, TangentLayout tl, SolveBuffers sb, int reuse_diagonal,
                                 double min_diag, double max_diag) {
-  if (sb.ctl != nullptr) {   // device-side LM control (oicc_device.h, lm_decide.cuh)
+  if (sb.ctl != nullptr) {   // device-side LM control (oicc_device.h, lm_decide.h)
     __shared__ LmCtl s_c;
     if (!lm_ctl_next_state(sb, blockIdx.x == 0 && threadIdx.x == 0, &s_c)) return;
     ne.base = s_c.nep[0]; sb.radius = s_c.radius; reuse_diagonal = s_c.reuse_diagonal;

@@ -5,10 +5,10 @@
 //   workgroup = one CHAIN of consecutive tiles (tiles.h), walked in time order; per tile of consecutive knot windows:
 //     P0  knots, tangent offsets, ring slots of the knots and the tile's unit descriptors -> LDS (one round trip: the knot
 //         range is predicted from the tile index while the descriptor is in flight); per knot pair the segment table (log, axis,
-//         Jr^-1: spline_seg.cuh), loaded from the table of this parameter vector or, on one-round problems, computed here;
+//         Jr^-1: spline_seg.h), loaded from the table of this parameter vector or, on one-round problems, computed here;
 //         the accumulator rows of the knots this tile is the first of the chain to touch are zeroed
 //     P1  every wave pulls units from the tile's queue:  lane = item (corner / IMU sample)
-//           spline evaluation, residual, analytic Jacobian rows (block_items.cuh) -> compact rows in the wave's LDS buffer
+//           spline evaluation, residual, analytic Jacobian rows (block_items.h) -> compact rows in the wave's LDS buffer
 //           per CELL (a view, or the samples sharing one set of knot windows) the augmented Gram matrix [J r]^T [J r]
 //           as 16x16 v_mfma_f64_16x16x4_f64 tiles, operands expanded from the compact rows while they are loaded
 //           tiles -> the band accumulator in LDS (ds_add_f64)
@@ -24,7 +24,7 @@
 #include <atomic>
 #include "oicc_device.h"
 #include "tiles.h"
-#include "block_items.cuh"
+#include "block_items.h"
 static_assert(oicc::kSegDoubles == oicc::kSegStride, "segment table stride");
 
 namespace oicc {
@@ -44,7 +44,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 struct LdsSeg { const double* base; __device__ __forceinline__ const double* operator()(int i) const { return base + i * kSegStride; } };
 struct LdsR3 { const double* base; __device__ __forceinline__ const double* operator()(int j) const { return base + 3 * j; } };
 
-// Sink of block_items.cuh: compact record of one item in the wave's row buffer and, for the parity tests, the dense rows
+// Sink of block_items.h: compact record of one item in the wave's row buffer and, for the parity tests, the dense rows
 // of the ABI layout (oicc_evaluate_blocks).  Record of item m (RowFmt::item_stride doubles, odd: conflict-free lane
 // strides): value (idx, r) at [idx * ROWS + r], factors behind the nbase * ROWS values.  Group pointers are formed once
 // per item, every store then has a compile-time offset.

@@ -1,7 +1,7 @@
 // A15: trajectory read-back of the spline estimator (one lane per timestamp).
 #include <hip/hip_runtime.h>
 #include "oicc_device.h"
-#include "spline_math.cuh"
+#include "spline_math.h"
 
 namespace oicc {
 
@@ -64,7 +64,7 @@ void launch_trajectory(const EvalCtx& ctx, int64_t n, const int32_t* s_so3, cons
 }  // namespace oicc
 
 // ---- debug entry point outside include/oicc_hip.h (tests/test_gpu_c5_reference_options.py): the DEVICE build of fast_sincos
-// (spline_math.cuh) on an array of arguments, so that it can be held against libm directly and not only through the residuals ----
+// (spline_math.h) on an array of arguments, so that it can be held against libm directly and not only through the residuals ----
 namespace oicc {
 __global__ void fast_sincos_kernel(int64_t n, const double* x, double* s, double* c) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

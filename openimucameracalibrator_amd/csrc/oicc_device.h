@@ -146,7 +146,7 @@ struct SolveBuffers {
   int bcr_delay = 0;            // debug: panel waves other than wave 0 start every panel this many ~1000-cycle sleeps late (option debug_bcr_delay)
   const LmCtl* ctl = nullptr;   // device-side LM control (round 5): the build kernels take the current normal equations, the radius and the
                                 // reuse-diagonal flag from it, every kernel of the solve returns at once when it says done
-  // the decision of the PREVIOUS iteration folded into this iteration's build kernel (lm_decide.cuh): the state that iteration ran
+  // the decision of the PREVIOUS iteration folded into this iteration's build kernel (lm_decide.h): the state that iteration ran
   // with and its results; every workgroup derives *ctl from them, one stores it (the control block and LmState alternate between two
   // slots from iteration to iteration, so nobody reads what another workgroup of the same launch writes)
   const LmCtl* ctl_prev = nullptr; const LmState* st_prev = nullptr; int64_t off_cost = 0;

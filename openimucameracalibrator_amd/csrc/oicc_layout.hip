@@ -301,7 +301,7 @@ int make_layout_device(oicc_problem* p, int flags, std::thread* tiles_thread, in
   const int ar = tl.a + 1;
   LA.reserve(p->d_ne, ne.total); LA.reserve(p->d_ne2, ne.total); LA.reserve(p->d_Mb, std::max<int64_t>(nband, 1)); LA.reserve(p->d_Mt, std::max<int64_t>(int64_t(ar) * tl.Pb, 1));
   LA.reserve(p->d_Mc, int64_t(ar) * ar); LA.reserve(p->d_scale, std::max(tl.P, 1)); LA.reserve(p->d_diag, std::max(tl.P, 1));
-  LA.reserve(p->d_D2, std::max(tl.P, 1)); LA.reserve(p->d_step, std::max(tl.P, 1)); LA.reserve(p->d_state, 2);   /* two slots: device-side LM control alternates them (lm_decide.cuh); the host-driven loop uses the first */ LA.reserve(p->d_ls, 2);
+  LA.reserve(p->d_D2, std::max(tl.P, 1)); LA.reserve(p->d_step, std::max(tl.P, 1)); LA.reserve(p->d_state, 2);   /* two slots: device-side LM control alternates them (lm_decide.h); the host-driven loop uses the first */ LA.reserve(p->d_ls, 2);
   LA.reserve(p->d_ws, size_t(std::max(solve_workspace_doubles(tl), bcr_workspace_doubles(tl))));
   if (!LA.commit(st)) { p->err = "hipMalloc normal equations failed"; return OICC_ERR_HIP; }
   if (tiles_thread && tiles_thread->joinable()) tiles_thread->join();   // (the host part of the tiles reads tl_tiles: the pointers go in behind it)

@@ -155,7 +155,7 @@ struct oicc_problem {
   oicc_problem* inner_src = nullptr;   // time-sharded ranks: the problem whose measurements (all ranks') the inner-iteration sweeps run over
   // device
   DevBuf<double> d_x, d_xc;
-  // segment tables (spline_seg.cuh) of the SO(3) knot pairs of the two parameter buffers, keyed by the buffer's address (d_x.p and
+  // segment tables (spline_seg.h) of the SO(3) knot pairs of the two parameter buffers, keyed by the buffer's address (d_x.p and
   // d_xc.p trade places when a step is accepted); valid = computed for the buffer's current contents
   struct SegTable { DevBuf<double> buf; const double* of = nullptr; bool valid = false; } seg_tab[2];
   SegTable* seg_of(const double* xbuf) { for (auto& t : seg_tab) if (t.of == xbuf) return &t; return nullptr; }

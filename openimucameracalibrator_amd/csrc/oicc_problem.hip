@@ -124,7 +124,7 @@ int device_lm_begin(oicc_problem* p, LmCtl h, int trace_cap) {
 }
 // Iteration k: damped solve -> retraction -> Jacobian pass at the candidate (its merge leaves the candidate's cost and max |g|).  The
 // DECISION of iteration k - 1 is taken inside this iteration's build kernel (every workgroup derives the state from the previous
-// one, lm_decide.cuh): no kernel of its own.  The control block and LmState alternate between two slots.  Nothing here waits.
+// one, lm_decide.h): no kernel of its own.  The control block and LmState alternate between two slots.  Nothing here waits.
 int device_lm_enqueue(oicc_problem* p, SolveBuffers sb, double min_diag, double max_diag, int k) {
   hipStream_t st = p->stream;
   LmCtl* const cur = p->d_ctl.p + (k & 1); LmState* const stc = p->d_state.p + (k & 1);
@@ -608,7 +608,7 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     inner_enabled = q->inner.blocks.size() >= 2;   // Ceres: "Reduced problem only contains one parameter block. Disabling inner iterations."
     return OICC_OK; };
   const bool line_search = p->opt["bounds_line_search"] != 0.0 && (p->act.ab || p->act.gb);   // Ceres: the program is bounds constrained
-  // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide.cuh).  Per iteration the host enqueues
+  // ---- plain LM: the trust-region logic runs ON THE DEVICE (LmCtl, lm_decide.h).  Per iteration the host enqueues
   // solve -> retraction -> Jacobian pass at the candidate (cost, gradient, normal equations in one pass: no separate cost pass); the
   // decision of an iteration is taken inside the NEXT iteration's build kernel (a kernel of its own only behind the last one), and the
   // host looks at a pinned word that kernel wrote, two iterations behind what it has enqueued: no copy, no event, no synchronisation

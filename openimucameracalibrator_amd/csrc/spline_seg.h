@@ -9,9 +9,9 @@
 // so3.hpp:326-340,480-488; unit quaternions stay unit to rounding, the value is normalised once at the end).
 // Values agree with the reference's evaluation order to a few ulp (tests: residuals 1e-12 against forward-mode Jets).
 //   reference: basalt_spline/ceres_spline_helper.h:101-187 (value :137-157, body rate :159-164)
-// Jacobians: right increments R_j <- R_j exp(eps_j) as in spline_math.cuh / SURVEY.md Appendix A.
+// Jacobians: right increments R_j <- R_j exp(eps_j) as in spline_math.h / SURVEY.md Appendix A.
 #pragma once
-#include "spline_math.cuh"
+#include "spline_math.h"
 
 namespace oicc {
 

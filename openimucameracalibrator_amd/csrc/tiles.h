@@ -22,7 +22,7 @@ namespace oicc {
 constexpr int kTileMaxWaves = 4;      // waves of a workgroup: TileParams::n_waves (4 = one per SIMD; 1: option accumulation = deterministic).  A second wave per SIMD
                                       // needs the item functions AND the Gram loop under 256 VGPRs and 8 row buffers in LDS: built and measured in round 4
                                       // (commit abc7bac: row-split records, correct, 20 % slower through ~500 spilled registers), not kept
-constexpr int kSegDoubles = 17;       // = kSegStride of spline_seg.cuh (checked in kernels_tiles.hip): doubles of one knot pair's segment table
+constexpr int kSegDoubles = 17;       // = kSegStride of spline_seg.h (checked in kernels_tiles.hip): doubles of one knot pair's segment table
 constexpr int kMaxTileKnots = 64;     // staged knots of one kind per tile (so3 / r3)
 
 struct TileDesc {
@@ -106,7 +106,7 @@ struct TileStatic {
   TileParams tp;          // gmax is taken from TileDyn
 };
 struct TileDyn {
-  const double* x; const double* seg;   // seg: kSegStride doubles per SO(3) knot pair of x (spline_seg.cuh), computed once per parameter vector; nullptr: every tile computes its own
+  const double* x; const double* seg;   // seg: kSegStride doubles per SO(3) knot pair of x (spline_seg.h), computed once per parameter vector; nullptr: every tile computes its own
   double* ne_base; double* cost_out;   // cost_out: where a cost pass adds its cost (the normal equations' cost slot, or LmState::cand_cost)
   double* dbg_res; double* dbg_jac; long long* prof; double* gmax; const uint8_t* view_rs;
   int32_t only_kind, pad;

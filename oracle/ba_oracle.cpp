@@ -26,7 +26,7 @@
 #include "../include/oicc_hip.h"
 #include "oicc_oracle_math.hpp"
 #define OICC_HOST_MATH 1
-#include "../openimucameracalibrator_amd/csrc/ba_math.cuh"   // product formulas, only for the *_analytic_rows cross-check hook
+#include "../openimucameracalibrator_amd/csrc/ba_math.h"   // product formulas, only for the *_analytic_rows cross-check hook
 
 using namespace oicc_oracle;
 

@@ -1099,7 +1099,7 @@ int oicc_oracle_num_threads(void) {
 #endif
 }
 
-// The product's branch-free sincos (spline_math.cuh: fast_sincos, compiled for the host like the rest of the analytic CPU path) on n
+// The product's branch-free sincos (spline_math.h: fast_sincos, compiled for the host like the rest of the analytic CPU path) on n
 // arguments -- tests/test_fast_sincos.py holds it to libm without a GPU.
 void oicc_oracle_debug_fast_sincos(const double* x, int64_t n, double* sn, double* cs) {
   for (int64_t i = 0; i < n; ++i) oicc::fast_sincos(x[i], sn + i, cs + i);

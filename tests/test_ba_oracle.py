@@ -1,5 +1,5 @@
 """View bundle adjustment, CPU side: the oracle's restatement of Theia's bundle adjuster
-against closed-form facts and synthetic truth, and the product's analytic Jacobian formulas (ba_math.cuh,
+against closed-form facts and synthetic truth, and the product's analytic Jacobian formulas (ba_math.h,
 compiled for the host inside the oracle library) against the oracle's forward-mode Jets."""
 import numpy as np
 import pytest
@@ -33,7 +33,7 @@ def ba_nc(ba):
 
 @pytest.mark.parametrize("camera", CAMERAS)
 def test_analytic_jacobians_match_jets(camera):
-    """d r / d [position | angle axis | intrinsics] of every observation: closed forms of ba_math.cuh vs Jets."""
+    """d r / d [position | angle axis | intrinsics] of every observation: closed forms of ba_math.h vs Jets."""
     ds = CC.make_calibration_dataset(camera, num_views=6, corners_per_view=30)
     ba = _adjuster(ds)
     ba._nc = len(ds["uv"])

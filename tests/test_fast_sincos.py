@@ -1,4 +1,4 @@
-"""The branch-free sincos of the SO(3) spline (csrc/spline_math.cuh: fast_sincos -- two-piece pi/2 reduction, fdlibm kernel polynomials,
+"""The branch-free sincos of the SO(3) spline (csrc/spline_math.h: fast_sincos -- two-piece pi/2 reduction, fdlibm kernel polynomials,
 quadrant by selects; round 5) against libm in extended precision, on the host build of the same source (the analytic CPU path of
 oracle/cpu_analytic.hpp compiles the product's item functions with OICC_HOST_MATH).  The kernels' results are held to the Jet oracle,
 whose sines and cosines are libm's, by the GPU parity tests; this pins the function itself, argument range included, without a GPU."""

@@ -165,7 +165,7 @@ def test_calc_times_edges_through_the_hip_library(dt_s, dt_r):
 
 
 def test_fast_sincos_on_the_device_against_libm():
-    """spline_math.cuh: fast_sincos (branch-free two-piece pi/2 reduction + the fdlibm kernel polynomials) replaced sincos() in
+    """spline_math.h: fast_sincos (branch-free two-piece pi/2 reduction + the fdlibm kernel polynomials) replaced sincos() in
     every SO(3) segment evaluation in round 5; the host build was compared with libm (tests/test_fast_sincos.py), the DEVICE build
     never was.  oicc_debug_fast_sincos evaluates it on the GPU for 2 M arguments -- dense in [-pi, pi] (half angles of segment
     rotations), out to +-100 (the range the function documents), around the multiples of pi/4 where the reduction changes quadrant,

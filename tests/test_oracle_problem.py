@@ -94,8 +94,8 @@ def test_recovers_planted_calibration_on_a_longer_sequence():
                                    E.CAM_LINE_DELAY])
 @pytest.mark.parametrize("camera", ["gopro9_division", "gopro6_fisheye", "gopro6_double_sphere"])
 def test_analytic_cpu_path_equals_forward_mode_jets(flags, camera):
-    """oracle option analytic_jacobians: the closed-form Jacobians of the device kernels (spline_math.cuh compiled for the
-    host + the chain rules of block_items.cuh, oracle/cpu_analytic.hpp) against forward-mode Jets, on the CPU: normal
+    """oracle option analytic_jacobians: the closed-form Jacobians of the device kernels (spline_math.h compiled for the
+    host + the chain rules of block_items.h, oracle/cpu_analytic.hpp) against forward-mode Jets, on the CPU: normal
     equations, per-block Jacobians, and the LM iterate sequence."""
     ds = synthetic.make_config("tiny", camera=camera)
     jets = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
