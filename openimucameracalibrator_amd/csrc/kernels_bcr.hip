@@ -590,7 +590,9 @@ __global__ __launch_bounds__(256) void bcri_schur_rows_kernel(BcrArgs A) {
   const int irs = ir < A.n ? ir : A.n;
   const int xk = (int)blockIdx.x;                       // 0: the left neighbour's coupling rows, 1: the right neighbour's, 2: arrow rows + rhs
   if (xk == 1 && !hasR) return;
-  const int xt = wave;
+  // strip of this wave: the left rows in reverse order, the right rows in order -- strip t pairs with t + 1 (left) / 5 + t (right)
+  // row tiles, so every SIMD gets the same number of products from the two workgroups of a pivot; the arrow strips rotate with the pivot
+  const int xt = xk == 0 ? 3 - wave : (xk == 1 ? wave : ((wave - (int)blockIdx.y) & 3));
   const double* SL = A.S + (A.offS_in + il / s) * 4096;
   const double* SR = A.S + (A.offS_in + i / s) * 4096;
   const double* Fg = A.F + (int64_t)i * 64 * a1;
@@ -651,14 +653,21 @@ __global__ __launch_bounds__(256) void bcri_schur_rows_kernel(BcrArgs A) {
   double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)irs * 64 * a1;
   double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
   const int npairs = xk == 0 ? xt + 1 : (xk == 1 ? 4 + xt + 1 : 8 + xt + 1);
-  for (int pr = 0; pr < npairs; ++pr) {
-    const int yk = xk == 0 ? 0 : (pr < 4 ? 0 : (xk == 1 || pr < 8 ? 1 : 2)), yt = pr < 4 ? pr : (pr < 8 && xk == 2 ? pr - 4 : (xk == 1 ? pr - 4 : pr - 8));
-    if (yk == 1 && !hasR) continue;
+  auto pair_of = [&](int pr, int& yk, int& yt) {
+    yk = xk == 0 ? 0 : (pr < 4 ? 0 : (xk == 1 || pr < 8 ? 1 : 2));
+    yt = pr < 4 ? pr : (xk == 2 && pr >= 8 ? pr - 8 : pr - 4);
+  };
+  auto load_pair = [&](int pr, double (&vy)[16]) {
+    int yk, yt; pair_of(pr, yk, yt);
     int sy; bool oky;
     const double* py = border_ptr(yk, yt, sy, oky);
-    double vy[16];
+    oky = oky && (yk != 1 || hasR);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
+  };
+  auto compute_pair = [&](int pr, const double (&vy)[16]) {
+    int yk, yt; pair_of(pr, yk, yt);
+    if (yk == 1 && !hasR) return;
     const bool swap = xk == 1 && yk == 0 && !il_is_pivot && !ghostR;
     bcr_v4d g0 = {0.0, 0.0, 0.0, 0.0}, g1 = {0.0, 0.0, 0.0, 0.0};
     if (swap) {
@@ -695,6 +704,17 @@ __global__ __launch_bounds__(256) void bcri_schur_rows_kernel(BcrArgs A) {
           if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
         }
       }
+    }
+  };
+  // the operands of pair p + 1 travel while the products of pair p run (two operand buffers)
+  double vya[16], vyb[16];
+  load_pair(0, vya);
+  for (int pr = 0; pr < npairs; pr += 2) {
+    if (pr + 1 < npairs) load_pair(pr + 1, vyb);
+    compute_pair(pr, vya);
+    if (pr + 1 < npairs) {
+      if (pr + 2 < npairs) load_pair(pr + 2, vya);
+      compute_pair(pr + 1, vyb);
     }
   }
 }
