@@ -48,7 +48,7 @@ struct BcrArgs {
   // substitution), it is the right neighbour of whichever local block is the last active one, and the coupling to it is always
   // stored local-variable major.  b0 = 0, ghost = 0: the whole band, as before.
   int b0, ghost;
-  int rows_min;                // host only: levels with at least this many pivots take bcri_schur_rows_kernel (0: the default, kSchurRowsMinPivots)
+  int rows_min;                // host only: levels with at least this many pivots take the low-register build of the Schur kernel (0: the default, kSchurRowsMinPivots)
   const LmCtl* ctl;            // device-side LM control (oicc_device.h): every kernel returns at once when the loop is done
 };
 #define BCR_RETURN_IF_DONE(A) do { if ((A).ctl != nullptr && (A).ctl->done != 0) return; } while (0)
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(64 * kInvWaves) void bcri_invert_kernel(BcrArgs A) 
 }
 
 // one workgroup (4 waves) per (pivot, 16-row tile x of the border rows, group of up to four column tiles y)
-__global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A, int g0) {   // g0: first group of this launch (12: the arrow rows only, next to bcri_schur_rows_kernel)
+template <bool LATE_Y>   // LATE_Y: the y operands are loaded behind the first product (fewer live registers: the build of the levels with many pivots)
+__global__ __launch_bounds__(256, (LATE_Y ? 6 : 1)) void bcri_schur_kernel(BcrArgs A, int g0) {   // g0: first group of this launch; LATE_Y: compiled for six waves per SIMD (80 registers)
   BCR_RETURN_IF_DONE(A);
   __shared__ double Ts[16][68];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -496,8 +497,10 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A, int g0) {   
   double vx[16], vz[16], vy[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) { vx[kk] = px[4 * kk * sx]; vz[kk] = pz[4 * kk * 64]; }
+  if (!LATE_Y) {
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
+    for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
+  }
   asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
   // T(x rows, columns 16 wave ..) = B_x Z: two accumulators, the dependent chain is 8 MFMAs
   bcr_v4d tq = {0.0, 0.0, 0.0, 0.0}, tq2 = {0.0, 0.0, 0.0, 0.0};
@@ -507,6 +510,11 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A, int g0) {   
     tq2 = __builtin_amdgcn_mfma_f64_16x16x4f64(okx ? vx[kk + 1] : 0.0, vz[kk + 1], tq2, 0, 0, 0);
   }
   tq += tq2;
+  if (LATE_Y) {
+    asm volatile("" ::: "memory");   // (not before the products above: their operands' registers are free now)
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
+  }
   // tq[r] <-> (column 16 wave + li, row lq + 4 r of the tile)
   const int trow0 = xk == 0 ? 16 * xt : (xk == 1 ? 64 + 16 * xt : 128 + 16 * xt);
 #pragma unroll
@@ -562,159 +570,6 @@ __global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A, int g0) {   
         unsafeAtomicAdd(A.Mc + q1 * a1 + q2, v);
         if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
       }
-    }
-  }
-}
-
-// Round 6, the levels with many pivots (throughput bound: BASELINE config 5, levels 0-3 = 0.17 of its 0.54 ms solve): the Schur
-// complement with one WAVE per 16-row strip of the border rows instead of one workgroup per strip.  In bcri_schur_kernel the four
-// waves of a strip's workgroup split the columns of Z -- every workgroup reads all of Z (32 KB) for 16 rows of T, waits at a barrier
-// for the other waves' columns, and a pivot is fifteen such workgroups (level 0 of config 5: 10 545 workgroups of ~7 us each at four
-// per compute unit = 81 us for 27 us of MFMA work).  Here a workgroup is (pivot, left | right | arrow rows): Z goes to LDS once,
-// wave w forms the whole strip T(rows 16 w .., all 64 columns) = B_w Z -- computed TRANSPOSED, Z B_w^T (Z is symmetric, bit for bit:
-// bcri_tail mirrors it), so that the four result tiles ARE the operands of the second product (lane (li, lq) holds T(row li,
-// column 16 ct + lq + 4 r) = operand element k = 4 (4 ct + r) + lq): no exchange through LDS, no barrier behind the staging of Z --
-// and multiplies it with the row tiles it pairs with.  Same products and the same order of every sum as the other kernel.
-constexpr int kRowsLDZ = 80;   // Z(k, c) at Zs[k * 80 + c]: the four k of an operand load (lq) land on disjoint bank groups
-__global__ __launch_bounds__(256) void bcri_schur_rows_kernel(BcrArgs A) {
-  BCR_RETURN_IF_DONE(A);
-  extern __shared__ double lds[];
-  double* const Zs = lds;                               // [64][kRowsLDZ]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lq = lane >> 4;
-  const int a1 = A.a + 1, s = A.s, rtf = A.rtf;
-  const int i = s * (2 * (int)blockIdx.y + 1), il = i - s, ir = i + s;
-  const bool ghostR = A.ghost != 0 && ir >= A.n;
-  const bool hasR = ir < A.n || ghostR;
-  const int irs = ir < A.n ? ir : A.n;
-  const int xk = (int)blockIdx.x;                       // 0: the left neighbour's coupling rows, 1: the right neighbour's, 2: arrow rows + rhs
-  if (xk == 1 && !hasR) return;
-  // strip of this wave: the left rows in reverse order, the right rows in order -- strip t pairs with t + 1 (left) / 5 + t (right)
-  // row tiles, so every SIMD gets the same number of products from the two workgroups of a pivot; the arrow strips rotate with the pivot
-  const int xt = xk == 0 ? 3 - wave : (xk == 1 ? wave : ((wave - (int)blockIdx.y) & 3));
-  const double* SL = A.S + (A.offS_in + il / s) * 4096;
-  const double* SR = A.S + (A.offS_in + i / s) * 4096;
-  const double* Fg = A.F + (int64_t)i * 64 * a1;
-  double* Zg = A.Lf + (int64_t)i * (192 + a1) * 64;
-  double* Tg = Zg + 4096;
-  {   // Z -> LDS, all loads in flight before the first store
-    double z[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) z[k] = Zg[tid + 256 * k];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const int e = tid + 256 * k; Zs[(e >> 6) * kRowsLDZ + (e & 63)] = z[k]; }
-  }
-  // border rows as MFMA operands: element (row 16 t + li, pivot variable k = 4 kk + lq)
-  auto border_ptr = [&](int kind, int t, int& stride, bool& ok) -> const double* {
-    if (kind == 0) { stride = 64; ok = true; return SL + lq * 64 + 16 * t + li; }
-    if (kind == 1) { stride = 64; ok = true; return SR + lq * 64 + 16 * t + li; }
-    const int q = 16 * t + li; ok = q < a1; stride = a1; return Fg + lq * a1 + (ok ? q : 0);
-  };
-  const bool active = xk < 2 || xt < rtf;               // (arrow rows: rtf strips, the other waves only help with the staging)
-  int sx; bool okx;
-  const double* px = border_ptr(xk, active ? xt : 0, sx, okx);
-  double vx[16];
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) vx[kk] = (active && okx) ? px[4 * kk * sx] : 0.0;
-  __syncthreads();
-  if (!active) return;
-  // the strip, transposed: tile ct = Z(16 ct .., :) B_x^T; lane (li, lq) gets T(row li, column 16 ct + lq + 4 r) in vt[4 ct + r]
-  double vt[16];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    const double* pz = Zs + lq * kRowsLDZ + 16 * ct + li;
-    double vz[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) vz[kk] = pz[4 * kk * kRowsLDZ];
-    bcr_v4d t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 16; kk += 2) {
-      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vz[kk], vx[kk], t0, 0, 0, 0);
-      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vz[kk + 1], vx[kk + 1], t1, 0, 0, 0);
-    }
-    t0 += t1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) vt[4 * ct + r] = t0[r];
-  }
-  {   // T stays in global memory for the back substitution (the strip's rows: once)
-    const int trow = (xk == 0 ? 0 : (xk == 1 ? 64 : 128)) + 16 * xt + li;
-    if (xk < 2 || 16 * xt + li < a1) {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tg[(int64_t)trow * 64 + 16 * ct + lq + 4 * r] = vt[4 * ct + r];
-    }
-  }
-  // the strip times the row tiles it pairs with: left -> (left, <= xt); right -> (left, all four), (right, <= xt);
-  // arrow -> (left, four), (right, four), (arrow, <= xt)
-  const bool il_is_pivot = ((il / (2 * s)) & 1) != 0;
-  double* Dl = A.D + (int64_t)il * 4096; double* Dr = A.D + (int64_t)irs * 4096;
-  double* Fl = A.F + (int64_t)il * 64 * a1; double* Fr = A.F + (int64_t)irs * 64 * a1;
-  double* So = A.S + (A.offS_out + il / (2 * s)) * 4096;
-  const int npairs = xk == 0 ? xt + 1 : (xk == 1 ? 4 + xt + 1 : 8 + xt + 1);
-  auto pair_of = [&](int pr, int& yk, int& yt) {
-    yk = xk == 0 ? 0 : (pr < 4 ? 0 : (xk == 1 || pr < 8 ? 1 : 2));
-    yt = pr < 4 ? pr : (xk == 2 && pr >= 8 ? pr - 8 : pr - 4);
-  };
-  auto load_pair = [&](int pr, double (&vy)[16]) {
-    int yk, yt; pair_of(pr, yk, yt);
-    int sy; bool oky;
-    const double* py = border_ptr(yk, yt, sy, oky);
-    oky = oky && (yk != 1 || hasR);
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
-  };
-  auto compute_pair = [&](int pr, const double (&vy)[16]) {
-    int yk, yt; pair_of(pr, yk, yt);
-    if (yk == 1 && !hasR) return;
-    const bool swap = xk == 1 && yk == 0 && !il_is_pivot && !ghostR;
-    bcr_v4d g0 = {0.0, 0.0, 0.0, 0.0}, g1 = {0.0, 0.0, 0.0, 0.0};
-    if (swap) {
-#pragma unroll
-      for (int kk = 0; kk < 16; kk += 2) {
-        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk], vy[kk], g0, 0, 0, 0);
-        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk + 1], vy[kk + 1], g1, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 16; kk += 2) {
-        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk], vt[kk], g0, 0, 0, 0);
-        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vy[kk + 1], vt[kk + 1], g1, 0, 0, 0);
-      }
-    }
-    g0 += g1;
-    // not swapped: g0[r] <-> (x row li, y row lq + 4 r); swapped: (y row li, x row lq + 4 r)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = -g0[r];
-      if (xk == 1 && yk == 0) {
-        if (!swap) { const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r; So[y * 64 + x] = v; }    // Q[c = il var][r = ir var]
-        else       { const int y = 16 * yt + li, x = 16 * xt + lq + 4 * r; So[x * 64 + y] = v; }    // Q[c = ir var][r = il var]
-      } else if (xk < 2) {
-        const int x = 16 * xt + li, y = 16 * yt + lq + 4 * r;
-        if (x >= y && v != 0.0) unsafeAtomicAdd((xk == 0 ? Dl : Dr) + y * 64 + x, v);
-      } else if (yk < 2) {
-        const int q = 16 * xt + li, y = 16 * yt + lq + 4 * r;
-        if (q < a1 && v != 0.0) unsafeAtomicAdd((yk == 0 ? Fl : Fr) + y * a1 + q, v);
-      } else {
-        const int q1 = 16 * xt + li, q2 = 16 * yt + lq + 4 * r;
-        if (q1 < a1 && q2 <= q1 && v != 0.0) {
-          unsafeAtomicAdd(A.Mc + q1 * a1 + q2, v);
-          if (q1 != q2) unsafeAtomicAdd(A.Mc + q2 * a1 + q1, v);
-        }
-      }
-    }
-  };
-  // the operands of pair p + 1 travel while the products of pair p run (two operand buffers)
-  double vya[16], vyb[16];
-  load_pair(0, vya);
-  for (int pr = 0; pr < npairs; pr += 2) {
-    if (pr + 1 < npairs) load_pair(pr + 1, vyb);
-    compute_pair(pr, vya);
-    if (pr + 1 < npairs) {
-      if (pr + 2 < npairs) load_pair(pr + 2, vya);
-      compute_pair(pr + 1, vyb);
     }
   }
 }
@@ -1007,7 +862,7 @@ int64_t bcr_workspace_doubles(const TangentLayout& tl) {
 }
 
 // ---- the launch sequence in pieces (shared by the one-GPU solve and the distributed one) ----
-constexpr int kSchurRowsMinPivots = 64;   // levels with at least this many pivots take bcri_schur_rows_kernel for the coupling rows
+constexpr int kSchurRowsMinPivots = 64;   // levels with at least this many pivots take the low-register build of the Schur kernel
 struct BcrLevels { int strides[40]; int npivs[40]; int nlev = 0; int64_t off_end = 0; };   // off_end: index of the coupling table behind the last level (distributed: the final coupling (block 0, ghost))
 // the damped system in block form (+ the inversions of level 0 in the same launch when they fit the chip at once); returns whether level 0 is inverted
 static bool bcr_launch_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag, double max_diag, BcrArgs A, hipStream_t st) {
@@ -1042,11 +897,10 @@ static void bcr_launch_forward(BcrArgs A, bool level0_inverted, BcrLevels& L, hi
     {
       BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
       if (!(level0_inverted && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(64 * kInvWaves), bcr_lds_inv(), st, Ai);
-      if (npiv >= (A.rows_min > 0 ? A.rows_min : kSchurRowsMinPivots) && !carry) {   // many pivots: one wave per strip of the border rows
-        const size_t lds_rows = (size_t)64 * kRowsLDZ * sizeof(double);
-        bcr_allow_lds(reinterpret_cast<const void*>(bcri_schur_rows_kernel), lds_rows);
-        hipLaunchKernelGGL(bcri_schur_rows_kernel, dim3(3, npiv), dim3(256), lds_rows, st, A);
-      } else hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A, 0);
+      // levels with many pivots are throughput bound (config 5, level 0: 10 545 workgroups in ten rounds of four per compute unit): the build
+      // of the kernel that loads the second product's operands BEHIND the first product holds fewer registers -- more workgroups resident
+      if (npiv >= (A.rows_min > 0 ? A.rows_min : kSchurRowsMinPivots)) hipLaunchKernelGGL(bcri_schur_kernel<true>, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A, 0);
+      else hipLaunchKernelGGL(bcri_schur_kernel<false>, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A, 0);
     }
     L.strides[L.nlev] = s; L.npivs[L.nlev] = npiv; ++L.nlev;
     off += m - 1 + g;
