@@ -19,7 +19,6 @@
 // until round 4 removed them (three kernels, ten instantiations: git history) -- the band sweep (kernels_cholesky.hip, algorithm 1)
 // is the independent solver the tests compare with.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include "oicc_device.h"
@@ -48,7 +47,6 @@ struct BcrArgs {
   // substitution), it is the right neighbour of whichever local block is the last active one, and the coupling to it is always
   // stored local-variable major.  b0 = 0, ghost = 0: the whole band, as before.
   int b0, ghost;
-  int rows_min;                // host only: levels with at least this many pivots take the low-register build of the Schur kernel (0: the default, kSchurRowsMinPivots)
   const LmCtl* ctl;            // device-side LM control (oicc_device.h): every kernel returns at once when the loop is done
 };
 #define BCR_RETURN_IF_DONE(A) do { if ((A).ctl != nullptr && (A).ctl->done != 0) return; } while (0)
@@ -452,8 +450,7 @@ __global__ __launch_bounds__(64 * kInvWaves) void bcri_invert_kernel(BcrArgs A) 
 }
 
 // one workgroup (4 waves) per (pivot, 16-row tile x of the border rows, group of up to four column tiles y)
-template <bool LATE_Y>   // LATE_Y: the y operands are loaded behind the first product (fewer live registers: the build of the levels with many pivots)
-__global__ __launch_bounds__(256, (LATE_Y ? 6 : 1)) void bcri_schur_kernel(BcrArgs A, int g0) {   // g0: first group of this launch; LATE_Y: compiled for six waves per SIMD (80 registers)
+__global__ __launch_bounds__(256) void bcri_schur_kernel(BcrArgs A) {
   BCR_RETURN_IF_DONE(A);
   __shared__ double Ts[16][68];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -473,7 +470,7 @@ __global__ __launch_bounds__(256, (LATE_Y ? 6 : 1)) void bcri_schur_kernel(BcrAr
   const bool hasR = ir < A.n || ghostR;             // (a pivot always has its left neighbour)
   const int irs = ir < A.n ? ir : A.n;              // where the right neighbour's D / F live
   // group -> row tile (kind xk: 0 left, 1 right, 2 arrow rows / rhs; index xt), column tiles (kind yk, ny of them), and who stores T
-  int g = (int)blockIdx.x + g0, xk, xt, yk, ny; bool store_t;
+  int g = (int)blockIdx.x, xk, xt, yk, ny; bool store_t;
   if (g < 4) { xk = 0; xt = g; yk = 0; ny = g + 1; store_t = true; }
   else if (g < 8) { xk = 1; xt = g - 4; yk = 0; ny = 4; store_t = false; }
   else if (g < 12) { xk = 1; xt = g - 8; yk = 1; ny = xt + 1; store_t = true; }
@@ -497,10 +494,8 @@ __global__ __launch_bounds__(256, (LATE_Y ? 6 : 1)) void bcri_schur_kernel(BcrAr
   double vx[16], vz[16], vy[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) { vx[kk] = px[4 * kk * sx]; vz[kk] = pz[4 * kk * 64]; }
-  if (!LATE_Y) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
-  }
+  for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
   asm volatile("" ::: "memory");   // (every load above is issued before the first MFMA)
   // T(x rows, columns 16 wave ..) = B_x Z: two accumulators, the dependent chain is 8 MFMAs
   bcr_v4d tq = {0.0, 0.0, 0.0, 0.0}, tq2 = {0.0, 0.0, 0.0, 0.0};
@@ -510,11 +505,6 @@ __global__ __launch_bounds__(256, (LATE_Y ? 6 : 1)) void bcri_schur_kernel(BcrAr
     tq2 = __builtin_amdgcn_mfma_f64_16x16x4f64(okx ? vx[kk + 1] : 0.0, vz[kk + 1], tq2, 0, 0, 0);
   }
   tq += tq2;
-  if (LATE_Y) {
-    asm volatile("" ::: "memory");   // (not before the products above: their operands' registers are free now)
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) vy[kk] = oky ? py[4 * kk * sy] : 0.0;
-  }
   // tq[r] <-> (column 16 wave + li, row lq + 4 r of the tile)
   const int trow0 = xk == 0 ? 16 * xt : (xk == 1 ? 64 + 16 * xt : 128 + 16 * xt);
 #pragma unroll
@@ -862,13 +852,11 @@ int64_t bcr_workspace_doubles(const TangentLayout& tl) {
 }
 
 // ---- the launch sequence in pieces (shared by the one-GPU solve and the distributed one) ----
-constexpr int kSchurRowsMinPivots = 64;   // levels with at least this many pivots take the low-register build of the Schur kernel
 struct BcrLevels { int strides[40]; int npivs[40]; int nlev = 0; int64_t off_end = 0; };   // off_end: index of the coupling table behind the last level (distributed: the final coupling (block 0, ghost))
 // the damped system in block form (+ the inversions of level 0 in the same launch when they fit the chip at once); returns whether level 0 is inverted
 static bool bcr_launch_build(const NormalEq& ne, const TangentLayout& tl, const SolveBuffers& sb, int reuse_diagonal, double min_diag, double max_diag, BcrArgs A, hipStream_t st) {
   const int n = A.n;
-  static const int fused_max = std::getenv("OICC_FUSED_MAX") ? std::atoi(std::getenv("OICC_FUSED_MAX")) : 512;   // (experiment)
-  const bool fused_build = n >= 2 && n <= fused_max && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
+  const bool fused_build = n >= 2 && n <= 512 && A.prof == nullptr;    // build + the inversions of level 0 in one launch (while the level-0 pivots fit on the chip at once)
   const int64_t work = (int64_t)(n + A.ghost) * 4096;
   A.s = 1; A.offS_in = 0; A.offS_out = 0;
   if (fused_build) {
@@ -897,10 +885,7 @@ static void bcr_launch_forward(BcrArgs A, bool level0_inverted, BcrLevels& L, hi
     {
       BcrArgs Ai = A; if (s != 1) Ai.prof = nullptr;
       if (!(level0_inverted && s == 1)) hipLaunchKernelGGL(k_inv, dim3(npiv), dim3(64 * kInvWaves), bcr_lds_inv(), st, Ai);
-      // levels with many pivots are throughput bound (config 5, level 0: 10 545 workgroups in ten rounds of four per compute unit): the build
-      // of the kernel that loads the second product's operands BEHIND the first product holds fewer registers -- more workgroups resident
-      if (npiv >= (A.rows_min > 0 ? A.rows_min : kSchurRowsMinPivots)) hipLaunchKernelGGL(bcri_schur_kernel<true>, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A, 0);
-      else hipLaunchKernelGGL(bcri_schur_kernel<false>, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A, 0);
+      hipLaunchKernelGGL(bcri_schur_kernel, dim3(12 + 3 * A.rtf, npiv + (carry ? 1 : 0)), dim3(256), 0, st, A);
     }
     L.strides[L.nlev] = s; L.npivs[L.nlev] = npiv; ++L.nlev;
     off += m - 1 + g;
@@ -938,7 +923,7 @@ int launch_bcr_solve(const NormalEq& ne, const TangentLayout& tl, const SolveBuf
   bcr_carve(A, sb.ws, n, a1);
   A.Mc = sb.Mc; A.x = sb.step_s; A.fail = &sb.st->chol_failed; A.prof = sb.prof;
   A.n = n; A.a = tl.a; A.Pb = tl.Pb; A.delay = sb.bcr_delay;
-  A.rtf = (a1 + 15) / 16; A.ctl = sb.ctl; A.rows_min = sb.bcr_rows_min;
+  A.rtf = (a1 + 15) / 16; A.ctl = sb.ctl;
   const bool inverted = bcr_launch_build(ne, tl, sb, reuse_diagonal, min_diag, max_diag, A, st);
   BcrLevels L;
   bcr_launch_forward(A, inverted, L, st);
@@ -1037,12 +1022,12 @@ DistViews bcr_dist_views(const TangentLayout& tl, const SolveBuffers& sb, const 
   A.x = w; w += (int64_t)(d.n_loc + 1) * 64 + tl.a + 8;
   A.Mc = w; w += (int64_t)a1 * a1;
   A.fail = &sb.st->chol_failed; A.prof = nullptr; A.n = d.n_loc; A.a = tl.a; A.Pb = (d.n_loc + ghost) * 64; A.delay = sb.bcr_delay;
-  A.rtf = (a1 + 15) / 16; A.ctl = nullptr; A.b0 = d.b0; A.ghost = ghost; A.rows_min = sb.bcr_rows_min;
+  A.rtf = (a1 + 15) / 16; A.ctl = nullptr; A.b0 = d.b0; A.ghost = ghost;
   BcrArgs& T = v.T;
   bcr_carve(T, w, d.nranks, a1); w += bcr_carve_doubles(d.nranks, a1);
   T.x = w; w += (int64_t)d.nranks * 64 + tl.a + 8;
   T.Mc = w; w += (int64_t)a1 * a1;
-  T.fail = A.fail; T.prof = nullptr; T.n = d.nranks; T.a = tl.a; T.Pb = d.nranks * 64; T.delay = sb.bcr_delay; T.rtf = A.rtf; T.ctl = nullptr; T.b0 = 0; T.ghost = 0; T.rows_min = sb.bcr_rows_min;
+  T.fail = A.fail; T.prof = nullptr; T.n = d.nranks; T.a = tl.a; T.Pb = d.nranks * 64; T.delay = sb.bcr_delay; T.rtf = A.rtf; T.ctl = nullptr; T.b0 = 0; T.ghost = 0;
   v.xt = T.x;
   return v;
 }

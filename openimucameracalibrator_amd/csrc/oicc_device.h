@@ -143,7 +143,6 @@ struct SolveBuffers {
   int algo;        // 0: auto (= 4 where it applies), 1: time-partitioned band sweep, 4: block cyclic reduction through the inverses of the pivot blocks (2, 3: the factor-based formulations of rounds 1-3, removed in round 4)
   double radius;   // trust-region radius of this step (kernel argument, no host->device copy)
   int bcr_max_border = 64;      // arrow + rhs rows the block cyclic reduction accepts (per problem: option bcr_max_border)
-  int bcr_rows_min = 0;         // levels of the cyclic reduction with at least this many pivots form their Schur complements one wave per border strip (0: default 64; option bcr_rows_min_pivots)
   int bcr_delay = 0;            // debug: panel waves other than wave 0 start every panel this many ~1000-cycle sleeps late (option debug_bcr_delay)
   const LmCtl* ctl = nullptr;   // device-side LM control (round 5): the build kernels take the current normal equations, the radius and the
                                 // reuse-diagonal flag from it, every kernel of the solve returns at once when it says done

@@ -250,7 +250,6 @@ struct oicc_problem {
     opt["debug_no_direct_rows"] = 0;   // 1: every accumulator row goes through its tile's slab (tests: both routes give the same sums)
     opt["debug_seg_precompute"] = 0;   // 1 / 2: segment tables always / never precomputed per parameter vector (default: by problem size)
     opt["debug_bcr_delay"] = 0;        // panel waves other than wave 0 of the BCR elimination start every panel this many ~1000-cycle sleeps late (tests)
-    opt["bcr_rows_min_pivots"] = 0;    // levels of the cyclic reduction with at least this many pivots take bcri_schur_rows_kernel (one wave per border strip); 0: the default (64), 1: every level (tests), 1e9: never
     opt["bcr_max_border"] = 64;        // arrow + rhs rows the block cyclic reduction accepts (kernels_bcr.hip: up to 64 by construction; round 2 held it at 32 until the panel hazard was settled, test_bcr_wide_borders_and_the_panel_hazard)
     opt["debug_check_ne"] = 0;   // 1: before every linear solve compare the current normal equations with a host copy taken when they became current
     opt["debug_sync"] = 0;       // 1: drain the stream after every pass (debugging of inter-kernel hazards)

@@ -85,7 +85,7 @@ int eval_pass(oicc_problem* p, const double* x, bool jac, double* dbg_res, doubl
 
 SolveBuffers solve_buffers(oicc_problem* p, long long* prof) {
   SolveBuffers sb{p->d_Mb.p, p->d_Mt.p, p->d_Mc.p, p->d_scale.p, p->d_diag.p, p->d_D2.p, p->d_step.p, p->d_state.p, prof, p->d_ws.p, (int64_t)p->d_ws.n, int(p->opt["solver_partitions"]), int(p->opt["solver_algorithm"])};
-  sb.radius = 0.0; sb.bcr_max_border = int(p->opt["bcr_max_border"]); sb.bcr_delay = int(p->opt["debug_bcr_delay"]); sb.bcr_rows_min = int(p->opt["bcr_rows_min_pivots"]);
+  sb.radius = 0.0; sb.bcr_max_border = int(p->opt["bcr_max_border"]); sb.bcr_delay = int(p->opt["debug_bcr_delay"]);
   return sb;
 }
 

@@ -369,32 +369,6 @@ def test_distributed_cyclic_reduction_leaves_a_small_residual_at_full_size(cfg, 
             assert len(fwd) == n and (fwd > 0).all() and (mid > 0).all()
 
 
-@pytest.mark.parametrize("cfg,flags", [("tiny", FLAGS1), ("C2", FLAGS1), ("C2", FLAGS1 | E.IMU_BIASES | E.IMU_INTRINSICS | E.CAM_LINE_DELAY), ("C3", FLAGS1), ("C4", FLAGS1)])
-def test_strip_per_wave_schur_kernel_takes_the_steps_of_the_strip_per_workgroup_kernel(cfg, flags):
-    """Round 6: levels of the cyclic reduction with >= 64 pivots (BASELINE config 5: levels 0-3) form their Schur complements with
-    bcri_schur_rows_kernel -- Z in LDS once per (pivot, left | right | arrow rows), one wave per 16-row strip, the strip computed
-    transposed so that its result tiles are the second product's operands.  Option bcr_rows_min_pivots = 1 sends EVERY level of the
-    smaller configurations through it (1e9: never): same LM iterates (1e-10: the same products in the same order; only the fp64
-    atomics onto shared targets arrive in another order), with 9, 10 and 28 border rows (one and two arrow strips), under LDS
-    poison and from a radius of 1e9 (rejected steps, reused diagonals); and the residual of one solve against the packed normal
-    equations."""
-    ds = synthetic.make_config(cfg)
-    out = []
-    for rows_min in (1, 10 ** 9):
-        cal = E.ImuCameraCalibrator().BatchInitSpline(ds)
-        tr = cal.trajectory_
-        tr.SetOption("bcr_rows_min_pivots", rows_min); tr.SetOption("debug_poison_lds", 1); tr.SetOption("initial_trust_region_radius", 1e9)
-        res, _, failed = tr.SolveResidual(flags, 1e4)
-        assert not failed and res < 1e-12, (rows_min, res)
-        s_ = tr.Optimize(8, flags)
-        out.append(([(i["cost"], i["step_is_successful"], i["step_norm"]) for i in tr.GetIterations()], tr.GetT_i_c(), s_))
-    (i1, t1, s1), (i0, t0, s0) = out
-    assert len(i1) == len(i0) >= 4 and s1["arrow_dim"] == s0["arrow_dim"]
-    for a, b in zip(i1, i0):
-        assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-10 * b[0] and abs(a[2] - b[2]) <= 1e-8 * max(b[2], 1e-12), (a, b)
-    assert np.abs(t1 - t0).max() < 1e-9
-
-
 def test_cyclic_reduction_on_c3_through_rejected_steps():
     """C3 (606 + 306 knots: 43 blocks, 6 levels of the cyclic reduction through the pivot inverses) against the partitioned band sweep,
     with LDS poisoned before every solve and through rejected steps (a start far from the valley)."""
