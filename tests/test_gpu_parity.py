@@ -362,9 +362,11 @@ def test_distributed_cyclic_reduction_leaves_a_small_residual_at_full_size(cfg, 
         assert not failed1
         for n in ranks:
             res, failed, fwd, mid = cal.trajectory_.DistributedSolveEmulated(FLAGS1, n, radius, repeats=1)
-            # 1e-12 with Ceres' radius (measured: 3e-15 for 2-3 ranks, growing with the number of separators to 3e-14 at 8 ranks and
-            # 5e-13 at 29 -- the top system's Schur complements pass through more explicit inverses); undamped, where the small
-            # configurations' knots beyond the last measurement are barely determined, 1e-8 (measured <= 6e-10; one GPU 3e-14)
+            # 1e-12 with Ceres' radius (measured: 3e-15 for 2-3 ranks, growing with the number of ranks to 3e-14 at 8 and 5e-13 at 29:
+            # every rank solves the top system itself, its fp64 atomics arrive in its own order, and the step is a patchwork of N
+            # solutions that each solve a slightly different nearby system -- the pieces differ by the FORWARD error, cond x eps);
+            # undamped, where the small configurations' knots beyond the last measurement are barely determined, 1e-8 (measured
+            # <= 6e-10; one GPU 3e-14)
             assert not failed and res < (1e-12 if radius == 1e4 else 1e-8), (cfg, n, radius, res, one)
             assert len(fwd) == n and (fwd > 0).all() and (mid > 0).all()
 
