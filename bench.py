@@ -392,6 +392,55 @@ def main():
         if summ is not None:
             out["full_calibration"] = dict(full_ref, solver_options="reference: inner iterations + bounds line search + projected gradient norm (impl.h:255-276)",
                                            plain_lm=dict(full_plain, solver_options="plain Levenberg-Marquardt steps (no inner sweeps)"))
+        # ---- extra: C5-size Jacobian pass on one GPU (before the CPU baselines: with their 128 OpenMP threads in the process the same
+        # set-up measured 12 ms instead of 6) --------------------------------
+        if not args.no_extra and world == 1:
+            try:
+                ds5 = synthetic.make_config("C5")
+                c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
+                s5 = c5.trajectory_.TimeLinearSolve(flags, repeats=5)
+                # one full LM iteration and one inner sweep at C5 size (the reference's solver options: every sweep visits all 30 011 parameter blocks)
+                c5.trajectory_.RunLmIterations(flags, 2)
+                torch.cuda.synchronize(); t1 = time.perf_counter(); c5.trajectory_.RunLmIterations(flags, 5); torch.cuda.synchronize()
+                lm5 = 1e3 * (time.perf_counter() - t1) / 5
+                c5r = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                c5r.trajectory_.UseReferenceSolverOptions()
+                s5r = c5r.trajectory_.Optimize(3, flags)
+                c5p = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                s5p = c5p.trajectory_.Optimize(1, flags)                     # plain LM: set-up without the inner-iteration plan
+                # the FULL C5 calibration with the reference's solver options (stage 1 + stage 2, as full_calibration above)
+                # (three fresh problems one after the other: the first large uploads / allocations of a process cost the runtime several
+                # times what later ones do -- round 6 measured 20 / 12 / 3 ms for the same 47 MB -- so the line carries the median run and all three)
+                c5_blocks, c5_corners, c5_accl = c5.num_blocks, c5.num_corners, int(c5.accl_accepted.sum())
+                del c5, c5r, c5p      # (one data set at a time, as a calibration run has it: with four C5 problems alive every new one maps ~0.6 GB of fresh device memory -- 13 ms of set-up against 6)
+                runs5 = []
+                for _ in range(3):
+                    c5f = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                    c5f.trajectory_.UseReferenceSolverOptions()
+                    t1 = time.perf_counter()
+                    f1 = c5f.trajectory_.Optimize(50, flags); rp5 = c5f.trajectory_.GetMeanReprojectionError(); f2 = c5f.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
+                    runs5.append(dict(seconds=time.perf_counter() - t1, stage1_iterations=f1["num_iterations"], stage2_iterations=f2["num_iterations"], inner_sweeps=f1["inner_sweeps"] + f2["inner_sweeps"],
+                                      seconds_inner=f1["seconds_inner"] + f2["seconds_inner"], seconds_setup=f1["seconds_setup"] + f2["seconds_setup"], final_cost=f1["final_cost"], final_reproj_error_px=rp5))
+                    del c5f
+                full5 = dict(sorted(runs5, key=lambda r: r["seconds"])[1], all_runs_seconds=[r["seconds"] for r in runs5], all_runs_seconds_setup=[r["seconds_setup"] for r in runs5],
+                             note="median of three fresh problems in this process, in the order run: all_runs_*")
+                setup_ref = sorted(r["seconds_setup"] for r in runs5)[1]
+                plain_setups = []
+                for _ in range(3):
+                    c5q = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
+                    plain_setups.append(c5q.trajectory_.Optimize(1, flags)["seconds_setup"]); del c5q
+                out["extra_c5_single_gpu"] = dict(blocks=c5_blocks, corners=c5_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false, 4, true> (chains of 8 tiles) + slab_merge_kernel",
+                                                  lm_step_ms=lm5, inner_sweep_ms=1e3 * s5r["seconds_inner"] / max(s5r["inner_sweeps"], 1), inner_sweeps_timed=s5r["inner_sweeps"],
+                                                  setup_ms_reference_options=1e3 * setup_ref, setup_ms_plain_lm=1e3 * sorted(plain_setups)[1],
+                                                  setup_note="seconds_setup of the summary (uploads, layout + buffers, tiles, inner-iteration plan; both stages for the reference options), median of three fresh problems with no other C5 problem alive; with the earlier problems of this process still alive: %.2f / %.2f ms" % (1e3 * s5r["seconds_setup"], 1e3 * s5p["seconds_setup"]),
+                                                  full_calibration_reference_options=full5,
+                                                  fp64_frac_of_78p6=(6.9e3 * c5_corners + 11.3e3 * c5_accl) / (p5 * 1e-3) / 78.6e12,
+                                                  kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
+                                                  blocks_per_s_jacobian_pass=c5_blocks / (p5 * 1e-3),
+                                                  fp64_TFLOPs=(6.9e3 * c5_corners + 11.3e3 * c5_accl) / (p5 * 1e-3) / 1e12)
+            except Exception as e:  # the extra must never break the bench line
+                out["extra_c5_single_gpu"] = {"error": str(e)[:200]}
         # ---- CPU baseline: the oracle (CPU restatement of the Ceres path) ----------
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -456,54 +505,6 @@ def main():
                 jets=dict(seconds=cj["seconds"], cores=nth_best, stage1_iterations=cj["stage1_iterations"], inner_sweeps=cj["inner_sweeps"], final_cost=cj["final_cost"]),
                 analytic=dict(seconds=ca["seconds"], cores=nth, stage1_iterations=ca["stage1_iterations"], inner_sweeps=ca["inner_sweeps"], final_cost=ca["final_cost"]),
                 gpu_seconds=full_ref["seconds"], speedup_vs_jets=cj["seconds"] / full_ref["seconds"], speedup_vs_analytic=ca["seconds"] / full_ref["seconds"], kind="port")
-        # ---- extra: C5-size Jacobian pass on one GPU --------------------------------
-        if not args.no_extra and world == 1:
-            try:
-                ds5 = synthetic.make_config("C5")
-                c5 = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
-                p5, k5 = c5.trajectory_.TimeJacobianPass(flags, repeats=5)
-                s5 = c5.trajectory_.TimeLinearSolve(flags, repeats=5)
-                # one full LM iteration and one inner sweep at C5 size (the reference's solver options: every sweep visits all 30 011 parameter blocks)
-                c5.trajectory_.RunLmIterations(flags, 2)
-                torch.cuda.synchronize(); t1 = time.perf_counter(); c5.trajectory_.RunLmIterations(flags, 5); torch.cuda.synchronize()
-                lm5 = 1e3 * (time.perf_counter() - t1) / 5
-                c5r = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
-                c5r.trajectory_.UseReferenceSolverOptions()
-                s5r = c5r.trajectory_.Optimize(3, flags)
-                c5p = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
-                s5p = c5p.trajectory_.Optimize(1, flags)                     # plain LM: set-up without the inner-iteration plan
-                # the FULL C5 calibration with the reference's solver options (stage 1 + stage 2, as full_calibration above)
-                # (three fresh problems one after the other: the first large uploads / allocations of a process cost the runtime several
-                # times what later ones do -- round 6 measured 20 / 12 / 3 ms for the same 47 MB -- so the line carries the median run and all three)
-                c5_blocks, c5_corners, c5_accl = c5.num_blocks, c5.num_corners, int(c5.accl_accepted.sum())
-                del c5, c5r, c5p      # (one data set at a time, as a calibration run has it: with four C5 problems alive every new one maps ~0.6 GB of fresh device memory -- 13 ms of set-up against 6)
-                runs5 = []
-                for _ in range(3):
-                    c5f = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
-                    c5f.trajectory_.UseReferenceSolverOptions()
-                    t1 = time.perf_counter()
-                    f1 = c5f.trajectory_.Optimize(50, flags); rp5 = c5f.trajectory_.GetMeanReprojectionError(); f2 = c5f.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
-                    runs5.append(dict(seconds=time.perf_counter() - t1, stage1_iterations=f1["num_iterations"], stage2_iterations=f2["num_iterations"], inner_sweeps=f1["inner_sweeps"] + f2["inner_sweeps"],
-                                      seconds_inner=f1["seconds_inner"] + f2["seconds_inner"], seconds_setup=f1["seconds_setup"] + f2["seconds_setup"], final_cost=f1["final_cost"], final_reproj_error_px=rp5))
-                    del c5f
-                full5 = dict(sorted(runs5, key=lambda r: r["seconds"])[1], all_runs_seconds=[r["seconds"] for r in runs5], all_runs_seconds_setup=[r["seconds_setup"] for r in runs5],
-                             note="median of three fresh problems in this process, in the order run: all_runs_*")
-                setup_ref = sorted(r["seconds_setup"] for r in runs5)[1]
-                plain_setups = []
-                for _ in range(3):
-                    c5q = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
-                    plain_setups.append(c5q.trajectory_.Optimize(1, flags)["seconds_setup"]); del c5q
-                out["extra_c5_single_gpu"] = dict(blocks=c5_blocks, corners=c5_corners, jacobian_pass_ms=p5, linear_solve_ms=s5, kernel="tile_kernel<true, false, 4, true> (chains of 8 tiles) + slab_merge_kernel",
-                                                  lm_step_ms=lm5, inner_sweep_ms=1e3 * s5r["seconds_inner"] / max(s5r["inner_sweeps"], 1), inner_sweeps_timed=s5r["inner_sweeps"],
-                                                  setup_ms_reference_options=1e3 * setup_ref, setup_ms_plain_lm=1e3 * sorted(plain_setups)[1],
-                                                  setup_note="seconds_setup of the summary (uploads, layout + buffers, tiles, inner-iteration plan; both stages for the reference options), median of three fresh problems with no other C5 problem alive; with the earlier problems of this process still alive: %.2f / %.2f ms" % (1e3 * s5r["seconds_setup"], 1e3 * s5p["seconds_setup"]),
-                                                  full_calibration_reference_options=full5,
-                                                  fp64_frac_of_78p6=(6.9e3 * c5_corners + 11.3e3 * c5_accl) / (p5 * 1e-3) / 78.6e12,
-                                                  kernel_ms=dict(view=k5[0], accel=k5[1], gyro=k5[2]),
-                                                  blocks_per_s_jacobian_pass=c5_blocks / (p5 * 1e-3),
-                                                  fp64_TFLOPs=(6.9e3 * c5_corners + 11.3e3 * c5_accl) / (p5 * 1e-3) / 1e12)
-            except Exception as e:  # the extra must never break the bench line
-                out["extra_c5_single_gpu"] = {"error": str(e)[:200]}
         # ---- extra: spline-error-weighting pre-stage, device vs the numpy oracle ----
         if not args.no_extra and world == 1:
             try:
