@@ -418,6 +418,7 @@ def main():
                 for _ in range(3):
                     c5f = E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds5)
                     c5f.trajectory_.UseReferenceSolverOptions()
+                    if os.environ.get("OICC_BENCH_VERBOSE_C5") == "1": c5f.trajectory_.SetOption("verbose", 2)   # (developer: the library's own set-up timers)
                     t1 = time.perf_counter()
                     f1 = c5f.trajectory_.Optimize(50, flags); rp5 = c5f.trajectory_.GetMeanReprojectionError(); f2 = c5f.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
                     runs5.append(dict(seconds=time.perf_counter() - t1, stage1_iterations=f1["num_iterations"], stage2_iterations=f2["num_iterations"], inner_sweeps=f1["inner_sweeps"] + f2["inner_sweeps"],
