@@ -621,17 +621,20 @@ __global__ __launch_bounds__(1024) void bcri_backward2_kernel(BcrArgs A, int npi
   const bool lone = (int)blockIdx.x >= npiv_upper;                  // the orphan: only a "left child", its right neighbour does not exist
   const int j = lone ? orphan + s : 2 * s * (2 * (int)blockIdx.x + 1);
   const int jl = j - 2 * s, jr = j + 2 * s;
-  const bool has_jr = !lone && jr < n;
+  // (distributed reduction: a right neighbour beyond the local blocks is the ghost block, whose solution sits behind them)
+  const bool ghost = A.ghost != 0;
+  const bool has_jr = !lone && (jr < n || ghost);
+  const int jrs = jr < n ? jr : n;
   // lower pivots: half 0 = j - s (neighbours jl, j), half 1 = j + s (neighbours j, jr)
   const int half = wave >> 3, hw = wave & 7;
   const int ci = half == 0 ? j - s : j + s;
   const bool child = half == 0 ? true : (!lone && ci < n);
-  const bool child_hasR = half == 0 ? !lone : jr < n;
+  const bool child_hasR = half == 0 ? (!lone || ghost) : (jr < n || ghost);
   auto xin = [&](int blk, int r) { const int gi = blk * 64 + r; return gi < A.Pb ? A.x[gi] : 0.0; };
   if (tid < 64) xs[0][tid] = xin(jl, tid);
-  else if (tid < 128) xs[2][tid - 64] = has_jr ? xin(jr, tid - 64) : 0.0;
+  else if (tid < 128) xs[2][tid - 64] = has_jr ? xin(jrs, tid - 64) : 0.0;
   else if (tid < 192) xs[3][tid - 128] = tid - 128 < a ? A.x[A.Pb + (tid - 128)] : 0.0;
-  else if (tid < 256 && lone) xs[1][tid - 192] = 0.0;
+  else if (tid < 256 && lone) xs[1][tid - 192] = ghost ? xin(n, tid - 192) : 0.0;   // (the orphan's right neighbour: none, or the ghost block)
   double l1[RW1], l2[RW2], y1 = 0.0, y2 = 0.0;
   {
     const double* T1 = A.Lf + j * ru64 + 4096;
@@ -1059,7 +1062,17 @@ int launch_bcr_dist_middle(const TangentLayout& tl, const SolveBuffers& sb, cons
   BcrArgs A = v.A;
   int strides[40], npivs[40], nlev = 0;
   for (int s = 1; s < A.n; s *= 2) { const int m = (A.n + s - 1) / s; strides[nlev] = s; npivs[nlev] = m / 2; ++nlev; }
-  for (int l = nlev - 1; l >= 0; --l) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); }
+  {   // two levels per launch as on one GPU (an even count of levels below: the uppermost alone, first)
+    int l = nlev - 1;
+    if (l >= 0 && !(l & 1)) { A.s = strides[l]; hipLaunchKernelGGL(bcri_backward_kernel, dim3(npivs[l]), dim3(64 * kBackWaves), 0, st, A); --l; }
+    for (; l >= 1; l -= 2) {
+      const int s = strides[l - 1];
+      int orphan = -1;
+      if (npivs[l - 1] > 2 * npivs[l]) orphan = s * (2 * (npivs[l - 1] - 1) + 1);
+      A.s = s;
+      hipLaunchKernelGGL(bcri_backward2_kernel, dim3(npivs[l] + (orphan >= 0 ? 1 : 0)), dim3(1024), 0, st, A, npivs[l], orphan);
+    }
+  }
   const int64_t nx = (int64_t)A.n * 64 + A.a;
   hipLaunchKernelGGL(bcr_dist_pack_x_kernel, dim3(int((nx + 255) / 256)), dim3(256), 0, st, v.A, d.xg + (int64_t)d.rank * d.x_piece, (int64_t)d.max_loc * 64);
   return 0;
