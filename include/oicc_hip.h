@@ -237,7 +237,7 @@ int oicc_add_gyroscope_measurements(oicc_problem* p, int64_t n,
  * decisions ON THE DEVICE -- per iteration the host enqueues solve, retraction, ONE Jacobian pass at the candidate (cost, gradient
  * and normal equations together) and a one-thread decision kernel (accept / reject, radius, tolerances: LmCtl, csrc/oicc_device.h)
  * and polls a pinned word one iteration behind; 0 = the host-driven loop (a separate cost pass, one read-back per iteration).
- * owner_computes_sweeps 1|0: see oicc_set_shard.
+ * owner_computes_sweeps 1|0, distributed_solve 1|0: see oicc_set_shard.
  * Inner iterations at scale (round 5; both are read when the plan of the sweeps is built): inner_wave_blocks 0|1|2 (0: sets of knot
  * blocks with at least 4 x compute-unit-count blocks run one wave per block, 1: every eligible set, 2: never),
  * inner_shared_launch_slots 65536 (a block every view / sample depends on with at least this many item slots is minimised by a
@@ -311,7 +311,15 @@ int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double*
  * (c) with an inner-iteration source (oicc_set_inner_iteration_source) the SWEEPS are owner-computes too (option
  * owner_computes_sweeps, default 1): a rank minimises only the knot blocks whose band rows it owns (plus the few blocks every view /
  * sample depends on, replicated; rank 0's result counts) and after every independent set the owners broadcast the knot ranges the set
- * changed -- the sweep's work divides by the number of ranks instead of being replicated. */
+ * changed -- the sweep's work divides by the number of ranks instead of being replicated.
+ * Round 6: (d) the LINEAR SOLVE is distributed too (option distributed_solve, default 1; the reference's solve is one
+ * SPARSE_NORMAL_CHOLESKY on one host, impl.h:257-272).  The cuts between the owned ranges lie on multiples of 64 rows, the blocks of the
+ * cyclic reduction: step (2) above shrinks to two doubles per row (diagonal and gradient: what every rank needs of ALL rows), every
+ * rank reduces the blocks of ITS range down to the range's first block, ONE all-gather moves the ranks' separator blocks (0.11 MB each),
+ * every rank solves the N-block top system and back-substitutes its own range, ONE all-gather moves the step.  The band rows never
+ * leave their owner.  The choice is part of what the ranks agree on in (b); where the geometry is not the cyclic reduction's (half
+ * bandwidth > 64, more than 63 arrow columns) or a rank would own no block, all ranks gather the band and solve the whole system as
+ * before.  Both gathers go through the same transport as (a): ncclAllGather, or OICC_XCHG_BROADCAST per owner on the hook. */
 enum { OICC_XCHG_SENDRECV = 0, OICC_XCHG_BROADCAST = 1 };
 typedef int (*oicc_exchange_fn)(void* user, int32_t op, void* send, int64_t send_count, void* recv, int64_t recv_count,
                                 int32_t peer, void* hip_stream);
