@@ -97,6 +97,38 @@ def test_c5_reference_options_one_outer_iteration_matches_the_oracle():
         assert np.abs(gj - gc).max() <= 1e-9 * (np.abs(gj).max() + np.sqrt(2 * jets[k, 3]) * s.max()), (which[k], jets[k, :3])
 
 
+def test_c5_full_calibration_with_the_reference_options_matches_the_oracle():
+    """The WHOLE BASELINE-config-5 calibration as the bench line times it (extra_c5_single_gpu.full_calibration_reference_options):
+    stage 1 to convergence with UseReferenceSolverOptions() -- four outer iterations, three full sweeps over 30 011 parameter blocks
+    at the default thresholds -- then stage 2 (line delay only), against the oracle (closed-form Jacobians in its sweeps and passes:
+    the one-iteration test above holds them to Jets): the same number of outer iterations and sweeps, every outer iterate's cost
+    to 1e-7 and its accept / reject flag, per-block LM iteration total within 0.5 %, final T_i_c / gravity 1e-6, every knot 1e-5
+    relative to 1 + |value| (three sweeps of rounding), line delay 1e-8 s, mean reprojection error 1e-6 px."""
+    ds = synthetic.make_config("C5")
+    gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
+    cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
+    for c in (gpu, cpu):
+        c.trajectory_.UseReferenceSolverOptions()
+    cpu.trajectory_.SetOption("analytic_jacobians", 1)
+    sg = gpu.trajectory_.Optimize(50, FLAGS1); sc = cpu.trajectory_.Optimize(50, FLAGS1)
+    ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
+    assert sg["termination"] == sc["termination"] == 0 and sg["num_iterations"] == sc["num_iterations"] >= 3 and len(ig) == len(ic), (sg, sc)
+    assert sg["inner_sweeps"] == sc["inner_sweeps"] >= 2
+    assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 0.005 * sc["inner_lm_iterations"], (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
+    for a, b in zip(ig, ic):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-6
+    for a, b in zip(gpu.trajectory_.GetKnots(), cpu.trajectory_.GetKnots()):
+        err = np.abs(a - b) / (1 + np.abs(b))
+        assert err.max() < 1e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    s2g = gpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY); s2c = cpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
+    assert s2g["num_iterations"] == s2c["num_iterations"] and s2g["inner_sweeps"] == s2c["inner_sweeps"] == 0
+    assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-7 * s2c["final_cost"]
+    assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-8
+    assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-6
+
+
 def _accepted(t, start, dt, knots):
     """CalcTimes, impl.h:764-788, in integers: refused before the start and when the window [s, s + 6) leaves the knots."""
     st = int(t) - start
