@@ -526,6 +526,20 @@ int oicc_debug_host_inner_plan(oicc_problem* p, int32_t flags, int32_t* out8, in
     }
   return nb;
 }
+// Round 6: the owner plan of a time-sharded problem (oicc_set_shard + oicc_declare_remote_measurements_from) from host data alone:
+// cuts[nranks + 1] = the band rows where the owned ranges begin (the last: the band dimension), rows_to[nranks] = how many partial
+// rows this rank sends to every other rank.  Returns the band dimension, or a negative status.
+int oicc_debug_host_owner_cuts(oicc_problem* p, int32_t flags, int32_t* cuts, int32_t* rows_to, int32_t cap) {
+  sync_groups(p);
+  make_layout_host(p, flags);
+  const oicc_problem::OwnerPlan& op = p->owner;
+  if (!op.valid) return -1;
+  const int n = p->shard_n;
+  if (cap < n + 1) return -2;
+  for (int k = 0; k <= n; ++k) cuts[k] = op.cut[size_t(k)];
+  if (rows_to) for (int k = 0; k < n; ++k) rows_to[k] = int32_t(op.send_rows[size_t(k)].size());
+  return p->L.Pb;
+}
 // What the round-5 kernels get of the plan oicc_debug_host_inner_plan built last: out6 = [sets on the one-wave-per-block kernel, large
 // shared blocks (sequence of launches), their parts in all, the largest part count, control blocks, workgroups of the set kernel];
 // parts_of_block[b] (may be null, `cap` entries) = parts of block b if it is a large shared block, else 0

@@ -166,3 +166,40 @@ def test_plan_at_scale_marks_wave_sets_and_large_shared_blocks():
     b3, _, w3 = small.trajectory_.plan(FLAGS1)
     shape3, parts3 = small.trajectory_.plan_shape(len(b3))
     assert shape3[0] == 0 and shape3[1] == 0 and shape3[4] == 2 and w3 > len(b3)
+
+
+@pytest.mark.parametrize("cfg,world", [("C1", 2), ("C1", 4), ("C2", 2), ("C2", 4), ("C2", 8), ("C3", 8), ("C5", 8)])
+def test_owned_ranges_of_time_shards_are_cut_on_64_row_blocks(cfg, world):
+    """Round 6 (distributed linear solve): every rank of a time-sharded problem derives the owner plan from its own
+    measurements and the DECLARED timestamps of the others (oicc_set_shard, oicc_declare_remote_measurements_from) -- host logic, built
+    here without a device for every rank in turn: all ranks derive the same cuts; every cut but the last lies on a multiple of 64
+    rows (the blocks of the cyclic reduction: a rank eliminates the blocks of its own range), ascending; every rank owns at least one
+    block (BASELINE config 5 on eight ranks: 175-177 of 1407); what rank a sends to rank b is what b expects from a."""
+    ds = synthetic.make_config(cfg)
+    cuts_all, send, pb = [], [], None
+    for r in range(world):
+        host = E.ImuCameraCalibrator(trajectory=_HostOnly()).BatchInitSpline(ds, shard=(r, world), owner_computes=True)
+        raw = host.trajectory_._raw
+        raw.oicc_debug_host_owner_cuts.restype = C.c_int
+        raw.oicc_debug_host_owner_cuts.argtypes = [_abi.H, C.c_int32, _abi.c_i32p, _abi.c_i32p, C.c_int32]
+        cuts = np.zeros(world + 1, dtype=np.int32); rows = np.zeros(world, dtype=np.int32)
+        n = raw.oicc_debug_host_owner_cuts(host.trajectory_._h, FLAGS1, cuts.ctypes.data_as(_abi.c_i32p), rows.ctypes.data_as(_abi.c_i32p), world + 1)
+        assert n > 0, n
+        pb = n if pb is None else pb
+        assert n == pb
+        cuts_all.append(cuts.copy()); send.append(rows.copy())
+    for c in cuts_all[1:]:
+        assert np.array_equal(c, cuts_all[0])
+    c = cuts_all[0]
+    assert c[0] == 0 and c[-1] == pb and (np.diff(c) > 0).all() and (c[:-1] % 64 == 0).all()
+    blocks = np.diff(np.concatenate([c[:-1] // 64, [(pb + 63) // 64]]))
+    assert (blocks >= 1).all() and blocks.sum() == (pb + 63) // 64
+    if cfg == "C5":
+        assert blocks.min() >= 170 and blocks.max() <= 182
+    # halo rows: only neighbours exchange rows, at most a few hundred each way
+    for a in range(world):
+        for b in range(world):
+            if abs(a - b) > 1:
+                assert send[a][b] == 0
+            elif a < b:   # (a cut rounded to a block boundary may leave all shared rows on one side of it: then only one of the two sends)
+                assert 0 < send[a][b] + send[b][a] and max(send[a][b], send[b][a]) <= 250, (a, b, send[a][b], send[b][a])
