@@ -1,9 +1,10 @@
 """GPU parity, round 6: BASELINE config 5 with the REFERENCE's solver options, CalcTimes edges through the HIP library, and the
 device build of fast_sincos against libm.  Run on an MI355X with `-m gpu`.
 
-Tolerances used here against what SURVEY.md 8(c) proposed: candidate cost before / behind every independent set 1e-7 relative
-(8c: cost 1e-8 for plain LM; a sweep is 30 011 small Levenberg-Marquardt loops whose accept / reject decisions see the summation
-order), per-block LM iteration totals 0.2 %, T_i_c / gravity 1e-6 (8c: 1e-7), sampled knots 1e-6.
+Tolerances used here against what SURVEY.md 8(c) proposed (cost 1e-8, parameters 1e-7): the candidate's cost before / behind every
+independent set 1e-9 relative, per-block LM iteration totals 0.01 %, outer iterates' costs 1e-10, T_i_c / gravity 1e-9, every knot
+1e-7 -- each two to three orders above what scripts/dbg_c5_margins.py measures on the whole C5 calibration (per-set costs 2e-12, IDENTICAL
+iteration totals 144 176 = 144 176, iterates 5e-14, T_i_c 5e-13, gravity 2e-12, knots 1e-10), so the tests fail on a defect, not on noise.
 """
 import ctypes
 
@@ -39,9 +40,9 @@ def test_c5_reference_options_one_outer_iteration_matches_the_oracle():
     the C5 numbers in the bench line, which until round 6 was only compared with other HIP kernels.  One outer iteration = one
     trust-region candidate + its full sweep, against the oracle:
       * the candidate's cost before the sweep and behind EVERY independent set (option debug_inner_set_costs: a mismatch names the
-        set), 1e-7 relative; the same number of sets with the same block counts;
-      * the sweep count, the total of per-block LM iterations (<= 0.2 %), the accepted iterate's cost, step norm, rho;
-      * T_i_c, gravity (1e-6), and EVERY SO(3) / R^3 knot (30 012 knots; 1e-6 relative to 1 + |value|).
+        set), 1e-9 relative; the same number of sets with the same block counts;
+      * the sweep count, the total of per-block LM iterations (<= 0.01 %), the accepted iterate's cost (1e-10), step norm, rho;
+      * T_i_c, gravity (1e-9), and EVERY SO(3) / R^3 knot (30 012 knots; 1e-7 relative to 1 + |value|).
     The oracle sweeps with its closed-form Jacobians (analytic_jacobians = 1: with Jets T_i_c's block alone -- 500 000 corners per
     evaluation, ~6 evaluations, one thread -- takes minutes); that choice is itself checked here: for a sample of 400 knot blocks
     + gravity the block's cost / gradient / Gauss-Newton matrix with forward-mode Jets equal the closed forms' to 1e-9, at the
@@ -59,22 +60,22 @@ def test_c5_reference_options_one_outer_iteration_matches_the_oracle():
     assert [n for n, _ in tg[0]] == [n for n, _ in tc[0]], ([n for n, _ in tg[0]], [n for n, _ in tc[0]])
     assert sum(n for n, _ in tg[0][1:]) > 30000 and max(n for n, _ in tg[0]) >= 1024      # sets that fill the device: the wave-per-block kernel's
     for k, ((n, a), (_, b)) in enumerate(zip(tg[0], tc[0])):
-        assert abs(a - b) <= 1e-7 * b, ("independent set %d (%d blocks; -1 = before the sweep)" % (k - 1, n), a, b)
+        assert abs(a - b) <= 1e-9 * b, ("independent set %d (%d blocks; -1 = before the sweep)" % (k - 1, n), a, b)
     assert tg[0][-1][1] < 0.5 * tg[0][0][1]                                                # the sweep is not a no-op at this point
-    assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 0.002 * sc["inner_lm_iterations"], (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
+    assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 1e-4 * sc["inner_lm_iterations"] + 2, (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
     ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     assert len(ig) == len(ic) == 2 and ig[1]["step_is_successful"] == ic[1]["step_is_successful"] == 1
-    assert abs(ig[1]["cost"] - ic[1]["cost"]) <= 1e-7 * ic[1]["cost"], (ig[1], ic[1])
+    assert abs(ig[1]["cost"] - ic[1]["cost"]) <= 1e-10 * ic[1]["cost"], (ig[1], ic[1])
     assert abs(ig[1]["cost"] - tg[0][-1][1]) <= 1e-12 * ig[1]["cost"]
     assert abs(ig[1]["step_norm"] - ic[1]["step_norm"]) <= 1e-6 * ic[1]["step_norm"], (ig[1], ic[1])
     assert abs(ig[1]["relative_decrease"] - ic[1]["relative_decrease"]) <= 1e-6, (ig[1], ic[1])
-    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
-    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-6
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-9
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-9
     kg, kc = gpu.trajectory_.GetKnots(), cpu.trajectory_.GetKnots()
     assert len(kg[0]) + len(kg[1]) > 30000
     for a, b in zip(kg, kc):
         err = np.abs(a - b) / (1 + np.abs(b))
-        assert err.max() < 1e-6, (err.max(), np.unravel_index(err.argmax(), err.shape))
+        assert err.max() < 1e-7, (err.max(), np.unravel_index(err.argmax(), err.shape))
     # the checker's closed forms against its Jets, at the swept point, on a sample of blocks
     raw = oracle_backend.load().raw
     raw.oicc_oracle_debug_num_inner_blocks.restype = ctypes.c_int
@@ -102,8 +103,8 @@ def test_c5_full_calibration_with_the_reference_options_matches_the_oracle():
     stage 1 to convergence with UseReferenceSolverOptions() -- four outer iterations, three full sweeps over 30 011 parameter blocks
     at the default thresholds -- then stage 2 (line delay only), against the oracle (closed-form Jacobians in its sweeps and passes:
     the one-iteration test above holds them to Jets): the same number of outer iterations and sweeps, every outer iterate's cost
-    to 1e-7 and its accept / reject flag, per-block LM iteration total within 0.5 %, final T_i_c / gravity 1e-6, every knot 1e-5
-    relative to 1 + |value| (three sweeps of rounding), line delay 1e-8 s, mean reprojection error 1e-6 px."""
+    to 1e-10 and its accept / reject flag, per-block LM iteration total within 0.01 % (measured: identical, 144 176), final T_i_c /
+    gravity 1e-9, every knot 1e-7 relative to 1 + |value|, line delay 1e-10 s, mean reprojection error 1e-8 px."""
     ds = synthetic.make_config("C5")
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
@@ -114,19 +115,19 @@ def test_c5_full_calibration_with_the_reference_options_matches_the_oracle():
     ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     assert sg["termination"] == sc["termination"] == 0 and sg["num_iterations"] == sc["num_iterations"] >= 3 and len(ig) == len(ic), (sg, sc)
     assert sg["inner_sweeps"] == sc["inner_sweeps"] >= 2
-    assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 0.005 * sc["inner_lm_iterations"], (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
+    assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 1e-4 * sc["inner_lm_iterations"] + 2, (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
     for a, b in zip(ig, ic):
-        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
-    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
-    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-6
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-10 * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-9
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-9
     for a, b in zip(gpu.trajectory_.GetKnots(), cpu.trajectory_.GetKnots()):
         err = np.abs(a - b) / (1 + np.abs(b))
-        assert err.max() < 1e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
+        assert err.max() < 1e-7, (err.max(), np.unravel_index(err.argmax(), err.shape))
     s2g = gpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY); s2c = cpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
     assert s2g["num_iterations"] == s2c["num_iterations"] and s2g["inner_sweeps"] == s2c["inner_sweeps"] == 0
-    assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-7 * s2c["final_cost"]
-    assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-8
-    assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-6
+    assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-10 * s2c["final_cost"]
+    assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-10
+    assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-8
 
 
 def _accepted(t, start, dt, knots):

@@ -709,16 +709,25 @@ def test_inner_iterations_match_the_oracle(cfg, flags):
     ig, ic = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     assert sg["num_iterations"] == sc["num_iterations"], ([i["cost"] for i in ig], [i["cost"] for i in ic])
     assert sg["inner_sweeps"] == sc["inner_sweeps"] >= 1
+    # Round 6: with the application's flag set the tolerances are SURVEY 8(c)'s or tighter -- cost 1e-9 (8c: 1e-8), T_i_c / gravity 1e-9
+    # (8c: 1e-7), identical totals of per-block LM iterations -- two orders above what scripts/dbg_c5_margins.py measures
+    # (profiles/r06l_parity_margins.log: costs <= 2e-12, T_i_c <= 5e-13, gravity <= 2e-12, the totals identical at every configuration);
+    # the other flag sets of the tiny problem keep the round-3 tolerances (bias knots at their bounds: not measured)
+    tight = flags == FLAGS1
     for a, b in zip(ig, ic):
-        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-7 * b["cost"], (a, b)
-    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < 1e-6
-    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < 1e-5
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= (1e-9 if tight else 1e-7) * b["cost"], (a, b)
+    assert np.abs(gpu.trajectory_.GetT_i_c() - cpu.trajectory_.GetT_i_c()).max() < (1e-9 if tight else 1e-6)
+    assert np.abs(gpu.trajectory_.GetGravity() - cpu.trajectory_.GetGravity()).max() < (1e-9 if tight else 1e-5)
+    if tight:
+        assert abs(sg["inner_lm_iterations"] - sc["inner_lm_iterations"]) <= 1e-3 * sc["inner_lm_iterations"] + 1, (sg["inner_lm_iterations"], sc["inner_lm_iterations"])
+        for a, b in zip(gpu.trajectory_.GetKnots(), cpu.trajectory_.GetKnots()):
+            assert (np.abs(a - b) / (1 + np.abs(b))).max() < 1e-8
     if cfg != "tiny":   # stage 2 of the application (continuous_time_imu_to_camera_calibration.cc:217-221): one parameter block -> Ceres disables the sweep
         s2g = gpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY); s2c = cpu.trajectory_.Optimize(10, E.CAM_LINE_DELAY)
         assert s2g["num_iterations"] == s2c["num_iterations"] and s2g["inner_sweeps"] == s2c["inner_sweeps"] == 0
-        assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-7 * s2c["final_cost"]
-        assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-8
-        assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-6
+        assert abs(s2g["final_cost"] - s2c["final_cost"]) <= 1e-10 * s2c["final_cost"]
+        assert abs(gpu.trajectory_.GetRSLineDelay() - cpu.trajectory_.GetRSLineDelay()) < 1e-12
+        assert abs(gpu.trajectory_.GetMeanReprojectionError() - cpu.trajectory_.GetMeanReprojectionError()) < 1e-10
     # and the sweep changes the trajectory of the solve (it is not a no-op)
     plain = E.ImuCameraCalibrator().BatchInitSpline(ds)
     sp = plain.trajectory_.Optimize(50, flags)
