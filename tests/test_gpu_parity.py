@@ -2,9 +2,10 @@
 oracle on the same seeded inputs.  Run on an MI355X with `-m gpu`.
 
 Tolerances (fp64): residuals 1e-12 abs+rel, tangent Jacobians
-1e-8 rel-to-row-scale (analytic vs forward-mode autodiff), J^T J / J^T r 1e-9
-rel-to-scale (summation order differs: fp64 atomics), LM iterates: cost 1e-8 rel,
-final parameters 1e-7.
+1e-8 rel-to-row-scale (analytic vs forward-mode autodiff), J^T J / J^T r 1e-10
+rel-to-scale as SURVEY proposes (round 6: tightened from 1e-9; measured <= 4e-14, scripts/dbg_ne_margins.py),
+LM iterates: cost 1e-8 rel, final parameters 1e-7 (the reference-option solves of the application's
+flag set: 1e-9 / 1e-9, profiles/r06l_parity_margins.log).
 """
 import numpy as np
 import pytest
@@ -63,8 +64,8 @@ def test_normal_equations(tiny, flags):
     cg, Hg, gg = gpu.trajectory_.Evaluate(flags)
     cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
     assert abs(cg - cc) <= 1e-11 * cc
-    assert rel_err(gg, gc) < 1e-9
-    assert rel_err(Hg, Hc) < 1e-9
+    assert rel_err(gg, gc) < 1e-10
+    assert rel_err(Hg, Hc) < 1e-10
     assert np.abs(Hg - Hg.T).max() <= 1e-13 * np.abs(Hg).max()   # arrow corner: two atomics per off-diagonal pair
     assert abs(gpu.trajectory_.EvaluateCost(flags) - cc) <= 1e-11 * cc
 
@@ -119,7 +120,7 @@ def test_c2_full_size_properties():
     ds, gpu, cpu = build_pair("C2")
     cg, _, gg = gpu.trajectory_.Evaluate(FLAGS1, want_H=False)
     cc, _, gc = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)
-    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-9
+    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-10
     s = gpu.trajectory_.Optimize(50, FLAGS1)
     assert s["termination"] == 0 and s["final_cost"] < 0.05 * s["initial_cost"]
     assert gpu.trajectory_.GetMeanReprojectionError() < 1.0
@@ -219,7 +220,7 @@ def test_bias_and_intrinsics_active_lm_matches_oracle(algo, intrinsics):
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     cg, Hg, gg = gpu.trajectory_.Evaluate(flags)
     cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
-    assert rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    assert rel_err(Hg, Hc) < 1e-10 and rel_err(gg, gc) < 1e-10
     sg = gpu.trajectory_.Optimize(15, flags); sc = cpu.trajectory_.Optimize(15, flags)
     assert sg["num_iterations"] == sc["num_iterations"] and sg["arrow_dim"] == sc["arrow_dim"] > 16
     assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-7 * sc["final_cost"]
@@ -270,7 +271,7 @@ def test_global_shutter_views_quirk_q2(unit_loss):
         c.trajectory_.SetOption("gs_unit_loss", unit_loss)
     cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1)
     cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
-    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-10 and rel_err(gg, gc) < 1e-10
     if unit_loss == 0:   # only IMU blocks carry cost
         ca = gpu.trajectory_.EvaluateBlocks(FLAGS1, 1, 3 * int(gpu.accl_accepted.sum()), False)[0]
         cy = gpu.trajectory_.EvaluateBlocks(FLAGS1, 2, 3 * int(gpu.gyro_accepted.sum()), False)[0]
@@ -428,7 +429,7 @@ def test_c3_fisheye_full_calibration():
     ds, gpu, cpu = build_pair("C3")
     cg, _, gg = gpu.trajectory_.Evaluate(FLAGS1, want_H=False)
     cc, _, gc = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)
-    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-9
+    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-10
     cpu.trajectory_.SetOption("analytic_jacobians", 0)   # Jets on the checker's side, every iterate up to convergence
     sc = cpu.trajectory_.Optimize(50, FLAGS1)
     sg = gpu.trajectory_.Optimize(50, FLAGS1)
@@ -455,7 +456,7 @@ def test_c4_double_sphere_line_delay_calibration():
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     cc, _, gc = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)                  # forward-mode Jets over 80 000 corners + 16 000 IMU blocks
     cg, _, gg = gpu.trajectory_.Evaluate(FLAGS1, want_H=False)
-    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-9
+    assert abs(cg - cc) <= 1e-10 * cc and rel_err(gg, gc) < 1e-10
     assert abs(gpu.trajectory_.EvaluateCost(FLAGS1) - cc) <= 1e-10 * cc
     s1 = gpu.trajectory_.Optimize(50, FLAGS1)
     assert s1["termination"] == 0 and s1["final_cost"] < 0.05 * s1["initial_cost"]
@@ -493,7 +494,7 @@ def test_c5_time_shards_sum_to_the_whole():
     # ... and the whole against the CPU oracle (forward-mode Jets, 410 000 residual blocks, P ~ 90 k): cost and gradient
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     c_cpu, _, g_cpu = cpu.trajectory_.Evaluate(FLAGS1, want_H=False)
-    assert g_cpu.shape == g_all.shape and abs(c_all - c_cpu) <= 1e-10 * c_cpu and rel_err(g_all, g_cpu) < 1e-9
+    assert g_cpu.shape == g_all.shape and abs(c_all - c_cpu) <= 1e-10 * c_cpu and rel_err(g_all, g_cpu) < 1e-10
     s = whole.trajectory_.Optimize(1, FLAGS1)
     assert s["num_successful_steps"] == 1 and s["final_cost"] < 0.5 * s["initial_cost"] and s["band_dim"] > 85000
     # at this size the segment tables come once per parameter vector (written by the retraction kernel for the candidate);
@@ -557,7 +558,7 @@ def test_ragged_views_empty_view_and_views_above_64_corners():
     gpu = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1); cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
-    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(Hg, Hc) < 1e-10 and rel_err(gg, gc) < 1e-10
     sg = gpu.trajectory_.Optimize(10, FLAGS1); sc = cpu.trajectory_.Optimize(10, FLAGS1)
     assert sg["num_iterations"] == sc["num_iterations"] and abs(sg["final_cost"] - sc["final_cost"]) <= 1e-8 * sc["final_cost"]
     assert gpu.trajectory_.GetMeanReprojectionError() == 0.0 == cpu.trajectory_.GetMeanReprojectionError()
@@ -575,7 +576,7 @@ def test_assembly_modes_match_the_oracle(tiny, mode, tile_windows, wide):
     for flags in (FLAGS1, FLAGS1 | E.IMU_BIASES, FLAGS1 | E.CAM_LINE_DELAY | E.IMU_BIASES | E.IMU_INTRINSICS, E.CAM_LINE_DELAY):
         cg, Hg, gg = gpu.trajectory_.Evaluate(flags); cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
         assert abs(cg - cc) <= 1e-11 * cc, (flags, cg, cc)
-        assert rel_err(Hg, Hc) < 1e-9 and rel_err(gg, gc) < 1e-9, (flags, rel_err(Hg, Hc), rel_err(gg, gc))
+        assert rel_err(Hg, Hc) < 1e-10 and rel_err(gg, gc) < 1e-10, (flags, rel_err(Hg, Hc), rel_err(gg, gc))
         assert np.abs(Hg - Hg.T).max() <= 1e-13 * np.abs(Hg).max()
         assert abs(gpu.trajectory_.EvaluateCost(flags) - cc) <= 1e-11 * cc
 
@@ -660,7 +661,7 @@ def test_interior_rows_stored_by_the_tile_equal_the_slab_route(cfg, tile_windows
     cpu = E.ImuCameraCalibrator(backend=oracle_backend.load()).BatchInitSpline(ds)
     cpu.trajectory_.SetOption("analytic_jacobians", 0)   # forward-mode Jets: none of the product's closed forms on the checker's side
     cc, Hc, gc = cpu.trajectory_.Evaluate(flags)
-    assert abs(ca - cc) <= 1e-11 * cc and rel_err(Ha, Hc) < 1e-10 and rel_err(ga, gc) < 1e-9
+    assert abs(ca - cc) <= 1e-11 * cc and rel_err(Ha, Hc) < 1e-10 and rel_err(ga, gc) < 1e-10
     sa = a.trajectory_.Optimize(6, flags); sb = b.trajectory_.Optimize(6, flags)
     assert sa["num_iterations"] == sb["num_iterations"] and abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * sb["final_cost"]
 
@@ -1023,16 +1024,16 @@ def test_points_flag_layout_and_normal_equations(cfg, flags):
         tg.SetOption("assembly", assembly)
         cg, Hg, gg = tg.Evaluate(flags)
         assert abs(cg - cc) <= 1e-11 * cc
-        assert rel_err(gg, gc) < 1e-9, (assembly, rel_err(gg, gc))
-        assert rel_err(Hg, Hc) < 1e-9, (assembly, rel_err(Hg, Hc))
+        assert rel_err(gg, gc) < 1e-10, (assembly, rel_err(gg, gc))
+        assert rel_err(Hg, Hc) < 1e-10, (assembly, rel_err(Hg, Hc))
         p0 = og[og >= 0].min()
-        assert rel_err(Hg[p0:, :], Hc[p0:, :]) < 1e-9 and rel_err(gg[p0:], gc[p0:]) < 1e-9      # the point rows on their own scale
+        assert rel_err(Hg[p0:, :], Hc[p0:, :]) < 1e-10 and rel_err(gg[p0:], gc[p0:]) < 1e-10      # the point rows on their own scale
         assert np.abs(Hg - Hg.T).max() <= 1e-13 * np.abs(Hg).max()
     tg.SetOption("assembly", 0)
     # the flag off again: the system of the other blocks is what it was (the layout cache keys on the flags)
     c0, H0, g0 = tg.Evaluate(flags & ~E.POINTS)
     c1, H1, g1 = tc.Evaluate(flags & ~E.POINTS)
-    assert H0.shape == H1.shape and rel_err(H0, H1) < 1e-9 and rel_err(g0, g1) < 1e-9
+    assert H0.shape == H1.shape and rel_err(H0, H1) < 1e-10 and rel_err(g0, g1) < 1e-10
 
 
 def test_points_flag_with_the_bounds_line_search_and_the_projected_gradient_norm():
@@ -1141,7 +1142,7 @@ def test_small_problems_of_varied_geometry_match_the_oracle(case):
         tg.SetOption("assembly", assembly)
         cg, Hg, gg = tg.Evaluate(flags)
         assert abs(cg - cc) <= 1e-11 * max(cc, 1e-300), (assembly, cg, cc)
-        assert rel_err(gg, gc) < 1e-9 and rel_err(Hg, Hc) < 1e-9, (assembly, rel_err(gg, gc), rel_err(Hg, Hc))
+        assert rel_err(gg, gc) < 1e-10 and rel_err(Hg, Hc) < 1e-10, (assembly, rel_err(gg, gc), rel_err(Hg, Hc))
     tg.SetOption("assembly", 0)
     sg, sc = tg.Optimize(4, flags), tc.Optimize(4, flags)
     ig, ic = tg.GetIterations(), tc.GetIterations()
@@ -1232,7 +1233,7 @@ def test_c5_sampled_normal_equations_and_first_lm_iterate_match_the_jet_oracle()
     scale = np.sqrt(np.abs(dg[:len(rows)] * dg[len(rows):])) + 1e-30
     assert np.count_nonzero(vc) > 0.6 * len(vc)          # (inside the band a third of the offsets couple SO(3) / R^3 knots that share no window)
     err = np.abs(vg - vc) / scale
-    assert err.max() < 1e-9, (err.max(), rows[err.argmax()], cols[err.argmax()])
+    assert err.max() < 1e-10, (err.max(), rows[err.argmax()], cols[err.argmax()])
     sg = gpu.trajectory_.Optimize(1, FLAGS1); sc = cpu.trajectory_.Optimize(1, FLAGS1)
     ig, ic_ = gpu.trajectory_.GetIterations(), cpu.trajectory_.GetIterations()
     assert len(ig) == len(ic_) == 2 and ig[1]["step_is_successful"] == ic_[1]["step_is_successful"] == 1
@@ -1262,7 +1263,7 @@ def test_measurements_added_out_of_time_order():
         scale = np.abs(Jc).max(axis=1, keepdims=True) + 1e-6 * np.abs(Jc).max() + 1e-30
         assert (np.abs(Jg - Jc) / scale).max() < 1e-8, kind
     cg, Hg, gg = gpu.trajectory_.Evaluate(FLAGS1); cc, Hc, gc = cpu.trajectory_.Evaluate(FLAGS1)
-    assert abs(cg - cc) <= 1e-11 * cc and rel_err(gg, gc) < 1e-9 and rel_err(Hg, Hc) < 1e-9
+    assert abs(cg - cc) <= 1e-11 * cc and rel_err(gg, gc) < 1e-10 and rel_err(Hg, Hc) < 1e-10
     # ... and equal to the time-ordered problem's
     ref = E.ImuCameraCalibrator().BatchInitSpline(ds)
     cr, Hr, gr = ref.trajectory_.Evaluate(FLAGS1)
