@@ -439,15 +439,25 @@ int inner_sweep(oicc_problem* p, double* xv, hipStream_t st, oicc_problem* shard
     if (ip.group_bigb0[g + 1] > ip.group_bigb0[g]) {   // the set's LARGE shared blocks: (evaluation, advance) launches until every loop says done
       const int nbb = ip.group_bigb0[g + 1] - ip.group_bigb0[g], nbw = ip.group_bigwg0[g + 1] - ip.group_bigwg0[g];
       const bool count = !owned || shard->shard_rank == 0;
-      std::vector<unsigned char> hc(size_t(ip.n_ctls) * sizeof(InnerCtl));
+      // the blocks' command words come back into pinned memory, one 4-byte copy per block (the advisor, round 5: a pageable copy of
+      // every control block per look); more than 32 large shared blocks in one set: the pageable route
+      oicc_problem* const ph = (shard != nullptr ? shard : p);
+      const bool pinned_words = ph->pin != nullptr && nbb <= 32;
+      std::vector<unsigned char> hc(pinned_words ? 0 : size_t(ip.n_ctls) * sizeof(InnerCtl));
       for (int pairs = 0, batch = 6; pairs < 256; pairs += batch, batch = 2) {   // two or three LM iterations = four or six pairs are the rule; pairs behind the end return at once (~3 us each, against ~30 us for another look at the command words)
         for (int k = 0; k < batch; ++k) {
           launch_inner_shared_eval(ip.d_args.p, xv, ip.d_big_wgs.p + ip.group_bigwg0[g], nbw, ip.d_partials.p, ip.big_max_parts, st);
           launch_inner_shared_advance(ip.d_args.p, xv, ip.d_big_blocks.p + ip.group_bigb0[g], ip.d_big_parts.p + ip.group_bigb0[g], nbb, ip.d_partials.p, ip.big_max_parts, ip.d_lm_states.p, count, st);
         }
-        HIPCK(p, hipMemcpyAsync(hc.data(), ip.d_ctls.p, hc.size(), hipMemcpyDeviceToHost, st)); HIPCK(p, hipStreamSynchronize(st));
+        if (pinned_words) {
+          for (int k = 0; k < nbb; ++k) { const InnerBlock& bb = ip.blocks[size_t(ip.big_blocks[size_t(ip.group_bigb0[g] + k)])];
+            HIPCK(p, hipMemcpyAsync(&ph->pin->inner_words[k], &ip.d_ctls.p[bb.ctl].word, sizeof(unsigned int), hipMemcpyDeviceToHost, st)); }
+        } else HIPCK(p, hipMemcpyAsync(hc.data(), ip.d_ctls.p, hc.size(), hipMemcpyDeviceToHost, st));
+        HIPCK(p, hipStreamSynchronize(st));
         bool all_done = true;
-        for (int k = 0; k < nbb; ++k) { const InnerBlock& bb = ip.blocks[size_t(ip.big_blocks[size_t(ip.group_bigb0[g] + k)])]; all_done = all_done && (reinterpret_cast<const InnerCtl*>(hc.data())[bb.ctl].word & 3u) == 2u; }
+        for (int k = 0; k < nbb; ++k) { const InnerBlock& bb = ip.blocks[size_t(ip.big_blocks[size_t(ip.group_bigb0[g] + k)])];
+          const unsigned int w = pinned_words ? ph->pin->inner_words[k] : reinterpret_cast<const InnerCtl*>(hc.data())[bb.ctl].word;
+          all_done = all_done && (w & 3u) == 2u; }
         if (all_done) break;
         if (pairs + batch >= 256) { p->err = "inner iterations: a shared block's Levenberg-Marquardt loop did not end within 256 (evaluation, advance) launches"; return OICC_ERR_STATE; }
       }

@@ -180,7 +180,7 @@ struct oicc_problem {
   // pinned word the decision kernel writes for the host (polled one iteration behind; no copy, no event in the loop)
   LmState* lm_state_cur = nullptr;   // device-side control: the LmState slot of the iteration being enqueued (the control block and LmState alternate between two slots)
   DevBuf<LmCtl> d_ctl; DevBuf<LmIterRec> d_trace; DevBuf<long long> d_stamps; LmHostMsg* hmsg = nullptr; LmHostMsg* hmsg_dev = nullptr; double wall_clock_hz = 1e8;
-  struct HostPin { LmState st; double cost; double radius; double ls[2]; };
+  struct HostPin { LmState st; double cost; double radius; double ls[2]; unsigned int inner_words[32]; };   // inner_words: command words of a set's large shared blocks (inner_sweep)
   HostPin* pin = nullptr;   // pinned: one read-back (state + candidate cost) and one 8-byte write per LM iteration
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // time tiles of the Jacobian pass (tiles.h): work lists, row formats, slabs
