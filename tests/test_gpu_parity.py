@@ -949,6 +949,14 @@ def test_distributed_cyclic_reduction_takes_the_steps_of_one_process(cfg, nproc,
         assert all(p_["dist_solves"] == 0 and p_["exchange"]["max_broadcast"] > 0.5 * rows * p_["band_row_doubles"] > limit for p_ in parts0)
 
 
+def test_more_ranks_than_blocks_fall_back_to_the_gathered_band(tmp_path):
+    """Degenerate sharding: C1 (five 64-column blocks) on EIGHT time shards -- the cuts, rounded to block boundaries, leave ranks that
+    own no block, so the distributed solve does not apply: every rank gathers the band (owned ranges of zero rows included) and solves
+    the whole system, and the eight processes still take the steps of one."""
+    parts, whole = _sharded_processes_take_the_steps_of_one("C1", FLAGS1, 0, 0, 1, tmp_path, 8)
+    assert all(p_["dist_ranks"] == 0 and p_["dist_solves"] == 0 for p_ in parts)
+
+
 def _sharded_processes_take_the_steps_of_one(cfg, flags, ls, inner, owner, tmp_path, nproc, iters=6):
     """Rank r of `nproc` PROCESSES holds the r-th time shard (remote measurements declared) and runs `oicc_optimize` with the
     all-reduce hook (`oicc_set_allreduce`): packed normal equations after every Jacobian pass, the candidate cost (accumulated in
