@@ -57,6 +57,7 @@ def main():
     cal = E.ImuCameraCalibrator().BatchInitSpline(ds, shard=(rank, world) if world > 1 else None, owner_computes=bool(owner))
     tr = cal.trajectory_
     tr.SetOption("bounds_line_search", ls); tr.SetOption("inner_iterations", inner)
+    if os.environ.get("OICC_TEST_RADIUS") is not None: tr.SetOption("initial_trust_region_radius", float(os.environ["OICC_TEST_RADIUS"]))
     if os.environ.get("OICC_TEST_DISTRIBUTED_SOLVE") is not None: tr.SetOption("distributed_solve", int(os.environ["OICC_TEST_DISTRIBUTED_SOLVE"]))
     shared_launch = os.environ.get("OICC_TEST_SHARED_LAUNCH_SLOTS")     # (tests: the shared blocks of the sweeps as a sequence of launches at any size)
     if shared_launch is not None: tr.SetOption("inner_shared_launch_slots", int(shared_launch))
@@ -72,7 +73,7 @@ def main():
     info = (ctypes.c_int64 * 4)()
     tr._b.lib.oicc_debug_dist_solve_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
     assert tr._b.lib.oicc_debug_dist_solve_info(tr._h, info) == 0
-    res = dict(dist_solves=int(info[0]), dist_first_block=int(info[1]), dist_blocks=int(info[2]), dist_ranks=int(info[3]), band_row_doubles=int(s["half_bandwidth"]) + 1 + int(s["arrow_dim"]) + 1, band_dim=int(s["band_dim"]), rank=rank, blocks=cal.num_blocks, iterations=[dict(cost=i["cost"], ok=i["step_is_successful"], gmax=i["gradient_max_norm"]) for i in it],
+    res = dict(rejected=int(s["num_unsuccessful_steps"]), dist_solves=int(info[0]), dist_first_block=int(info[1]), dist_blocks=int(info[2]), dist_ranks=int(info[3]), band_row_doubles=int(s["half_bandwidth"]) + 1 + int(s["arrow_dim"]) + 1, band_dim=int(s["band_dim"]), rank=rank, blocks=cal.num_blocks, iterations=[dict(cost=i["cost"], ok=i["step_is_successful"], gmax=i["gradient_max_norm"]) for i in it],
                final_cost=s["final_cost"], inner_sweeps=s["inner_sweeps"], inner_lm_iterations=s["inner_lm_iterations"], T_i_c=[float(v) for v in tr.GetT_i_c()], hook_calls=calls["n"], hook_doubles=calls["doubles"], hook_max_doubles=calls["max"], P=int(s["num_parameters_tangent"]), exchange=xch)
     json.dump(res, open(out, "w"))
     dist.barrier()

@@ -949,6 +949,16 @@ def test_distributed_cyclic_reduction_takes_the_steps_of_one_process(cfg, nproc,
         assert all(p_["dist_solves"] == 0 and p_["exchange"]["max_broadcast"] > 0.5 * rows * p_["band_row_doubles"] > limit for p_ in parts0)
 
 
+def test_distributed_cyclic_reduction_through_rejected_steps(tmp_path, monkeypatch):
+    """The tiny problem with the bias knots free, on two ranks, from a trust-region radius of 1e9 (the case of
+    test_device_side_lm_control_takes_the_steps_of_the_host_loop: iterations 2-5 and 11 are REJECTED): the distributed solve runs with
+    reused diagonals and shrinking radii (every rank rebuilds its blocks from the kept diagonal) and a wider arrow (bias knots) --
+    the same accept / reject sequence and costs as one process."""
+    monkeypatch.setenv("OICC_TEST_RADIUS", "1e9")
+    parts, whole = _sharded_processes_take_the_steps_of_one("tiny", FLAGS1 | E.IMU_BIASES, 0, 0, 1, tmp_path, 2, iters=12)
+    assert whole["rejected"] >= 3 and all(p_["rejected"] == whole["rejected"] and p_["dist_ranks"] == 2 and p_["dist_solves"] >= 12 for p_ in parts), (whole["rejected"], [(p_["rejected"], p_["dist_ranks"], p_["dist_solves"]) for p_ in parts])
+
+
 def test_more_ranks_than_blocks_fall_back_to_the_gathered_band(tmp_path):
     """Degenerate sharding: C1 (five 64-column blocks) on EIGHT time shards -- the cuts, rounded to block boundaries, leave ranks that
     own no block, so the distributed solve does not apply: every rank gathers the band (owned ranges of zero rows included) and solves
