@@ -54,15 +54,18 @@ int rccl_broadcast_from_root(oicc_problem* p, void* device_ptr, int64_t count_do
 // All ranks continue from identical bits: `xv` (a parameter vector) and, with `with_state`, the step scalars of LmState.
 // Native RCCL: rank 0's copy is broadcast.  All-reduce hook (no broadcast there): the mean over the ranks of a pack that the hook
 // sums (kernels_solve.hip) -- the ranks' values differ in the last bits only (fp64 atomics of their own solves / sweeps).
-int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st) {
+// x_identical (round 6): the candidate was retracted from a step every rank holds bit for bit (the gathered step of the distributed
+// solve: elementwise retraction of identical inputs) -- only the step's scalars, summed with atomics on every rank, still travel.
+int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st, bool x_identical) {
+  if (x_identical && !with_state) return OICC_OK;
   if (p->rccl_comm != nullptr) {
     if (p->rccl_nranks <= 1) return OICC_OK;
-    if (rccl_broadcast_from_root(p, xv, p->pl.total, st) != 0 || (with_state && rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) {
+    if ((!x_identical && rccl_broadcast_from_root(p, xv, p->pl.total, st) != 0) || (with_state && rccl_broadcast_from_root(p, p->d_state.p, int64_t(sizeof(LmState) / sizeof(double)), st) != 0)) {
       p->err = "broadcast of the candidate failed"; return OICC_ERR_STATE; }
     return OICC_OK;
   }
   if (p->reduce == nullptr) return OICC_OK;
-  const int64_t n = p->pl.total;
+  const int64_t n = x_identical ? 0 : p->pl.total;
   if (!p->d_rank_pack.resize(size_t(n + 5))) { p->err = "hipMalloc rank pack"; return OICC_ERR_HIP; }
   launch_rank_pack(xv, n, with_state ? p->d_state.p : nullptr, p->d_rank_pack.p, st);
   if (p->reduce(p->reduce_user, p->d_rank_pack.p, n + 5, st) != 0) { p->err = "allreduce callback failed"; return OICC_ERR_STATE; }
@@ -173,10 +176,11 @@ int dist_solve(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb_in, d
   rc = shard_allgather(p, ds.d.xg, ds.d.x_piece, st); if (rc) return rc;
   launch_bcr_dist_finish(p->tl, sb, ds.d, st);
   HIPCK(p, hipGetLastError());
-  ++ds.solves;
+  ++ds.solves; ds.last_step_gathered = true;
   return OICC_OK;
 }
 int lm_solve_any(oicc_problem* p, const NormalEq& ne, const SolveBuffers& sb, double radius, int reuse_diagonal, double min_diag, double max_diag, hipStream_t st) {
+  p->dist.last_step_gathered = false;
   if (p->shard_n > 1 && p->reduce != nullptr && dist_solve_usable(p)) return dist_solve(p, ne, sb, radius, reuse_diagonal, min_diag, max_diag, st);
   if (launch_lm_solve(ne, p->tl, sb, radius, reuse_diagonal, min_diag, max_diag, st) != 0) {
     p->err = "band/arrow geometry exceeds the single-workgroup solver (half bandwidth or arrow too large for 160 KB LDS)"; return OICC_ERR_UNSUPPORTED; }

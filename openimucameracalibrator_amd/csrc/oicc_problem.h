@@ -138,7 +138,9 @@ struct oicc_problem {
   DevBuf<int32_t> d_xrows, d_xcut; DevBuf<double> d_xsend, d_xrecv, d_xgather, d_xagree;
   // distributed linear solve (round 6; kernels_bcr.hip launch_bcr_dist_*, oicc_exchange.hip dist_solve): every rank reduces the 64-column
   // blocks of its own range, the ranks' separators are gathered and solved by all, the step is gathered -- the band never travels
-  struct DistSolve { bool usable = false; int64_t gen = -1; BcrDist d; std::vector<int32_t> b0; DevBuf<int32_t> d_b0; DevBuf<double> ws, msg, xg; double ms_forward = 0, ms_gather = 0, ms_middle = 0, ms_gather_x = 0; int64_t solves = 0; } dist;
+  struct DistSolve { bool usable = false; int64_t gen = -1; BcrDist d; std::vector<int32_t> b0; DevBuf<int32_t> d_b0; DevBuf<double> ws, msg, xg; double ms_forward = 0, ms_gather = 0, ms_middle = 0, ms_gather_x = 0; int64_t solves = 0;
+                     bool last_step_gathered = false;   // the last solve left the SAME step, bit for bit, on every rank (the gathered pieces): its retraction needs no broadcast of the candidate
+                   } dist;
   bool has_ld_block = false, has_tic_block = false, has_acc = false, has_gyr = false;
   std::vector<uint8_t> pts_seen_global; int64_t pts_seen_meas_gen = -1, meas_gen = 0;   // SplineOptimFlags::POINTS on time shards: which board points ANY rank's views observe (summed once through the reduction, prepare()); meas_gen counts the Add* calls
   bool has_remote_views = false;   // other ranks hold views too: under SplineOptimFlags::POINTS every board point is a variable on every rank (which points they see is not declared)
@@ -303,7 +305,7 @@ int read_cost(oicc_problem* p, double* cost);
 void rccl_release(oicc_problem* p);   // destroys the problem's communicator, if any
 int rccl_reduce_in_place(void* user, void* device_ptr, int64_t count, void* stream);
 int rccl_broadcast_from_root(oicc_problem* p, void* device_ptr, int64_t count_doubles, hipStream_t stream);
-int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st);
+int make_rank_consistent(oicc_problem* p, double* xv, bool with_state, hipStream_t st, bool x_identical = false);
 bool owner_exchange_ready(const oicc_problem* p);
 int owner_exchange_agree(oicc_problem* p, hipStream_t st, bool* use);   // collective (every rank of a sharded problem calls it at the same point)
 int shard_broadcast_begin(oicc_problem* p);                                                      // pieces of the parameter vector from their owners, in place:

@@ -696,8 +696,11 @@ int oicc_optimize(oicc_problem* p, int32_t max_iters, int32_t flags, oicc_summar
     // norms, Cholesky flag) are broadcast, so that all ranks evaluate, decide and continue from bit-identical state.
     // (all-reduce hook without RCCL: the mean over the ranks instead, make_rank_consistent)
     if (p->reduce != nullptr && !(p->rccl_comm != nullptr && p->rccl_nranks <= 1)) {
-      rc = make_rank_consistent(p, p->d_xc.p, true, st); if (rc) return rc;
-      p->seg_invalidate(p->d_xc.p);   // rank 0's knots replaced this rank's
+      // (round 6: behind the distributed solve every rank retracted the same gathered step -- the candidates are identical already,
+      // only the step's scalars travel: the step is the only full-length vector a sharded iteration exchanges)
+      const bool same = p->dist.last_step_gathered;
+      rc = make_rank_consistent(p, p->d_xc.p, true, st, same); if (rc) return rc;
+      if (!same) p->seg_invalidate(p->d_xc.p);   // rank 0's knots replaced this rank's
     }
     HIPCK(p, hipEventRecord(ev[1], st));
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, cand_dst); if (rc) return rc;   // (cost slot cleared by lm_retract_kernel, cand_cost by the solver's build kernel)
@@ -902,8 +905,9 @@ int oicc_run_lm_iterations(oicc_problem* p, int32_t flags, int32_t steps) {
       if (sgt) sgt->valid = p->seg_precomputed();
     }
     if (p->reduce != nullptr && !(p->rccl_comm != nullptr && p->rccl_nranks <= 1)) {
-      rc = make_rank_consistent(p, p->d_xc.p, true, st); if (rc) return rc;
-      p->seg_invalidate(p->d_xc.p);
+      const bool same = p->dist.last_step_gathered;
+      rc = make_rank_consistent(p, p->d_xc.p, true, st, same); if (rc) return rc;
+      if (!same) p->seg_invalidate(p->d_xc.p);
     }
     rc = eval_pass(p, p->d_xc.p, false, nullptr, nullptr, -1, true, nullptr, false, nullptr, false, &p->d_state.p->cand_cost); if (rc) return rc;   // as in oicc_optimize: the candidate cost comes back inside LmState
     HIPCK(p, hipMemcpyAsync(&pin->st, p->d_state.p, sizeof(LmState), hipMemcpyDeviceToHost, st));

@@ -930,6 +930,8 @@ def test_distributed_cyclic_reduction_takes_the_steps_of_one_process(cfg, nproc,
     parts, whole = _sharded_processes_take_the_steps_of_one(cfg, FLAGS1, 0, 0, 1, tmp_path, nproc, iters=iters)
     nit = len(whole["iterations"])
     assert all(p_["dist_ranks"] == nproc and p_["dist_solves"] >= nit - 1 and p_["dist_blocks"] >= 1 for p_ in parts), [(p_["dist_ranks"], p_["dist_solves"], p_["dist_blocks"]) for p_ in parts]
+    # every rank retracts the same gathered step: no candidate is broadcast (only the step's scalars travel), and the ranks end BIT-identical
+    assert all(p_["T_i_c"] == parts[0]["T_i_c"] and p_["final_cost"] == parts[0]["final_cost"] for p_ in parts[1:])
     assert sum(p_["dist_blocks"] for p_ in parts) == (whole["band_dim"] + 63) // 64 and [p_["dist_first_block"] for p_ in parts] == sorted(p_["dist_first_block"] for p_ in parts)
     # the largest message any rank received: one of the three gathers (top-system slot, solution slot, diagonal + gradient), never a band range
     a1 = parts[0]["P"] - whole["band_dim"] + 1
