@@ -316,8 +316,8 @@ int oicc_time_allreduce(oicc_problem* p, int32_t flags, int32_t repeats, double*
  * SPARSE_NORMAL_CHOLESKY on one host, impl.h:257-272).  The cuts between the owned ranges lie on multiples of 64 rows, the blocks of the
  * cyclic reduction: step (2) above shrinks to two doubles per row (diagonal and gradient: what every rank needs of ALL rows), every
  * rank reduces the blocks of ITS range down to the range's first block, ONE all-gather moves the ranks' separator blocks (0.11 MB each),
- * every rank solves the N-block top system and back-substitutes its own range, ONE all-gather moves the step.  The band rows never
- * leave their owner.  The choice is part of what the ranks agree on in (b); where the geometry is not the cyclic reduction's (half
+ * every rank solves the N-block top system and back-substitutes its own range, ONE all-gather moves the step -- the same bits on
+ * every rank, so the candidate is not broadcast any more (only the step's scalars are).  The band rows never leave their owner.  The choice is part of what the ranks agree on in (b); where the geometry is not the cyclic reduction's (half
  * bandwidth > 64, more than 63 arrow columns) or a rank would own no block, all ranks gather the band and solve the whole system as
  * before.  Both gathers go through the same transport as (a): ncclAllGather, or OICC_XCHG_BROADCAST per owner on the hook. */
 enum { OICC_XCHG_SENDRECV = 0, OICC_XCHG_BROADCAST = 1 };
