@@ -309,12 +309,15 @@ def main():
             make_gpu = lambda: E.ImuCameraCalibrator(device=local_rank).BatchInitSpline(ds)
             full_calibration(make_gpu, True)                                   # warm-up: code objects of the inner-iteration kernels
             # (the median of three fresh calibrations each: one run is 5 ms of wall clock, a hiccup of the box is 10 % of it)
-            runs_ref = [full_calibration(make_gpu, True) for _ in range(3)]
-            full_ref, summ, _ = sorted(runs_ref, key=lambda r: r[0]["seconds"])[1]
-            full_ref = dict(full_ref, all_runs_seconds=[r[0]["seconds"] for r in runs_ref])
-            runs_plain = [full_calibration(make_gpu, False) for _ in range(3)]
-            full_plain = sorted(runs_plain, key=lambda r: r[0]["seconds"])[1][0]
-            full_plain = dict(full_plain, all_runs_seconds=[r[0]["seconds"] for r in runs_plain])
+            def three(reference_options):   # (one problem alive at a time: the calibrator of a run is released before the next is built)
+                runs = []
+                for _ in range(3):
+                    r_, s_, c_ = full_calibration(make_gpu, reference_options)
+                    runs.append((r_, s_)); del c_
+                mid = sorted(runs, key=lambda r: r[0]["seconds"])[1]
+                return dict(mid[0], all_runs_seconds=[r[0]["seconds"] for r in runs]), mid[1]
+            full_ref, summ = three(True)
+            full_plain, _ = three(False)
             hb = summ["half_bandwidth"]
         else:   # no collective may run on rank 0 alone: half bandwidth from the tangent layout (span of the knots of one SO(3) window and the R^3 windows it overlaps)
             so3o, r3o = lay["so3"], lay["r3"]
