@@ -440,6 +440,28 @@ __device__ __forceinline__ void inner_eval_item(const InnerArgs& A, const double
   else { imu_const_init<1>(ic, P.scal + 17, P.scal + 7); imu_item<1, JAC>(ic, Quat{q0[0], q0[1], q0[2], q0[3]}, sg, kr, R.d[0], 0.0, R.d[2], bk, m, R.d[6], sink); }
 }
 
+// the same item from the per-item records of the plan (inner_records_kernel), where they exist: runs -> record -> board point instead
+// of runs -> corner -> view -> view arrays -> board point
+__device__ __forceinline__ void inner_load_item_any(const InnerArgs& A, const double* xv, const InnerBlock& blk, int i, ItemRec& R) {
+  if (A.rec[0] == nullptr) { inner_load_item(A, xv, blk, i, R); return; }
+  R.kind = -1; R.s_so3 = 0; R.s_r3 = 0; R.sx = 0;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) R.d[k] = 0.0;
+  if (i >= blk.n_slots) return;
+  int idx = 0, off = i;
+  for (int r = 0; r < blk.nruns; ++r) {
+    const InnerRun run = A.runs[blk.run0 + r];
+    if (R.kind < 0 && off >= 0 && off < run.count) { R.kind = run.kind; idx = run.first + off; }
+    off -= (run.count + 63) & ~63;
+  }
+  if (R.kind < 0) return;
+  const InnerItemRec q = A.rec[R.kind][idx];
+  R.s_so3 = q.s_so3; R.s_r3 = q.s_r3; R.sx = q.sx;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) R.d[k] = q.d[k];
+  if (R.kind == 0) { const double* X = xv + A.ctx.pl.pts + 4 * (int64_t)(q.sx >> 1); R.d[6] = X[0]; R.d[7] = X[1]; R.d[8] = X[2]; R.d[9] = X[3]; }
+}
+
 // lane's item record <-> its column of the LDS staging arrays (slot = round * threads + tid)
 template <int SLOTS>
 __device__ __forceinline__ void item_store(const ItemRec& R, int* si, double* sd, int slot) {
@@ -465,7 +487,7 @@ __device__ __forceinline__ void inner_eval_items(const InnerArgs& A, const doubl
   int slot = tid;
   for (int base = part * T; base < blk.n_slots; base += nparts * T, slot += T) {
     ItemRec R;
-    if (staged) item_fetch<CFG::SLOTS>(R, si, sd, slot); else inner_load_item(A, xv, blk, base + tid, R);
+    if (staged) item_fetch<CFG::SLOTS>(R, si, sd, slot); else inner_load_item_any(A, xv, blk, base + tid, R);
     if (__ballot(R.kind >= 0) == 0ull) continue;   // (padding slots of the last wave of a run)
     if (JAC) for (int k = 0; k < 3 * JS; ++k) J[k] = 0.0;
     res[0] = 0.0; res[1] = 0.0; res[2] = 0.0;
@@ -822,7 +844,7 @@ __global__ void __launch_bounds__(InnerCfg<MODE>::T) inner_set_kernel(const Inne
   if (staged) {
     int slot = tid;
     for (int base = wg.part * kInnerThreads; base < blk.n_slots; base += wg.nparts * kInnerThreads, slot += kInnerThreads) {
-      ItemRec R; inner_load_item(A, xv, blk, base + tid, R); item_store<kInnerSlots>(R, s_item_i, s_item_d, slot);
+      ItemRec R; inner_load_item_any(A, xv, blk, base + tid, R); item_store<kInnerSlots>(R, s_item_i, s_item_d, slot);
     }
   }
   if (master) {

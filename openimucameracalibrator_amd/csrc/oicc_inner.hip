@@ -342,7 +342,7 @@ int build_inner_plan(oicc_problem* p, int flags) {
     PA.add(ip.d_big_wgs, ip.big_wgs); PA.add(ip.d_big_blocks, ip.big_blocks); PA.add(ip.d_big_parts, ip.big_parts);
     PA.reserve(ip.d_partials, size_t(std::max(ip.n_ctls, 1)) * size_t(ip.big_max_parts) * 56); PA.reserve(ip.d_lm_states, size_t(std::max(ip.n_ctls, 1)) * inner_lm_state_bytes());
   }
-  bool any_wave = false; for (char w : ip.group_wave) any_wave = any_wave || w;
+  bool any_wave = true;   // (round 6: the per-item records also feed the staging of inner_set_kernel -- one dependent load level per item instead of three)
   if (any_wave) { PA.reserve(ip.d_rec[0], p->corner_view.size()); PA.reserve(ip.d_rec[1], p->acc.size()); PA.reserve(ip.d_rec[2], p->gyr.size()); }
   if (!PA.commit(st)) { p->err = "hipMalloc inner iterations"; return OICC_ERR_HIP; }
   if (any_wave) launch_inner_records(view_data(p), imu_data(p->acc, p->d_acc), imu_data(p->gyr, p->d_gyr), ip.d_rec[0].p, ip.d_rec[1].p, ip.d_rec[2].p, st);   // (the measurements are on the device: prepare() ran)
